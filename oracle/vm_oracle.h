@@ -1,0 +1,152 @@
+/*
+ * vm_oracle.h -- CPU ORACLE (test infrastructure, NOT the product path).
+ *
+ * A plain-C restatement of the halfway-domain morph solver of
+ * liaojing/videomorphing, written from the reference's CUDA/C++ sources as a
+ * specification.  Every function cites the reference file:line it follows
+ * (paths relative to /root/reference).
+ *
+ * Who may use this: tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg -- as the checker / the timed CPU baseline only.  The
+ * product (videomorphing_amd/, include/vmorph.h) never links or calls it.
+ *
+ * PARITY STATUS: the reference holds no tests, golden vectors or fixtures for
+ * this path, none of its CUDA sources build here (nvcc,
+ * OpenCV, Qt, MKL absent) and Algorithm/stencils.cpp only builds with
+ * stand-in headers, which is not allowed.  The oracle is therefore pinned by
+ *   (1) cross-consistency of two independent statements of the thin-plate
+ *       operator inside the reference (stencils.cpp:156-261 vs the dense
+ *       matrix rows of morph.cu:439-469), checked for all 25 border classes,
+ *   (2) the table rows the survey recorded from a run of stencils.cpp
+ *       (tests/golden/stencil_rows.json), and
+ *   (3) analytic known-answer tests (tests/test_oracle_kat.py).
+ * With no reference-run outputs for the iterative optimizer itself, this is
+ * "parity unpinned" in the sense of the task statement for the optimizer
+ * trajectory; see DESIGN.md section (c).
+ *
+ * Numerics: float32 throughout, evaluated in the reference's expression
+ * order, compiled with -ffp-contract=off so that every operation is an IEEE
+ * basic operation (+,-,*,/,sqrt).  CUDA's 1.8 fixed-point texture filtering
+ * weights are NOT emulated: bilinear taps use exact float weights.
+ * Orders the reference leaves to atomics are fixed as row-major over the
+ * committing pixels of a phase.
+ */
+#ifndef VM_ORACLE_H
+#define VM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VMO_BCOND_NONE = 0, VMO_BCOND_CORNER = 1, VMO_BCOND_BORDER = 2 };
+
+/* KernParameters, Algorithm/parameters.h:54-72 */
+typedef struct {
+    float w_temp, w_ui, w_tps, w_ssim;
+    float ssim_clamp;
+    float eps;
+    int   bcond;
+} vmo_params;
+
+/* One connected point pair of Parameters::lp/rp/cnt already resolved to
+ * full-resolution pixel coordinates (Algorithm/morph.cu:357-366). */
+typedef struct {
+    float lx, ly;      /* left  point, full-res pixel index */
+    float rx, ry;      /* right point, full-res pixel index */
+    float weight;      /* MIN(weight_l, weight_r)            */
+} vmo_constraint;
+
+/* One page of one PyramidLevel (Algorithm/Pyramid.h:52-98), tight rows. */
+typedef struct {
+    int w, h;
+    float inv_wh;                 /* pyramid.cu:537 */
+    int imp_rs, imp_rows;         /* pyramid.cu:538-539 */
+    float *img0, *img1;           /* w*h luma, [0,255] */
+    float *v;                     /* 2*w*h, interleaved (x,y) */
+    float *luma, *mean, *var;     /* 2*w*h each, .x = img0, .y = img1 */
+    float *cross, *value, *counter;
+    float *tps_axy, *tps_b;       /* w*h, 2*w*h */
+    float *ui_axy, *ui_b;         /* w*h, 2*w*h */
+    uint32_t *impmask;            /* imp_rs*imp_rows */
+} vmo_level;
+
+/* field ids for vmo_level_field() */
+enum {
+    VMO_F_IMG0 = 0, VMO_F_IMG1, VMO_F_V, VMO_F_LUMA, VMO_F_MEAN, VMO_F_VAR,
+    VMO_F_CROSS, VMO_F_VALUE, VMO_F_COUNTER, VMO_F_TPS_AXY, VMO_F_TPS_B,
+    VMO_F_UI_AXY, VMO_F_UI_B, VMO_F_IMPMASK
+};
+
+/* --- small pieces --------------------------------------------------------- */
+int   vmo_calc_border(int p, int dim);                       /* morph.cu:39-81 */
+float vmo_ssim(float mx, float my, float vx, float vy, float cross,
+               float counter, float clamp);                  /* morph.cu:85-118 */
+float vmo_tex2d(const float *img, int w, int h, float x, float y);
+void  vmo_tex2d_f2(const float *img, int w, int h, float x, float y, float *out2);
+void  vmo_tps_stencil(float *out625);                        /* stencils.cpp:156-261 */
+void  vmo_tps_rows_from_dense(float *out625);                /* morph.cu:439-469 */
+void  vmo_io_stencil(int *out625);                           /* stencils.cpp:10-71 */
+void  vmo_improvmask_stencil(uint32_t *out225);              /* stencils.cpp:90-126 */
+
+/* --- level objects -------------------------------------------------------- */
+vmo_level *vmo_level_create(int w, int h);
+void       vmo_level_destroy(vmo_level *l);
+void      *vmo_level_field(vmo_level *l, int field);
+
+/* --- hot path ------------------------------------------------------------- */
+/* kernel_initialize_level + init_improving_mask, morph.cu:173-260 (+ the
+ * zero-fill of morph.cu:300-314) */
+void vmo_init_level(vmo_level *l, float ssim_clamp);
+/* UI constraint linearisation, morph.cu:345-388 */
+void vmo_splat_constraints(vmo_level *l, int w0, int h0,
+                           const vmo_constraint *c, int n);
+/* one "iteration" = 4 tile-offset launches of kernel_optimize_level,
+ * morph.cu:1281-1345 + 1382-1385.  Returns 1 if any pixel improved.
+ * stats (may be NULL): [0] += pixel visits, [1] += candidate (active) visits,
+ * [2] += commits, [3] += energy evaluations. */
+int  vmo_optimize_iter(vmo_level *l, const vmo_params *p, double *stats);
+/* the do/while of Morph::optimize_level, morph.cu:1378-1390; returns the
+ * number of iterations executed */
+int  vmo_optimize_level(vmo_level *l, const vmo_params *p, float max_iter,
+                        double *stats);
+/* spatial half of upsample(), upsample.cu:260-286 */
+void vmo_upsample_v(vmo_level *dst, const vmo_level *src);
+/* Morph::cpu_optimize_level, morph.cu:419-590 (banded solve, see .c) */
+int  vmo_coarse_solve(vmo_level *l, int w0, int h0, const vmo_params *p,
+                      const vmo_constraint *c, int n);
+/* total energy of the current field (diagnostic, derived from the terms of
+ * morph.cu:730-761): returns E_ssim, E_tps, E_ui in out3 */
+void vmo_energy(const vmo_level *l, const vmo_params *p, double *out3);
+
+/* --- compositor ----------------------------------------------------------- */
+/* kernel_render_halfway_image, render.cu:16-60.  ext0/ext1: float4 RGBA
+ * canvases (w+2ex)x(h+2ex); v,u: w*h float2; out: w*h*3 bytes */
+void vmo_render_halfway(uint8_t *out, int w, int h, int ex,
+                        float color_fa, float geo_fa, int color_from,
+                        const float *ext0, const float *ext1,
+                        const float *v, const float *u);
+/* CMatchingThread::update_result/Resize, MatchingThread.cpp:22-136: scale v
+ * by (W0/W,H0/H) and bilinearly resize to w0 x h0 */
+void vmo_upscale_result(float *dst, int w0, int h0,
+                        const float *v, int w, int h);
+/* CPoissonExt::prepare + poissonExtend, PoissonExt.cpp:49-362.  rgba_ext:
+ * (w+2ex)x(h+2ex) RGBA8 canvas, in/out.  other: w*h RGBA8 crop of the other
+ * image; v: w*h float2; side 1 or 2.  Returns CG iterations used (the
+ * reference uses MKL DSS; see .c). */
+int  vmo_poisson_extend(uint8_t *rgba_ext, int w, int h, int ex,
+                        const uint8_t *other, const float *v, int side,
+                        double tol, int max_it, double *rel_res);
+/* classification + fill only (PoissonExt.cpp:49-141): type[] (0/1/2) out */
+int  vmo_poisson_prepare(uint8_t *rgba_ext, int w, int h, int ex,
+                         const uint8_t *other, const float *v, int side,
+                         int *type_out);
+
+void vmo_set_threads(int n);   /* OpenMP threads for the timed CPU baseline */
+int  vmo_get_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
