@@ -1,0 +1,198 @@
+/*
+ * vmorph.h -- C-ABI of the MI355X-native halfway-domain morph solver.
+ *
+ * This is the drop-in boundary for the hot path of liaojing/videomorphing:
+ * the entry points below are what a binding of the reference's L3 solver API
+ * (Algorithm/morph.h, Pyramid.h, parameters.h; UI/RenderWidget.h:52-57;
+ * Algorithm/PoissonExt.h) would call.  Each declaration cites the reference
+ * interface it replaces (paths relative to the reference repository).
+ * INTEGRATION.md shows the reference-side stubs.
+ *
+ * Conventions
+ *  - extern "C", opaque handles, plain pointers and sizes; no exceptions
+ *    cross the ABI.  Every function returns VM_OK (0) or a negative VM_E_*
+ *    code; vm_last_error() returns a thread-local message for the last error.
+ *    (The reference throws std::runtime_error from rod::check_cuda_error,
+ *    include/util/error.cpp:9-23; the C++ facade re-raises from these codes.)
+ *  - One vm_ctx per device and host thread; all work of a context is
+ *    stream-ordered on the context's HIP stream.  The caller owns host memory,
+ *    the context owns device memory.
+ *  - One vm_pyr holds ONE frame pair (a depth-1 pyramid: the independent-pair
+ *    formulation of BASELINE.json; the reference's temporal coupling,
+ *    morph.cu:1394-1439, is out of scope).  Level 0 is the finest level, level
+ *    nlevels-1 the coarsest one, which only ever holds `v` (it is solved
+ *    densely on the host, morph.cu:152).
+ *  - Images and fields cross the boundary as tight or pitched row-major host
+ *    arrays; `pitch` counts ELEMENTS of the array's scalar type per row
+ *    (floats), 0 meaning tight.  float2 fields are interleaved (x,y).
+ *  - There is no CPU fallback: if the HIP device or the code object is
+ *    missing, vm_ctx_create fails with VM_E_DEVICE.
+ */
+#ifndef VMORPH_H
+#define VMORPH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VM_OK            0
+#define VM_E_INVALID    -1   /* bad argument */
+#define VM_E_DEVICE     -2   /* HIP error (message in vm_last_error) */
+#define VM_E_STATE      -3   /* call out of order (e.g. optimize before init) */
+#define VM_E_NUMERIC    -4   /* coarse solve / Poisson solve failed */
+#define VM_E_CANCELLED  -5   /* run_flag went to 0 */
+
+typedef struct vm_ctx vm_ctx;
+typedef struct vm_pyr vm_pyr;
+
+/* enum BoundaryCondition, Algorithm/parameters.h:9-14 */
+enum { VM_BCOND_NONE = 0, VM_BCOND_CORNER = 1, VM_BCOND_BORDER = 2 };
+
+/* struct KernParameters, Algorithm/parameters.h:54-72 (same fields, same order) */
+typedef struct {
+    float w_temp, w_ui, w_tps, w_ssim;
+    float ssim_clamp;
+    float eps;
+    int   bcond;
+} vm_kern_params;
+
+/* One connected point pair (Parameters::lp/rp/cnt, parameters.h:16-27, 45-47)
+ * resolved by the caller to full-resolution pixel indices, as consumed at
+ * Algorithm/morph.cu:357-366: weight = MIN(weight_l, weight_r). */
+typedef struct {
+    float lx, ly, rx, ry;
+    float weight;
+} vm_constraint;
+
+/* arithmetic mode of the optimizer kernels */
+enum {
+    VM_MATH_EXACT = 0,  /* IEEE +,-,*,/,sqrt, no contraction: bit-identical to the CPU oracle */
+    VM_MATH_FAST  = 1   /* fused multiply-add, v_rcp/v_sqrt approximations: the
+                           analogue of the reference's --use_fast_math build
+                           (MdiEditor.vcxproj:208-213) */
+};
+
+/* progress of one optimize_level call; mirrors the public progress members of
+ * class Morph (Algorithm/morph.h:19-20) */
+typedef struct {
+    int    iters;          /* iterations executed (4 tile-offset sweeps each)  */
+    int    improving;      /* 1 if the last executed iteration still improved  */
+    double pixel_iters;    /* iters * W * H  (morph.cu:1389)                    */
+    float  elapsed_ms;     /* HIP-event time of the sweep kernels on the stream */
+    int    launches;       /* sweep kernel launches enqueued                    */
+} vm_progress;
+
+/* device-state arrays a test or a UI may read back (vm_level_get_field) */
+enum {
+    VM_F_IMG0 = 0, VM_F_IMG1, VM_F_V, VM_F_LUMA, VM_F_MEAN, VM_F_VAR, VM_F_CROSS,
+    VM_F_VALUE, VM_F_COUNTER, VM_F_TPS_AXY, VM_F_TPS_B, VM_F_UI_AXY, VM_F_UI_B,
+    VM_F_IMPMASK
+};
+
+const char *vm_last_error(void);
+const char *vm_version(void);
+
+/* ---- context ------------------------------------------------------------- */
+/* replaces MdiEditor::CudaInit device selection, UI/MdiEditor.cpp:54-75 */
+int  vm_ctx_create(int device, vm_ctx **out);
+void vm_ctx_destroy(vm_ctx *ctx);
+int  vm_ctx_sync(vm_ctx *ctx);
+/* copy_to_symbol(c_params, KernParameters), Algorithm/morph.cu:1355-1358 */
+int  vm_set_params(vm_ctx *ctx, const vm_kern_params *p);
+int  vm_get_params(vm_ctx *ctx, vm_kern_params *p);
+int  vm_set_math_mode(vm_ctx *ctx, int mode);
+/* device facts for reports: name (<=255 chars), CU count, HBM bytes */
+int  vm_device_info(vm_ctx *ctx, char *name256, int *cus, uint64_t *hbm_bytes);
+
+/* ---- pyramid / levels ---------------------------------------------------- */
+/* Pyramid::append_new + PyramidLevel ctor, Algorithm/pyramid.cu:525-543 */
+int  vm_pyramid_create(vm_ctx *ctx, int nlevels, const int *w, const int *h, vm_pyr **out);
+/* Pyramid::clear, Algorithm/pyramid.cu:19-49 */
+void vm_pyramid_destroy(vm_pyr *pyr);
+int  vm_pyramid_levels(vm_pyr *pyr);
+int  vm_level_dims(vm_pyr *pyr, int lvl, int *w, int *h, int *rowstride);
+/* the cudaMemcpy2DToArray uploads of luma in Pyramid::build, pyramid.cu:275-280 */
+int  vm_level_upload_luma(vm_pyr *pyr, int lvl, const float *img0, const float *img1, int pitch);
+/* lvl.v.copy_from_host, Algorithm/morph.cu:588 */
+int  vm_level_set_v(vm_pyr *pyr, int lvl, const float *v_xy, int pitch);
+/* the cudaMemcpy2D of CMatchingThread::update_result, MatchingThread.cpp:38-40 */
+int  vm_level_get_v(vm_pyr *pyr, int lvl, float *v_xy, int pitch);
+/* read back any state array, tight rows: float (h*w), float2 (h*w*2) or, for
+ * VM_F_IMPMASK, uint32 ((h+4)/5+2) x ((w+4)/5+2) */
+int  vm_level_get_field(vm_pyr *pyr, int lvl, int field, void *host);
+/* Morph::clear_level, Algorithm/morph.cu:392-414 */
+int  vm_level_clear(vm_pyr *pyr, int lvl);
+
+/* ---- solver -------------------------------------------------------------- */
+/* Morph::cpu_optimize_level, Algorithm/morph.cu:419-590 (host banded solve of
+ * the coarsest level, result uploaded to the level's v) */
+int  vm_coarse_solve(vm_pyr *pyr, int lvl, int w0, int h0, const vm_constraint *c, int n);
+/* upsample(PyramidLevel&dest, PyramidLevel&orig), Algorithm/upsample.cu:260-286 */
+int  vm_upsample_v(vm_pyr *pyr, int dst_lvl, int src_lvl);
+/* Morph::initialize_level, Algorithm/morph.cu:264-390: window sums, SSIM value,
+ * TPS linearisation, improving mask, and the UI-constraint splat (done on the
+ * device; w0,h0 = full-resolution size the constraint coordinates refer to) */
+int  vm_init_level(vm_pyr *pyr, int lvl, int w0, int h0, const vm_constraint *c, int n);
+/* Morph::optimize_level, Algorithm/morph.cu:1353-1391.  Runs until no pixel
+ * improves, iter >= max_iter, or *run_flag == 0 (may be NULL).  fixed_work != 0
+ * ignores the convergence exit (always max_iter iterations). */
+int  vm_optimize_level(vm_pyr *pyr, int lvl, float max_iter, volatile const int *run_flag,
+                       int fixed_work, vm_progress *out);
+/* Morph::calculate_halfway_parametrization, Algorithm/morph.cu:150-168: the
+ * whole coarse-to-fine solve.  per_level (may be NULL) receives nlevels-1
+ * entries, index = level. */
+int  vm_solve(vm_pyr *pyr, float max_iter, float max_iter_drop_factor,
+              const vm_constraint *c, int n, volatile const int *run_flag,
+              int fixed_work, vm_progress *per_level);
+/* CMatchingThread::update_result + Resize, Algorithm/MatchingThread.cpp:22-100:
+ * v of level `lvl` scaled by (W0/W, H0/H) and bilinearly resized to w0 x h0 */
+int  vm_upscale_result(vm_pyr *pyr, int lvl, int w0, int h0, float *v_xy_out, int pitch);
+
+/* ---- compositor ---------------------------------------------------------- */
+typedef struct vm_frame vm_frame;
+/* device-resident inputs of one output frame: the two Poisson-extended RGBA8
+ * canvases (w+2ex)x(h+2ex) (Pyramid::_extends1/_extends2, Pyramid.h:44-45),
+ * the full-resolution halfway field and quadratic path (Pyramid::_vector,
+ * _qpath).  Replaces the per-frame cudaMallocArray/H2D uploads of
+ * RenderWidget::RenderStage2, UI/RenderWidget.cpp:229-266.  qpath may be NULL
+ * (zero path: CQuadraticPath is disabled in the reference app). */
+int  vm_frame_create(vm_ctx *ctx, int w, int h, int ex, vm_frame **out);
+void vm_frame_destroy(vm_frame *f);
+int  vm_frame_upload(vm_frame *f, const uint8_t *ext0_rgba, const uint8_t *ext1_rgba,
+                     const float *v_xy, const float *qpath_xy);
+int  vm_frame_download_ext(vm_frame *f, int side, uint8_t *ext_rgba);
+/* take v straight from a solved pyramid level (device to device, with the
+ * update_result upscale) */
+int  vm_frame_set_v_from_level(vm_frame *f, vm_pyr *pyr, int lvl);
+/* render_halfway_image, Algorithm/render.cu:62-96 (UI/RenderWidget.h:52-57);
+ * rgb_out: h rows of w RGB8 pixels, pitch in bytes (0 = tight) */
+int  vm_render_halfway(vm_frame *f, float color_fa, float geo_fa, int color_from,
+                       uint8_t *rgb_out, int pitch_bytes);
+/* same, output left on the device (for timing / chaining) */
+int  vm_render_halfway_dev(vm_frame *f, float color_fa, float geo_fa, int color_from,
+                           float *elapsed_ms);
+/* CPoissonExt::prepare + poissonExtend for one side (1 or 2) of the frame,
+ * Algorithm/PoissonExt.cpp:49-362, on the device-resident canvases: matrix-free
+ * preconditioned CG instead of MKL DSS.  iters/rel_res may be NULL. */
+int  vm_poisson_extend(vm_frame *f, int side, float tol, int max_it,
+                       int *iters, float *rel_res, float *elapsed_ms);
+
+/* ---- multi-GPU ----------------------------------------------------------- */
+/* The shared parameter block every rank needs (KernParameters + iteration
+ * control + constraints), flattened so that any transport -- the RCCL
+ * broadcast of bench.py / the C++ driver -- can ship it. */
+typedef struct {
+    vm_kern_params kp;
+    float max_iter, max_iter_drop_factor;
+    int   start_res, math_mode, n_constraints;
+} vm_param_block;
+/* in-place RCCL broadcast of `bytes` at device pointer `dev_buf` from rank
+ * `root` on communicator `nccl_comm` (an ncclComm_t), on the context's stream */
+int  vm_rccl_bcast(vm_ctx *ctx, void *nccl_comm, void *dev_buf, uint64_t bytes, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,305 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle.
+
+EXACT arithmetic mode is required to be BIT-IDENTICAL to the oracle (both sides
+use only IEEE +,-,*,/,sqrt in the same order; the commit order the reference
+leaves to atomics is fixed row-major on both sides).  FAST mode (fused
+multiply-add, v_rcp/v_sqrt) is held to the float tolerances of SURVEY.md
+section 8(d), written next to each assertion.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from videomorphing_amd import capi, morph, synth
+
+pytestmark = pytest.mark.gpu
+
+STATE = ["luma", "mean", "var", "cross", "value", "tps_b", "ui_axy", "ui_b", "counter", "tps_axy"]
+
+
+def _params(O, **kw):
+    return O.default_params(**kw)
+
+
+def _kp(P):
+    k = capi.KernParams()
+    for f, _ in capi.KernParams._fields_:
+        setattr(k, f, getattr(P, f))
+    return k
+
+
+def _make_level(gpu_ctx, O, w, h, v0=None, cons=(), seed=0, frame=0, P=None):
+    """One level on both sides with identical inputs, initialised."""
+    P = P or _params(O)
+    i0, i1 = synth.make_pair(w, h, frame=frame)
+    if v0 is None:
+        rng = np.random.RandomState(seed)
+        v0 = (0.8 * synth.displacement(w, h) + 0.05 * rng.randn(h, w, 2)).astype(np.float32)
+    lo = O.Level(w, h)
+    lo.set_images(i0, i1)
+    lo.field("v")[...] = v0
+    lo.init(P.ssim_clamp)
+    lo.splat(w, h, cons)
+    gpu_ctx.set_params(_kp(P))
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build_levels([(w, h), (max((w + 1) // 2, 5), max((h + 1) // 2, 5))])
+    pyr.upload_luma(1, i0, i1)
+    pyr[1].v = v0
+    ca, n = morph._cons_array(cons)
+    capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, ca, n))
+    return lo, pyr, P
+
+
+def _assert_state_equal(lo, lg, fields=STATE + ["v"], exact=True, tol=0.0):
+    for f in fields:
+        a, b = lo.field(f), (lg.v if f == "v" else lg.field(f))
+        if exact:
+            bad = np.flatnonzero(a.view(np.uint32).ravel() != b.view(np.uint32).ravel())
+            assert bad.size == 0, "%s: %d of %d words differ, first at %d: %r vs %r" % (
+                f, bad.size, a.size, bad[0], a.ravel()[bad[0]], b.ravel()[bad[0]])
+        else:
+            assert np.allclose(a, b, rtol=tol, atol=tol), "%s: max abs diff %g" % (f, np.abs(a - b).max())
+    assert np.array_equal(lo.field("impmask"), lg.field("impmask")), "improving mask differs"
+
+
+@pytest.mark.parametrize("w,h", [(96, 64), (150, 97), (69, 21), (33, 7), (5, 5)])
+def test_init_level_exact(gpu_ctx, oracle, w, h):
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    cons = [(10, 10, 14, 12, 1.0), (w - 8.0, h - 3.0, w - 10.0, h - 4.0, 0.5)] if w > 40 else []
+    lo, pyr, _ = _make_level(gpu_ctx, oracle, w, h, cons=cons)
+    _assert_state_equal(lo, pyr[1])
+
+
+@pytest.mark.parametrize("w,h,iters", [(96, 64, 3), (150, 97, 2), (200, 40, 2), (64, 16, 2)])
+def test_sweep_exact(gpu_ctx, oracle, w, h, iters):
+    """bit-tight sweeps: identical accept/reject set, identical state"""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    lo, pyr, P = _make_level(gpu_ctx, oracle, w, h)
+    for it in range(iters):
+        imp_o = lo.optimize_iter(P)
+        pr = capi.Progress()
+        capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 1.0, None, 0, C.byref(pr)))
+        assert pr.iters == 1 and pr.improving == imp_o
+        _assert_state_equal(lo, pyr[1])
+
+
+@pytest.mark.parametrize("bcond", [capi.BCOND_NONE, capi.BCOND_CORNER, capi.BCOND_BORDER])
+def test_sweep_exact_constraints_bcond(gpu_ctx, oracle, bcond):
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    w, h = 120, 75
+    cons = synth.make_constraints(w, h, 6)
+    P = _params(oracle, bcond=bcond)
+    lo, pyr, P = _make_level(gpu_ctx, oracle, w, h, cons=cons, P=P)
+    for it in range(3):
+        lo.optimize_iter(P)
+        capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 1.0, None, 0, None))
+    _assert_state_equal(lo, pyr[1])
+
+
+def test_identical_images_no_motion(gpu_ctx, oracle):
+    """KAT: identical images, v0 = 0 -> (almost) nothing moves: the SSIM values sit
+    at 1 up to rounding, so only rounding-level flukes can be accepted; GPU and
+    oracle agree bit for bit on which"""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    w, h = 96, 64
+    i0, _ = synth.make_pair(w, h)
+    P = _params(oracle)
+    lo = oracle.Level(w, h)
+    lo.set_images(i0, i0)
+    lo.init(0.0)
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build_levels([(w, h), (48, 32)])
+    pyr.upload_luma(1, i0, i0)
+    pyr[1].v = np.zeros((h, w, 2), np.float32)
+    gpu_ctx.set_params(_kp(P))
+    capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+    it_o = lo.optimize(P, 20)
+    pr = capi.Progress()
+    capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 20.0, None, 0, C.byref(pr)))
+    assert pr.iters == it_o
+    _assert_state_equal(lo, pyr[1])
+    assert np.abs(pyr[1].v).max() < 0.05
+    assert pyr[1].field("value").min() > 0.999
+
+
+def test_full_solve_exact_256(gpu_ctx, oracle):
+    """BASELINE config 1 geometry (256^2, 3 levels), fewer iterations: the whole
+    coarse-to-fine solve is bit-identical to the oracle, including iteration counts."""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    w = h = 256
+    i0, i1 = synth.make_pair(w, h)
+    pyr_imgs = synth.build_pyramid(i0, i1, 3)
+    P = _params(oracle)
+    per = []
+    lo = oracle.solve(pyr_imgs, P, 30, 1.0, threads=8, per_level=per)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 30, 1.0, 64
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build(i0, i1, 64)
+    assert pyr.size() == 4
+    m = morph.Morph(prm, pyr)
+    assert m.calculate_halfway_parametrization() is True
+    assert [m.progress[el]["iters"] for el in (2, 1)] == [p[1] for p in per]
+    a, b = lo.field("v"), pyr[1].v
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "max |dv| = %g" % np.abs(a - b).max()
+    # and the solve actually found the synthetic displacement
+    d = synth.displacement(w, h)
+    assert np.sqrt(((b - d) ** 2).sum(-1).mean()) < 0.5
+
+
+def test_fast_mode_tolerance(gpu_ctx, oracle):
+    """FAST arithmetic: 1-sweep max|dv| <= 1e-3 px except for a <= 0.5 % fraction of
+    pixels whose accept/reject decision flipped; after a full level the fields agree
+    statistically: RMS dv <= 0.05 px, >= 99 % of pixels within 0.25 px, SSIM energy
+    within 0.5 %."""
+    w, h = 160, 120
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    lo, pyr, P = _make_level(gpu_ctx, oracle, w, h)
+    lo.optimize_iter(P)
+    capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 1.0, None, 0, None))
+    dv = np.abs(lo.field("v") - pyr[1].v).max(-1)
+    assert (dv > 1e-3).mean() <= 5e-3, "fraction flipped %g" % (dv > 1e-3).mean()
+    it_o = lo.optimize(P, 60)
+    pr = capi.Progress()
+    capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 60.0, None, 0, C.byref(pr)))
+    a, b = lo.field("v"), pyr[1].v
+    dv = np.sqrt(((a - b) ** 2).sum(-1))
+    assert np.sqrt((dv ** 2).mean()) <= 0.05, np.sqrt((dv ** 2).mean())
+    assert (dv < 0.25).mean() >= 0.99
+    eo = (1 - lo.field("value")).sum()
+    eg = (1 - pyr[1].field("value")).sum()
+    assert abs(eo - eg) <= 0.005 * eo + 1e-3
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+
+
+def test_upsample_exact(gpu_ctx, oracle):
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    for (dw, dh) in [(97, 75), (128, 64)]:
+        sw, sh = (dw + 1) // 2, (dh + 1) // 2
+        rng = np.random.RandomState(3)
+        v = rng.randn(sh, sw, 2).astype(np.float32)
+        src, dst = oracle.Level(sw, sh), oracle.Level(dw, dh)
+        src.field("v")[...] = v
+        dst.upsample_from(src)
+        pyr = morph.Pyramid(gpu_ctx)
+        pyr.build_levels([(dw, dh), (sw, sh)])
+        pyr[2].v = v
+        capi.check(pyr._L.vm_upsample_v(pyr._h, 0, 1))
+        assert np.array_equal(dst.field("v").view(np.uint32), pyr[1].v.view(np.uint32))
+
+
+def test_coarse_solve_matches_oracle(gpu_ctx, oracle):
+    """host banded solve vs the oracle's: same linear system, two independent
+    implementations -> agree to 1e-4 px; zero constraints -> exactly zero"""
+    w, h, w0, h0 = 60, 34, 1920, 1080
+    cons = synth.make_constraints(w0, h0, 8)
+    for bcond in (capi.BCOND_BORDER, capi.BCOND_CORNER):
+        P = _params(oracle, bcond=bcond)
+        lo = oracle.Level(w, h)
+        assert lo.coarse_solve(w0, h0, P, cons) == 0
+        gpu_ctx.set_params(_kp(P))
+        pyr = morph.Pyramid(gpu_ctx)
+        pyr.build_levels([(120, 68), (w, h)])
+        ca, n = morph._cons_array(cons)
+        capi.check(pyr._L.vm_coarse_solve(pyr._h, 1, w0, h0, ca, n))
+        a, b = lo.field("v"), pyr[2].v
+        assert np.abs(a).max() > 0.1
+        assert np.abs(a - b).max() <= 1e-4, np.abs(a - b).max()
+    capi.check(pyr._L.vm_coarse_solve(pyr._h, 1, w0, h0, None, 0))
+    assert not pyr[2].v.any()
+
+
+def test_upscale_result_exact(gpu_ctx, oracle):
+    rng = np.random.RandomState(5)
+    for (w, h, w0, h0) in [(120, 68, 1920, 1080), (64, 48, 64, 48), (50, 40, 101, 77)]:
+        v = rng.randn(h, w, 2).astype(np.float32)
+        pyr = morph.Pyramid(gpu_ctx)
+        pyr.build_levels([(w, h), ((w + 1) // 2, (h + 1) // 2)])
+        pyr[1].v = v
+        out = np.zeros((h0, w0, 2), np.float32)
+        capi.check(pyr._L.vm_upscale_result(pyr._h, 0, w0, h0, out.ctypes.data, 0))
+        ref = oracle.upscale_result(v, w0, h0)
+        assert np.array_equal(ref.view(np.uint32), out.view(np.uint32)), np.abs(ref - out).max()
+
+
+def _frame_inputs(w, h, ex, seed=0):
+    rgb0, rgb1 = synth.make_rgb_pair(w, h)
+    e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
+    rng = np.random.RandomState(seed)
+    v = (synth.displacement(w, h) + 0.1 * rng.randn(h, w, 2)).astype(np.float32)
+    return e0, e1, v
+
+
+@pytest.mark.parametrize("color_from,geo,col", [(0, 0.0, 0.0), (1, 0.5, 0.5), (2, 1.0, 1.0), (1, 0.3, 0.7)])
+def test_render_exact(gpu_ctx, oracle, color_from, geo, col):
+    """render_halfway: byte-identical frames given identical inputs"""
+    w, h, ex = 150, 90, 15
+    e0, e1, v = _frame_inputs(w, h, ex)
+    u = (0.3 * np.random.RandomState(9).randn(h, w, 2)).astype(np.float32)
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(e0, e1, v, u)
+    out = fr.render_halfway(col, geo, color_from)
+    ref = oracle.render_halfway(w, h, ex, col, geo, color_from, e0.astype(np.float32),
+                                e1.astype(np.float32), v, u)
+    assert np.array_equal(out, ref), "differing bytes: %d" % (out != ref).sum()
+
+
+def test_render_identity(gpu_ctx):
+    """KAT 9: v = 0, u = 0 reproduces the original crop / the exact blend"""
+    w, h, ex = 64, 48, 6
+    e0, e1, _ = _frame_inputs(w, h, ex)
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(e0, e1, np.zeros((h, w, 2), np.float32), None)
+    assert np.array_equal(fr.render_halfway(0.0, 0.5, 0), e0[ex:ex + h, ex:ex + w, :3])
+    assert np.array_equal(fr.render_halfway(0.0, 0.5, 2), e1[ex:ex + h, ex:ex + w, :3])
+
+
+def test_poisson_extend(gpu_ctx, oracle):
+    """classification + fill are byte-identical to the oracle; the solved colours
+    agree within +-1 level (both solvers truncate a float solution to integers) on
+    >= 99.9 % of the extended pixels, relative residual <= 1e-5"""
+    w, h, ex = 96, 64, 10
+    e0, e1, v = _frame_inputs(w, h, ex)
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(e0, e1, v, None)
+    for side, ext, other in ((1, e0, e1), (2, e1, e0)):
+        crop = other[ex:ex + h, ex:ex + w]
+        ref, it_o, rr_o = oracle.poisson_extend(ext, w, h, ex, crop, v, side, tol=1e-9)
+        it, rr, ms = fr.poisson_extend(side, tol=1e-5, max_it=5000)
+        out = fr.download_ext(side)
+        assert rr <= 1e-5
+        assert np.array_equal(out[..., 3], ref[..., 3])
+        d = np.abs(out[..., :3].astype(np.int32) - ref[..., :3].astype(np.int32))
+        assert (d <= 1).mean() >= 0.999 and d.max() <= 2, (d.max(), (d > 1).mean())
+        # the interior is untouched
+        assert np.array_equal(out[ex + 1:ex + h - 1, ex + 1:ex + w - 1], ext[ex + 1:ex + h - 1, ex + 1:ex + w - 1])
+
+
+def test_errors_are_loud(gpu_ctx, vmlib):
+    """error behaviour: bad calls return codes + messages, never crash"""
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build_levels([(64, 48), (32, 24)])
+    with pytest.raises(capi.VmError) as e:
+        capi.check(vmlib.vm_optimize_level(pyr._h, 0, 10.0, None, 0, None))
+    assert e.value.code == capi.VM_E_STATE
+    with pytest.raises(capi.VmError):
+        capi.check(vmlib.vm_init_level(pyr._h, 1, 64, 48, None, 0))  # coarsest level
+    with pytest.raises(capi.VmError):
+        capi.check(vmlib.vm_level_dims(pyr._h, 7, None, None, None))
+    h = C.c_void_p()
+    assert vmlib.vm_ctx_create(99, C.byref(h)) == capi.VM_E_INVALID
+
+
+def test_cancellation(gpu_ctx, oracle):
+    """run_flag == 0 stops the solve (Morph m_cb, morph.cu:156,1390)"""
+    w, h = 128, 96
+    i0, i1 = synth.make_pair(w, h)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor = 400, 1.0
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build(i0, i1, 32)
+    flag = C.c_int(0)
+    m = morph.Morph(prm, pyr, flag)
+    assert m.calculate_halfway_parametrization() is True
+    assert m.progress == {}  # no level ran

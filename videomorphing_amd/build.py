@@ -1,0 +1,83 @@
+"""Builds libvmorph_hip.so (HIP kernels + C-ABI) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU.  The optimizer kernels are compiled twice
+from one source: the EXACT arithmetic mode with -ffp-contract=off (bit-identical
+to the CPU oracle) and the FAST mode with fused multiply-adds.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libvmorph_hip.so")
+ARCH = "gfx950"
+
+COMMON = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+          "-I" + os.path.join(HERE, "..", "include")]
+
+# (source, object, extra flags)
+UNITS = [
+    ("vm_morph_kernels.hip", "vm_morph_kernels_exact.o", ["-DVM_EXACT=1", "-ffp-contract=off"]),
+    ("vm_morph_kernels.hip", "vm_morph_kernels_fast.o", ["-DVM_EXACT=0", "-ffp-contract=fast"]),
+    ("vm_render.hip", "vm_render.o", ["-ffp-contract=off"]),
+    ("vm_poisson.hip", "vm_poisson.o", ["-ffp-contract=off"]),
+    ("vm_api.cpp", "vm_api.o", ["-x", "hip"]),
+    ("vm_host.cpp", "vm_host.o", ["-x", "hip"]),
+    ("vm_frame.cpp", "vm_frame.o", ["-x", "hip"]),
+    ("vm_poisson_api.cpp", "vm_poisson_api.o", ["-x", "hip"]),
+]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newer(path, deps):
+    if not os.path.exists(path):
+        return True
+    t = os.path.getmtime(path)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "vmorph.h"))
+    headers.append(os.path.abspath(__file__))
+    hipcc = _hipcc()
+    jobs = []
+    for src, obj, extra in UNITS:
+        s, o = os.path.join(CSRC, src), os.path.join(OBJ, obj)
+        if not os.path.exists(s):
+            raise FileNotFoundError(s)
+        if force or _newer(o, [s] + headers):
+            jobs.append([hipcc] + COMMON + extra + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("build failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn.strip():
+                print(warn)
+    objs = [os.path.join(OBJ, o) for _, o, _ in UNITS]
+    if force or jobs or _newer(LIB, objs):
+        run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,123 @@
+"""ctypes binding of the C-ABI (include/vmorph.h) -- thin, no logic.
+
+The shared library is built in-tree by videomorphing_amd.build.  Loading
+fails loudly when it is missing; creating a context fails loudly when there is
+no HIP device (there is no CPU fallback in the product path).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvmorph_hip.so")
+
+VM_OK = 0
+VM_E_INVALID, VM_E_DEVICE, VM_E_STATE, VM_E_NUMERIC, VM_E_CANCELLED = -1, -2, -3, -4, -5
+BCOND_NONE, BCOND_CORNER, BCOND_BORDER = 0, 1, 2
+MATH_EXACT, MATH_FAST = 0, 1
+
+FIELDS = {  # name -> (id, channels)
+    "img0": (0, 1), "img1": (1, 1), "v": (2, 2), "luma": (3, 2), "mean": (4, 2), "var": (5, 2),
+    "cross": (6, 1), "value": (7, 1), "counter": (8, 1), "tps_axy": (9, 1), "tps_b": (10, 2),
+    "ui_axy": (11, 1), "ui_b": (12, 2), "impmask": (13, 1),
+}
+
+# every symbol include/vmorph.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "vm_last_error", "vm_version", "vm_ctx_create", "vm_ctx_destroy", "vm_ctx_sync",
+    "vm_set_params", "vm_get_params", "vm_set_math_mode", "vm_device_info",
+    "vm_pyramid_create", "vm_pyramid_destroy", "vm_pyramid_levels", "vm_level_dims",
+    "vm_level_upload_luma", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
+    "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
+    "vm_solve", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
+    "vm_frame_download_ext", "vm_frame_set_v_from_level", "vm_render_halfway",
+    "vm_render_halfway_dev", "vm_poisson_extend", "vm_rccl_bcast",
+]
+
+
+class KernParams(C.Structure):
+    """struct KernParameters, Algorithm/parameters.h:54-72."""
+    _fields_ = [("w_temp", C.c_float), ("w_ui", C.c_float), ("w_tps", C.c_float),
+                ("w_ssim", C.c_float), ("ssim_clamp", C.c_float), ("eps", C.c_float),
+                ("bcond", C.c_int)]
+
+
+class Constraint(C.Structure):
+    _fields_ = [("lx", C.c_float), ("ly", C.c_float), ("rx", C.c_float), ("ry", C.c_float),
+                ("weight", C.c_float)]
+
+
+class Progress(C.Structure):
+    _fields_ = [("iters", C.c_int), ("improving", C.c_int), ("pixel_iters", C.c_double),
+                ("elapsed_ms", C.c_float), ("launches", C.c_int)]
+
+
+class ParamBlock(C.Structure):
+    _fields_ = [("kp", KernParams), ("max_iter", C.c_float), ("max_iter_drop_factor", C.c_float),
+                ("start_res", C.c_int), ("math_mode", C.c_int), ("n_constraints", C.c_int)]
+
+
+class VmError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "vmorph error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -m videomorphing_amd.build` "
+                          "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    L.vm_last_error.restype = C.c_char_p
+    L.vm_version.restype = C.c_char_p
+    sig = {
+        "vm_ctx_create": [i, C.POINTER(vp)],
+        "vm_ctx_sync": [vp],
+        "vm_set_params": [vp, C.POINTER(KernParams)],
+        "vm_get_params": [vp, C.POINTER(KernParams)],
+        "vm_set_math_mode": [vp, i],
+        "vm_device_info": [vp, C.c_char_p, C.POINTER(i), C.POINTER(C.c_uint64)],
+        "vm_pyramid_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(vp)],
+        "vm_pyramid_levels": [vp],
+        "vm_level_dims": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)],
+        "vm_level_upload_luma": [vp, i, vp, vp, i],
+        "vm_level_set_v": [vp, i, vp, i],
+        "vm_level_get_v": [vp, i, vp, i],
+        "vm_level_get_field": [vp, i, i, vp],
+        "vm_level_clear": [vp, i],
+        "vm_coarse_solve": [vp, i, i, i, vp, i],
+        "vm_upsample_v": [vp, i, i],
+        "vm_init_level": [vp, i, i, i, vp, i],
+        "vm_optimize_level": [vp, i, f, vp, i, C.POINTER(Progress)],
+        "vm_solve": [vp, f, f, vp, i, vp, i, vp],
+        "vm_upscale_result": [vp, i, i, i, vp, i],
+        "vm_frame_create": [vp, i, i, i, C.POINTER(vp)],
+        "vm_frame_upload": [vp, vp, vp, vp, vp],
+        "vm_frame_download_ext": [vp, i, vp],
+        "vm_frame_set_v_from_level": [vp, vp, i],
+        "vm_render_halfway": [vp, f, f, i, vp, i],
+        "vm_render_halfway_dev": [vp, f, f, i, C.POINTER(f)],
+        "vm_poisson_extend": [vp, i, f, i, C.POINTER(i), C.POINTER(f), C.POINTER(f)],
+        "vm_rccl_bcast": [vp, vp, vp, C.c_uint64, i],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = i
+    for name in ("vm_ctx_destroy", "vm_pyramid_destroy", "vm_frame_destroy"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = None
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != VM_OK:
+        raise VmError(rc, load().vm_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,540 @@
+// vm_api.cpp -- implementation of the C-ABI declared in include/vmorph.h:
+// contexts, pyramids, host<->device copies, the host-side coarse solve and the
+// coarse-to-fine driver.  Kernels live in vm_morph_kernels.hip (optimizer),
+// vm_render.hip (compositor) and vm_poisson.hip (boundary extension).
+#include "vm_internal.h"
+#include "vm_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+int vm_fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+extern "C" const char *vm_last_error(void) { return g_err.c_str(); }
+extern "C" const char *vm_version(void) { return "vmorph-mi355x 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------
+// constant tables (thin-plate stencil per border class, improving-mask window
+// bits).  Product-side generator: the stencil row of a pixel is the Hessian
+// row of the discrete bending energy  sum (dxx v)^2 + (dyy v)^2 + 2 (dxy v)^2
+// over all operator placements that fit in the image -- what
+// Algorithm/stencils.cpp:156-261 tabulates per border class.
+static void build_tables(uint32_t *tab)
+{
+    float tps[5][5][5][5];
+    memset(tps, 0, sizeof(tps));
+    // a 5x5 image realises every border class pair once: pixel (n,m) has class (m,n)
+    const int N = 5;
+    struct Op { int n; int dx[4], dy[4]; float c[4]; float w; };
+    const Op ops[3] = {
+        {3, {-1, 0, 1, 0}, {0, 0, 0, 0}, {1, -2, 1, 0}, 1.0f},  // dxx, centred
+        {3, {0, 0, 0, 0}, {-1, 0, 1, 0}, {1, -2, 1, 0}, 1.0f},  // dyy, centred
+        {4, {0, 1, 0, 1}, {0, 0, 1, 1}, {1, -1, -1, 1}, 2.0f},  // dxy on the cell (x..x+1, y..y+1)
+    };
+    for (int k = 0; k < 3; ++k)
+        for (int cy = 0; cy < N; ++cy)
+            for (int cx = 0; cx < N; ++cx) {
+                const Op &o = ops[k];
+                bool fits = true;
+                for (int t = 0; t < o.n; ++t) {
+                    int x = cx + o.dx[t], y = cy + o.dy[t];
+                    if (x < 0 || x >= N || y < 0 || y >= N) fits = false;
+                }
+                if (!fits) continue;
+                // d/dv_p of w*(sum c_t v_t)^2 = 2 w c_p sum c_t v_t
+                for (int p = 0; p < o.n; ++p)
+                    for (int t = 0; t < o.n; ++t) {
+                        int px = cx + o.dx[p], py = cy + o.dy[p];
+                        int qx = cx + o.dx[t], qy = cy + o.dy[t];
+                        tps[py][px][qy - py + 2][qx - px + 2] += 2.0f * o.w * o.c[p] * o.c[t];
+                    }
+            }
+    for (int i = 0; i < 625; ++i) {
+        float f = (&tps[0][0][0][0])[i];
+        memcpy(&tab[VM_TAB_TPS + i], &f, 4);
+    }
+    // improving-mask bits (stencils.cpp:90-126): for a pixel at (ox,oy) inside
+    // its 5x5 block, which bits of the 3x3 neighbouring blocks fall in its window
+    for (int oy = 0; oy < 5; ++oy)
+        for (int ox = 0; ox < 5; ++ox)
+            for (int by = 0; by < 3; ++by)
+                for (int bx = 0; bx < 3; ++bx) {
+                    uint32_t m = 0;
+                    for (int ry = 0; ry < 5; ++ry)
+                        for (int rx = 0; rx < 5; ++rx) {
+                            int wx = (bx - 1) * 5 + rx - ox, wy = (by - 1) * 5 + ry - oy;
+                            if (wx >= -2 && wx <= 2 && wy >= -2 && wy <= 2)
+                                m |= 1u << (rx + ry * 5);
+                        }
+                    tab[VM_TAB_IMP + ((oy * 5 + ox) * 3 + by) * 3 + bx] = m;
+                }
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int vm_ctx_create(int device, vm_ctx **out)
+{
+    if (!out) return vm_fail(VM_E_INVALID, "vm_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return vm_fail(VM_E_DEVICE, "vm_ctx_create: no HIP device (%s); there is no CPU fallback",
+                       hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return vm_fail(VM_E_INVALID, "vm_ctx_create: device %d out of range (0..%d)", device, ndev - 1);
+    VM_HIP(hipSetDevice(device));
+    vm_ctx *c = new vm_ctx();
+    c->device = device;
+    c->math_mode = VM_MATH_EXACT;
+    c->kp = {10.0f, 1e5f, 0.05f, 100.0f, 0.0f, 0.01f, VM_BCOND_NONE}; // UI/MdiEditor.cpp:131-140
+    hipError_t e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e2 != hipSuccess) { delete c; return vm_fail(VM_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e2)); }
+    VM_HIP(hipEventCreate(&c->ev0));
+    VM_HIP(hipEventCreate(&c->ev1));
+    uint32_t tab[VM_TAB_WORDS];
+    build_tables(tab);
+    VM_HIP(hipMalloc((void **)&c->tables, sizeof(tab)));
+    VM_HIP(hipMemcpy(c->tables, tab, sizeof(tab), hipMemcpyHostToDevice));
+    c->flags_cap = 4096;
+    VM_HIP(hipMalloc((void **)&c->flags, c->flags_cap * sizeof(uint32_t)));
+    VM_HIP(hipHostMalloc((void **)&c->flags_host, c->flags_cap * sizeof(uint32_t), hipHostMallocDefault));
+    *out = c;
+    return VM_OK;
+}
+
+extern "C" void vm_ctx_destroy(vm_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    hipFree(c->tables);
+    hipFree(c->flags);
+    hipHostFree(c->flags_host);
+    hipFree(c->cons_dev);
+    hipEventDestroy(c->ev0);
+    hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int vm_ctx_sync(vm_ctx *c)
+{
+    if (!c) return vm_fail(VM_E_INVALID, "ctx is NULL");
+    VM_HIP(hipStreamSynchronize(c->stream));
+    return VM_OK;
+}
+
+extern "C" int vm_set_params(vm_ctx *c, const vm_kern_params *p)
+{
+    if (!c || !p) return vm_fail(VM_E_INVALID, "vm_set_params: NULL argument");
+    if (p->bcond < VM_BCOND_NONE || p->bcond > VM_BCOND_BORDER)
+        return vm_fail(VM_E_INVALID, "vm_set_params: bcond %d", p->bcond);
+    if (!(p->eps > 0)) return vm_fail(VM_E_INVALID, "vm_set_params: eps must be > 0");
+    c->kp = *p;
+    return VM_OK;
+}
+
+extern "C" int vm_get_params(vm_ctx *c, vm_kern_params *p)
+{
+    if (!c || !p) return vm_fail(VM_E_INVALID, "vm_get_params: NULL argument");
+    *p = c->kp;
+    return VM_OK;
+}
+
+extern "C" int vm_set_math_mode(vm_ctx *c, int mode)
+{
+    if (!c || (mode != VM_MATH_EXACT && mode != VM_MATH_FAST))
+        return vm_fail(VM_E_INVALID, "vm_set_math_mode: bad argument");
+    c->math_mode = mode;
+    return VM_OK;
+}
+
+extern "C" int vm_device_info(vm_ctx *c, char *name256, int *cus, uint64_t *hbm)
+{
+    if (!c) return vm_fail(VM_E_INVALID, "ctx is NULL");
+    hipDeviceProp_t pr;
+    VM_HIP(hipGetDeviceProperties(&pr, c->device));
+    if (name256) snprintf(name256, 256, "%s (%s)", pr.name, pr.gcnArchName);
+    if (cus) *cus = pr.multiProcessorCount;
+    if (hbm) *hbm = (uint64_t)pr.totalGlobalMem;
+    return VM_OK;
+}
+
+// ---------------------------------------------------------------------------
+static void level_free(vm_level &l)
+{
+    hipFree(l.slab);
+    l.slab = nullptr;
+    l.has_state = false;
+}
+
+// one slab per level: every array starts on a 256-byte boundary
+static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
+{
+    size_t n = (size_t)l.rs * l.h;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t off = 0;
+    size_t o_v = off; off += al(n * 8);
+    size_t o_img0 = off, o_img1 = off, o_luma = off, o_mean = off, o_var = off, o_tpsb = off,
+           o_uib = off, o_cross = off, o_value = off, o_uiaxy = off, o_imp = off;
+    if (with_images) {
+        o_img0 = off; off += al(n * 4);
+        o_img1 = off; off += al(n * 4);
+        o_luma = off; off += al(n * 8);
+        o_mean = off; off += al(n * 8);
+        o_var = off; off += al(n * 8);
+        o_tpsb = off; off += al(n * 8);
+        o_uib = off; off += al(n * 8);
+        o_cross = off; off += al(n * 4);
+        o_value = off; off += al(n * 4);
+        o_uiaxy = off; off += al(n * 4);
+        o_imp = off; off += al((size_t)l.imp_rs * l.imp_rows * 4);
+    }
+    VM_HIP(hipMalloc((void **)&l.slab, off));
+    // stream-ordered: the context's stream does not synchronise with the null stream
+    VM_HIP(hipMemsetAsync(l.slab, 0, off, c->stream));
+    l.slab_bytes = off;
+    char *b = (char *)l.slab;
+    VmLevelView &V = l.view;
+    V.w = l.w; V.h = l.h; V.rs = l.rs;
+    V.inv_wh = 1.0f / (l.w * l.h);          // pyramid.cu:537
+    V.imp_rs = l.imp_rs; V.imp_rows = l.imp_rows;
+    V.v = (float2 *)(b + o_v);
+    if (with_images) {
+        V.img0 = (const float *)(b + o_img0); V.img1 = (const float *)(b + o_img1);
+        V.luma = (float2 *)(b + o_luma); V.mean = (float2 *)(b + o_mean);
+        V.var = (float2 *)(b + o_var); V.tps_b = (float2 *)(b + o_tpsb);
+        V.ui_b = (float2 *)(b + o_uib); V.cross = (float *)(b + o_cross);
+        V.value = (float *)(b + o_value); V.ui_axy = (float *)(b + o_uiaxy);
+        V.impmask = (uint32_t *)(b + o_imp);
+    } else {
+        V.img0 = V.img1 = nullptr;
+        V.luma = V.mean = V.var = V.tps_b = V.ui_b = nullptr;
+        V.cross = V.value = V.ui_axy = nullptr;
+        V.impmask = nullptr;
+    }
+    return VM_OK;
+}
+
+extern "C" int vm_pyramid_create(vm_ctx *c, int nlevels, const int *w, const int *h, vm_pyr **out)
+{
+    if (!c || !w || !h || !out || nlevels < 2)
+        return vm_fail(VM_E_INVALID, "vm_pyramid_create: need ctx, sizes and >= 2 levels");
+    for (int i = 0; i < nlevels; ++i)
+        if (w[i] < 5 || h[i] < 5)
+            return vm_fail(VM_E_INVALID, "vm_pyramid_create: level %d is %dx%d (min 5x5)", i, w[i], h[i]);
+    VM_HIP(hipSetDevice(c->device));
+    vm_pyr *p = new vm_pyr();
+    p->ctx = c;
+    p->lv.resize(nlevels);
+    for (int i = 0; i < nlevels; ++i) {
+        vm_level &l = p->lv[i];
+        l.w = w[i]; l.h = h[i];
+        l.rs = (w[i] + 31) / 32 * 32;               // pyramid.cu:535
+        l.imp_rs = (w[i] + 4) / 5 + 2;              // pyramid.cu:538
+        l.imp_rows = (h[i] + 4) / 5 + 2;            // pyramid.cu:539
+        int rc = level_alloc(c, l, i != nlevels - 1);
+        if (rc != VM_OK) { vm_pyramid_destroy(p); return rc; }
+    }
+    *out = p;
+    return VM_OK;
+}
+
+extern "C" void vm_pyramid_destroy(vm_pyr *p)
+{
+    if (!p) return;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    for (auto &l : p->lv) level_free(l);
+    delete p;
+}
+
+extern "C" int vm_pyramid_levels(vm_pyr *p) { return p ? (int)p->lv.size() : 0; }
+
+#define CHECK_LVL(p, lvl)                                                        \
+    if (!(p)) return vm_fail(VM_E_INVALID, "%s: pyramid is NULL", __func__);     \
+    if ((lvl) < 0 || (lvl) >= (int)(p)->lv.size())                               \
+        return vm_fail(VM_E_INVALID, "%s: level %d out of range", __func__, (lvl));
+
+extern "C" int vm_level_dims(vm_pyr *p, int lvl, int *w, int *h, int *rs)
+{
+    CHECK_LVL(p, lvl);
+    if (w) *w = p->lv[lvl].w;
+    if (h) *h = p->lv[lvl].h;
+    if (rs) *rs = p->lv[lvl].rs;
+    return VM_OK;
+}
+
+extern "C" int vm_level_upload_luma(vm_pyr *p, int lvl, const float *img0, const float *img1, int pitch)
+{
+    CHECK_LVL(p, lvl);
+    vm_level &l = p->lv[lvl];
+    if (!l.view.img0) return vm_fail(VM_E_STATE, "vm_level_upload_luma: coarsest level holds no images");
+    if (!img0 || !img1) return vm_fail(VM_E_INVALID, "vm_level_upload_luma: NULL image");
+    if (pitch == 0) pitch = l.w;
+    if (pitch < l.w) return vm_fail(VM_E_INVALID, "vm_level_upload_luma: pitch < width");
+    hipStream_t s = p->ctx->stream;
+    VM_HIP(hipMemcpy2DAsync((void *)l.view.img0, l.rs * 4, img0, (size_t)pitch * 4, (size_t)l.w * 4, l.h, hipMemcpyHostToDevice, s));
+    VM_HIP(hipMemcpy2DAsync((void *)l.view.img1, l.rs * 4, img1, (size_t)pitch * 4, (size_t)l.w * 4, l.h, hipMemcpyHostToDevice, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}
+
+extern "C" int vm_level_set_v(vm_pyr *p, int lvl, const float *v, int pitch)
+{
+    CHECK_LVL(p, lvl);
+    vm_level &l = p->lv[lvl];
+    if (!v) return vm_fail(VM_E_INVALID, "vm_level_set_v: NULL");
+    if (pitch == 0) pitch = 2 * l.w;
+    if (pitch < 2 * l.w) return vm_fail(VM_E_INVALID, "vm_level_set_v: pitch < 2*width");
+    hipStream_t s = p->ctx->stream;
+    VM_HIP(hipMemcpy2DAsync(l.view.v, l.rs * 8, v, (size_t)pitch * 4, (size_t)l.w * 8, l.h, hipMemcpyHostToDevice, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}
+
+extern "C" int vm_level_get_v(vm_pyr *p, int lvl, float *v, int pitch)
+{
+    CHECK_LVL(p, lvl);
+    vm_level &l = p->lv[lvl];
+    if (!v) return vm_fail(VM_E_INVALID, "vm_level_get_v: NULL");
+    if (pitch == 0) pitch = 2 * l.w;
+    if (pitch < 2 * l.w) return vm_fail(VM_E_INVALID, "vm_level_get_v: pitch < 2*width");
+    hipStream_t s = p->ctx->stream;
+    VM_HIP(hipMemcpy2DAsync(v, (size_t)pitch * 4, l.view.v, l.rs * 8, (size_t)l.w * 8, l.h, hipMemcpyDeviceToHost, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}
+
+extern "C" int vm_level_get_field(vm_pyr *p, int lvl, int field, void *host)
+{
+    CHECK_LVL(p, lvl);
+    vm_level &l = p->lv[lvl];
+    if (!host) return vm_fail(VM_E_INVALID, "vm_level_get_field: NULL");
+    const VmLevelView &V = l.view;
+    hipStream_t s = p->ctx->stream;
+    const void *src = nullptr;
+    int elem = 4;
+    switch (field) {
+    case VM_F_IMG0: src = V.img0; break;
+    case VM_F_IMG1: src = V.img1; break;
+    case VM_F_V: src = V.v; elem = 8; break;
+    case VM_F_LUMA: src = V.luma; elem = 8; break;
+    case VM_F_MEAN: src = V.mean; elem = 8; break;
+    case VM_F_VAR: src = V.var; elem = 8; break;
+    case VM_F_CROSS: src = V.cross; break;
+    case VM_F_VALUE: src = V.value; break;
+    case VM_F_TPS_B: src = V.tps_b; elem = 8; break;
+    case VM_F_UI_AXY: src = V.ui_axy; break;
+    case VM_F_UI_B: src = V.ui_b; elem = 8; break;
+    case VM_F_COUNTER: {
+        // pure function of position (morph.cu:225): not stored on the device
+        float *o = (float *)host;
+        for (int y = 0; y < l.h; ++y)
+            for (int x = 0; x < l.w; ++x)
+                o[(size_t)y * l.w + x] = (float)((std::min(y, 2) + std::min(l.h - 1 - y, 2) + 1) *
+                                                  (std::min(x, 2) + std::min(l.w - 1 - x, 2) + 1));
+        return VM_OK;
+    }
+    case VM_F_TPS_AXY: {
+        // tps[B][2][2]/2 (morph.cu:242): not stored on the device
+        uint32_t tab[VM_TAB_WORDS];
+        build_tables(tab);
+        auto cls = [](int q, int dim) { return q < 2 ? q : (q == dim - 2 ? 3 : (q == dim - 1 ? 4 : 2)); };
+        float *o = (float *)host;
+        for (int y = 0; y < l.h; ++y)
+            for (int x = 0; x < l.w; ++x) {
+                float f;
+                memcpy(&f, &tab[VM_TAB_TPS + (cls(y, l.h) * 5 + cls(x, l.w)) * 25 + 12], 4);
+                o[(size_t)y * l.w + x] = f / 2;
+            }
+        return VM_OK;
+    }
+    case VM_F_IMPMASK:
+        if (!V.impmask) return vm_fail(VM_E_STATE, "level has no state");
+        VM_HIP(hipMemcpyAsync(host, V.impmask, (size_t)l.imp_rs * l.imp_rows * 4, hipMemcpyDeviceToHost, s));
+        VM_HIP(hipStreamSynchronize(s));
+        return VM_OK;
+    default:
+        return vm_fail(VM_E_INVALID, "vm_level_get_field: unknown field %d", field);
+    }
+    if (!src) return vm_fail(VM_E_STATE, "vm_level_get_field: level %d has no such array", lvl);
+    VM_HIP(hipMemcpy2DAsync(host, (size_t)l.w * elem, src, (size_t)l.rs * elem, (size_t)l.w * elem, l.h, hipMemcpyDeviceToHost, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}
+
+extern "C" int vm_level_clear(vm_pyr *p, int lvl)
+{
+    CHECK_LVL(p, lvl);
+    // Morph::clear_level frees the per-level state; the slab stays allocated
+    // (288 GB of HBM: reuse beats hipFree/hipMalloc churn), it is only marked stale
+    p->lv[lvl].has_state = false;
+    return VM_OK;
+}
+
+// ---------------------------------------------------------------------------
+static int upload_constraints(vm_ctx *c, const vm_constraint *cons, int n)
+{
+    if (n <= 0) return VM_OK;
+    if (n > c->cons_cap) {
+        hipFree(c->cons_dev);
+        c->cons_dev = nullptr;
+        c->cons_cap = 0;
+        VM_HIP(hipMalloc((void **)&c->cons_dev, (size_t)n * sizeof(vm_constraint)));
+        c->cons_cap = n;
+    }
+    VM_HIP(hipMemcpyAsync(c->cons_dev, cons, (size_t)n * sizeof(vm_constraint), hipMemcpyHostToDevice, c->stream));
+    VM_HIP(hipStreamSynchronize(c->stream)); // the host buffer belongs to the caller
+    return VM_OK;
+}
+
+extern "C" int vm_coarse_solve(vm_pyr *p, int lvl, int w0, int h0, const vm_constraint *cons, int n)
+{
+    CHECK_LVL(p, lvl);
+    if (n < 0 || (n > 0 && !cons)) return vm_fail(VM_E_INVALID, "vm_coarse_solve: constraints");
+    vm_level &l = p->lv[lvl];
+    std::vector<float> v((size_t)2 * l.w * l.h, 0.0f);
+    int rc = vm_host_coarse_solve(l.w, l.h, w0, h0, p->ctx->kp, cons, n, v.data());
+    if (rc != VM_OK) return rc;
+    return vm_level_set_v(p, lvl, v.data(), 0);
+}
+
+extern "C" int vm_upsample_v(vm_pyr *p, int dst, int src)
+{
+    CHECK_LVL(p, dst);
+    CHECK_LVL(p, src);
+    vm_level &d = p->lv[dst], &s = p->lv[src];
+    if (p->ctx->math_mode == VM_MATH_EXACT)
+        vm_launch_upsample_exact(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, p->ctx->stream);
+    else
+        vm_launch_upsample_fast(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, p->ctx->stream);
+    VM_HIP(hipGetLastError());
+    return VM_OK;
+}
+
+extern "C" int vm_init_level(vm_pyr *p, int lvl, int w0, int h0, const vm_constraint *cons, int n)
+{
+    CHECK_LVL(p, lvl);
+    vm_level &l = p->lv[lvl];
+    vm_ctx *c = p->ctx;
+    if (!l.view.img0) return vm_fail(VM_E_STATE, "vm_init_level: the coarsest level is solved by vm_coarse_solve");
+    if (n < 0 || (n > 0 && !cons)) return vm_fail(VM_E_INVALID, "vm_init_level: constraints");
+    int rc = upload_constraints(c, cons, n);
+    if (rc != VM_OK) return rc;
+    if (c->math_mode == VM_MATH_EXACT) {
+        vm_launch_init_level_exact(l.view, c->kp.ssim_clamp, c->tables, c->stream);
+        if (n > 0) vm_launch_splat_exact(l.view, w0, h0, c->cons_dev, n, c->stream);
+    } else {
+        vm_launch_init_level_fast(l.view, c->kp.ssim_clamp, c->tables, c->stream);
+        if (n > 0) vm_launch_splat_fast(l.view, w0, h0, c->cons_dev, n, c->stream);
+    }
+    VM_HIP(hipGetLastError());
+    l.has_state = true;
+    return VM_OK;
+}
+
+extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile const int *run_flag,
+                                 int fixed_work, vm_progress *out)
+{
+    CHECK_LVL(p, lvl);
+    vm_level &l = p->lv[lvl];
+    vm_ctx *c = p->ctx;
+    if (!l.has_state) return vm_fail(VM_E_STATE, "vm_optimize_level: level %d not initialised", lvl);
+    VmKParams P = {c->kp.w_ui, c->kp.w_tps, c->kp.w_ssim, c->kp.ssim_clamp, c->kp.eps, c->kp.bcond};
+    // iterations the reference loop would run: do { ... iter++ } while (iter < max_iter && improving)
+    int cap = 1;
+    while ((float)cap < max_iter) ++cap;
+    if (cap > c->flags_cap) {
+        hipFree(c->flags);
+        hipHostFree(c->flags_host);
+        c->flags = nullptr; c->flags_host = nullptr;
+        VM_HIP(hipMalloc((void **)&c->flags, (size_t)cap * 4));
+        VM_HIP(hipHostMalloc((void **)&c->flags_host, (size_t)cap * 4, hipHostMallocDefault));
+        c->flags_cap = cap;
+    }
+    hipStream_t s = c->stream;
+    VM_HIP(hipMemsetAsync(c->flags, 0, (size_t)cap * 4, s));
+    const bool exact = c->math_mode == VM_MATH_EXACT;
+    const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
+    int done = 0, launches = 0, executed = cap, improving = 1;
+    bool cancelled = false;
+    VM_HIP(hipEventRecord(c->ev0, s));
+    // Iterations are enqueued in batches; each sweep kernel of iteration i exits
+    // at once when iteration i-1 did not improve (device-side flag), so running
+    // past convergence inside a batch costs launch latency only, and the host
+    // reads the flags once per batch instead of once per iteration.
+    int batch = 8;
+    while (done < cap) {
+        int nb = std::min(batch, cap - done);
+        for (int it = done; it < done + nb; ++it)
+            for (int k = 0; k < 4; ++k) {
+                if (exact) vm_launch_optimize_exact(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, it, fixed_work, s);
+                else vm_launch_optimize_fast(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, it, fixed_work, s);
+                ++launches;
+            }
+        VM_HIP(hipGetLastError());
+        VM_HIP(hipMemcpyAsync(c->flags_host + done, c->flags + done, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+        VM_HIP(hipStreamSynchronize(s));
+        bool stop = false;
+        for (int it = done; it < done + nb; ++it)
+            if (c->flags_host[it] == 0) {
+                improving = 0;
+                if (!fixed_work) { executed = it + 1; stop = true; break; }
+            } else improving = 1;
+        done += nb;
+        if (stop) break;
+        if (run_flag && !*run_flag) { executed = done; cancelled = true; break; }
+        batch = std::min(batch * 2, 64);
+    }
+    VM_HIP(hipEventRecord(c->ev1, s));
+    VM_HIP(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    VM_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (out) {
+        out->iters = executed;
+        out->improving = improving;
+        out->pixel_iters = (double)executed * l.w * l.h;
+        out->elapsed_ms = ms;
+        out->launches = launches;
+    }
+    return cancelled ? vm_fail(VM_E_CANCELLED, "vm_optimize_level: cancelled by run_flag") : VM_OK;
+}
+
+extern "C" int vm_solve(vm_pyr *p, float max_iter, float drop, const vm_constraint *cons, int n,
+                        volatile const int *run_flag, int fixed_work, vm_progress *per_level)
+{
+    if (!p) return vm_fail(VM_E_INVALID, "vm_solve: pyramid is NULL");
+    if (!(drop > 0)) return vm_fail(VM_E_INVALID, "vm_solve: max_iter_drop_factor must be > 0");
+    const int L = (int)p->lv.size();
+    const int w0 = p->lv[0].w, h0 = p->lv[0].h;
+    // Morph::calculate_halfway_parametrization, morph.cu:150-168
+    int rc = vm_coarse_solve(p, L - 1, w0, h0, cons, n);
+    if (rc != VM_OK) return rc;
+    float mi = max_iter;
+    for (int el = L - 2; el >= 0; --el) {
+        if (run_flag && !*run_flag) return vm_fail(VM_E_CANCELLED, "vm_solve: cancelled by run_flag");
+        if ((rc = vm_upsample_v(p, el, el + 1)) != VM_OK) return rc;
+        if ((rc = vm_init_level(p, el, w0, h0, cons, n)) != VM_OK) return rc;
+        if ((rc = vm_optimize_level(p, el, mi, run_flag, fixed_work, per_level ? &per_level[el] : nullptr)) != VM_OK) return rc;
+        // clear_level: the level's state stays allocated; v is kept for the result
+        mi /= drop;
+    }
+    return VM_OK;
+}

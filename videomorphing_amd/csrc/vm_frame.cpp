@@ -1,0 +1,142 @@
+// vm_frame.cpp -- device-resident frame objects of the compositor: the C-ABI
+// around vm_render.hip (render_halfway_image, Algorithm/render.cu:62-96) and
+// the result upscale (CMatchingThread::update_result, MatchingThread.cpp:22-100).
+#include "vm_host.h"
+#include "vm_poisson.h"
+
+#include <cstring>
+
+extern "C" int vm_frame_create(vm_ctx *c, int w, int h, int ex, vm_frame **out)
+{
+    if (!c || !out || w < 1 || h < 1 || ex < 0)
+        return vm_fail(VM_E_INVALID, "vm_frame_create: bad argument");
+    VM_HIP(hipSetDevice(c->device));
+    vm_frame *f = new vm_frame();
+    f->ctx = c;
+    f->w = w; f->h = h; f->ex = ex;
+    f->cw = w + 2 * ex; f->ch = h + 2 * ex;
+    f->rs = (w + 31) / 32 * 32; // UI/RenderWidget.cpp:235
+    size_t nc = (size_t)f->cw * f->ch, nv = (size_t)f->rs * h;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void **)&f->ext[k], nc * 4);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipMalloc((void **)&f->crop[k], (size_t)w * h * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->v, nv * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->u, nv * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->out, (size_t)w * h * 3);
+    if (e == hipSuccess) e = hipMemsetAsync(f->v, 0, nv * 8, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(f->u, 0, nv * 8, c->stream);
+    if (e != hipSuccess) {
+        vm_frame_destroy(f);
+        return vm_fail(VM_E_DEVICE, "vm_frame_create: %s", hipGetErrorString(e));
+    }
+    *out = f;
+    return VM_OK;
+}
+
+extern "C" void vm_frame_destroy(vm_frame *f)
+{
+    if (!f) return;
+    hipSetDevice(f->ctx->device);
+    hipStreamSynchronize(f->ctx->stream);
+    hipFree(f->ext[0]); hipFree(f->ext[1]);
+    hipFree(f->crop[0]); hipFree(f->crop[1]);
+    hipFree(f->v); hipFree(f->u); hipFree(f->out); hipFree(f->pws);
+    delete f;
+}
+
+extern "C" int vm_frame_upload(vm_frame *f, const uint8_t *e0, const uint8_t *e1, const float *v,
+                               const float *q)
+{
+    if (!f) return vm_fail(VM_E_INVALID, "vm_frame_upload: frame is NULL");
+    hipStream_t s = f->ctx->stream;
+    size_t nc = (size_t)f->cw * f->ch * 4;
+    const uint8_t *e[2] = {e0, e1};
+    for (int k = 0; k < 2; ++k)
+        if (e[k]) {
+            VM_HIP(hipMemcpyAsync(f->ext[k], e[k], nc, hipMemcpyHostToDevice, s));
+            // the originals both sides' fills sample from (cloned before any solve)
+            vm_poisson_launch_crop(f->crop[k], f->ext[k], f->w, f->h, f->ex, s);
+        }
+    if (v) VM_HIP(hipMemcpy2DAsync(f->v, (size_t)f->rs * 8, v, (size_t)f->w * 8, (size_t)f->w * 8, f->h, hipMemcpyHostToDevice, s));
+    if (q) VM_HIP(hipMemcpy2DAsync(f->u, (size_t)f->rs * 8, q, (size_t)f->w * 8, (size_t)f->w * 8, f->h, hipMemcpyHostToDevice, s));
+    else VM_HIP(hipMemsetAsync(f->u, 0, (size_t)f->rs * f->h * 8, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}
+
+extern "C" int vm_frame_download_ext(vm_frame *f, int side, uint8_t *ext)
+{
+    if (!f || !ext || (side != 1 && side != 2))
+        return vm_fail(VM_E_INVALID, "vm_frame_download_ext: bad argument");
+    hipStream_t s = f->ctx->stream;
+    VM_HIP(hipMemcpyAsync(ext, f->ext[side - 1], (size_t)f->cw * f->ch * 4, hipMemcpyDeviceToHost, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}
+
+extern "C" int vm_frame_set_v_from_level(vm_frame *f, vm_pyr *p, int lvl)
+{
+    if (!f || !p || lvl < 0 || lvl >= (int)p->lv.size())
+        return vm_fail(VM_E_INVALID, "vm_frame_set_v_from_level: bad argument");
+    if (p->ctx != f->ctx) return vm_fail(VM_E_INVALID, "frame and pyramid belong to different contexts");
+    vm_level &l = p->lv[lvl];
+    vm_launch_upscale(f->v, f->w, f->h, f->rs, l.view.v, l.w, l.h, l.rs, f->ctx->stream);
+    VM_HIP(hipGetLastError());
+    return VM_OK;
+}
+
+extern "C" int vm_upscale_result(vm_pyr *p, int lvl, int w0, int h0, float *out, int pitch)
+{
+    if (!p || lvl < 0 || lvl >= (int)p->lv.size() || !out || w0 < 1 || h0 < 1)
+        return vm_fail(VM_E_INVALID, "vm_upscale_result: bad argument");
+    if (pitch == 0) pitch = 2 * w0;
+    if (pitch < 2 * w0) return vm_fail(VM_E_INVALID, "vm_upscale_result: pitch < 2*w0");
+    vm_level &l = p->lv[lvl];
+    hipStream_t s = p->ctx->stream;
+    float2 *tmp = nullptr;
+    VM_HIP(hipMalloc((void **)&tmp, (size_t)w0 * h0 * 8));
+    vm_launch_upscale(tmp, w0, h0, w0, l.view.v, l.w, l.h, l.rs, s);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(out, (size_t)pitch * 4, tmp, (size_t)w0 * 8, (size_t)w0 * 8, h0, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(tmp);
+    if (e != hipSuccess) return vm_fail(VM_E_DEVICE, "vm_upscale_result: %s", hipGetErrorString(e));
+    return VM_OK;
+}
+
+static int render_dev(vm_frame *f, float color_fa, float geo_fa, int color_from, float *ms)
+{
+    if (!f) return vm_fail(VM_E_INVALID, "vm_render_halfway: frame is NULL");
+    if (color_from < 0 || color_from > 2) return vm_fail(VM_E_INVALID, "vm_render_halfway: color_from %d", color_from);
+    vm_ctx *c = f->ctx;
+    if (ms) VM_HIP(hipEventRecord(c->ev0, c->stream));
+    vm_launch_render(f->out, f->w * 3, f->w, f->h, f->rs, f->ex, color_fa, geo_fa, color_from,
+                     f->ext[0], f->ext[1], f->v, f->u, c->stream);
+    VM_HIP(hipGetLastError());
+    if (ms) {
+        VM_HIP(hipEventRecord(c->ev1, c->stream));
+        VM_HIP(hipEventSynchronize(c->ev1));
+        VM_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    }
+    return VM_OK;
+}
+
+extern "C" int vm_render_halfway_dev(vm_frame *f, float color_fa, float geo_fa, int color_from, float *ms)
+{
+    return render_dev(f, color_fa, geo_fa, color_from, ms);
+}
+
+extern "C" int vm_render_halfway(vm_frame *f, float color_fa, float geo_fa, int color_from,
+                                 uint8_t *rgb, int pitch)
+{
+    if (!rgb) return vm_fail(VM_E_INVALID, "vm_render_halfway: output is NULL");
+    int rc = render_dev(f, color_fa, geo_fa, color_from, nullptr);
+    if (rc != VM_OK) return rc;
+    if (pitch == 0) pitch = f->w * 3;
+    if (pitch < f->w * 3) return vm_fail(VM_E_INVALID, "vm_render_halfway: pitch < 3*w");
+    hipStream_t s = f->ctx->stream;
+    VM_HIP(hipMemcpy2DAsync(rgb, pitch, f->out, (size_t)f->w * 3, (size_t)f->w * 3, f->h, hipMemcpyDeviceToHost, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}

@@ -1,0 +1,62 @@
+// vm_host.h -- host-side objects behind the opaque handles of include/vmorph.h.
+#ifndef VM_HOST_H
+#define VM_HOST_H
+
+#include "vm_internal.h"
+#include <vector>
+
+int vm_fail(int code, const char *fmt, ...);
+
+#define VM_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return vm_fail(VM_E_DEVICE, "%s:%d %s: %s", __FILE__, __LINE__, #call,         \
+                           hipGetErrorString(e_));                                         \
+    } while (0)
+
+struct vm_ctx {
+    int device = 0;
+    int math_mode = VM_MATH_EXACT;
+    vm_kern_params kp{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t *tables = nullptr;      // VM_TAB_WORDS words
+    uint32_t *flags = nullptr;       // per-iteration "improving" flags (device)
+    uint32_t *flags_host = nullptr;  // pinned mirror
+    int flags_cap = 0;
+    vm_constraint *cons_dev = nullptr;
+    int cons_cap = 0;
+};
+
+struct vm_level {
+    int w = 0, h = 0, rs = 0, imp_rs = 0, imp_rows = 0;
+    void *slab = nullptr;
+    size_t slab_bytes = 0;
+    bool has_state = false;
+    VmLevelView view{};
+};
+
+struct vm_pyr {
+    vm_ctx *ctx = nullptr;
+    std::vector<vm_level> lv;
+};
+
+struct vm_frame {
+    vm_ctx *ctx = nullptr;
+    int w = 0, h = 0, ex = 0, cw = 0, ch = 0, rs = 0;
+    uchar4 *ext[2] = {nullptr, nullptr};  // (w+2ex) x (h+2ex) RGBA8 canvases
+    uchar4 *crop[2] = {nullptr, nullptr}; // w x h originals (CPoissonExt::_image1/_image2, PoissonExt.cpp:26-27)
+    float2 *v = nullptr, *u = nullptr;    // h x rs
+    uint8_t *out = nullptr;               // h x w x 3
+    // Poisson workspace (allocated on first use)
+    void *pws = nullptr;
+    size_t pws_bytes = 0;
+};
+
+// Morph::cpu_optimize_level (morph.cu:419-590) on the host: v_out is a tight
+// (h, w, 2) array
+int vm_host_coarse_solve(int w, int h, int w0, int h0, const vm_kern_params &kp,
+                         const vm_constraint *cons, int n, float *v_out);
+
+#endif

@@ -1,0 +1,69 @@
+// vm_internal.h -- shared between the C-ABI implementation and the HIP kernels.
+#ifndef VM_INTERNAL_H
+#define VM_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vmorph.h"
+
+// Tile geometry of the sweep schedule.  It is part of the algorithm's
+// definition (which pixels are relaxed together decides the result), so it is
+// kept equal to the reference's kernel_optimize_level (morph.cu:594-598,
+// 1291-1292): 64x16 pixel tiles on a 69x21 pitch, four offset passes.
+#define VM_TILE_W 64
+#define VM_TILE_H 16
+#define VM_PITCH_X 69
+#define VM_PITCH_Y 21
+#define VM_HALO_W (VM_TILE_W + 4)
+#define VM_HALO_H (VM_TILE_H + 4)
+#define VM_NCELL (VM_HALO_W * VM_HALO_H)
+
+// Device view of one level (the role of KernPyramidLevel, Pyramid.h:100-158).
+// All per-pixel arrays share the row stride `rs` (elements), a multiple of 32
+// so that every row of every array starts on a 128-byte line.
+struct VmLevelView {
+    int w, h, rs;
+    float inv_wh;
+    int imp_rs, imp_rows;
+    const float *img0, *img1;
+    float2 *v, *luma, *mean, *var, *tps_b, *ui_b;
+    float *cross, *value, *ui_axy;
+    uint32_t *impmask;
+};
+
+struct VmKParams {
+    float w_ui, w_tps, w_ssim, ssim_clamp, eps;
+    int bcond;
+};
+
+// constant tables living in one device buffer: 625 floats (thin-plate stencil
+// per border class) followed by 225 uint32 (improving-mask window bits)
+#define VM_TAB_TPS 0
+#define VM_TAB_IMP 625
+#define VM_TAB_WORDS (625 + 225)
+
+// launchers implemented once per arithmetic mode (vm_morph_kernels.hip is
+// compiled twice: -DVM_EXACT=1 -ffp-contract=off and -DVM_EXACT=0)
+#define VM_DECL_LAUNCHERS(SUFFIX)                                                             \
+    void vm_launch_init_level_##SUFFIX(const VmLevelView &L, float ssim_clamp,                \
+                                       const uint32_t *tables, hipStream_t s);                \
+    void vm_launch_optimize_##SUFFIX(const VmLevelView &L, const VmKParams &P,                \
+                                     const uint32_t *tables, int offx, int offy,              \
+                                     uint32_t *flags, int iter_idx, int fixed_work,           \
+                                     hipStream_t s);                                          \
+    void vm_launch_upsample_##SUFFIX(float2 *dst, int dw, int dh, int drs, const float2 *src, \
+                                     int sw, int sh, int srs, hipStream_t s);                 \
+    void vm_launch_splat_##SUFFIX(const VmLevelView &L, int w0, int h0,                       \
+                                  const vm_constraint *dev_c, int n, hipStream_t s);
+
+VM_DECL_LAUNCHERS(exact)
+VM_DECL_LAUNCHERS(fast)
+
+// compositor / result delivery (single arithmetic mode)
+void vm_launch_upscale(float2 *dst, int w0, int h0, int dpitch, const float2 *v, int w, int h,
+                       int rs, hipStream_t s);
+void vm_launch_render(uint8_t *out, int out_pitch, int w, int h, int rs, int ex, float color_fa,
+                      float geo_fa, int color_from, const uchar4 *ext0, const uchar4 *ext1,
+                      const float2 *v, const float2 *u, hipStream_t s);
+
+#endif

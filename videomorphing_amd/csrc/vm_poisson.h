@@ -1,0 +1,24 @@
+// vm_poisson.h -- launchers of vm_poisson.hip (Poisson boundary extension).
+#ifndef VM_POISSON_H
+#define VM_POISSON_H
+
+#include "vm_internal.h"
+
+// CG scalars, resident in device memory (one set per colour channel)
+struct VmCgScalars {
+    double rz[3], rz_new[3], pq[3], rr[3], rr_new[3], bb[3];
+    int iters;
+    int pad;
+};
+
+void vm_poisson_launch_crop(uchar4 *dst, const uchar4 *ext, int w, int h, int ex, hipStream_t s);
+void vm_poisson_launch_prepare(uchar4 *ext, uint8_t *type, const uchar4 *other, const float2 *v,
+                               int w, int h, int rs, int ex, int sign, hipStream_t s);
+void vm_poisson_launch_setup(const uchar4 *ext, const uint8_t *type, float4 *B, float4 *X,
+                             float4 *R, float4 *P, VmCgScalars *sc, int cw, int ch, hipStream_t s);
+void vm_poisson_launch_iter(float4 *X, float4 *R, float4 *P, float4 *Q, const float4 *B,
+                            const uint8_t *type, VmCgScalars *sc, int cw, int ch, hipStream_t s);
+void vm_poisson_launch_paste(uchar4 *ext, const uint8_t *type, const float4 *X, int cw, int ch,
+                             hipStream_t s);
+
+#endif

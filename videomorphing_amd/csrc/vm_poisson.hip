@@ -1,0 +1,375 @@
+// vm_poisson.hip -- Poisson boundary extension on the device (gfx950).
+//
+// What: CPoissonExt::prepare + poissonExtend, Algorithm/PoissonExt.cpp:49-362,
+// for one side of one frame: classify the extended canvas, fill the outside
+// ring by following the halfway field into the other image, and solve the
+// screened 5-point Poisson system that PoissonExt.cpp:214-312 assembles.
+//
+// How: the reference builds a CSR matrix on the host and factorises it with
+// Intel MKL DSS (PoissonExt.cpp:321-329).  Here nothing is assembled: the
+// operator is applied matrix-free from the 1-byte type map, the three colour
+// channels ride together in one float4 per pixel (16-byte coalesced accesses),
+// and the system is solved by Jacobi-preconditioned conjugate gradients whose
+// scalars (alpha, beta, residual norms) stay in device memory, so an iteration
+// is three kernel launches with no host round trip.  Dot products accumulate
+// in double.  HBM-bound: ~5 float4 vectors touched per unknown per iteration.
+#include "vm_internal.h"
+#include "vm_poisson.h"
+
+namespace {
+
+__device__ __forceinline__ bool is_marker(uchar4 c)
+{
+    return c.x == 255 && c.y == 0 && c.z == 255 && c.w == 0;
+}
+
+// classification, PoissonExt.cpp:59-101
+__global__ __launch_bounds__(256) void k_classify(const uchar4 *__restrict__ ext, uint8_t *type,
+                                                  int cw, int ch)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= ch)
+        return;
+    const size_t ii = (size_t)y * cw + x;
+    uint8_t t = 0;
+    if (ext[ii].w > 0)
+        t = 2;
+    else if ((y > 0 && ext[ii - cw].w > 0) || (y < ch - 1 && ext[ii + cw].w > 0) ||
+             (x > 0 && ext[ii - 1].w > 0) || (x < cw - 1 && ext[ii + 1].w > 0))
+        t = 1;
+    type[ii] = t;
+}
+
+// BilineaGetColor_clamp<Vec2f,Vec2f>, PoissonExt.cpp:367-397
+__device__ __forceinline__ float2 bil_v(const float2 *__restrict__ v, int w, int h, int rs,
+                                        float px, float py)
+{
+    const int x0 = (int)floorf(px), y0 = (int)floorf(py);
+    const int x1 = (int)ceilf(px), y1 = (int)ceilf(py);
+    const float a = px - x0, b = py - y0;
+    const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
+    const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+    const float2 v00 = v[cy0 * rs + cx0], v01 = v[cy1 * rs + cx0];
+    const float2 v10 = v[cy0 * rs + cx1], v11 = v[cy1 * rs + cx1];
+    float2 r;
+    r.x = v00.x * (1 - a) * (1 - b) + v01.x * (1 - a) * b + v10.x * a * (1 - b) + v11.x * a * b;
+    r.y = v00.y * (1 - a) * (1 - b) + v01.y * (1 - a) * b + v10.y * a * (1 - b) + v11.y * a * b;
+    return r;
+}
+
+__device__ __forceinline__ uint8_t sat_u8(float f)
+{
+    // cv::saturate_cast<uchar>(float): round half to even, clamp
+    float r = rintf(f);
+    return (uint8_t)fminf(fmaxf(r, 0.0f), 255.0f);
+}
+
+// outside-pixel fill, PoissonExt.cpp:104-137
+__global__ __launch_bounds__(256) void k_fill(uchar4 *ext, const uint8_t *__restrict__ type,
+                                              const uchar4 *__restrict__ other,
+                                              const float2 *__restrict__ vf, int w, int h, int rs,
+                                              int ex, int sign)
+{
+    const int cw = w + 2 * ex, ch = h + 2 * ex;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= ch)
+        return;
+    const size_t ii = (size_t)y * cw + x;
+    if (type[ii] != 2)
+        return;
+    const float sg = (float)sign;
+    float qx = (float)(x - ex), qy = (float)(y - ex);
+    float px = qx, py = qy;
+    float2 v = bil_v(vf, w, h, rs, px, py);
+    const float al = 0.8f;
+    for (int i = 0; i < 20; ++i) {
+        px = qx + v.x * sg;
+        py = qy + v.y * sg;
+        float2 t = bil_v(vf, w, h, rs, px, py);
+        v.x = al * t.x + (1 - al) * v.x;
+        v.y = al * t.y + (1 - al) * v.y;
+    }
+    qx = px + v.x * sg;
+    qy = py + v.y * sg;
+    uchar4 o = make_uchar4(255, 0, 255, 0);
+    if (qx >= 0 && qy >= 0 && qx < w && qy < h) {
+        const int x0 = (int)floorf(qx), y0 = (int)floorf(qy);
+        const int x1 = (int)ceilf(qx), y1 = (int)ceilf(qy);
+        const float a = qx - x0, b = qy - y0;
+        const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
+        const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+        const uchar4 c00 = other[(size_t)cy0 * w + cx0], c01 = other[(size_t)cy1 * w + cx0];
+        const uchar4 c10 = other[(size_t)cy0 * w + cx1], c11 = other[(size_t)cy1 * w + cx1];
+#define BL(f) ((float)c00.f * (1 - a) * (1 - b) + (float)c01.f * (1 - a) * b + \
+               (float)c10.f * a * (1 - b) + (float)c11.f * a * b)
+        uchar4 c = make_uchar4(sat_u8(BL(x)), sat_u8(BL(y)), sat_u8(BL(z)), sat_u8(BL(w)));
+#undef BL
+        if (c.w == 0)
+            o = c;
+    }
+    ext[ii] = o;
+}
+
+__device__ __forceinline__ float4 grad(const uchar4 *__restrict__ ext, const uint8_t *__restrict__ type,
+                                       size_t a, size_t b)
+{
+    // gx/gy of PoissonExt.cpp:146-183: colour(a) - colour(b) when both are
+    // outside pixels carrying a real colour, else 0
+    if (type[a] <= 1 || type[b] <= 1)
+        return make_float4(0, 0, 0, 0);
+    const uchar4 ca = ext[a], cb = ext[b];
+    if (is_marker(ca) || is_marker(cb))
+        return make_float4(0, 0, 0, 0);
+    return make_float4((float)ca.x - (float)cb.x, (float)ca.y - (float)cb.y, (float)ca.z - (float)cb.z, 0);
+}
+
+// right-hand side and diagonal, PoissonExt.cpp:214-270; also the initial guess
+__global__ __launch_bounds__(256) void k_setup(const uchar4 *__restrict__ ext,
+                                               const uint8_t *__restrict__ type, float4 *B,
+                                               float4 *X, int cw, int ch)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= ch)
+        return;
+    const size_t ii = (size_t)y * cw + x;
+    const uint8_t t = type[ii];
+    float4 b = make_float4(0, 0, 0, 0);
+    float diag = 0;
+    if (t == 1) {
+        const uchar4 c = ext[ii];
+        diag += 1.0f;
+        b.x += (float)c.x; b.y += (float)c.y; b.z += (float)c.z;
+    }
+    if (t > 0) {
+        if (y - 1 >= 0 && type[ii - cw] > 0) { float4 g = grad(ext, type, ii, ii - cw); diag += 1; b.x += g.x; b.y += g.y; b.z += g.z; }
+        if (x - 1 >= 0 && type[ii - 1] > 0) { float4 g = grad(ext, type, ii, ii - 1); diag += 1; b.x += g.x; b.y += g.y; b.z += g.z; }
+        if (x + 1 < cw && type[ii + 1] > 0) { float4 g = grad(ext, type, ii + 1, ii); diag += 1; b.x -= g.x; b.y -= g.y; b.z -= g.z; }
+        if (y + 1 < ch && type[ii + cw] > 0) { float4 g = grad(ext, type, ii + cw, ii); diag += 1; b.x -= g.x; b.y -= g.y; b.z -= g.z; }
+    }
+    b.w = diag; // the diagonal travels in the spare lane
+    B[ii] = b;
+    // initial guess: the colour already there (ring and filled pixels), mid grey on holes
+    float4 x0 = make_float4(0, 0, 0, 0);
+    if (t > 0) {
+        const uchar4 c = ext[ii];
+        x0 = is_marker(c) ? make_float4(128.f, 128.f, 128.f, 0) : make_float4((float)c.x, (float)c.y, (float)c.z, 0);
+    }
+    X[ii] = x0;
+}
+
+__device__ __forceinline__ float4 apply_A(const float4 *__restrict__ P, const uint8_t *__restrict__ type,
+                                          float diag, size_t ii, int x, int y, int cw, int ch)
+{
+    float4 c = P[ii];
+    float4 s = make_float4(diag * c.x, diag * c.y, diag * c.z, 0);
+    if (y - 1 >= 0 && type[ii - cw] > 0) { float4 n = P[ii - cw]; s.x -= n.x; s.y -= n.y; s.z -= n.z; }
+    if (x - 1 >= 0 && type[ii - 1] > 0) { float4 n = P[ii - 1]; s.x -= n.x; s.y -= n.y; s.z -= n.z; }
+    if (x + 1 < cw && type[ii + 1] > 0) { float4 n = P[ii + 1]; s.x -= n.x; s.y -= n.y; s.z -= n.z; }
+    if (y + 1 < ch && type[ii + cw] > 0) { float4 n = P[ii + cw]; s.x -= n.x; s.y -= n.y; s.z -= n.z; }
+    return s;
+}
+
+// block reduction of three doubles, then one double atomic per block and channel
+__device__ __forceinline__ void block_sum3(double a, double b, double c, double *dst)
+{
+    __shared__ double sh[3][4];
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o);
+        b += __shfl_down(b, o);
+        c += __shfl_down(c, o);
+    }
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane == 0) { sh[0][wave] = a; sh[1][wave] = b; sh[2][wave] = c; }
+    __syncthreads();
+    if (tid < 3) {
+        double s = sh[tid][0] + sh[tid][1] + sh[tid][2] + sh[tid][3];
+        if (s != 0) atomicAdd(&dst[tid], s);
+    }
+    __syncthreads();
+}
+
+// r = b - A x, z = r / diag, p = z;  scal.rz[c] = r.z, scal.bb[c] = b.b, scal.rr[c] = r.r
+__global__ __launch_bounds__(256) void k_cg_init(const float4 *__restrict__ B, const float4 *__restrict__ X,
+                                                 float4 *R, float4 *P, const uint8_t *__restrict__ type,
+                                                 VmCgScalars *sc, int cw, int ch)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    double rz[3] = {0, 0, 0}, bb[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
+    if (x < cw && y < ch) {
+        const size_t ii = (size_t)y * cw + x;
+        if (type[ii] > 0) {
+            const float4 b = B[ii];
+            const float4 ax = apply_A(X, type, b.w, ii, x, y, cw, ch);
+            const float4 r = make_float4(b.x - ax.x, b.y - ax.y, b.z - ax.z, 0);
+            const float inv = 1.0f / b.w;
+            R[ii] = r;
+            P[ii] = make_float4(r.x * inv, r.y * inv, r.z * inv, 0);
+            rz[0] = (double)r.x * r.x * inv; rz[1] = (double)r.y * r.y * inv; rz[2] = (double)r.z * r.z * inv;
+            bb[0] = (double)b.x * b.x; bb[1] = (double)b.y * b.y; bb[2] = (double)b.z * b.z;
+            rr[0] = (double)r.x * r.x; rr[1] = (double)r.y * r.y; rr[2] = (double)r.z * r.z;
+        } else {
+            R[ii] = make_float4(0, 0, 0, 0);
+            P[ii] = make_float4(0, 0, 0, 0);
+        }
+    }
+    block_sum3(rz[0], rz[1], rz[2], sc->rz);
+    block_sum3(bb[0], bb[1], bb[2], sc->bb);
+    block_sum3(rr[0], rr[1], rr[2], sc->rr);
+}
+
+// q = A p;  pq[c] += p.q
+__global__ __launch_bounds__(256) void k_cg_spmv(const float4 *__restrict__ P, float4 *Q,
+                                                 const float4 *__restrict__ B,
+                                                 const uint8_t *__restrict__ type, VmCgScalars *sc,
+                                                 int cw, int ch)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    double pq[3] = {0, 0, 0};
+    if (x < cw && y < ch) {
+        const size_t ii = (size_t)y * cw + x;
+        if (type[ii] > 0) {
+            const float4 q = apply_A(P, type, B[ii].w, ii, x, y, cw, ch);
+            const float4 p = P[ii];
+            Q[ii] = q;
+            pq[0] = (double)p.x * q.x; pq[1] = (double)p.y * q.y; pq[2] = (double)p.z * q.z;
+        }
+    }
+    block_sum3(pq[0], pq[1], pq[2], sc->pq);
+}
+
+// alpha = rz/pq;  x += alpha p;  r -= alpha q;  rz_new += r.(r/diag);  rr_new += r.r
+__global__ __launch_bounds__(256) void k_cg_update(float4 *X, float4 *R, const float4 *__restrict__ P,
+                                                   const float4 *__restrict__ Q,
+                                                   const float4 *__restrict__ B,
+                                                   const uint8_t *__restrict__ type, VmCgScalars *sc,
+                                                   int cw, int ch)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
+    if (x < cw && y < ch) {
+        const size_t ii = (size_t)y * cw + x;
+        if (type[ii] > 0) {
+            float al[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                al[c] = sc->pq[c] > 0 ? (float)(sc->rz[c] / sc->pq[c]) : 0.0f;
+            const float4 p = P[ii], q = Q[ii];
+            float4 xx = X[ii], r = R[ii];
+            xx.x += al[0] * p.x; xx.y += al[1] * p.y; xx.z += al[2] * p.z;
+            r.x -= al[0] * q.x; r.y -= al[1] * q.y; r.z -= al[2] * q.z;
+            X[ii] = xx;
+            R[ii] = r;
+            const float inv = 1.0f / B[ii].w;
+            rz[0] = (double)r.x * r.x * inv; rz[1] = (double)r.y * r.y * inv; rz[2] = (double)r.z * r.z * inv;
+            rr[0] = (double)r.x * r.x; rr[1] = (double)r.y * r.y; rr[2] = (double)r.z * r.z;
+        }
+    }
+    block_sum3(rz[0], rz[1], rz[2], sc->rz_new);
+    block_sum3(rr[0], rr[1], rr[2], sc->rr_new);
+}
+
+// beta = rz_new/rz;  p = r/diag + beta p
+__global__ __launch_bounds__(256) void k_cg_dir(float4 *P, const float4 *__restrict__ R,
+                                                const float4 *__restrict__ B,
+                                                const uint8_t *__restrict__ type,
+                                                const VmCgScalars *sc, int cw, int ch)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= ch)
+        return;
+    const size_t ii = (size_t)y * cw + x;
+    if (type[ii] == 0)
+        return;
+    float be[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        be[c] = sc->rz[c] > 0 ? (float)(sc->rz_new[c] / sc->rz[c]) : 0.0f;
+    const float inv = 1.0f / B[ii].w;
+    const float4 r = R[ii];
+    float4 p = P[ii];
+    p.x = r.x * inv + be[0] * p.x;
+    p.y = r.y * inv + be[1] * p.y;
+    p.z = r.z * inv + be[2] * p.z;
+    P[ii] = p;
+}
+
+// rotate the scalars for the next iteration; record the residual history
+__global__ void k_cg_rotate(VmCgScalars *sc)
+{
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        sc->rz[c] = sc->rz_new[c];
+        sc->rr[c] = sc->rr_new[c];
+        sc->rz_new[c] = 0;
+        sc->rr_new[c] = 0;
+        sc->pq[c] = 0;
+    }
+    if (threadIdx.x == 0)
+        sc->iters += 1;
+}
+
+// paste, PoissonExt.cpp:333-346
+__global__ __launch_bounds__(256) void k_paste(uchar4 *ext, const uint8_t *__restrict__ type,
+                                               const float4 *__restrict__ X, int cw, int ch)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= ch)
+        return;
+    const size_t ii = (size_t)y * cw + x;
+    if (type[ii] == 0)
+        return;
+    const float4 v = X[ii];
+    ext[ii] = make_uchar4((uint8_t)(int)fminf(fmaxf(v.x, 0.0f), 255.0f),
+                          (uint8_t)(int)fminf(fmaxf(v.y, 0.0f), 255.0f),
+                          (uint8_t)(int)fminf(fmaxf(v.z, 0.0f), 255.0f), 0);
+}
+
+__global__ __launch_bounds__(256) void k_crop(uchar4 *dst, const uchar4 *__restrict__ ext, int w, int h,
+                                              int ex)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h)
+        return;
+    dst[(size_t)y * w + x] = ext[(size_t)(y + ex) * (w + 2 * ex) + x + ex];
+}
+
+inline dim3 grid2(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
+const dim3 B2(64, 4);
+
+} // namespace
+
+void vm_poisson_launch_crop(uchar4 *dst, const uchar4 *ext, int w, int h, int ex, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_crop, grid2(w, h), B2, 0, s, dst, ext, w, h, ex);
+}
+
+void vm_poisson_launch_prepare(uchar4 *ext, uint8_t *type, const uchar4 *other, const float2 *v,
+                               int w, int h, int rs, int ex, int sign, hipStream_t s)
+{
+    const int cw = w + 2 * ex, ch = h + 2 * ex;
+    hipLaunchKernelGGL(k_classify, grid2(cw, ch), B2, 0, s, ext, type, cw, ch);
+    hipLaunchKernelGGL(k_fill, grid2(cw, ch), B2, 0, s, ext, type, other, v, w, h, rs, ex, sign);
+}
+
+void vm_poisson_launch_setup(const uchar4 *ext, const uint8_t *type, float4 *B, float4 *X,
+                             float4 *R, float4 *P, VmCgScalars *sc, int cw, int ch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_setup, grid2(cw, ch), B2, 0, s, ext, type, B, X, cw, ch);
+    hipLaunchKernelGGL(k_cg_init, grid2(cw, ch), B2, 0, s, B, X, R, P, type, sc, cw, ch);
+}
+
+void vm_poisson_launch_iter(float4 *X, float4 *R, float4 *P, float4 *Q, const float4 *B,
+                            const uint8_t *type, VmCgScalars *sc, int cw, int ch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cg_spmv, grid2(cw, ch), B2, 0, s, P, Q, B, type, sc, cw, ch);
+    hipLaunchKernelGGL(k_cg_update, grid2(cw, ch), B2, 0, s, X, R, P, Q, B, type, sc, cw, ch);
+    hipLaunchKernelGGL(k_cg_dir, grid2(cw, ch), B2, 0, s, P, R, B, type, sc, cw, ch);
+    hipLaunchKernelGGL(k_cg_rotate, dim3(1), dim3(64), 0, s, sc);
+}
+
+void vm_poisson_launch_paste(uchar4 *ext, const uint8_t *type, const float4 *X, int cw, int ch,
+                             hipStream_t s)
+{
+    hipLaunchKernelGGL(k_paste, grid2(cw, ch), B2, 0, s, ext, type, X, cw, ch);
+}

@@ -1,0 +1,425 @@
+"""Host-side mirror of the reference's L3 solver API over the C-ABI.
+
+Same names, argument meaning and progress/cancellation behaviour as
+Algorithm/parameters.h (Parameters, KernParameters, Conp, Connect,
+BoundaryCondition), Algorithm/Pyramid.h (Pyramid, PyramidLevel),
+Algorithm/morph.h (Morph) and Algorithm/MatchingThread.h (CMatchingThread), so
+that tests read like drivers of the reference.  This module holds no
+numerics: everything runs in libvmorph_hip.so.  (The C++ facade with the same
+shape is include/vmorph/*.hpp.)
+
+Scope: one frame pair per Pyramid (depth 1, the independent-pair formulation).
+"""
+import ctypes as C
+import threading
+import time
+
+import numpy as np
+
+from . import capi
+from .capi import BCOND_NONE, BCOND_CORNER, BCOND_BORDER, MATH_EXACT, MATH_FAST  # noqa: F401
+from . import synth
+
+
+class Conp(object):
+    """struct Conp, parameters.h:22-26: p = (x, y, frame, is_key), weight."""
+
+    def __init__(self, x, y, z=0, w=1, weight=1.0):
+        self.p = (int(x), int(y), int(z), int(w))
+        self.weight = float(weight)
+
+
+class Connect(object):
+    """struct Connect, parameters.h:16-20: li/ri = (track, frame) indices."""
+
+    def __init__(self, li, ri):
+        self.li = tuple(li)
+        self.ri = tuple(ri)
+
+
+class Parameters(object):
+    """struct Parameters, parameters.h:29-52, defaults of UI/MdiEditor.cpp:131-140."""
+
+    def __init__(self):
+        self.w_ui, self.w_tps, self.w_ssim, self.w_temp = 1e5, 0.05, 100.0, 10.0
+        self.ssim_clamp = 0.0
+        self.eps = 0.01
+        self.max_iter = 1000
+        self.start_res = 8
+        self.max_iter_drop_factor = 2.0
+        self.bcond = BCOND_NONE
+        self.lp, self.rp, self.cnt = [], [], []
+        self.verbose = False
+
+    def add_point_pair(self, lx, ly, rx, ry, weight=1.0, frame=0):
+        """Convenience: one key-point track per side plus its connection."""
+        self.lp.append([Conp(lx, ly, frame, 1, weight)])
+        self.rp.append([Conp(rx, ry, frame, 1, weight)])
+        k = len(self.lp) - 1
+        self.cnt.append([Connect((k, 0), (k, 0))])
+
+    def constraints(self, conz=0):
+        """Resolve lp/rp/cnt as morph.cu:354-366 does for page `conz`."""
+        out = []
+        for row in self.cnt:
+            for c in row:
+                l = self.lp[c.li[0]][c.li[1]]
+                r = self.rp[c.ri[0]][c.ri[1]]
+                if l.p[2] != conz:
+                    continue
+                out.append((l.p[0], l.p[1], r.p[0], r.p[1], min(l.weight, r.weight)))
+        return np.asarray(out, dtype=np.float32).reshape(-1, 5)
+
+
+class KernParameters(capi.KernParams):
+    """struct KernParameters(const Parameters&), parameters.h:54-72."""
+
+    def __init__(self, p=None):
+        capi.KernParams.__init__(self)
+        if p is not None:
+            self.w_temp, self.w_ui, self.w_tps, self.w_ssim = p.w_temp, p.w_ui, p.w_tps, p.w_ssim
+            self.ssim_clamp, self.eps, self.bcond = p.ssim_clamp, p.eps, int(p.bcond)
+
+
+class Context(object):
+    """One HIP device + stream (vm_ctx)."""
+
+    def __init__(self, device=0, math_mode=MATH_EXACT):
+        self._L = capi.load()
+        h = C.c_void_p()
+        capi.check(self._L.vm_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.set_math_mode(math_mode)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vm_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_params(self, kp):
+        capi.check(self._L.vm_set_params(self._h, C.byref(kp)))
+
+    def set_math_mode(self, mode):
+        capi.check(self._L.vm_set_math_mode(self._h, int(mode)))
+        self.math_mode = int(mode)
+
+    def sync(self):
+        capi.check(self._L.vm_ctx_sync(self._h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int(0), C.c_uint64(0)
+        capi.check(self._L.vm_device_info(self._h, name, C.byref(cus), C.byref(mem)))
+        return name.value.decode(), cus.value, mem.value
+
+
+def _cons_array(cons):
+    cons = np.asarray(cons if cons is not None else [], dtype=np.float32).reshape(-1, 5)
+    n = len(cons)
+    arr = (capi.Constraint * max(n, 1))()
+    for k in range(n):
+        arr[k] = capi.Constraint(*[float(x) for x in cons[k]])
+    return arr, n
+
+
+class PyramidLevel(object):
+    """struct PyramidLevel, Pyramid.h:52-98 (geometry + device-state access)."""
+
+    def __init__(self, pyr, el, w, h):
+        self._pyr, self._el = pyr, el
+        self.width, self.height, self.depth = int(w), int(h), 1
+        self.rowstride = (self.width + 31) // 32 * 32         # pyramid.cu:535
+        self.pagestride = self.rowstride * self.height
+        self.inv_wh = np.float32(1.0) / np.float32(self.width * self.height)
+        self.impmask_rowstride = (self.width + 4) // 5 + 2
+        self.impmask_pagestride = self.impmask_rowstride * ((self.height + 4) // 5 + 2)
+        self.factor_d = 1.0
+
+    def _lvl(self):
+        if self._el < 1:
+            raise capi.VmError(capi.VM_E_STATE, "pyramid[0] is the full-resolution placeholder")
+        return self._el - 1
+
+    def field(self, name):
+        """Copy a device-state array to the host: (h,w), (h,w,2) or the mask words."""
+        fid, ch = capi.FIELDS[name]
+        L = self._pyr._L
+        if name == "impmask":
+            out = np.zeros(((self.height + 4) // 5 + 2, self.impmask_rowstride), dtype=np.uint32)
+        elif ch == 2:
+            out = np.zeros((self.height, self.width, 2), dtype=np.float32)
+        else:
+            out = np.zeros((self.height, self.width), dtype=np.float32)
+        capi.check(L.vm_level_get_field(self._pyr._h, self._lvl(), fid, out.ctypes.data))
+        return out
+
+    @property
+    def v(self):
+        out = np.zeros((self.height, self.width, 2), dtype=np.float32)
+        capi.check(self._pyr._L.vm_level_get_v(self._pyr._h, self._lvl(), out.ctypes.data, 0))
+        return out
+
+    @v.setter
+    def v(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        assert arr.shape == (self.height, self.width, 2)
+        capi.check(self._pyr._L.vm_level_set_v(self._pyr._h, self._lvl(), arr.ctypes.data, 0))
+
+
+class Pyramid(object):
+    """class Pyramid, Pyramid.h:14-48.  pyramid[0] is the full-resolution
+    placeholder (pyramid.cu:220); pyramid[1..size()-1] run finest to coarsest;
+    the last level holds no images (pyramid.cu:329)."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self._L = capi.load()
+        self._h = None
+        self._levels = []
+        self._vector, self._qpath = [], []
+        self._extends1, self._extends2, self._results = [], [], []
+
+    def size(self):
+        return len(self._levels)
+
+    __len__ = size
+
+    def __getitem__(self, idx):
+        return self._levels[idx]
+
+    def back(self):
+        return self._levels[-1]
+
+    def clear(self):
+        if self._h:
+            self._L.vm_pyramid_destroy(self._h)
+            self._h = None
+        self._levels = []
+        self._vector, self._qpath = [], []
+        self._extends1, self._extends2 = [], []
+
+    __del__ = clear
+
+    def build_levels(self, sizes):
+        """Allocate from explicit (w, h) level sizes, finest first."""
+        self.clear()
+        n = len(sizes)
+        ws = (C.c_int * n)(*[int(s[0]) for s in sizes])
+        hs = (C.c_int * n)(*[int(s[1]) for s in sizes])
+        h = C.c_void_p()
+        capi.check(self._L.vm_pyramid_create(self._ctx._h, n, ws, hs, C.byref(h)))
+        self._h = h
+        self._levels = [PyramidLevel(self, 0, sizes[0][0], sizes[0][1])]
+        for k, (w, hh) in enumerate(sizes):
+            self._levels.append(PyramidLevel(self, k + 1, w, hh))
+
+    def upload_luma(self, el, img0, img1):
+        img0 = np.ascontiguousarray(img0, dtype=np.float32)
+        img1 = np.ascontiguousarray(img1, dtype=np.float32)
+        lv = self._levels[el]
+        assert img0.shape == (lv.height, lv.width) and img1.shape == img0.shape
+        capi.check(self._L.vm_level_upload_luma(self._h, el - 1, img0.ctypes.data,
+                                                img1.ctypes.data, 0))
+
+    def build(self, img0, img1, start_res, nlevels=None):
+        """Pyramid::build(video0, video1, ..., start_res), pyramid.cu:166-485, for
+        one frame pair of float luma images.  Level geometry follows the
+        reference (integer form of pyramid.cu:230-240, ceil halving :466-467);
+        the images of the coarser levels come from a 2x2 box filter (the
+        reference's Nehab-Hoppe B-spline prefiltered scale() is a 'next' row)."""
+        h, w = img0.shape
+        n = nlevels if nlevels is not None else synth.num_levels(w, h, start_res)
+        n = max(n, 2)
+        pyr = synth.build_pyramid(img0, img1, n)
+        self.build_levels([(p[0].shape[1], p[0].shape[0]) for p in pyr])
+        for k in range(n - 1):
+            self.upload_luma(k + 1, pyr[k][0], pyr[k][1])
+        self._vector = [np.zeros((h, w, 2), dtype=np.float32)]
+        self._qpath = [np.zeros((h, w, 2), dtype=np.float32)]
+        return pyr
+
+
+class Morph(object):
+    """class Morph, morph.h:10-31."""
+
+    def __init__(self, params, pyramid, run_flag=None, fixed_work=False):
+        self.m_params, self.m_pyramid = params, pyramid
+        # bool& run_flag of the reference: a shared int the caller may clear
+        self.m_cb = run_flag if run_flag is not None else C.c_int(1)
+        self.fixed_work = bool(fixed_work)
+        # ctor, morph.cu:122-141
+        self._total_l = pyramid.size() - 1
+        self._current_l = self._total_l
+        self._total_iter = self._current_iter = 0.0
+        self._max_iter = float(params.max_iter)
+        iter_num = int(params.max_iter)
+        for el in range(self._total_l - 1, 0, -1):
+            lv = pyramid[el]
+            self._total_iter += iter_num * lv.width * lv.height * lv.depth
+            iter_num = int(iter_num / params.max_iter_drop_factor)
+        self.progress = {}
+
+    def params(self):
+        return self.m_params
+
+    def calculate_halfway_parametrization(self):
+        """morph.cu:150-168; returns True like the reference.  Raises VmError
+        (the reference throws std::runtime_error from rod::check_cuda_error)."""
+        P, pyr, L = self.m_params, self.m_pyramid, self.m_pyramid._L
+        ctx = pyr._ctx
+        ctx.set_params(KernParameters(P))
+        cons, n = _cons_array(P.constraints(0))
+        w0, h0 = pyr[0].width, pyr[0].height
+        flag = C.cast(C.pointer(self.m_cb), C.c_void_p)
+        capi.check(L.vm_coarse_solve(pyr._h, self._total_l - 1, w0, h0, cons, n))
+        self._current_l = self._total_l - 1
+        while self._current_l > 0:
+            if self.m_cb.value:
+                el = self._current_l
+                capi.check(L.vm_upsample_v(pyr._h, el - 1, el))
+                capi.check(L.vm_init_level(pyr._h, el - 1, w0, h0, cons, n))
+                pr = capi.Progress()
+                rc = L.vm_optimize_level(pyr._h, el - 1, self._max_iter, flag,
+                                         int(self.fixed_work), C.byref(pr))
+                if rc != capi.VM_E_CANCELLED:
+                    capi.check(rc)
+                lv = pyr[el]
+                # morph.cu:1389-1391: the level is accounted as max_iter sweeps
+                self._current_iter += lv.width * lv.height * self._max_iter
+                self.progress[el] = dict(iters=pr.iters, improving=pr.improving,
+                                         pixel_iters=pr.pixel_iters, elapsed_ms=pr.elapsed_ms,
+                                         launches=pr.launches, width=lv.width, height=lv.height)
+                capi.check(L.vm_level_clear(pyr._h, el - 1))
+                self._max_iter /= P.max_iter_drop_factor
+            self._current_l -= 1
+        return True
+
+
+class MatchingThread(object):
+    """class CMatchingThread, MatchingThread.h:7-37, on threading.Thread."""
+
+    def __init__(self, parameters, pyramids, fixed_work=False):
+        self._parameters, self._pyramids = parameters, pyramids
+        self._flag = C.c_int(1)
+        self.percentage = 0.0
+        self.run_time = 0.0
+        self.gpu_morph = Morph(parameters, pyramids, self._flag, fixed_work)
+        self._thread = None
+        self.error = None
+
+    @property
+    def runflag(self):
+        return bool(self._flag.value)
+
+    @runflag.setter
+    def runflag(self, v):
+        self._flag.value = 1 if v else 0
+
+    def run(self):
+        """MatchingThread.cpp:138-150"""
+        t0 = time.time()
+        try:
+            self.gpu_morph.calculate_halfway_parametrization()
+        except Exception as e:  # surfaced to the caller of wait()
+            self.error = e
+        self.run_time = time.time() - t0
+        if self.error is None:
+            self.update_result()
+
+    def start(self):
+        self._thread = threading.Thread(target=self.run)
+        self._thread.start()
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+        if self.error is not None:
+            raise self.error
+
+    def update_result(self):
+        """MatchingThread.cpp:22-84: fetch v of the current level, scale to full
+        resolution and store it in pyramid._vector[0]."""
+        pyr = self._pyramids
+        el = max(self.gpu_morph._current_l, 1)
+        w0, h0 = pyr[0].width, pyr[0].height
+        out = np.zeros((h0, w0, 2), dtype=np.float32)
+        capi.check(pyr._L.vm_upscale_result(pyr._h, el - 1, w0, h0, out.ctypes.data, 0))
+        pyr._vector = [out]
+        m = self.gpu_morph
+        self.percentage = (m._current_iter / m._total_iter * 100.0) if m._total_iter else 100.0
+        return out
+
+
+class Frame(object):
+    """Device-resident inputs of one output frame (vm_frame): the compositor
+    side of RenderWidget::RenderStage2 and CPoissonExt."""
+
+    def __init__(self, ctx, w, h, ex):
+        self._ctx, self._L = ctx, capi.load()
+        self.w, self.h, self.ex = int(w), int(h), int(ex)
+        hh = C.c_void_p()
+        capi.check(self._L.vm_frame_create(ctx._h, self.w, self.h, self.ex, C.byref(hh)))
+        self._h = hh
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vm_frame_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def upload(self, ext0=None, ext1=None, v=None, qpath=None):
+        def ptr(a, dt):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dtype=dt)
+            return a, a.ctypes.data
+        cw, ch = self.w + 2 * self.ex, self.h + 2 * self.ex
+        a0, p0 = ptr(ext0, np.uint8)
+        a1, p1 = ptr(ext1, np.uint8)
+        av, pv = ptr(v, np.float32)
+        aq, pq = ptr(qpath, np.float32)
+        for a in (a0, a1):
+            assert a is None or a.shape == (ch, cw, 4)
+        for a in (av, aq):
+            assert a is None or a.shape == (self.h, self.w, 2)
+        capi.check(self._L.vm_frame_upload(self._h, p0, p1, pv, pq))
+
+    def set_v_from_level(self, pyramid, el):
+        capi.check(self._L.vm_frame_set_v_from_level(self._h, pyramid._h, el - 1))
+
+    def download_ext(self, side):
+        out = np.zeros((self.h + 2 * self.ex, self.w + 2 * self.ex, 4), dtype=np.uint8)
+        capi.check(self._L.vm_frame_download_ext(self._h, side, out.ctypes.data))
+        return out
+
+    def render_halfway(self, color_fa, geo_fa, color_from):
+        """render_halfway_image, render.cu:62-96 -> (h, w, 3) uint8."""
+        out = np.zeros((self.h, self.w, 3), dtype=np.uint8)
+        capi.check(self._L.vm_render_halfway(self._h, color_fa, geo_fa, color_from,
+                                             out.ctypes.data, 0))
+        return out
+
+    def render_halfway_dev(self, color_fa, geo_fa, color_from):
+        ms = C.c_float(0)
+        capi.check(self._L.vm_render_halfway_dev(self._h, color_fa, geo_fa, color_from, C.byref(ms)))
+        return ms.value
+
+    def poisson_extend(self, side, tol=1e-5, max_it=20000):
+        """CPoissonExt::prepare + poissonExtend for one side (PoissonExt.cpp:19-41)."""
+        it, rr, ms = C.c_int(0), C.c_float(0), C.c_float(0)
+        capi.check(self._L.vm_poisson_extend(self._h, side, tol, max_it, C.byref(it),
+                                             C.byref(rr), C.byref(ms)))
+        return it.value, rr.value, ms.value
+
+
+def make_extended(rgb, ex):
+    """Extended RGBA8 canvas of Pyramid::build, pyramid.cu:186-200: filled with
+    (255,255,255,255), the image pasted at (ex,ex) with alpha 0."""
+    h, w = rgb.shape[:2]
+    can = np.full((h + 2 * ex, w + 2 * ex, 4), 255, dtype=np.uint8)
+    can[ex:ex + h, ex:ex + w, :3] = rgb
+    can[ex:ex + h, ex:ex + w, 3] = 0
+    return can
