@@ -1,0 +1,248 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the halfway-domain morph solver.
+
+Metric (BASELINE.json): Mpixel*iters/s of the halfway optimizer on a 1080p frame
+pair, 6-level pyramid (start_res 32), 500 iterations per level (config[1]).
+
+A "step" = one complete coarse-to-fine solve (vm_solve: coarse solve, then per
+level upsample + init + sweeps) of ONE synthetic 1080p frame pair whose pyramid
+is already resident in HBM.  value = sum over levels of W*H*iterations executed
+(the reference's own progress unit, morph.cu:1389) divided by wall time, summed
+over all ranks.  Independent frame pairs shard across GPUs with no data-path
+collective (weak scaling: K pairs per GPU); the only collective is one RCCL
+broadcast of the shared parameter block.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+W, H, START_RES, MAX_ITER, DROP = 1920, 1080, 32, 500.0, 1.0
+ALG_BYTES_PER_VISIT = 100.0      # 76 B read + 24 B written per pixel-visit
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def tile_visits(w, h):
+    """pixel-visits of the 4 tile-offset launches of one iteration (64x16 tiles, 69x21 pitch)"""
+    def cover(dim, tile, pitch, off):
+        n, t = 0, off
+        while t < dim:
+            n += min(tile, dim - t)
+            t += pitch
+        return n
+    tot = 0
+    for ox in (0, 64):
+        for oy in (0, 16):
+            tot += cover(w, 64, 69, ox) * cover(h, 16, 21, oy)
+    return tot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--math", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--size", default=None, help="WxH override (debug only; invalid as a result)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    w, h = W, H
+    if args.size:
+        w, h = [int(x) for x in args.size.lower().split("x")]
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from videomorphing_amd import capi, morph, synth
+
+    # ---- the shared parameter block: rank 0 decides, one RCCL broadcast ----
+    blk = capi.ParamBlock()
+    if rank == 0:
+        P = morph.Parameters()
+        blk.kp = morph.KernParameters(P)
+        blk.max_iter, blk.max_iter_drop_factor, blk.start_res = MAX_ITER, DROP, START_RES
+        blk.math_mode = capi.MATH_FAST if args.math == "fast" else capi.MATH_EXACT
+        blk.n_constraints = 0
+    raw = np.frombuffer(bytes(blk), dtype=np.uint8).copy()
+    t = torch.from_numpy(raw).cuda()
+    if world > 1:
+        dist.broadcast(t, src=0)     # backend "nccl" is RCCL on ROCm (xGMI within the node)
+    C.memmove(C.addressof(blk), t.cpu().numpy().tobytes(), C.sizeof(blk))
+
+    ctx = morph.Context(local_rank, blk.math_mode)
+    ctx.set_params(blk.kp)
+    L = capi.load()
+
+    # ---- inputs: K+W independent frame pairs per rank, pyramids resident in HBM ----
+    nlev = synth.num_levels(w, h, blk.start_res)
+    npairs = args.steps + args.warmup
+    pyrs = []
+    for k in range(npairs):
+        frame = rank * npairs + k
+        i0, i1 = synth.make_pair(w, h, frame=frame)
+        p = morph.Pyramid(ctx)
+        p.build(i0, i1, blk.start_res, nlevels=nlev)
+        pyrs.append(p)
+    sizes = [(pyrs[0][el].width, pyrs[0][el].height) for el in range(1, nlev + 1)]
+
+    def solve(p, fixed=0):
+        prog = (capi.Progress * (nlev - 1))()
+        capi.check(L.vm_solve(p._h, blk.max_iter, blk.max_iter_drop_factor, None, 0, None, fixed, prog))
+        return prog
+
+    def sync_all():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        solve(pyrs[k])
+    sync_all()
+    t0 = time.perf_counter()
+    progs = [solve(pyrs[args.warmup + k]) for k in range(args.steps)]
+    ctx.sync()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sync_all()
+
+    pix_iters = sum(pr[i].pixel_iters for pr in progs for i in range(nlev - 1))
+    kern_ms = sum(pr[i].elapsed_ms for pr in progs for i in range(nlev - 1))
+    launches = sum(pr[i].launches for pr in progs for i in range(nlev - 1))
+    alg_bytes = 0.0
+    for pr in progs:
+        for i in range(nlev - 1):
+            # launches enqueued past convergence exit at once: count executed iterations only
+            alg_bytes += pr[i].iters * tile_visits(*sizes[i]) * ALG_BYTES_PER_VISIT
+    iters_per_level = [[pr[i].iters for i in range(nlev - 1)] for pr in progs]
+
+    stats = torch.tensor([el, pix_iters], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        el_max, pix_total = tmax[0].item(), tsum[1].item()
+    else:
+        el_max, pix_total = el, pix_iters
+
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        # fixed-work (no convergence exit) and EXACT-arithmetic rates, one solve each
+        p = pyrs[0]
+        ctx.sync(); t1 = time.perf_counter(); pr = solve(p, fixed=1); ctx.sync(); dt = time.perf_counter() - t1
+        extras["fixed_work_mpix_iters_per_s"] = round(sum(pr[i].pixel_iters for i in range(nlev - 1)) / dt / 1e6, 2)
+        other = capi.MATH_EXACT if blk.math_mode == capi.MATH_FAST else capi.MATH_FAST
+        ctx.set_math_mode(other)
+        ctx.sync(); t1 = time.perf_counter(); pr = solve(p); ctx.sync(); dt = time.perf_counter() - t1
+        extras["%s_math_mpix_iters_per_s" % ("exact" if other == capi.MATH_EXACT else "fast")] = round(
+            sum(pr[i].pixel_iters for i in range(nlev - 1)) / dt / 1e6, 2)
+        ctx.set_math_mode(blk.math_mode)
+        # compositor: frames/s of render_halfway with device-resident inputs
+        ex = int(0.1 * max(w, h))
+        rgb0, rgb1 = synth.make_rgb_pair(w, h)
+        fr = morph.Frame(ctx, w, h, ex)
+        fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
+        fr.set_v_from_level(p, 1)
+        fr.render_halfway_dev(0.5, 0.5, 1)
+        ms = [fr.render_halfway_dev(0.5, 0.1 * k, 1) for k in range(1, 10)]
+        extras["render_frames_per_s"] = round(1000.0 / (sum(ms) / len(ms)), 1)
+        fr.close()
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(np, synth, blk)
+
+    if rank == 0:
+        avg_launch_us = kern_ms * 1e3 / max(launches, 1)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixel*iters/s (halfway optimizer, 1080p pair, 6-level pyramid, 500 iters/level)",
+            "value": round(pix_total / el_max / 1e6, 2),
+            "unit": "Mpixel*iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el_max / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "config[1]: %dx%d frame pair, %d-level pyramid (start_res %d), max_iter %d/level, drop %g, one pair per step per GPU"
+                                   % (w, h, nlev, blk.start_res, int(blk.max_iter), blk.max_iter_drop_factor),
+                       "math_mode": "fast" if blk.math_mode == capi.MATH_FAST else "exact",
+                       "semantics": "reference (stop when no pixel improves)",
+                       "iters_per_level_fine_to_coarse": iters_per_level[0],
+                       "parallelism": "independent frame pairs, %d rank(s), 1 RCCL broadcast" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_optimize (sweep)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "avg_launch_us": round(avg_launch_us, 2), "launches": launches,
+                         "alg_bytes_per_pixel_visit": ALG_BYTES_PER_VISIT},
+            "cpu_baseline": cpu,
+        }
+        out.update(extras)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(np, synth, blk):
+    """The CPU restatement (oracle, OpenMP over tiles) timed on this host: a bounded
+    sample of the same workload -- the 480x270 level of the same pyramid, started
+    from the upsampled solution of the coarser levels, for a fixed number of sweeps."""
+    import oracle as O
+    threads = os.cpu_count() or 1
+    O.lib().vmo_set_threads(threads)
+    i0, i1 = synth.make_pair(W, H, frame=0)
+    pyr = synth.build_pyramid(i0, i1, synth.num_levels(W, H, START_RES))
+    P = O.default_params()
+    for f, _ in P._fields_:
+        setattr(P, f, getattr(blk.kp, f))
+    # coarse levels (cheap) to get a realistic start, then time the 480x270 level
+    lv = O.solve(pyr[3:], P, 200, 1.0, threads=threads)     # 240x135 .. 60x34
+    tgt = O.Level(pyr[2][0].shape[1], pyr[2][0].shape[0])
+    tgt.set_images(*pyr[2])
+    tgt.upsample_from(lv)
+    tgt.init(P.ssim_clamp)
+    stats = np.zeros(4)
+    t0 = time.perf_counter()
+    iters = 0
+    while time.perf_counter() - t0 < 12.0 and iters < 500:
+        imp = tgt.optimize_iter(P, stats)
+        iters += 1
+        if not imp:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(tgt.w * tgt.h * iters / dt / 1e6, 3), "unit": "Mpixel*iters/s",
+            "cores": threads, "kind": "port",
+            "sample": "%d sweeps of the %dx%d level of the same pyramid (oracle, OpenMP over tiles), %.1f s"
+                      % (iters, tgt.w, tgt.h, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,9 @@ typedef struct {
     double pixel_iters;    /* iters * W * H  (morph.cu:1389)                    */
     float  elapsed_ms;     /* HIP-event time of the sweep kernels on the stream */
     int    launches;       /* sweep kernel launches enqueued                    */
+    double active_tiles;   /* tile visits that were not skipped by the mask     */
+    double candidates;     /* pixel visits that ran the line search             */
+    double commits;        /* accepted moves                                    */
 } vm_progress;
 
 /* device-state arrays a test or a UI may read back (vm_level_get_field) */

@@ -48,7 +48,8 @@ class Constraint(C.Structure):
 
 class Progress(C.Structure):
     _fields_ = [("iters", C.c_int), ("improving", C.c_int), ("pixel_iters", C.c_double),
-                ("elapsed_ms", C.c_float), ("launches", C.c_int)]
+                ("elapsed_ms", C.c_float), ("launches", C.c_int),
+                ("active_tiles", C.c_double), ("candidates", C.c_double), ("commits", C.c_double)]
 
 
 class ParamBlock(C.Structure):

@@ -114,6 +114,8 @@ extern "C" int vm_ctx_create(int device, vm_ctx **out)
     c->flags_cap = 4096;
     VM_HIP(hipMalloc((void **)&c->flags, c->flags_cap * sizeof(uint32_t)));
     VM_HIP(hipHostMalloc((void **)&c->flags_host, c->flags_cap * sizeof(uint32_t), hipHostMallocDefault));
+    VM_HIP(hipMalloc((void **)&c->stats, c->flags_cap * 4 * sizeof(uint32_t)));
+    VM_HIP(hipHostMalloc((void **)&c->stats_host, c->flags_cap * 4 * sizeof(uint32_t), hipHostMallocDefault));
     *out = c;
     return VM_OK;
 }
@@ -126,6 +128,8 @@ extern "C" void vm_ctx_destroy(vm_ctx *c)
     hipFree(c->tables);
     hipFree(c->flags);
     hipHostFree(c->flags_host);
+    hipFree(c->stats);
+    hipHostFree(c->stats_host);
     hipFree(c->cons_dev);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
@@ -462,36 +466,55 @@ extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile co
     int cap = 1;
     while ((float)cap < max_iter) ++cap;
     if (cap > c->flags_cap) {
-        hipFree(c->flags);
-        hipHostFree(c->flags_host);
-        c->flags = nullptr; c->flags_host = nullptr;
+        hipFree(c->flags); hipHostFree(c->flags_host);
+        hipFree(c->stats); hipHostFree(c->stats_host);
+        c->flags = c->flags_host = c->stats = c->stats_host = nullptr;
+        c->flags_cap = 0;
         VM_HIP(hipMalloc((void **)&c->flags, (size_t)cap * 4));
         VM_HIP(hipHostMalloc((void **)&c->flags_host, (size_t)cap * 4, hipHostMallocDefault));
+        VM_HIP(hipMalloc((void **)&c->stats, (size_t)cap * 16));
+        VM_HIP(hipHostMalloc((void **)&c->stats_host, (size_t)cap * 16, hipHostMallocDefault));
         c->flags_cap = cap;
     }
     hipStream_t s = c->stream;
     VM_HIP(hipMemsetAsync(c->flags, 0, (size_t)cap * 4, s));
+    VM_HIP(hipMemsetAsync(c->stats, 0, (size_t)cap * 16, s));
     const bool exact = c->math_mode == VM_MATH_EXACT;
+    // workgroup size of the sweep: EXACT relaxes one pixel per lane (256 lanes per
+    // tile phase); FAST fans every pixel out over 4..32 lanes, so it takes the
+    // largest workgroup the CU offers
+    const int threads = c->sweep_threads ? c->sweep_threads : (exact ? 256 : 1024);
+    double st_tiles = 0, st_cand = 0, st_commit = 0;
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
     int done = 0, launches = 0, executed = cap, improving = 1;
     bool cancelled = false;
-    VM_HIP(hipEventRecord(c->ev0, s));
+    float ms = 0;
     // Iterations are enqueued in batches; each sweep kernel of iteration i exits
     // at once when iteration i-1 did not improve (device-side flag), so running
     // past convergence inside a batch costs launch latency only, and the host
-    // reads the flags once per batch instead of once per iteration.
+    // reads the flags once per batch instead of once per iteration.  The HIP
+    // events bracket the sweep launches of each batch on the context's stream.
     int batch = 8;
     while (done < cap) {
         int nb = std::min(batch, cap - done);
+        VM_HIP(hipEventRecord(c->ev0, s));
         for (int it = done; it < done + nb; ++it)
             for (int k = 0; k < 4; ++k) {
-                if (exact) vm_launch_optimize_exact(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, it, fixed_work, s);
-                else vm_launch_optimize_fast(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, it, fixed_work, s);
+                if (exact) vm_launch_optimize_exact(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
+                else vm_launch_optimize_fast(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
                 ++launches;
             }
+        VM_HIP(hipEventRecord(c->ev1, s));
         VM_HIP(hipGetLastError());
         VM_HIP(hipMemcpyAsync(c->flags_host + done, c->flags + done, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+        VM_HIP(hipMemcpyAsync(c->stats_host + 4 * done, c->stats + 4 * done, (size_t)nb * 16, hipMemcpyDeviceToHost, s));
         VM_HIP(hipStreamSynchronize(s));
+        for (int it = done; it < done + nb; ++it) {
+            st_tiles += c->stats_host[4 * it]; st_cand += c->stats_host[4 * it + 1]; st_commit += c->stats_host[4 * it + 2];
+        }
+        float bms = 0;
+        VM_HIP(hipEventElapsedTime(&bms, c->ev0, c->ev1));
+        ms += bms;
         bool stop = false;
         for (int it = done; it < done + nb; ++it)
             if (c->flags_host[it] == 0) {
@@ -503,16 +526,15 @@ extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile co
         if (run_flag && !*run_flag) { executed = done; cancelled = true; break; }
         batch = std::min(batch * 2, 64);
     }
-    VM_HIP(hipEventRecord(c->ev1, s));
-    VM_HIP(hipEventSynchronize(c->ev1));
-    float ms = 0;
-    VM_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     if (out) {
         out->iters = executed;
         out->improving = improving;
         out->pixel_iters = (double)executed * l.w * l.h;
         out->elapsed_ms = ms;
         out->launches = launches;
+        out->active_tiles = st_tiles;
+        out->candidates = st_cand;
+        out->commits = st_commit;
     }
     return cancelled ? vm_fail(VM_E_CANCELLED, "vm_optimize_level: cancelled by run_flag") : VM_OK;
 }

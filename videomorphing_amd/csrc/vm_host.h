@@ -24,6 +24,9 @@ struct vm_ctx {
     uint32_t *tables = nullptr;      // VM_TAB_WORDS words
     uint32_t *flags = nullptr;       // per-iteration "improving" flags (device)
     uint32_t *flags_host = nullptr;  // pinned mirror
+    uint32_t *stats = nullptr;       // per-iteration activity counters, 4 words each (device)
+    uint32_t *stats_host = nullptr;  // pinned mirror
+    int sweep_threads = 0;           // 0 = automatic
     int flags_cap = 0;
     vm_constraint *cons_dev = nullptr;
     int cons_cap = 0;

@@ -245,18 +245,37 @@ __global__ __launch_bounds__(256) void SUF(k_upsample)(float2 *__restrict__ dst,
 // ---------------------------------------------------------------------------
 // The sweep kernel: kernel_optimize_level and its device helpers,
 // morph.cu:592-1345.
+//
+// One workgroup of T threads (T = 256..1024, chosen per level by the host)
+// relaxes one 64x16 tile through the reference's four Jacobi phases.  Per phase:
+//   1. the (at most 256) pixels of the phase are tested against the improving
+//      mask and the candidates are compacted into an LDS list;
+//   2. every candidate is handed to a group of L consecutive lanes, L the
+//      largest power of two <= T / #candidates (4..32; 1 in EXACT mode).  The L
+//      lanes split the 25 window neighbours of the pixel between them, keep
+//      their share of the window sums in registers for the whole line search,
+//      and combine the per-neighbour SSIM terms with DPP butterflies, so the
+//      ~21 dependent energy evaluations of a pixel cost 25/L SSIM evaluations
+//      each instead of 25.  Dense phases fill the machine with pixels, sparse
+//      phases (the common case once the improving mask has pruned the level)
+//      fill it with neighbours: the latency of a nearly idle tile, which bounds
+//      the launch, drops by up to 25x;
+//   3. accepted moves are published as per-pixel records and every tile+halo
+//      cell gathers the records of the pixels whose window covers it, in a
+//      fixed order (no float atomics anywhere, LDS or global).
 
 struct TileLds {
     float2 mean[VM_NCELL], var[VM_NCELL], tpsb[VM_NCELL];
     float cross[VM_NCELL], value[VM_NCELL];
-    // commit records of the current phase, one per tile pixel of the phase
+    // per phase pixel (slot = (y>>1)*32 + (x>>1) inside the tile)
     float2 d_mean[256], d_var[256], d_step[256];
     float d_cross[256];
-    int d_ok[256];
+    int d_ok[256];           // 0: untouched, 1: commit, 2: candidate that failed
+    int list[256];           // compacted candidate slots
+    int n_act;
     float tps[625];
     uint32_t imp[225];
-    uint32_t mask[6][16]; // improving-mask words covering the tile +-1 block
-    int mask_bx0, mask_by0;
+    uint32_t mask[6][16];    // improving-mask words covering the tile +-1 block
 };
 
 struct PixelCtx {
@@ -268,10 +287,16 @@ struct PixelCtx {
     float2 tps_b, ui_b;
 };
 
-// ssim_change (morph.cu:671-728) + energy_change (:730-761), flag == false
+#if VM_EXACT
+// ---- EXACT: literal ssim_change (morph.cu:671-728) + energy_change (:730-761),
+// flag == false; one lane per pixel, neighbours read from LDS in row-major order
+struct NbCache {};
+__device__ __forceinline__ void nb_load(NbCache &, const VmLevelView &, const VmKParams &,
+                                        const TileLds &, const PixelCtx &, int, int) {}
+
 __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKParams &P,
-                                               const TileLds &S, const PixelCtx &c, float dx,
-                                               float dy)
+                                               const TileLds &S, const NbCache &,
+                                               const PixelCtx &c, float dx, float dy, int)
 {
     const float vx = c.v.x + dx, vy = c.v.y + dy;
     const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - vx + 0.5f, c.py - vy + 0.5f);
@@ -306,6 +331,113 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
     v_ui += c.ui_b.y * dy;
     return (P.w_ui * v_ui + P.w_ssim * change + 0.0f) * L.inv_wh + P.w_tps * v_tps;
 }
+#define VM_MIN_FANOUT 1
+#define VM_MAX_FANOUT 1
+#else
+// ---- FAST: the same energy, evaluated by L lanes per pixel.  Lane `sub` owns the
+// window neighbours sub, sub+L, sub+2L, ... (at most VM_SMAX of them) and keeps
+// their sums, pre-divided by the window count, in registers.
+#define VM_SMAX 7
+#define VM_MIN_FANOUT 4
+#define VM_MAX_FANOUT 32
+struct NbCache {
+    float A[VM_SMAX], B[VM_SMAX], VX[VM_SMAX], VY[VM_SMAX], X[VM_SMAX], IN[VM_SMAX], M[VM_SMAX];
+    float VAL[VM_SMAX]; // current SSIM value of the neighbour (the differences value - new
+                        // are summed, as the reference does: they are 1e-3..1e-6 of the values)
+};
+
+__device__ __forceinline__ float dpp_xor1(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_half_mirror(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_mirror(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float swz_xor16(float x)
+{
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));
+}
+// sum over the aligned group of Lf lanes (Lf = 4, 8, 16 or 32, uniform in the
+// workgroup); every lane of the group ends with the same bits
+__device__ __forceinline__ float group_sum(float x, int Lf)
+{
+    x += dpp_xor1(x);
+    x += dpp_xor2(x);
+    if (Lf >= 8) x += dpp_half_mirror(x);
+    if (Lf >= 16) x += dpp_mirror(x);
+    if (Lf >= 32) x += swz_xor16(x);
+    return x;
+}
+
+__device__ __forceinline__ void nb_load(NbCache &nb, const VmLevelView &L, const VmKParams &P,
+                                        const TileLds &S, const PixelCtx &c, int sub, int Lf)
+{
+#pragma unroll
+    for (int j = 0; j < VM_SMAX; ++j) {
+        const int k = sub + j * Lf;
+        const int i = k / 5, jj = k - i * 5;
+        const int qx = c.px + jj - 2, qy = c.py + i - 2;
+        const bool ok = k < 25 && qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
+        const int cell = ok ? c.hc + i * VM_HALO_W + jj : 0;
+        const float n = ok ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 1.0f;
+        const float in = ok ? __builtin_amdgcn_rcpf(n) : 0.0f;
+        const float2 m = S.mean[cell], q = S.var[cell];
+        nb.A[j] = m.x * in;
+        nb.B[j] = m.y * in;
+        nb.VX[j] = q.x * in;
+        nb.VY[j] = q.y * in;
+        nb.X[j] = S.cross[cell] * in;
+        nb.IN[j] = in;
+        nb.M[j] = ok ? 1.0f : 0.0f;
+        nb.VAL[j] = S.value[cell];
+    }
+}
+
+__device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKParams &P,
+                                               const TileLds &, const NbCache &nb,
+                                               const PixelCtx &c, float dx, float dy, int Lf)
+{
+    const float vx = c.v.x + dx, vy = c.v.y + dy;
+    const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - vx + 0.5f, c.py - vy + 0.5f);
+    const float ly = tap(L.img1, L.w, L.h, L.rs, c.px + vx + 0.5f, c.py + vy + 0.5f);
+    const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
+    const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
+    const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
+    const float dcross = lx * ly - c.old_luma.x * c.old_luma.y;
+    const float c2 = 58.5225f, c3 = 29.26125f;
+    float acc = 0;
+#pragma unroll
+    for (int j = 0; j < VM_SMAX; ++j) {
+        if (j * Lf < 25) { // uniform in the workgroup
+            const float in = nb.IN[j];
+            const float a = fmaf(dmx, in, nb.A[j]), b = fmaf(dmy, in, nb.B[j]);
+            const float sx = fmaxf(fmaf(-a, a, fmaf(dvx, in, nb.VX[j])), 0.0f);
+            const float sy = fmaxf(fmaf(-b, b, fmaf(dvy, in, nb.VY[j])), 0.0f);
+            const float cov = fmaf(-a, b, fmaf(dcross, in, nb.X[j]));
+            const float ss = __builtin_amdgcn_sqrtf(sx * sy);
+            const float num = fmaf(2.0f, ss, c2) * (fabsf(cov) + c3);
+            const float den = (sx + sy + c2) * (ss + c3);
+            float val = num * __builtin_amdgcn_rcpf(den);
+            val = fmaxf(fminf(val, 1.0f), P.ssim_clamp);
+            acc = fmaf(nb.M[j], nb.VAL[j] - val, acc);
+        }
+    }
+    const float change = group_sum(acc, Lf);
+    const float dd = dx * dx + dy * dy;
+    const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
+    const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
+    return (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
+}
+#endif
 
 // fover_update_isec_min, morph.cu:794-831
 __device__ __forceinline__ void fover_isec(float cx, float cy, float gx, float gy, float e0x,
@@ -365,14 +497,15 @@ __device__ __forceinline__ bool pixel_locked(const VmLevelView &L, int bcond, in
     return false;
 }
 
-__global__ __launch_bounds__(256) void SUF(k_optimize)(VmLevelView L, VmKParams P,
-                                                       const uint32_t *__restrict__ tables,
-                                                       int offx, int offy,
-                                                       uint32_t *__restrict__ flags, int iter_idx,
-                                                       int fixed_work)
+__global__ __launch_bounds__(1024) void SUF(k_optimize)(VmLevelView L, VmKParams P,
+                                                        const uint32_t *__restrict__ tables,
+                                                        int offx, int offy,
+                                                        uint32_t *__restrict__ flags,
+                                                        uint32_t *__restrict__ stats, int iter_idx,
+                                                        int fixed_work)
 {
     __shared__ TileLds S;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, T = blockDim.x;
 
     // converged in the previous iteration: nothing left to do (sticky)
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
@@ -399,13 +532,13 @@ __global__ __launch_bounds__(256) void SUF(k_optimize)(VmLevelView L, VmKParams 
     if (!__syncthreads_or(mymask != 0))
         return;
 
-    for (int k = tid; k < 625; k += 256)
+    for (int k = tid; k < 625; k += T)
         S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
-    if (tid < 225)
-        S.imp[tid] = tables[VM_TAB_IMP + tid];
+    for (int k = tid; k < 225; k += T)
+        S.imp[k] = tables[VM_TAB_IMP + k];
 
     // --- LoadSSIM (morph.cu:1214-1234) + the tile's tps.b ---
-    for (int c = tid; c < VM_NCELL; c += 256) {
+    for (int c = tid; c < VM_NCELL; c += T) {
         int gx = ox - 2 + c % VM_HALO_W, gy = oy - 2 + c / VM_HALO_W;
         bool in = gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
         int g = gy * L.rs + gx;
@@ -415,127 +548,167 @@ __global__ __launch_bounds__(256) void SUF(k_optimize)(VmLevelView L, VmKParams 
         S.cross[c] = in ? L.cross[g] : 0.0f;
         S.value[c] = in ? L.value[g] : 0.0f;
     }
+    if (tid == 0)
+        S.n_act = 0;
     __syncthreads();
 
-    const int tx = tid & 31, ty = tid >> 5;
     bool improving = false;
+    uint32_t st_cand = 0, st_commit = 0;
 
     for (int pi = 0; pi < 2; ++pi) {
         for (int pj = 0; pj < 2; ++pj) {
-            // ---- optimize_pixel (morph.cu:1030-1083) on the pre-phase state ----
-            PixelCtx c;
-            c.px = ox + tx * 2 + pj;
-            c.py = oy + ty * 2 + pi;
-            c.hc = (ty * 2 + pi) * VM_HALO_W + (tx * 2 + pj);
-            c.idx = c.py * L.rs + c.px;
-            const bool inside = c.px < L.w && c.py < L.h;
-            bool candidate = false, ok = false;
-            float2 newv = make_float2(0, 0), step = make_float2(0, 0);
-            const int oxb = c.px % 5, oyb = c.py % 5;
-            int mcx = 0, mcy = 0; // own block inside S.mask
-            if (inside) {
-                // get_improve_mask_idx, morph.cu:621-646
-                mcx = c.px / 5 - bx0;
-                mcy = c.py / 5 - by0;
-                const int begi = oyb >= 2 ? 1 : 0, begj = oxb >= 2 ? 1 : 0;
-                const uint32_t *ib = S.imp + (oyb * 5 + oxb) * 9;
+            // ---- 1. candidates of this phase (get_improve_mask_idx, morph.cu:621-646;
+            // pixel_on_border :648-667) ----
+            if (tid < 256) {
+                const int tx = tid & 31, ty = tid >> 5;
+                const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
+                int state = 0;
+                if (px < L.w && py < L.h) {
+                    const int oxb = px % 5, oyb = py % 5;
+                    const int mcx = px / 5 - bx0, mcy = py / 5 - by0;
+                    const int begi = oyb >= 2 ? 1 : 0, begj = oxb >= 2 ? 1 : 0;
+                    const uint32_t *ib = S.imp + (oyb * 5 + oxb) * 9;
+                    bool hit = false;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (S.mask[mcy + begi + i - 1][mcx + begj + j - 1] &
-                            ib[(begi + i) * 3 + begj + j])
-                            candidate = true;
-            }
-            const bool in_mask = candidate;
-            if (candidate && pixel_locked(L, P.bcond, c.px, c.py))
-                candidate = false;
-            if (candidate) {
-                c.v = L.v[c.idx];
-                c.old_luma = L.luma[c.idx];
-                c.ui_axy = L.ui_axy[c.idx];
-                c.ui_b = L.ui_b[c.idx];
-                c.tps_b = S.tpsb[c.hc + 2 * VM_HALO_W + 2];
-                c.tps_axy = S.tps[(border_class(c.py, L.h) * 5 + border_class(c.px, L.w)) * 25 + 12] / 2;
-                // compute_gradient, morph.cu:763-778
-                float gx = energy_change(L, P, S, c, P.eps, 0) - energy_change(L, P, S, c, -P.eps, 0);
-                float gy = energy_change(L, P, S, c, 0, P.eps) - energy_change(L, P, S, c, 0, -P.eps);
-                gx = -gx;
-                gy = -gy;
-                const float ng = fsqrt(gx * gx + gy * gy);
-                if (ng != 0) {
-                    gx = fdiv(gx, ng);
-                    gy = fdiv(gy, ng);
-                    // prevent_foldover, morph.cu:872-883
-                    float t_min = 10;
-                    fover_ring(L, c.px, c.py, -1.0f, -c.v.x, -c.v.y, -gx, -gy, t_min);
-                    fover_ring(L, c.px, c.py, 1.0f, c.v.x, c.v.y, gx, gy, t_min);
-                    float cc = fmaxf(t_min - P.eps, 0.0f);
-                    // golden_section_search, morph.cu:885-947
-                    const float R = 0.618033989f, C = 1.0f - R;
-                    float a = 0;
-                    float b = a * R + cc * C, x = b * R + cc * C;
-                    float fb = energy_change(L, P, S, c, gx * b, gy * b);
-                    float fx = energy_change(L, P, S, c, gx * x, gy * x);
-                    while (cc - a > P.eps) {
-                        const bool lt = fx < fb;
-                        if (lt) {
-                            a = b;
-                            b = x;
-                            x = b * R + cc * C;
-                        } else {
-                            cc = x;
-                            x = b * R + a * C;
-                        }
-                        const float f = energy_change(L, P, S, c, gx * x, gy * x);
-                        if (lt) {
-                            fb = fx;
-                            fx = f;
-                        } else {
-                            float t = b;
-                            b = x;
-                            x = t;
-                            fx = fb;
-                            fb = f;
-                        }
+                        for (int j = 0; j < 2; ++j)
+                            if (S.mask[mcy + begi + i - 1][mcx + begj + j - 1] &
+                                ib[(begi + i) * 3 + begj + j])
+                                hit = true;
+                    if (hit) {
+                        state = 2; // in the mask: its bit is cleared unless it commits
+                        if (!pixel_locked(L, P.bcond, px, py))
+                            S.list[atomicAdd(&S.n_act, 1)] = tid;
                     }
-                    const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
-                    if (fmin < 0) {
-                        step = make_float2(gx * tmin, gy * tmin);
-                        newv = make_float2(c.v.x + step.x, c.v.y + step.y);
-                        ok = true;
+                }
+                S.d_ok[tid] = state;
+            }
+            __syncthreads();
+            const int n_act = S.n_act;
+
+            if (n_act > 0) {
+                st_cand += n_act;
+                // ---- 2. optimize_pixel (morph.cu:1030-1083) on the pre-phase state,
+                // L lanes per candidate ----
+                int Lf = VM_MIN_FANOUT;
+                while (Lf * 2 <= VM_MAX_FANOUT && Lf * 2 * n_act <= T)
+                    Lf *= 2;
+                const int slots = T / Lf;
+                const int sub = tid & (Lf - 1), grp = tid / Lf;
+                for (int base = 0; base < n_act; base += slots) {
+                    const int li = base + grp;
+                    if (li < n_act) {
+                        const int slot = S.list[li];
+                        const int tx = slot & 31, ty = slot >> 5;
+                        PixelCtx c;
+                        c.px = ox + tx * 2 + pj;
+                        c.py = oy + ty * 2 + pi;
+                        c.hc = (ty * 2 + pi) * VM_HALO_W + (tx * 2 + pj);
+                        c.idx = c.py * L.rs + c.px;
+                        c.v = L.v[c.idx];
+                        c.old_luma = L.luma[c.idx];
+                        c.ui_axy = L.ui_axy[c.idx];
+                        c.ui_b = L.ui_b[c.idx];
+                        c.tps_b = S.tpsb[c.hc + 2 * VM_HALO_W + 2];
+                        c.tps_axy = S.tps[(border_class(c.py, L.h) * 5 + border_class(c.px, L.w)) * 25 + 12] / 2;
+                        NbCache nb;
+                        nb_load(nb, L, P, S, c, sub, Lf);
+                        // compute_gradient, morph.cu:763-778
+                        float gx = energy_change(L, P, S, nb, c, P.eps, 0, Lf) - energy_change(L, P, S, nb, c, -P.eps, 0, Lf);
+                        float gy = energy_change(L, P, S, nb, c, 0, P.eps, Lf) - energy_change(L, P, S, nb, c, 0, -P.eps, Lf);
+                        gx = -gx;
+                        gy = -gy;
+                        const float ng = fsqrt(gx * gx + gy * gy);
+                        if (ng != 0) {
+                            gx = fdiv(gx, ng);
+                            gy = fdiv(gy, ng);
+                            // prevent_foldover, morph.cu:872-883
+                            float t_min = 10;
+                            fover_ring(L, c.px, c.py, -1.0f, -c.v.x, -c.v.y, -gx, -gy, t_min);
+                            fover_ring(L, c.px, c.py, 1.0f, c.v.x, c.v.y, gx, gy, t_min);
+                            float cc = fmaxf(t_min - P.eps, 0.0f);
+                            // golden_section_search, morph.cu:885-947
+                            const float R = 0.618033989f, C = 1.0f - R;
+                            float a = 0;
+                            float b = a * R + cc * C, x = b * R + cc * C;
+                            float fb = energy_change(L, P, S, nb, c, gx * b, gy * b, Lf);
+                            float fx = energy_change(L, P, S, nb, c, gx * x, gy * x, Lf);
+                            while (cc - a > P.eps) {
+                                const bool lt = fx < fb;
+                                if (lt) {
+                                    a = b;
+                                    b = x;
+                                    x = b * R + cc * C;
+                                } else {
+                                    cc = x;
+                                    x = b * R + a * C;
+                                }
+                                const float f = energy_change(L, P, S, nb, c, gx * x, gy * x, Lf);
+                                if (lt) {
+                                    fb = fx;
+                                    fx = f;
+                                } else {
+                                    float t = b;
+                                    b = x;
+                                    x = t;
+                                    fx = fb;
+                                    fb = f;
+                                }
+                            }
+                            const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
+                            if (fmin < 0 && sub == 0) {
+                                S.d_step[slot] = make_float2(gx * tmin, gy * tmin);
+                                S.d_ok[slot] = 1;
+                            }
+                        }
                     }
                 }
             }
             __syncthreads();
 
-            // ---- commit_pixel_motion (morph.cu:990-1026): own-pixel state and
-            // the record the per-cell gather below reads ----
-            S.d_ok[tid] = ok ? 1 : 0;
-            if (ok) {
-                const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - newv.x + 0.5f, c.py - newv.y + 0.5f);
-                const float ly = tap(L.img1, L.w, L.h, L.rs, c.px + newv.x + 0.5f, c.py + newv.y + 0.5f);
-                L.luma[c.idx] = make_float2(lx, ly);
-                S.d_mean[tid] = make_float2(lx - c.old_luma.x, ly - c.old_luma.y);
-                S.d_var[tid] = make_float2(lx * lx - c.old_luma.x * c.old_luma.x,
-                                           ly * ly - c.old_luma.y * c.old_luma.y);
-                S.d_cross[tid] = lx * ly - c.old_luma.x * c.old_luma.y;
-                S.d_step[tid] = step;
-                L.ui_b[c.idx] = make_float2(c.ui_b.x + 2 * step.x * c.ui_axy,
-                                            c.ui_b.y + 2 * step.y * c.ui_axy);
-                L.v[c.idx] = newv;
-                atomicOr(&S.mask[mcy][mcx], 1u << (oxb + oyb * 5));
-            } else if (in_mask) {
-                atomicAnd(&S.mask[mcy][mcx], ~(1u << (oxb + oyb * 5)));
+            // ---- 3. commit_pixel_motion (morph.cu:990-1026): own-pixel state, mask
+            // bit, and the record the per-cell gather below reads ----
+            bool ok = false;
+            if (tid < 256) {
+                const int state = S.d_ok[tid];
+                if (state != 0) {
+                    const int tx = tid & 31, ty = tid >> 5;
+                    const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
+                    const int mcx = px / 5 - bx0, mcy = py / 5 - by0;
+                    const uint32_t bit = 1u << ((px % 5) + (py % 5) * 5);
+                    if (state == 1) {
+                        ok = true;
+                        const int idx = py * L.rs + px;
+                        const float2 v = L.v[idx], ol = L.luma[idx], st = S.d_step[tid];
+                        const float2 newv = make_float2(v.x + st.x, v.y + st.y);
+                        const float lx = tap(L.img0, L.w, L.h, L.rs, px - newv.x + 0.5f, py - newv.y + 0.5f);
+                        const float ly = tap(L.img1, L.w, L.h, L.rs, px + newv.x + 0.5f, py + newv.y + 0.5f);
+                        L.luma[idx] = make_float2(lx, ly);
+                        S.d_mean[tid] = make_float2(lx - ol.x, ly - ol.y);
+                        S.d_var[tid] = make_float2(lx * lx - ol.x * ol.x, ly * ly - ol.y * ol.y);
+                        S.d_cross[tid] = lx * ly - ol.x * ol.y;
+                        const float axy = L.ui_axy[idx];
+                        const float2 ub = L.ui_b[idx];
+                        L.ui_b[idx] = make_float2(ub.x + 2 * st.x * axy, ub.y + 2 * st.y * axy);
+                        L.v[idx] = newv;
+                        atomicOr(&S.mask[mcy][mcx], bit);
+                    } else {
+                        atomicAnd(&S.mask[mcy][mcx], ~bit);
+                    }
+                }
             }
-            const bool any = __syncthreads_or(ok);
-            if (any) {
+            if (tid == 0)
+                S.n_act = 0;
+            const int ncommit = __syncthreads_count(ok);
+            if (ncommit) {
                 improving = true;
+                st_commit += ncommit;
                 // ssim_update (morph.cu:951-988) + the tps.b scatter (:1006-1015) as
                 // a gather: every tile+halo cell adds the records of the committed
                 // pixels whose 5x5 window contains it, in row-major order of those
                 // pixels; then UpdateSSIM (:1258-1279)
-                for (int cell = tid; cell < VM_NCELL; cell += 256) {
+                for (int cell = tid; cell < VM_NCELL; cell += T) {
                     const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2; // tile-relative
                     const int qx = ox + rx, qy = oy + ry;
                     if (qx < 0 || qx >= L.w || qy < 0 || qy >= L.h)
@@ -550,7 +723,7 @@ __global__ __launch_bounds__(256) void SUF(k_optimize)(VmLevelView L, VmKParams 
                     for (int y = ylo; y <= yhi; y += 2)
                         for (int x = xlo; x <= xhi; x += 2) {
                             const int rec = (y >> 1) * 32 + (x >> 1);
-                            if (!S.d_ok[rec])
+                            if (S.d_ok[rec] != 1)
                                 continue;
                             touched = true;
                             const float2 dm = S.d_mean[rec], dv = S.d_var[rec], st = S.d_step[rec];
@@ -580,7 +753,7 @@ __global__ __launch_bounds__(256) void SUF(k_optimize)(VmLevelView L, VmKParams 
 
     // ---- SaveSSIM (morph.cu:1236-1256), tps.b and the owned mask words ----
     if (improving) {
-        for (int c = tid; c < VM_NCELL; c += 256) {
+        for (int c = tid; c < VM_NCELL; c += T) {
             int gx = ox - 2 + c % VM_HALO_W, gy = oy - 2 + c / VM_HALO_W;
             if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h)
                 continue;
@@ -598,8 +771,14 @@ __global__ __launch_bounds__(256) void SUF(k_optimize)(VmLevelView L, VmKParams 
         if (mx >= 1 && mx <= nbx - 2 && my >= 1 && my <= nby - 2)
             L.impmask[(by0 + my + 1) * L.imp_rs + (bx0 + mx + 1)] = S.mask[my][mx];
     }
-    if (improving && tid == 0)
-        atomicOr(&flags[iter_idx], 1u);
+    if (tid == 0) {
+        if (improving)
+            atomicOr(&flags[iter_idx], 1u);
+        // per-iteration activity counters: active tiles, candidate visits, commits
+        atomicAdd(&stats[iter_idx * 4 + 0], 1u);
+        atomicAdd(&stats[iter_idx * 4 + 1], st_cand);
+        atomicAdd(&stats[iter_idx * 4 + 2], st_commit);
+    }
 }
 
 } // namespace
@@ -615,12 +794,12 @@ void SUF(vm_launch_init_level)(const VmLevelView &L, float ssim_clamp, const uin
 }
 
 void SUF(vm_launch_optimize)(const VmLevelView &L, const VmKParams &P, const uint32_t *tables,
-                             int offx, int offy, uint32_t *flags, int iter_idx, int fixed_work,
-                             hipStream_t s)
+                             int offx, int offy, uint32_t *flags, uint32_t *stats, int iter_idx,
+                             int fixed_work, int threads, hipStream_t s)
 {
-    dim3 b(256), g((L.w + VM_PITCH_X - 1) / VM_PITCH_X, (L.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
-    hipLaunchKernelGGL(SUF(k_optimize), g, b, 0, s, L, P, tables, offx, offy, flags, iter_idx,
-                       fixed_work);
+    dim3 b(threads), g((L.w + VM_PITCH_X - 1) / VM_PITCH_X, (L.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
+    hipLaunchKernelGGL(SUF(k_optimize), g, b, 0, s, L, P, tables, offx, offy, flags, stats,
+                       iter_idx, fixed_work);
 }
 
 void SUF(vm_launch_upsample)(float2 *dst, int dw, int dh, int drs, const float2 *src, int sw,
