@@ -75,18 +75,18 @@ def main():
     from videomorphing_amd import capi, morph, synth
 
     # ---- the shared parameter block: rank 0 decides, one RCCL broadcast ----
+    from videomorphing_amd import dist as vdist
     blk = capi.ParamBlock()
     if rank == 0:
         P = morph.Parameters()
         blk.kp = morph.KernParameters(P)
         blk.max_iter, blk.max_iter_drop_factor, blk.start_res = MAX_ITER, DROP, START_RES
         blk.math_mode = capi.MATH_FAST if args.math == "fast" else capi.MATH_EXACT
-        blk.n_constraints = 0
-    raw = np.frombuffer(bytes(blk), dtype=np.uint8).copy()
-    t = torch.from_numpy(raw).cuda()
+    raw = vdist.pack_block(blk)
     if world > 1:
-        dist.broadcast(t, src=0)     # backend "nccl" is RCCL on ROCm (xGMI within the node)
-    C.memmove(C.addressof(blk), t.cpu().numpy().tobytes(), C.sizeof(blk))
+        # backend "nccl" is RCCL on ROCm (xGMI within the node)
+        raw = vdist.broadcast_block(raw, torch.device("cuda", local_rank))
+    blk, _cons = vdist.unpack_block(raw)
 
     ctx = morph.Context(local_rank, blk.math_mode)
     ctx.set_params(blk.kp)
@@ -136,13 +136,8 @@ def main():
             alg_bytes += pr[i].iters * tile_visits(*sizes[i]) * ALG_BYTES_PER_VISIT
     iters_per_level = [[pr[i].iters for i in range(nlev - 1)] for pr in progs]
 
-    stats = torch.tensor([el, pix_iters], dtype=torch.float64, device="cuda")
     if world > 1:
-        tmax = stats.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = stats.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        el_max, pix_total = tmax[0].item(), tsum[1].item()
+        el_max, pix_total = vdist.reduce_report(el, pix_iters, torch.device("cuda", local_rank))
     else:
         el_max, pix_total = el, pix_iters
 
@@ -171,7 +166,7 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(np, synth, blk)
+        cpu = cpu_baseline(np, synth, blk, pyrs[args.warmup])
 
     if rank == 0:
         avg_launch_us = kern_ms * 1e3 / max(launches, 1)
@@ -211,37 +206,38 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(np, synth, blk):
-    """The CPU restatement (oracle, OpenMP over tiles) timed on this host: a bounded
-    sample of the same workload -- the 480x270 level of the same pyramid, started
-    from the upsampled solution of the coarser levels, for a fixed number of sweeps."""
+def cpu_baseline(np, synth, blk, gpu_pyr):
+    """The CPU restatement (oracle, OpenMP over tiles) timed on this host on a bounded
+    sample of the same workload: the first sweeps of the finest (1920x1080) level of
+    the solve just timed, started -- like the GPU path -- from the upsampled solution
+    of the 960x540 level."""
     import oracle as O
     threads = os.cpu_count() or 1
     O.lib().vmo_set_threads(threads)
-    i0, i1 = synth.make_pair(W, H, frame=0)
-    pyr = synth.build_pyramid(i0, i1, synth.num_levels(W, H, START_RES))
     P = O.default_params()
     for f, _ in P._fields_:
         setattr(P, f, getattr(blk.kp, f))
-    # coarse levels (cheap) to get a realistic start, then time the 480x270 level
-    lv = O.solve(pyr[3:], P, 200, 1.0, threads=threads)     # 240x135 .. 60x34
-    tgt = O.Level(pyr[2][0].shape[1], pyr[2][0].shape[0])
-    tgt.set_images(*pyr[2])
-    tgt.upsample_from(lv)
+    w, h = gpu_pyr[1].width, gpu_pyr[1].height
+    frame_imgs = gpu_pyr[1].field("img0"), gpu_pyr[1].field("img1")
+    coarse = O.Level(gpu_pyr[2].width, gpu_pyr[2].height)
+    coarse.field("v")[...] = gpu_pyr[2].v
+    tgt = O.Level(w, h)
+    tgt.set_images(*frame_imgs)
+    tgt.upsample_from(coarse)
     tgt.init(P.ssim_clamp)
     stats = np.zeros(4)
     t0 = time.perf_counter()
     iters = 0
-    while time.perf_counter() - t0 < 12.0 and iters < 500:
+    while time.perf_counter() - t0 < 12.0 and iters < int(blk.max_iter):
         imp = tgt.optimize_iter(P, stats)
         iters += 1
         if not imp:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(tgt.w * tgt.h * iters / dt / 1e6, 3), "unit": "Mpixel*iters/s",
+    return {"value": round(w * h * iters / dt / 1e6, 3), "unit": "Mpixel*iters/s",
             "cores": threads, "kind": "port",
-            "sample": "%d sweeps of the %dx%d level of the same pyramid (oracle, OpenMP over tiles), %.1f s"
-                      % (iters, tgt.w, tgt.h, dt)}
+            "sample": "first %d sweeps of the %dx%d level of the same solve (oracle, OpenMP over tiles, "
+                      "%d threads), %.1f s; %.0f energy evaluations" % (iters, w, h, threads, dt, stats[3])}
 
 
 if __name__ == "__main__":

@@ -633,6 +633,21 @@ static void optimize_pixel(const vmo_level *l, const vmo_params *P, int px, int 
     }
 }
 
+float vmo_dbg_foldover(const vmo_level *l, const vmo_params *P, int px, int py, float gx, float gy)
+{
+    int idx = py * l->w + px;
+    return prevent_foldover(l, P, px, py, l->v[2 * idx], l->v[2 * idx + 1], gx, gy);
+}
+
+float vmo_dbg_energy_change(const vmo_level *l, const vmo_params *P, int px, int py, float dx, float dy)
+{
+    tables_init();
+    sweep_stats st = {0, 0, 0, 0};
+    int idx = py * l->w + px;
+    return energy_change(l, P, px, py, l->v[2 * idx], l->v[2 * idx + 1],
+                         l->luma[2 * idx], l->luma[2 * idx + 1], dx, dy, &st);
+}
+
 /* One thread block of kernel_optimize_level, morph.cu:1281-1345: the 64x16
  * tile whose first pixel is (ox,oy); 4 phases, each Jacobi on the pre-phase
  * state, commits applied in row-major order of the committing pixels

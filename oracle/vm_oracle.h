@@ -143,6 +143,11 @@ int  vmo_poisson_prepare(uint8_t *rgba_ext, int w, int h, int ex,
                          const uint8_t *other, const float *v, int side,
                          int *type_out);
 
+/* test hooks: prevent_foldover (morph.cu:872-883) and energy_change (:730-761)
+ * evaluated at one pixel of an initialised level */
+float vmo_dbg_foldover(const vmo_level *l, const vmo_params *p, int px, int py, float gx, float gy);
+float vmo_dbg_energy_change(const vmo_level *l, const vmo_params *p, int px, int py, float dx, float dy);
+
 void vmo_set_threads(int n);   /* OpenMP threads for the timed CPU baseline */
 int  vmo_get_threads(void);
 

@@ -103,6 +103,10 @@ def lib():
     L.vmo_poisson_prepare.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_void_p]
     L.vmo_poisson_prepare.restype = C.c_int
+    L.vmo_dbg_foldover.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_float, C.c_float]
+    L.vmo_dbg_foldover.restype = C.c_float
+    L.vmo_dbg_energy_change.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_float, C.c_float]
+    L.vmo_dbg_energy_change.restype = C.c_float
     L.vmo_set_threads.argtypes = [C.c_int]
     L.vmo_set_threads.restype = None
     L.vmo_get_threads.restype = C.c_int

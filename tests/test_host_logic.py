@@ -1,0 +1,122 @@
+"""Host-side logic of the mirror API and the bench accounting (CPU only)."""
+import numpy as np
+
+import bench
+from videomorphing_amd import capi, dist, morph, synth
+
+
+def test_level_geometry_tables_of_the_survey():
+    # level geometry of the BASELINE configs
+    def sizes(w, h, start_res):
+        n = synth.num_levels(w, h, start_res)
+        out = [(w, h)]
+        for _ in range(n - 1):
+            w, h = (w + 1) // 2, (h + 1) // 2
+            out.append((w, h))
+        return out
+    assert sizes(256, 256, 64) == [(256, 256), (128, 128), (64, 64)]
+    assert sizes(1920, 1080, 32) == [(1920, 1080), (960, 540), (480, 270), (240, 135), (120, 68), (60, 34)]
+    assert sizes(3840, 2160, 32) == [(3840, 2160), (1920, 1080), (960, 540), (480, 270), (240, 135),
+                                     (120, 68), (60, 34)]
+    i0, i1 = synth.make_pair(97, 61)
+    pyr = synth.build_pyramid(i0, i1, 3)
+    assert [p[0].shape for p in pyr] == [(61, 97), (31, 49), (16, 25)]
+
+
+def test_synthetic_inputs_are_deterministic_and_in_range():
+    a0, a1 = synth.make_pair(80, 48, frame=2)
+    b0, b1 = synth.make_pair(80, 48, frame=2)
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1)
+    assert a0.dtype == np.float32 and 16 <= a0.min() and a0.max() <= 240 and a0.std() > 20
+    c0, _ = synth.make_pair(80, 48, frame=3)
+    assert not np.array_equal(a0, c0)
+    d = synth.displacement(1920, 1080)
+    assert abs(np.abs(d).max() - 19.2) < 0.05           # A = 0.01 W
+    cons = synth.make_constraints(1920, 1080, 8)
+    assert cons.shape == (8, 5) and np.all(cons[:, 4] == 1) and np.all(cons[:, :4] == np.rint(cons[:, :4]))
+
+
+def test_parameters_mirror_defaults_and_constraint_resolution():
+    P = morph.Parameters()          # UI/MdiEditor.cpp:131-140
+    assert (P.w_ssim, P.ssim_clamp, P.w_tps, P.w_ui, P.w_temp) == (100.0, 0.0, 0.05, 1e5, 10.0)
+    assert (P.max_iter, P.max_iter_drop_factor, P.eps, P.start_res, P.bcond) == (1000, 2.0, 0.01, 8, 0)
+    kp = morph.KernParameters(P)
+    assert [getattr(kp, f) for f, _ in capi.KernParams._fields_][:6] == [
+        10.0, np.float32(1e5), np.float32(0.05), 100.0, 0.0, np.float32(0.01)]
+    # tracks with one point per frame; only connections whose left point sits on page 0 count
+    P.lp = [[morph.Conp(10, 20, 0, 1, 1.0), morph.Conp(11, 21, 1, 0, 0.4)]]
+    P.rp = [[morph.Conp(14, 22, 0, 1, 0.6), morph.Conp(15, 23, 1, 0, 0.9)]]
+    P.cnt = [[morph.Connect((0, 0), (0, 0)), morph.Connect((0, 1), (0, 1))]]
+    c = P.constraints(0)
+    assert c.shape == (1, 5) and c[0].tolist() == [10, 20, 14, 22, np.float32(0.6)]
+    assert P.constraints(1)[0].tolist() == [11, 21, 15, 23, np.float32(0.4)]
+    P2 = morph.Parameters()
+    P2.add_point_pair(1, 2, 3, 4, 0.5)
+    assert P2.constraints(0).tolist() == [[1, 2, 3, 4, 0.5]]
+
+
+class _FakeLevel(object):
+    def __init__(self, w, h):
+        self.width, self.height, self.depth = w, h, 1
+
+
+class _FakePyramid(object):
+    def __init__(self, sizes):
+        self._lv = [_FakeLevel(*sizes[0])] + [_FakeLevel(*s) for s in sizes]
+
+    def size(self):
+        return len(self._lv)
+
+    def __getitem__(self, i):
+        return self._lv[i]
+
+
+def test_morph_progress_accounting_follows_the_reference_ctor():
+    """Morph ctor, morph.cu:122-141: _total_iter sums iter_num*W*H over the optimised
+    levels with iter_num divided by the drop factor from coarse to fine"""
+    P = morph.Parameters()
+    P.max_iter, P.max_iter_drop_factor = 1000, 2.0
+    pyr = _FakePyramid([(256, 256), (128, 128), (64, 64)])
+    m = morph.Morph(P, pyr)
+    assert m._total_l == 3 and m._current_l == 3 and m._max_iter == 1000.0
+    assert m._total_iter == 1000 * 128 * 128 + 500 * 256 * 256
+
+
+def test_make_extended_canvas():
+    rgb = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)
+    can = morph.make_extended(rgb, 2)      # pyramid.cu:186-200
+    assert can.shape == (6, 7, 4) and can[0, 0].tolist() == [255, 255, 255, 255]
+    assert np.array_equal(can[2:4, 2:5, :3], rgb) and can[2:4, 2:5, 3].max() == 0
+
+
+def test_bench_algorithmic_byte_accounting():
+    # visits per pixel per iteration -> 4*64*16/(69*21) = 2.827 for large levels
+    v = bench.tile_visits(1920, 1080)
+    assert abs(v / (1920.0 * 1080.0) - 2.827) < 0.06   # 2.775: edge tiles are clipped
+    # brute force on a small level
+    w, h = 150, 50
+    cnt = 0
+    for ox in (0, 64):
+        for oy in (0, 16):
+            for bx in range((w + 68) // 69):
+                for by in range((h + 20) // 21):
+                    for y in range(by * 21 + oy, by * 21 + oy + 16):
+                        for x in range(bx * 69 + ox, bx * 69 + ox + 64):
+                            cnt += int(x < w and y < h)
+    assert bench.tile_visits(w, h) == cnt
+
+
+def test_param_block_roundtrip_and_sharding():
+    blk = capi.ParamBlock()
+    blk.kp = morph.KernParameters(morph.Parameters())
+    blk.max_iter, blk.max_iter_drop_factor, blk.start_res, blk.math_mode = 500.0, 1.0, 32, 1
+    cons = synth.make_constraints(1920, 1080, 8)
+    raw = dist.pack_block(blk, cons)
+    b2, c2 = dist.unpack_block(raw)
+    assert bytes(b2) == bytes(blk) and np.array_equal(c2, cons) and b2.n_constraints == 8
+    # 60 pairs over 8 GPUs: blocks of 7 or 8, every pair exactly once
+    shards = [dist.shard_pairs(60, 8, r) for r in range(8)]
+    assert sorted(sum(shards, [])) == list(range(60))
+    assert set(len(s) for s in shards) <= {7, 8}
+    assert all(s == list(range(s[0], s[-1] + 1)) for s in shards)
+    assert dist.shard_pairs(30, 4, 3) == list(range(23, 30))
