@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--math", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--semantics", default="fixed", choices=["fixed", "reference"],
+                    help="fixed: every level runs its max_iter sweeps (BASELINE config: 500 iters/level); "
+                         "reference: a level stops when no pixel improved (morph.cu:1390)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--size", default=None, help="WxH override (debug only; invalid as a result)")
@@ -104,7 +107,9 @@ def main():
         pyrs.append(p)
     sizes = [(pyrs[0][el].width, pyrs[0][el].height) for el in range(1, nlev + 1)]
 
-    def solve(p, fixed=0):
+    FIXED = 1 if args.semantics == "fixed" else 0
+
+    def solve(p, fixed=FIXED):
         prog = (capi.Progress * (nlev - 1))()
         capi.check(L.vm_solve(p._h, blk.max_iter, blk.max_iter_drop_factor, None, 0, None, fixed, prog))
         return prog
@@ -135,6 +140,10 @@ def main():
             # launches enqueued past convergence exit at once: count executed iterations only
             alg_bytes += pr[i].iters * tile_visits(*sizes[i]) * ALG_BYTES_PER_VISIT
     iters_per_level = [[pr[i].iters for i in range(nlev - 1)] for pr in progs]
+    activity = {"active_tile_visits": sum(pr[i].active_tiles for pr in progs for i in range(nlev - 1)) / len(progs),
+                "line_searches": sum(pr[i].candidates for pr in progs for i in range(nlev - 1)) / len(progs),
+                "commits": sum(pr[i].commits for pr in progs for i in range(nlev - 1)) / len(progs),
+                "pixel_visits": sum(pr[i].iters * tile_visits(*sizes[i]) for pr in progs for i in range(nlev - 1)) / len(progs)}
 
     if world > 1:
         el_max, pix_total = vdist.reduce_report(el, pix_iters, torch.device("cuda", local_rank))
@@ -143,10 +152,13 @@ def main():
 
     extras = {}
     if rank == 0 and not args.no_extras:
-        # fixed-work (no convergence exit) and EXACT-arithmetic rates, one solve each
+        # the other stopping rule and the other arithmetic mode, one solve each
         p = pyrs[0]
-        ctx.sync(); t1 = time.perf_counter(); pr = solve(p, fixed=1); ctx.sync(); dt = time.perf_counter() - t1
-        extras["fixed_work_mpix_iters_per_s"] = round(sum(pr[i].pixel_iters for i in range(nlev - 1)) / dt / 1e6, 2)
+        ctx.sync(); t1 = time.perf_counter(); pr = solve(p, fixed=1 - FIXED); ctx.sync(); dt = time.perf_counter() - t1
+        extras["%s_semantics" % ("reference" if FIXED else "fixed")] = {
+            "mpix_iters_per_s": round(sum(pr[i].pixel_iters for i in range(nlev - 1)) / dt / 1e6, 2),
+            "ms_per_solve": round(dt * 1e3, 2),
+            "iters_per_level_fine_to_coarse": [pr[i].iters for i in range(nlev - 1)]}
         other = capi.MATH_EXACT if blk.math_mode == capi.MATH_FAST else capi.MATH_FAST
         ctx.set_math_mode(other)
         ctx.sync(); t1 = time.perf_counter(); pr = solve(p); ctx.sync(); dt = time.perf_counter() - t1
@@ -189,7 +201,8 @@ def main():
             "config": {"workload": "config[1]: %dx%d frame pair, %d-level pyramid (start_res %d), max_iter %d/level, drop %g, one pair per step per GPU"
                                    % (w, h, nlev, blk.start_res, int(blk.max_iter), blk.max_iter_drop_factor),
                        "math_mode": "fast" if blk.math_mode == capi.MATH_FAST else "exact",
-                       "semantics": "reference (stop when no pixel improves)",
+                       "semantics": "fixed work: every sweep of every level is launched" if FIXED
+                                    else "reference: a level stops when no pixel improved",
                        "iters_per_level_fine_to_coarse": iters_per_level[0],
                        "parallelism": "independent frame pairs, %d rank(s), 1 RCCL broadcast" % world},
             "roofline": {"bound": "hbm", "kernel": "k_optimize (sweep)",
@@ -199,6 +212,7 @@ def main():
                          "alg_bytes_per_pixel_visit": ALG_BYTES_PER_VISIT},
             "cpu_baseline": cpu,
         }
+        out["activity_per_solve"] = {k: round(v) for k, v in activity.items()}
         out.update(extras)
         print(json.dumps(out), flush=True)
     if world > 1:

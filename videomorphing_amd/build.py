@@ -16,7 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvmorph_hip.so")
 ARCH = "gfx950"
 
-COMMON = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+COMMON = os.environ.get("VM_DEFS", "").split() + ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
           "-I" + os.path.join(HERE, "..", "include")]
 
 # (source, object, extra flags)

@@ -58,7 +58,8 @@ __device__ __forceinline__ int window_count(int p, int dim)
     return min(p, 2) + min(dim - 1 - p, 2) + 1;
 }
 
-// ssim(), morph.cu:85-118
+#if VM_EXACT
+// ssim(), morph.cu:85-118, literally
 __device__ __forceinline__ float ssim_value(float mx, float my, float vx, float vy, float cross,
                                             float counter, float clamp)
 {
@@ -79,6 +80,40 @@ __device__ __forceinline__ float ssim_value(float mx, float my, float vx, float 
     float value = c * s;
     return fmaxf(fminf(1.0f, value), clamp);
 }
+#else
+// FAST form of ssim(): a, b = window means (sum * 1/n); sx2, sy2, sxy = raw second
+// moment sums; n the window count, in = 1/n.  The variances are formed as
+// (sum - n a a) / n like the reference does -- measured: forming them from
+// pre-divided sums (E[x^2] - a^2) quantises the line search's tiny energy
+// differences enough to cost 6 % of SSIM energy after 86 sweeps -- but with one
+// rcp and one sqrt per evaluation:
+//   c*s = (2 sx sy + c2)(|cov| + c3) / ((sx^2 + sy^2 + c2)(sx sy + c3)),  sx sy = sqrt(vx vy)
+// Every SSIM value of FAST mode (stored ones and the trial ones of the line
+// search) comes from this one function.
+__device__ __forceinline__ float ssim_core(float a, float b, float sx2, float sy2, float sxy,
+                                           float n, float in, float clamp)
+{
+    const float c2 = 58.5225f, c3 = 29.26125f;
+    const float na = n * a, nb = n * b;
+    const float vx = fmaxf(fmaf(-na, a, sx2) * in, 0.0f);
+    const float vy = fmaxf(fmaf(-nb, b, sy2) * in, 0.0f);
+    const float cov = fmaf(-na, b, sxy) * in;
+    const float ss = __builtin_amdgcn_sqrtf(vx * vy);
+    const float num = fmaf(2.0f, ss, c2) * (fabsf(cov) + c3);
+    const float den = (vx + vy + c2) * (ss + c3);
+    const float val = num * __builtin_amdgcn_rcpf(den);
+    return fmaxf(fminf(val, 1.0f), clamp);
+}
+
+__device__ __forceinline__ float ssim_value(float mx, float my, float vx, float vy, float cross,
+                                            float counter, float clamp)
+{
+    if (counter <= 1)
+        return 0;
+    const float in = __builtin_amdgcn_rcpf(counter);
+    return ssim_core(mx * in, my * in, vx, vy, cross, counter, in, clamp);
+}
+#endif
 
 // tex2D(linear, clamp, unnormalised) on a pitched f32 image: texel centres at
 // i+0.5 (morph.cu:316-322); exact float weights
@@ -339,9 +374,13 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
 // their sums, pre-divided by the window count, in registers.
 #define VM_SMAX 7
 #define VM_MIN_FANOUT 4
+#ifndef VM_MAX_FANOUT
 #define VM_MAX_FANOUT 32
+#endif
 struct NbCache {
-    float A[VM_SMAX], B[VM_SMAX], VX[VM_SMAX], VY[VM_SMAX], X[VM_SMAX], IN[VM_SMAX], M[VM_SMAX];
+    float A[VM_SMAX], B[VM_SMAX];                   // window means (sum / n)
+    float VX[VM_SMAX], VY[VM_SMAX], X[VM_SMAX];       // raw second-moment sums
+    float N[VM_SMAX], IN[VM_SMAX], M[VM_SMAX];         // count, 1/count, validity
     float VAL[VM_SMAX]; // current SSIM value of the neighbour (the differences value - new
                         // are summed, as the reference does: they are 1e-3..1e-6 of the values)
 };
@@ -393,9 +432,10 @@ __device__ __forceinline__ void nb_load(NbCache &nb, const VmLevelView &L, const
         const float2 m = S.mean[cell], q = S.var[cell];
         nb.A[j] = m.x * in;
         nb.B[j] = m.y * in;
-        nb.VX[j] = q.x * in;
-        nb.VY[j] = q.y * in;
-        nb.X[j] = S.cross[cell] * in;
+        nb.VX[j] = q.x;
+        nb.VY[j] = q.y;
+        nb.X[j] = S.cross[cell];
+        nb.N[j] = n;
         nb.IN[j] = in;
         nb.M[j] = ok ? 1.0f : 0.0f;
         nb.VAL[j] = S.value[cell];
@@ -413,21 +453,14 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
     const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
     const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
     const float dcross = lx * ly - c.old_luma.x * c.old_luma.y;
-    const float c2 = 58.5225f, c3 = 29.26125f;
     float acc = 0;
 #pragma unroll
     for (int j = 0; j < VM_SMAX; ++j) {
         if (j * Lf < 25) { // uniform in the workgroup
             const float in = nb.IN[j];
-            const float a = fmaf(dmx, in, nb.A[j]), b = fmaf(dmy, in, nb.B[j]);
-            const float sx = fmaxf(fmaf(-a, a, fmaf(dvx, in, nb.VX[j])), 0.0f);
-            const float sy = fmaxf(fmaf(-b, b, fmaf(dvy, in, nb.VY[j])), 0.0f);
-            const float cov = fmaf(-a, b, fmaf(dcross, in, nb.X[j]));
-            const float ss = __builtin_amdgcn_sqrtf(sx * sy);
-            const float num = fmaf(2.0f, ss, c2) * (fabsf(cov) + c3);
-            const float den = (sx + sy + c2) * (ss + c3);
-            float val = num * __builtin_amdgcn_rcpf(den);
-            val = fmaxf(fminf(val, 1.0f), P.ssim_clamp);
+            const float val = ssim_core(fmaf(dmx, in, nb.A[j]), fmaf(dmy, in, nb.B[j]),
+                                        nb.VX[j] + dvx, nb.VY[j] + dvy, nb.X[j] + dcross,
+                                        nb.N[j], in, P.ssim_clamp);
             acc = fmaf(nb.M[j], nb.VAL[j] - val, acc);
         }
     }
