@@ -220,13 +220,31 @@ def main():
         dist.destroy_process_group()
 
 
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(np, synth, blk, gpu_pyr):
     """The CPU restatement (oracle, OpenMP over tiles) timed on this host on a bounded
     sample of the same workload: the first sweeps of the finest (1920x1080) level of
     the solve just timed, started -- like the GPU path -- from the upsampled solution
     of the 960x540 level."""
     import oracle as O
-    threads = os.cpu_count() or 1
+    threads = effective_cpus()
     O.lib().vmo_set_threads(threads)
     P = O.default_params()
     for f, _ in P._fields_:
