@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--semantics", default="fixed", choices=["fixed", "reference"],
                     help="fixed: every level runs its max_iter sweeps (BASELINE config: 500 iters/level); "
                          "reference: a level stops when no pixel improved (morph.cu:1390)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="independent frame pairs solved concurrently per GPU (one HIP stream and one "
+                         "host thread each); 1 = one pair at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--size", default=None, help="WxH override (debug only; invalid as a result)")
@@ -91,8 +94,11 @@ def main():
         raw = vdist.broadcast_block(raw, torch.device("cuda", local_rank))
     blk, _cons = vdist.unpack_block(raw)
 
-    ctx = morph.Context(local_rank, blk.math_mode)
-    ctx.set_params(blk.kp)
+    nctx = max(1, args.inflight)
+    ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(nctx)]
+    for c in ctxs:
+        c.set_params(blk.kp)
+    ctx = ctxs[0]
     L = capi.load()
 
     # ---- inputs: K+W independent frame pairs per rank, pyramids resident in HBM ----
@@ -102,7 +108,7 @@ def main():
     for k in range(npairs):
         frame = rank * npairs + k
         i0, i1 = synth.make_pair(w, h, frame=frame)
-        p = morph.Pyramid(ctx)
+        p = morph.Pyramid(ctxs[k % nctx])
         p.build(i0, i1, blk.start_res, nlevels=nlev)
         pyrs.append(p)
     sizes = [(pyrs[0][el].width, pyrs[0][el].height) for el in range(1, nlev + 1)]
@@ -114,19 +120,38 @@ def main():
         capi.check(L.vm_solve(p._h, blk.max_iter, blk.max_iter_drop_factor, None, 0, None, fixed, prog))
         return prog
 
+    def run_steps(ps):
+        """solve the pyramids; with several contexts, one host thread per context works
+        through that context's pyramids (a vm_ctx is single-threaded by contract)"""
+        if nctx == 1:
+            return [solve(p) for p in ps]
+        from concurrent.futures import ThreadPoolExecutor
+        groups = {}
+        for i, p in enumerate(ps):
+            groups.setdefault(id(p._ctx), []).append((i, p))
+        out = [None] * len(ps)
+
+        def work(items):
+            for i, p in items:
+                out[i] = solve(p)
+        with ThreadPoolExecutor(max_workers=len(groups)) as ex:   # ctypes calls release the GIL
+            list(ex.map(work, groups.values()))
+        return out
+
     def sync_all():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        solve(pyrs[k])
+    run_steps(pyrs[:args.warmup])
     sync_all()
     t0 = time.perf_counter()
-    progs = [solve(pyrs[args.warmup + k]) for k in range(args.steps)]
-    ctx.sync()
+    progs = run_steps(pyrs[args.warmup:])
+    for c in ctxs:
+        c.sync()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     sync_all()
@@ -204,6 +229,7 @@ def main():
                        "semantics": "fixed work: every sweep of every level is launched" if FIXED
                                     else "reference: a level stops when no pixel improved",
                        "iters_per_level_fine_to_coarse": iters_per_level[0],
+                       "pairs_in_flight_per_gpu": nctx,
                        "parallelism": "independent frame pairs, %d rank(s), 1 RCCL broadcast" % world},
             "roofline": {"bound": "hbm", "kernel": "k_optimize (sweep)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

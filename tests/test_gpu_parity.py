@@ -84,6 +84,46 @@ def test_sweep_exact(gpu_ctx, oracle, w, h, iters):
         _assert_state_equal(lo, pyr[1])
 
 
+@pytest.mark.parametrize("w,h,parts,threads", [(96, 64, 8, 1024), (150, 97, 3, 256), (69, 21, 1, 512), (200, 40, 5, 1024)])
+def test_sweep_exact_split_schedule(gpu_ctx, oracle, w, h, parts, threads):
+    """the SPLIT schedule (decide/commit kernels, a tile's candidates spread over `parts`
+    workgroups) gives the same bits as the oracle, and mixing schedules between calls
+    is seamless (both work on the same state in HBM)"""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    cons = synth.make_constraints(w, h, 4)
+    P = _params(oracle, bcond=capi.BCOND_BORDER)
+    lo, pyr, P = _make_level(gpu_ctx, oracle, w, h, cons=cons, P=P)
+    try:
+        for it, mode in enumerate([capi.SWEEP_SPLIT, capi.SWEEP_SPLIT, capi.SWEEP_TILE, capi.SWEEP_SPLIT]):
+            gpu_ctx.set_tuning(mode, threads, parts)
+            imp_o = lo.optimize_iter(P)
+            pr = capi.Progress()
+            capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 1.0, None, 0, C.byref(pr)))
+            assert pr.iters == 1 and pr.improving == imp_o and pr.commits > 0
+            _assert_state_equal(lo, pyr[1])
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+
+
+def test_fast_split_matches_fast_tile_statistically(gpu_ctx, oracle):
+    """FAST: the two schedules differ only in lane fan-out (tree-sum order); after 20
+    sweeps their fields agree to RMS <= 0.01 px"""
+    w, h = 120, 68
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    res = []
+    try:
+        for mode in (capi.SWEEP_TILE, capi.SWEEP_SPLIT):
+            gpu_ctx.set_tuning(mode, 0, 0)
+            lo, pyr, P = _make_level(gpu_ctx, oracle, w, h)
+            capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 20.0, None, 0, None))
+            res.append(pyr[1].v)
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    dv = np.sqrt(((res[0] - res[1]) ** 2).sum(-1))
+    assert np.sqrt((dv ** 2).mean()) <= 0.01 and dv.max() < 0.1, (np.sqrt((dv ** 2).mean()), dv.max())
+
+
 @pytest.mark.parametrize("bcond", [capi.BCOND_NONE, capi.BCOND_CORNER, capi.BCOND_BORDER])
 def test_sweep_exact_constraints_bcond(gpu_ctx, oracle, bcond):
     gpu_ctx.set_math_mode(capi.MATH_EXACT)

@@ -23,6 +23,8 @@ COMMON = os.environ.get("VM_DEFS", "").split() + ["-O3", "-fPIC", "-std=c++17", 
 UNITS = [
     ("vm_morph_kernels.hip", "vm_morph_kernels_exact.o", ["-DVM_EXACT=1", "-ffp-contract=off"]),
     ("vm_morph_kernels.hip", "vm_morph_kernels_fast.o", ["-DVM_EXACT=0", "-ffp-contract=fast"]),
+    ("vm_sweep_kernels.hip", "vm_sweep_kernels_exact.o", ["-DVM_EXACT=1", "-ffp-contract=off"]),
+    ("vm_sweep_kernels.hip", "vm_sweep_kernels_fast.o", ["-DVM_EXACT=0", "-ffp-contract=fast"]),
     ("vm_render.hip", "vm_render.o", ["-ffp-contract=off"]),
     ("vm_poisson.hip", "vm_poisson.o", ["-ffp-contract=off"]),
     ("vm_api.cpp", "vm_api.o", ["-x", "hip"]),

@@ -169,6 +169,17 @@ extern "C" int vm_set_math_mode(vm_ctx *c, int mode)
     return VM_OK;
 }
 
+extern "C" int vm_set_tuning(vm_ctx *c, int sweep_mode, int threads, int parts)
+{
+    if (!c || sweep_mode < VM_SWEEP_AUTO || sweep_mode > VM_SWEEP_SPLIT || threads < 0 || parts < 0 ||
+        (threads && (threads % 64 || threads < 256 || threads > 1024)) || parts > 64)
+        return vm_fail(VM_E_INVALID, "vm_set_tuning: bad argument");
+    c->sweep_mode = sweep_mode;
+    c->sweep_threads = threads;
+    c->sweep_parts = parts;
+    return VM_OK;
+}
+
 extern "C" int vm_device_info(vm_ctx *c, char *name256, int *cus, uint64_t *hbm)
 {
     if (!c) return vm_fail(VM_E_INVALID, "ctx is NULL");
@@ -196,7 +207,7 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
     size_t off = 0;
     size_t o_v = off; off += al(n * 8);
     size_t o_img0 = off, o_img1 = off, o_luma = off, o_mean = off, o_var = off, o_tpsb = off,
-           o_uib = off, o_cross = off, o_value = off, o_uiaxy = off, o_imp = off;
+           o_uib = off, o_cross = off, o_value = off, o_uiaxy = off, o_imp = off, o_rst = off, o_rsp = off;
     if (with_images) {
         o_img0 = off; off += al(n * 4);
         o_img1 = off; off += al(n * 4);
@@ -209,6 +220,8 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
         o_value = off; off += al(n * 4);
         o_uiaxy = off; off += al(n * 4);
         o_imp = off; off += al((size_t)l.imp_rs * l.imp_rows * 4);
+        o_rst = off; off += al(n * 4);
+        o_rsp = off; off += al(n * 8);
     }
     VM_HIP(hipMalloc((void **)&l.slab, off));
     // stream-ordered: the context's stream does not synchronise with the null stream
@@ -227,11 +240,15 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
         V.ui_b = (float2 *)(b + o_uib); V.cross = (float *)(b + o_cross);
         V.value = (float *)(b + o_value); V.ui_axy = (float *)(b + o_uiaxy);
         V.impmask = (uint32_t *)(b + o_imp);
+        V.rec_state = (uint32_t *)(b + o_rst);
+        V.rec_step = (float2 *)(b + o_rsp);
     } else {
         V.img0 = V.img1 = nullptr;
         V.luma = V.mean = V.var = V.tps_b = V.ui_b = nullptr;
         V.cross = V.value = V.ui_axy = nullptr;
         V.impmask = nullptr;
+        V.rec_state = nullptr;
+        V.rec_step = nullptr;
     }
     return VM_OK;
 }
@@ -458,6 +475,7 @@ extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile co
                                  int fixed_work, vm_progress *out)
 {
     CHECK_LVL(p, lvl);
+    std::lock_guard<std::recursive_mutex> lock(p->ctx->mu);
     vm_level &l = p->lv[lvl];
     vm_ctx *c = p->ctx;
     if (!l.has_state) return vm_fail(VM_E_STATE, "vm_optimize_level: level %d not initialised", lvl);
@@ -484,7 +502,13 @@ extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile co
     // tile phase); FAST fans every pixel out over 4..32 lanes, so it takes the
     // largest workgroup the CU offers
     const int threads = c->sweep_threads ? c->sweep_threads : (exact ? 256 : 1024);
+    const int tiles_per_pass = ((l.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
+    // SPLIT schedule: workgroups per tile so that a pass roughly fills the 256 CUs
+    const int parts = c->sweep_parts ? c->sweep_parts : std::max(1, std::min(8, 256 / tiles_per_pass));
+    if (c->sweep_mode != VM_SWEEP_TILE) // epochs restart with every call: forget old records
+        VM_HIP(hipMemsetAsync(l.view.rec_state, 0, (size_t)l.rs * l.h * 4, s));
     double st_tiles = 0, st_cand = 0, st_commit = 0;
+    double dense_prev = 1e9; // line searches per active tile and phase in the previous batch
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
     int done = 0, launches = 0, executed = cap, improving = 1;
     bool cancelled = false;
@@ -497,21 +521,41 @@ extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile co
     int batch = 8;
     while (done < cap) {
         int nb = std::min(batch, cap - done);
+        // schedule of this batch.  SPLIT pays 8 launches per pass instead of 1, so it is
+        // used where a pass is short on tiles and long on line searches: the level has
+        // too few tiles to occupy the CUs, and the previous batch still ran >= 24 line
+        // searches per active tile and phase (the first batch of a level is dense).
+        bool split = c->sweep_mode == VM_SWEEP_SPLIT;
+        if (c->sweep_mode == VM_SWEEP_AUTO)
+            split = tiles_per_pass <= 16 && dense_prev >= 24.0;
         VM_HIP(hipEventRecord(c->ev0, s));
         for (int it = done; it < done + nb; ++it)
             for (int k = 0; k < 4; ++k) {
-                if (exact) vm_launch_optimize_exact(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
-                else vm_launch_optimize_fast(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
-                ++launches;
+                if (split) {
+                    if (exact) vm_launch_optimize_split_exact(l.view, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
+                    else vm_launch_optimize_split_fast(l.view, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
+                    launches += 8;
+                } else {
+                    if (exact) vm_launch_optimize_exact(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
+                    else vm_launch_optimize_fast(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
+                    ++launches;
+                }
             }
         VM_HIP(hipEventRecord(c->ev1, s));
         VM_HIP(hipGetLastError());
         VM_HIP(hipMemcpyAsync(c->flags_host + done, c->flags + done, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
         VM_HIP(hipMemcpyAsync(c->stats_host + 4 * done, c->stats + 4 * done, (size_t)nb * 16, hipMemcpyDeviceToHost, s));
         VM_HIP(hipStreamSynchronize(s));
+        double b_tiles = 0, b_cand = 0;
         for (int it = done; it < done + nb; ++it) {
-            st_tiles += c->stats_host[4 * it]; st_cand += c->stats_host[4 * it + 1]; st_commit += c->stats_host[4 * it + 2];
+            // [0] tile visits (TILE schedule), [3] tile-phases with records (SPLIT schedule)
+            b_tiles += c->stats_host[4 * it] + 0.25 * c->stats_host[4 * it + 3];
+            b_cand += c->stats_host[4 * it + 1];
+            st_commit += c->stats_host[4 * it + 2];
         }
+        st_tiles += b_tiles;
+        st_cand += b_cand;
+        dense_prev = b_tiles > 0 ? b_cand / (4.0 * b_tiles) : 0.0;
         float bms = 0;
         VM_HIP(hipEventElapsedTime(&bms, c->ev0, c->ev1));
         ms += bms;
@@ -543,6 +587,7 @@ extern "C" int vm_solve(vm_pyr *p, float max_iter, float drop, const vm_constrai
                         volatile const int *run_flag, int fixed_work, vm_progress *per_level)
 {
     if (!p) return vm_fail(VM_E_INVALID, "vm_solve: pyramid is NULL");
+    std::lock_guard<std::recursive_mutex> lock(p->ctx->mu);
     if (!(drop > 0)) return vm_fail(VM_E_INVALID, "vm_solve: max_iter_drop_factor must be > 0");
     const int L = (int)p->lv.size();
     const int w0 = p->lv[0].w, h0 = p->lv[0].h;

@@ -3,6 +3,7 @@
 #define VM_HOST_H
 
 #include "vm_internal.h"
+#include <mutex>
 #include <vector>
 
 int vm_fail(int code, const char *fmt, ...);
@@ -16,6 +17,7 @@ int vm_fail(int code, const char *fmt, ...);
     } while (0)
 
 struct vm_ctx {
+    std::recursive_mutex mu;         // a context is single-threaded by contract; this makes misuse safe
     int device = 0;
     int math_mode = VM_MATH_EXACT;
     vm_kern_params kp{};
@@ -27,6 +29,8 @@ struct vm_ctx {
     uint32_t *stats = nullptr;       // per-iteration activity counters, 4 words each (device)
     uint32_t *stats_host = nullptr;  // pinned mirror
     int sweep_threads = 0;           // 0 = automatic
+    int sweep_mode = 0;              // VM_SWEEP_AUTO / TILE / SPLIT
+    int sweep_parts = 0;             // workgroups per tile in the SPLIT schedule, 0 = automatic
     int flags_cap = 0;
     vm_constraint *cons_dev = nullptr;
     int cons_cap = 0;

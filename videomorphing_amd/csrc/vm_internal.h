@@ -29,6 +29,9 @@ struct VmLevelView {
     float2 *v, *luma, *mean, *var, *tps_b, *ui_b;
     float *cross, *value, *ui_axy;
     uint32_t *impmask;
+    // decision records of the SPLIT sweep schedule (vm_sweep_kernels.hip)
+    uint32_t *rec_state;
+    float2 *rec_step;
 };
 
 struct VmKParams {
@@ -51,6 +54,11 @@ struct VmKParams {
                                      const uint32_t *tables, int offx, int offy,              \
                                      uint32_t *flags, uint32_t *stats, int iter_idx,          \
                                      int fixed_work, int threads, hipStream_t s);             \
+    void vm_launch_optimize_split_##SUFFIX(const VmLevelView &L, const VmKParams &P,          \
+                                           const uint32_t *tables, int offx, int offy,        \
+                                           int pass, uint32_t *flags, uint32_t *stats,        \
+                                           int iter_idx, int fixed_work, int threads,         \
+                                           int parts, hipStream_t s);                         \
     void vm_launch_upsample_##SUFFIX(float2 *dst, int dw, int dh, int drs, const float2 *src, \
                                      int sw, int sh, int srs, hipStream_t s);                 \
     void vm_launch_splat_##SUFFIX(const VmLevelView &L, int w0, int h0,                       \

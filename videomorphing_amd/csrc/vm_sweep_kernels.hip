@@ -1,0 +1,891 @@
+// vm_sweep_kernels.hip -- the sweep of the halfway optimizer for gfx950:
+// kernel_optimize_level and its device helpers, Algorithm/morph.cu:592-1345.
+//
+// Compiled twice (see vm_morph_common.h): EXACT is bit-identical to the CPU
+// oracle, FAST is the production arithmetic.
+//
+// What is computed is fixed by the reference (it defines the result): 64x16 tiles
+// on a 69x21 pitch, four offset passes per iteration, four Jacobi phases per tile;
+// per candidate pixel an improving-mask test, a finite-difference gradient, the
+// fold-over bound, a golden-section line search and an accept-if-lower commit.
+//
+// How it is computed is CDNA4-first.  Two schedules share every device function:
+//
+//  TILE schedule (k_optimize, one launch per pass): one workgroup of T threads
+//  owns one tile; window sums, SSIM values, tps.b and the tile's improving-mask
+//  words live in LDS for the four phases.  Per phase the candidates are compacted
+//  and each gets L = 4..32 consecutive lanes (L = largest power of two <=
+//  T/#candidates) that split the 25 window neighbours, keep their share of the
+//  sums in registers for the whole line search and combine SSIM terms with DPP
+//  butterflies.  Tiles without a set mask bit return after one 96-word load, so a
+//  pruned level costs almost nothing -- this is the schedule of large levels.
+//
+//  SPLIT schedule (k_decide + k_commit, two launches per phase): for levels with
+//  too few tiles to fill 256 CUs, a tile's candidates are divided over K
+//  workgroups (so every pixel gets 32 lanes and the ~21 dependent energy
+//  evaluations of a phase take ~1/6 of the time), decisions go to per-pixel
+//  records in HBM, and a second kernel applies them.  State stays in HBM/L2
+//  between the two (a 120x68 level is 0.6 MB).
+//
+// Commits are applied by a per-cell gather of the committed pixels' records in a
+// fixed order: deterministic, one owner per cell, no float atomics (the reference
+// uses 75 shared + 25 global float atomics per accepted pixel, morph.cu:951-1015).
+#include "vm_morph_common.h"
+
+namespace {
+
+struct TileLds {
+    float2 mean[VM_NCELL], var[VM_NCELL], tpsb[VM_NCELL];
+    float cross[VM_NCELL], value[VM_NCELL];
+    // per phase pixel (slot = (y>>1)*32 + (x>>1) inside the tile)
+    float2 d_mean[256], d_var[256], d_step[256];
+    float d_cross[256];
+    int d_ok[256];           // 0: untouched, 1: commit, 2: mask hit that did not move
+    int list[256];           // compacted slots
+    int wave_cnt[4];
+    float tps[625];
+    uint32_t imp[225];
+    uint32_t mask[6][16];    // improving-mask words covering the tile +-1 block
+};
+
+// the LDS of the SPLIT kernels: no window sums
+struct SplitLds {
+    float2 d_mean[256], d_var[256], d_step[256];
+    float d_cross[256];
+    int d_ok[256];
+    int list[256];
+    int wave_cnt[4];
+    float tps[625];
+    uint32_t imp[225];
+    uint32_t mask[6][16];
+};
+
+struct PixelCtx {
+    int px, py;
+    int idx;         // global element index
+    float2 v, old_luma;
+    float tps_axy, ui_axy;
+    float2 tps_b, ui_b;
+};
+
+// where the 5x5 window sums of a pixel come from
+struct LdsSrc {
+    const TileLds *S;
+    int hc; // LDS cell of (px-2, py-2)
+    __device__ __forceinline__ void load(int i, int j, float2 &m, float2 &q, float &cr, float &val) const
+    {
+        const int c = hc + i * VM_HALO_W + j;
+        m = S->mean[c]; q = S->var[c]; cr = S->cross[c]; val = S->value[c];
+    }
+};
+struct GlbSrc {
+    const VmLevelView *L;
+    int g0; // global index of (px-2, py-2)
+    __device__ __forceinline__ void load(int i, int j, float2 &m, float2 &q, float &cr, float &val) const
+    {
+        const int g = g0 + i * L->rs + j;
+        m = L->mean[g]; q = L->var[g]; cr = L->cross[g]; val = L->value[g];
+    }
+};
+
+#if VM_EXACT
+// ---- EXACT: literal ssim_change (morph.cu:671-728) + energy_change (:730-761),
+// flag == false; one lane per pixel, neighbours visited in row-major order
+#define VM_MIN_FANOUT 1
+#define VM_MAX_FANOUT 1
+struct NbCache {};
+template <bool INTERIOR, class Src>
+__device__ __forceinline__ void nb_load(NbCache &, const VmLevelView &, const Src &, const PixelCtx &, int, int) {}
+
+template <bool INTERIOR, class Src>
+__device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKParams &P, const Src &src,
+                                               const NbCache &, const PixelCtx &c, float dx, float dy, int)
+{
+    const float vx = c.v.x + dx, vy = c.v.y + dy;
+    const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - vx + 0.5f, c.py - vy + 0.5f);
+    const float ly = tap(L.img1, L.w, L.h, L.rs, c.px + vx + 0.5f, c.py + vy + 0.5f);
+    const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
+    const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
+    const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
+    const float dcross = lx * ly - c.old_luma.x * c.old_luma.y;
+    float change = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int qy = c.py + i - 2;
+        const int ny = window_count(qy, L.h);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int qx = c.px + j - 2;
+            if (qx < 0 || qx >= L.w || qy < 0 || qy >= L.h)
+                continue;
+            const float counter = (float)(ny * window_count(qx, L.w));
+            float2 m, q;
+            float cr, val;
+            src.load(i, j, m, q, cr, val);
+            const float ns = ssim_value(m.x + dmx, m.y + dmy, q.x + dvx, q.y + dvy, cr + dcross, counter,
+                                        P.ssim_clamp);
+            change += val - ns;
+        }
+    }
+    float v_tps = c.tps_axy * (dx * dx + dy * dy);
+    v_tps += c.tps_b.x * dx;
+    v_tps += c.tps_b.y * dy;
+    float v_ui = c.ui_axy * (dx * dx + dy * dy);
+    v_ui += c.ui_b.x * dx;
+    v_ui += c.ui_b.y * dy;
+    return (P.w_ui * v_ui + P.w_ssim * change + 0.0f) * L.inv_wh + P.w_tps * v_tps;
+}
+#else
+// ---- FAST: the same energy, evaluated by L lanes per pixel.  Lane `sub` owns the
+// window neighbours sub, sub+L, sub+2L, ... (at most VM_SMAX of them) and keeps
+// their sums in registers.  INTERIOR pixels (>= 4 from every border) have 25
+// in-image neighbours with a full window each: count, 1/count and validity
+// become compile-time constants.
+#define VM_SMAX 7
+#define VM_MIN_FANOUT 4
+#ifndef VM_MAX_FANOUT
+#define VM_MAX_FANOUT 32
+#endif
+struct NbCache {
+    float A[VM_SMAX], B[VM_SMAX];                   // window means (sum / n)
+    float VX[VM_SMAX], VY[VM_SMAX], X[VM_SMAX];     // raw second-moment sums
+    float VAL[VM_SMAX];                             // current SSIM value (value - new is summed,
+                                                    // as the reference does: 1e-3..1e-6 of the values)
+    float N[VM_SMAX], IN[VM_SMAX], M[VM_SMAX];      // border pixels only: count, 1/count, validity
+};
+
+__device__ __forceinline__ float dpp_xor1(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_half_mirror(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_mirror(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float swz_xor16(float x)
+{
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));
+}
+// sum over the aligned group of Lf lanes (Lf = 4, 8, 16 or 32, uniform in the
+// workgroup); every lane of the group ends with the same bits
+__device__ __forceinline__ float group_sum(float x, int Lf)
+{
+    x += dpp_xor1(x);
+    x += dpp_xor2(x);
+    if (Lf >= 8) x += dpp_half_mirror(x);
+    if (Lf >= 16) x += dpp_mirror(x);
+    if (Lf >= 32) x += swz_xor16(x);
+    return x;
+}
+
+template <bool INTERIOR, class Src>
+__device__ __forceinline__ void nb_load(NbCache &nb, const VmLevelView &L, const Src &src, const PixelCtx &c,
+                                        int sub, int Lf)
+{
+#pragma unroll
+    for (int j = 0; j < VM_SMAX; ++j) {
+        const int k = sub + j * Lf;
+        const int i = k / 5, jj = k - i * 5;
+        const int qx = c.px + jj - 2, qy = c.py + i - 2;
+        const bool ok = k < 25 && (INTERIOR || (qx >= 0 && qx < L.w && qy >= 0 && qy < L.h));
+        float2 m, q;
+        float cr, val;
+        src.load(ok ? i : 2, ok ? jj : 2, m, q, cr, val);
+        float n = 25.0f, in = 0.04f;
+        if (!INTERIOR) {
+            n = ok ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
+            in = n == 25.0f ? 0.04f : __builtin_amdgcn_rcpf(n);
+            nb.N[j] = n;
+            nb.IN[j] = in;
+            nb.M[j] = ok ? 1.0f : 0.0f;
+        }
+        nb.A[j] = m.x * in;
+        nb.B[j] = m.y * in;
+        nb.VX[j] = q.x;
+        nb.VY[j] = q.y;
+        nb.X[j] = cr;
+        nb.VAL[j] = val;
+    }
+}
+
+template <bool INTERIOR, class Src>
+__device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKParams &P, const Src &,
+                                               const NbCache &nb, const PixelCtx &c, float dx, float dy, int Lf)
+{
+    const float vx = c.v.x + dx, vy = c.v.y + dy;
+    const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - vx + 0.5f, c.py - vy + 0.5f);
+    const float ly = tap(L.img1, L.w, L.h, L.rs, c.px + vx + 0.5f, c.py + vy + 0.5f);
+    const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
+    const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
+    const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
+    const float dcross = lx * ly - c.old_luma.x * c.old_luma.y;
+    float acc = 0;
+#pragma unroll
+    for (int j = 0; j < VM_SMAX; ++j) {
+        if (j * Lf < 25) { // uniform in the workgroup
+            if (INTERIOR) {
+                // the last slot of a lane may lie past the 25th neighbour: it then holds a copy
+                // of the centre neighbour and is masked by the k < 25 test below
+                const float val = ssim_core(fmaf(dmx, 0.04f, nb.A[j]), fmaf(dmy, 0.04f, nb.B[j]), nb.VX[j] + dvx,
+                                            nb.VY[j] + dvy, nb.X[j] + dcross, 25.0f, P.ssim_clamp);
+                const float d = nb.VAL[j] - val;
+                acc += ((threadIdx.x & (Lf - 1)) + j * Lf < 25) ? d : 0.0f;
+            } else {
+                const float in = nb.IN[j];
+                const float val = ssim_core(fmaf(dmx, in, nb.A[j]), fmaf(dmy, in, nb.B[j]), nb.VX[j] + dvx,
+                                            nb.VY[j] + dvy, nb.X[j] + dcross, nb.N[j], P.ssim_clamp);
+                acc = fmaf(nb.M[j], nb.VAL[j] - val, acc);
+            }
+        }
+    }
+    const float change = group_sum(acc, Lf);
+    const float dd = dx * dx + dy * dy;
+    const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
+    const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
+    return (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
+}
+#endif
+
+// fover_update_isec_min, morph.cu:794-831
+__device__ __forceinline__ void fover_isec(float cx, float cy, float gx, float gy, float e0x, float e0y,
+                                           float e1x, float e1y, float &t_min)
+{
+    float dex = e1x - e0x, dey = e1y - e0y;
+    float dcx = cx - e0x, dcy = cy - e0y;
+    float d = dey * gx - dex * gy;
+    float ud = gx * dcy - gy * dcx;
+    int sign = signbit(d) ? 1 : 0;
+    if (sign) {
+        ud = -ud;
+        d = -d;
+    }
+    if (ud >= 0 && ud <= d) {
+        float td = dex * dcy - dey * dcx;
+        td *= (float)(-sign * 2 + 1);
+        if (td >= 0 && td < t_min * d)
+            t_min = td / d; // one division per accepted crossing: IEEE in both modes
+    }
+}
+
+// fover_calc_isec_min (morph.cu:833-870) with fover_calc_vtx (:782-792, note the
+// `p - off` of the original) for one sign
+__device__ __forceinline__ void fover_ring(const VmLevelView &L, int px, int py, float sgn, float vx, float vy,
+                                           float gx, float gy, float &t_min)
+{
+    const int rx[8] = {-1, 0, 1, 1, 1, 0, -1, -1};
+    const int ry[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
+    float ex[8], ey[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float ux = vx, uy = vy;
+        int qx = px + rx[k], qy = py + ry[k];
+        if (qx >= 0 && qx < L.w && qy >= 0 && qy < L.h) {
+            float2 nv = L.v[qy * L.rs + qx];
+            ux = sgn * nv.x;
+            uy = sgn * nv.y;
+        }
+        ex[k] = ux + (float)(px - rx[k]);
+        ey[k] = uy + (float)(py - ry[k]);
+    }
+    const float cx = (float)px + vx, cy = (float)py + vy;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        fover_isec(cx, cy, gx, gy, ex[k], ey[k], ex[(k + 1) & 7], ey[(k + 1) & 7], t_min);
+}
+
+// pixel_on_border, morph.cu:648-667 (BCOND_CORNER exactly as written there)
+__device__ __forceinline__ bool pixel_locked(const VmLevelView &L, int bcond, int px, int py)
+{
+    if (bcond == VM_BCOND_CORNER)
+        return (px == 0 && py == 0) || (px == 0 && py == L.h - 1) ||
+               (px == L.w - 1 && py == 0 && px == L.w - 1 && py == L.h - 1);
+    if (bcond == VM_BCOND_BORDER)
+        return px == 0 || py == 0 || px == L.w - 1 || py == L.h - 1;
+    return false;
+}
+
+// optimize_pixel (morph.cu:1030-1083) after the mask test: gradient, fold-over bound,
+// golden-section search.  All L lanes of the pixel's group run it in lockstep and
+// agree bit for bit.  Returns true and the accepted step when the energy drops.
+template <bool INTERIOR, class Src>
+__device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P, const Src &src,
+                                       const PixelCtx &c, int sub, int Lf, float2 &step)
+{
+    NbCache nb;
+    nb_load<INTERIOR>(nb, L, src, c, sub, Lf);
+#define ENERGY(DX, DY) energy_change<INTERIOR>(L, P, src, nb, c, (DX), (DY), Lf)
+    // The energy is evaluated at exactly two places of the instruction stream (not at
+    // the reference's seven): the sweep kernels must stay inside the instruction cache.
+    // compute_gradient, morph.cu:763-778: g = -(E(+eps x) - E(-eps x), E(+eps y) - E(-eps y))
+    float gx = 0, gy = 0;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const float sgn = (k & 1) ? -1.0f : 1.0f;
+        const float e = ENERGY(k < 2 ? sgn * P.eps : 0.0f, k < 2 ? 0.0f : sgn * P.eps) * sgn;
+        if (k < 2)
+            gx += e; // (0 + E+) + (-E-) == E+ - E- bit for bit
+        else
+            gy += e;
+    }
+    gx = -gx;
+    gy = -gy;
+    const float ng = fsqrt(gx * gx + gy * gy);
+    if (ng == 0)
+        return false;
+    gx = fdiv(gx, ng);
+    gy = fdiv(gy, ng);
+    // prevent_foldover, morph.cu:872-883
+    float t_min = 10;
+    fover_ring(L, c.px, c.py, -1.0f, -c.v.x, -c.v.y, -gx, -gy, t_min);
+    fover_ring(L, c.px, c.py, 1.0f, c.v.x, c.v.y, gx, gy, t_min);
+    float cc = fmaxf(t_min - P.eps, 0.0f);
+    // golden_section_search, morph.cu:885-947: step 0 and 1 evaluate the two initial
+    // interior points b and x, later steps shrink the bracket
+    const float R = 0.618033989f, C = 1.0f - R;
+    float a = 0;
+    float b = a * R + cc * C, x = b * R + cc * C;
+    float fb = 0, fx = 0;
+#pragma unroll 1
+    for (int s = 0;; ++s) {
+        float t = s == 0 ? b : x;
+        bool lt = false;
+        if (s >= 2) {
+            if (!(cc - a > P.eps))
+                break;
+            lt = fx < fb;
+            if (lt) {
+                a = b;
+                b = x;
+                x = b * R + cc * C;
+            } else {
+                cc = x;
+                x = b * R + a * C;
+            }
+            t = x;
+        }
+        const float f = ENERGY(gx * t, gy * t);
+        if (s == 0) {
+            fb = f;
+        } else if (s == 1) {
+            fx = f;
+        } else if (lt) {
+            fb = fx;
+            fx = f;
+        } else {
+            const float tmp = b;
+            b = x;
+            x = tmp;
+            fx = fb;
+            fb = f;
+        }
+    }
+#undef ENERGY
+    const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
+    if (!(fmin < 0))
+        return false;
+    step = make_float2(gx * tmin, gy * tmin);
+    return true;
+}
+
+// everything of a pixel that the energy needs besides the window sums
+__device__ __forceinline__ void ctx_load(PixelCtx &c, const VmLevelView &L, const float *s_tps, int px, int py)
+{
+    c.px = px;
+    c.py = py;
+    c.idx = py * L.rs + px;
+    c.v = L.v[c.idx];
+    c.old_luma = L.luma[c.idx];
+    c.ui_axy = L.ui_axy[c.idx];
+    c.ui_b = L.ui_b[c.idx];
+    c.tps_axy = s_tps[(border_class(py, L.h) * 5 + border_class(px, L.w)) * 25 + 12] / 2;
+}
+
+__device__ __forceinline__ bool is_interior(const VmLevelView &L, int px, int py)
+{
+#ifdef VM_NO_INTERIOR
+    return false;
+#endif
+    return px >= 4 && px < L.w - 4 && py >= 4 && py < L.h - 4;
+}
+
+// geometry of the improving-mask words around a tile
+struct MaskGeom {
+    int bx0, by0, nbx, nby;
+};
+__device__ __forceinline__ MaskGeom mask_geom(const VmLevelView &L, int ox, int oy)
+{
+    MaskGeom g;
+    g.bx0 = ox / 5 - 1;
+    g.by0 = oy / 5 - 1;
+    const int bx1 = min(ox + VM_TILE_W - 1, L.w - 1) / 5 + 1;
+    const int by1 = min(oy + VM_TILE_H - 1, L.h - 1) / 5 + 1;
+    g.nbx = bx1 - g.bx0 + 1; // <= 16
+    g.nby = by1 - g.by0 + 1; // <= 6
+    return g;
+}
+
+// get_improve_mask_idx, morph.cu:621-646, on the LDS copy of the mask words
+__device__ __forceinline__ bool mask_hit(const uint32_t (*mask)[16], const uint32_t *imp, const MaskGeom &g,
+                                         int px, int py)
+{
+    const int oxb = px % 5, oyb = py % 5;
+    const int mcx = px / 5 - g.bx0, mcy = py / 5 - g.by0;
+    const int begi = oyb >= 2 ? 1 : 0, begj = oxb >= 2 ? 1 : 0;
+    const uint32_t *ib = imp + (oyb * 5 + oxb) * 9;
+    bool hit = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (mask[mcy + begi + i - 1][mcx + begj + j - 1] & ib[(begi + i) * 3 + begj + j])
+                hit = true;
+    return hit;
+}
+
+// ordered compaction of the (at most 256) flagged phase pixels of a workgroup into
+// list[]: slot order, hence identical in every workgroup that looks at the same tile.
+// Every thread of the workgroup calls it; returns the number of entries.
+__device__ __forceinline__ int compact256(bool flag, int tid, int *list, int *wave_cnt)
+{
+    const unsigned long long b = __ballot(flag);
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid < 256 && lane == 0)
+        wave_cnt[wave] = __popcll(b);
+    __syncthreads();
+    const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+    if (tid < 256 && flag) {
+        const int off = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        list[off + __popcll(b & ((1ull << lane) - 1ull))] = tid;
+    }
+    __syncthreads();
+    return c0 + c1 + c2 + c3;
+}
+
+// commit_pixel_motion (morph.cu:990-1026) for the pixel of slot `tid`: own-pixel state,
+// the record the per-cell gather reads, the mask bit.  Returns true for a commit.
+template <class LdsT>
+__device__ __forceinline__ bool commit_own(LdsT &S, const VmLevelView &L, const MaskGeom &g, int tid, int ox,
+                                           int oy, int pi, int pj)
+{
+    const int state = S.d_ok[tid];
+    if (state == 0)
+        return false;
+    const int tx = tid & 31, ty = tid >> 5;
+    const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
+    const int mcx = px / 5 - g.bx0, mcy = py / 5 - g.by0;
+    const uint32_t bit = 1u << ((px % 5) + (py % 5) * 5);
+    if (state != 1) {
+        atomicAnd(&S.mask[mcy][mcx], ~bit);
+        return false;
+    }
+    const int idx = py * L.rs + px;
+    const float2 v = L.v[idx], ol = L.luma[idx], st = S.d_step[tid];
+    const float2 newv = make_float2(v.x + st.x, v.y + st.y);
+    const float lx = tap(L.img0, L.w, L.h, L.rs, px - newv.x + 0.5f, py - newv.y + 0.5f);
+    const float ly = tap(L.img1, L.w, L.h, L.rs, px + newv.x + 0.5f, py + newv.y + 0.5f);
+    L.luma[idx] = make_float2(lx, ly);
+    S.d_mean[tid] = make_float2(lx - ol.x, ly - ol.y);
+    S.d_var[tid] = make_float2(lx * lx - ol.x * ol.x, ly * ly - ol.y * ol.y);
+    S.d_cross[tid] = lx * ly - ol.x * ol.y;
+    const float axy = L.ui_axy[idx];
+    const float2 ub = L.ui_b[idx];
+    L.ui_b[idx] = make_float2(ub.x + 2 * st.x * axy, ub.y + 2 * st.y * axy);
+    L.v[idx] = newv;
+    atomicOr(&S.mask[mcy][mcx], bit);
+    return true;
+}
+
+// ssim_update (morph.cu:951-988) + the tps.b scatter (:1006-1015) as a gather: the
+// tile+halo cell (rx, ry) adds the records of the committed pixels of this phase
+// whose 5x5 window contains it, in row-major order of those pixels.  Returns whether
+// any record touched the cell; the caller then recomputes the SSIM value
+// (UpdateSSIM, :1258-1279).
+template <class LdsT>
+__device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L, int ox, int oy, int rx, int ry,
+                                            int pi, int pj, float2 &m, float2 &q, float &cr, float2 &tb)
+{
+    int ylo = max(ry - 2, 0), yhi = min(ry + 2, VM_TILE_H - 1);
+    int xlo = max(rx - 2, 0), xhi = min(rx + 2, VM_TILE_W - 1);
+    ylo += (ylo & 1) ^ pi;
+    xlo += (xlo & 1) ^ pj;
+    bool touched = false;
+    for (int y = ylo; y <= yhi; y += 2)
+        for (int x = xlo; x <= xhi; x += 2) {
+            const int rec = (y >> 1) * 32 + (x >> 1);
+            if (S.d_ok[rec] != 1)
+                continue;
+            touched = true;
+            const float2 dm = S.d_mean[rec], dv = S.d_var[rec], st = S.d_step[rec];
+            m.x += dm.x;
+            m.y += dm.y;
+            q.x += dv.x;
+            q.y += dv.y;
+            cr += S.d_cross[rec];
+            const int By = border_class(oy + y, L.h), Bx = border_class(ox + x, L.w);
+            const float k = S.tps[(By * 5 + Bx) * 25 + (ry - y + 2) * 5 + (rx - x + 2)];
+            tb.x += st.x * k;
+            tb.y += st.y * k;
+        }
+    return touched;
+}
+
+// ===========================================================================
+// TILE schedule
+__global__ __launch_bounds__(1024) void SUF(k_optimize)(VmLevelView L, VmKParams P,
+                                                        const uint32_t *__restrict__ tables, int offx, int offy,
+                                                        uint32_t *__restrict__ flags,
+                                                        uint32_t *__restrict__ stats, int iter_idx, int fixed_work)
+{
+    __shared__ TileLds S;
+    const int tid = threadIdx.x, T = blockDim.x;
+
+    // converged in the previous iteration: nothing left to do (sticky)
+    if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
+        return;
+
+    const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
+    if (ox >= L.w || oy >= L.h)
+        return;
+
+    // --- improving-mask words of the tile and its ring of neighbour blocks ---
+    const MaskGeom g = mask_geom(L, ox, oy);
+    uint32_t mymask = 0;
+    if (tid < g.nbx * g.nby) {
+        int mx = tid % g.nbx, my = tid / g.nbx;
+        mymask = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)];
+        S.mask[my][mx] = mymask;
+    }
+    // tile-level early out: no set bit anywhere near the tile means no pixel of it is a
+    // candidate in any phase, and re-deriving the SSIM values from unchanged sums
+    // reproduces them bit for bit
+    if (!__syncthreads_or(mymask != 0))
+        return;
+
+    for (int k = tid; k < 625; k += T)
+        S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
+    for (int k = tid; k < 225; k += T)
+        S.imp[k] = tables[VM_TAB_IMP + k];
+
+    // --- LoadSSIM (morph.cu:1214-1234) + the tile's tps.b ---
+    for (int c = tid; c < VM_NCELL; c += T) {
+        int gx = ox - 2 + c % VM_HALO_W, gy = oy - 2 + c / VM_HALO_W;
+        bool in = gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
+        int gi = gy * L.rs + gx;
+        S.mean[c] = in ? L.mean[gi] : make_float2(0, 0);
+        S.var[c] = in ? L.var[gi] : make_float2(0, 0);
+        S.tpsb[c] = in ? L.tps_b[gi] : make_float2(0, 0);
+        S.cross[c] = in ? L.cross[gi] : 0.0f;
+        S.value[c] = in ? L.value[gi] : 0.0f;
+    }
+    __syncthreads();
+
+    bool improving = false;
+    uint32_t st_cand = 0, st_commit = 0;
+
+    for (int pi = 0; pi < 2; ++pi) {
+        for (int pj = 0; pj < 2; ++pj) {
+            // ---- 1. candidates of this phase ----
+            bool cand = false;
+            if (tid < 256) {
+                const int px = ox + (tid & 31) * 2 + pj, py = oy + (tid >> 5) * 2 + pi;
+                int state = 0;
+                if (px < L.w && py < L.h && mask_hit(S.mask, S.imp, g, px, py)) {
+                    state = 2; // in the mask: its bit is cleared unless it commits
+                    cand = !pixel_locked(L, P.bcond, px, py);
+                }
+                S.d_ok[tid] = state;
+            }
+            const int n_act = compact256(cand, tid, S.list, S.wave_cnt);
+
+            if (n_act > 0) {
+                st_cand += n_act;
+                // ---- 2. line searches on the pre-phase state, L lanes per candidate ----
+                int Lf = VM_MIN_FANOUT;
+                while (Lf * 2 <= VM_MAX_FANOUT && Lf * 2 * n_act <= T)
+                    Lf *= 2;
+                const int slots = T / Lf;
+                const int sub = tid & (Lf - 1), grp = tid / Lf;
+                for (int base = 0; base < n_act; base += slots) {
+                    const int li = base + grp;
+                    const int slot = S.list[min(li, n_act - 1)];
+                    const int tx = slot & 31, ty = slot >> 5;
+                    const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
+                    // the constant-count fast path is taken per WAVE (all its pixels interior):
+                    // a per-pixel choice would make mixed waves run both line searches
+                    const bool wave_interior = __all(li >= n_act || is_interior(L, px, py));
+                    if (li < n_act) {
+                        PixelCtx c;
+                        ctx_load(c, L, S.tps, px, py);
+                        LdsSrc src{&S, (ty * 2 + pi) * VM_HALO_W + (tx * 2 + pj)};
+                        c.tps_b = S.tpsb[src.hc + 2 * VM_HALO_W + 2];
+                        float2 step;
+                        const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step)
+                                                      : decide<false>(L, P, src, c, sub, Lf, step);
+                        if (ok && sub == 0) {
+                            S.d_step[slot] = step;
+                            S.d_ok[slot] = 1;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- 3. commits ----
+            const bool ok = tid < 256 && commit_own(S, L, g, tid, ox, oy, pi, pj);
+            const int ncommit = __syncthreads_count(ok);
+            if (ncommit) {
+                improving = true;
+                st_commit += ncommit;
+                for (int cell = tid; cell < VM_NCELL; cell += T) {
+                    const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2; // tile-relative
+                    const int qx = ox + rx, qy = oy + ry;
+                    if (qx < 0 || qx >= L.w || qy < 0 || qy >= L.h)
+                        continue;
+                    float2 m = S.mean[cell], q = S.var[cell], tb = S.tpsb[cell];
+                    float cr = S.cross[cell];
+                    if (gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb)) {
+                        S.mean[cell] = m;
+                        S.var[cell] = q;
+                        S.cross[cell] = cr;
+                        S.tpsb[cell] = tb;
+                        const float counter = (float)(window_count(qy, L.h) * window_count(qx, L.w));
+                        S.value[cell] = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- SaveSSIM (morph.cu:1236-1256), tps.b and the owned mask words ----
+    if (improving) {
+        for (int c = tid; c < VM_NCELL; c += T) {
+            int gx = ox - 2 + c % VM_HALO_W, gy = oy - 2 + c / VM_HALO_W;
+            if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h)
+                continue;
+            int gi = gy * L.rs + gx;
+            L.mean[gi] = S.mean[c];
+            L.var[gi] = S.var[c];
+            L.tps_b[gi] = S.tpsb[c];
+            L.cross[gi] = S.cross[c];
+            L.value[gi] = S.value[c];
+        }
+    }
+    if (tid < g.nbx * g.nby) {
+        int mx = tid % g.nbx, my = tid / g.nbx;
+        // words owned by this tile: blocks that contain one of its pixels
+        if (mx >= 1 && mx <= g.nbx - 2 && my >= 1 && my <= g.nby - 2)
+            L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)] = S.mask[my][mx];
+    }
+    if (tid == 0) {
+        if (improving)
+            atomicOr(&flags[iter_idx], 1u);
+        // per-iteration activity counters: active tiles, line searches, commits
+        atomicAdd(&stats[iter_idx * 4 + 0], 1u);
+        atomicAdd(&stats[iter_idx * 4 + 1], st_cand);
+        atomicAdd(&stats[iter_idx * 4 + 2], st_commit);
+    }
+}
+
+// ===========================================================================
+// SPLIT schedule.  Decision records: rec_state[pixel] = epoch << 2 | state
+// (1: commit, 2: mask hit that did not move), valid only for the current epoch
+// (one epoch per phase, so nothing is ever cleared); rec_step[pixel] = accepted step.
+
+__global__ __launch_bounds__(1024) void SUF(k_decide)(VmLevelView L, VmKParams P,
+                                                      const uint32_t *__restrict__ tables, int offx, int offy,
+                                                      int pi, int pj, int parts, uint32_t epoch,
+                                                      const uint32_t *__restrict__ flags, int iter_idx,
+                                                      int fixed_work)
+{
+    __shared__ SplitLds S;
+    const int tid = threadIdx.x, T = blockDim.x;
+    if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
+        return;
+    const int part = blockIdx.x % parts, tile = blockIdx.x / parts;
+    const int gxn = (L.w + VM_PITCH_X - 1) / VM_PITCH_X;
+    const int ox = (tile % gxn) * VM_PITCH_X + offx, oy = (tile / gxn) * VM_PITCH_Y + offy;
+    if (ox >= L.w || oy >= L.h)
+        return;
+    const MaskGeom g = mask_geom(L, ox, oy);
+    uint32_t mymask = 0;
+    if (tid < g.nbx * g.nby) {
+        int mx = tid % g.nbx, my = tid / g.nbx;
+        mymask = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)];
+        S.mask[my][mx] = mymask;
+    }
+    if (!__syncthreads_or(mymask != 0))
+        return;
+    for (int k = tid; k < 625; k += T)
+        S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
+    for (int k = tid; k < 225; k += T)
+        S.imp[k] = tables[VM_TAB_IMP + k];
+    __syncthreads();
+
+    // every mask hit of the phase, in slot order: the list is the same in all `parts`
+    // workgroups of the tile, entry i belongs to workgroup i % parts
+    bool hit = false;
+    if (tid < 256) {
+        const int px = ox + (tid & 31) * 2 + pj, py = oy + (tid >> 5) * 2 + pi;
+        hit = px < L.w && py < L.h && mask_hit(S.mask, S.imp, g, px, py);
+    }
+    const int n_hit = compact256(hit, tid, S.list, S.wave_cnt);
+    const int n_mine = (n_hit - part + parts - 1) / parts;
+    if (n_mine <= 0)
+        return;
+    int Lf = VM_MIN_FANOUT;
+    while (Lf * 2 <= VM_MAX_FANOUT && Lf * 2 * n_mine <= T)
+        Lf *= 2;
+    const int slots = T / Lf;
+    const int sub = tid & (Lf - 1), grp = tid / Lf;
+    for (int base = 0; base < n_mine; base += slots) {
+        const int m = base + grp;
+        const int slot = S.list[part + parts * min(m, n_mine - 1)];
+        const int px = ox + (slot & 31) * 2 + pj, py = oy + (slot >> 5) * 2 + pi;
+        const bool wave_interior = __all(m >= n_mine || is_interior(L, px, py));
+        if (m < n_mine) {
+            uint32_t state = 2;
+            float2 step = make_float2(0, 0);
+            if (!pixel_locked(L, P.bcond, px, py)) {
+                PixelCtx c;
+                ctx_load(c, L, S.tps, px, py);
+                c.tps_b = L.tps_b[c.idx];
+                GlbSrc src{&L, (py - 2) * L.rs + (px - 2)};
+                const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step)
+                                              : decide<false>(L, P, src, c, sub, Lf, step);
+                if (ok)
+                    state = 1;
+            }
+            if (sub == 0) {
+                L.rec_step[py * L.rs + px] = step;
+                L.rec_state[py * L.rs + px] = (epoch << 2) | state;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void SUF(k_commit)(VmLevelView L, VmKParams P,
+                                                     const uint32_t *__restrict__ tables, int offx, int offy,
+                                                     int pi, int pj, uint32_t epoch,
+                                                     uint32_t *__restrict__ flags, uint32_t *__restrict__ stats,
+                                                     int iter_idx, int fixed_work)
+{
+    __shared__ SplitLds S;
+    const int tid = threadIdx.x, T = blockDim.x; // T == 256
+    if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
+        return;
+    const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
+    if (ox >= L.w || oy >= L.h)
+        return;
+    // the records of this tile's phase pixels
+    int state = 0;
+    {
+        const int px = ox + (tid & 31) * 2 + pj, py = oy + (tid >> 5) * 2 + pi;
+        if (px < L.w && py < L.h) {
+            const uint32_t r = L.rec_state[py * L.rs + px];
+            if ((r >> 2) == epoch) {
+                state = (int)(r & 3u);
+                if (state == 1)
+                    S.d_step[tid] = L.rec_step[py * L.rs + px];
+            }
+        }
+        S.d_ok[tid] = state;
+    }
+    const int n_rec = __syncthreads_count(state != 0);
+    if (n_rec == 0)
+        return;
+    const MaskGeom g = mask_geom(L, ox, oy);
+    if (tid < g.nbx * g.nby) {
+        int mx = tid % g.nbx, my = tid / g.nbx;
+        S.mask[my][mx] = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)];
+    }
+    for (int k = tid; k < 625; k += T)
+        S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
+    __syncthreads();
+    const bool ok = commit_own(S, L, g, tid, ox, oy, pi, pj);
+    const int ncommit = __syncthreads_count(ok);
+    if (ncommit) {
+        for (int cell = tid; cell < VM_NCELL; cell += T) {
+            const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2;
+            const int qx = ox + rx, qy = oy + ry;
+            if (qx < 0 || qx >= L.w || qy < 0 || qy >= L.h)
+                continue;
+            const int gi = qy * L.rs + qx;
+            // cheap pre-test before touching HBM: any committed record in reach?
+            float2 m = make_float2(0, 0), q = m, tb = m;
+            float cr = 0;
+            int ylo = max(ry - 2, 0), yhi = min(ry + 2, VM_TILE_H - 1);
+            int xlo = max(rx - 2, 0), xhi = min(rx + 2, VM_TILE_W - 1);
+            ylo += (ylo & 1) ^ pi;
+            xlo += (xlo & 1) ^ pj;
+            bool any = false;
+            for (int y = ylo; y <= yhi; y += 2)
+                for (int x = xlo; x <= xhi; x += 2)
+                    any = any || S.d_ok[(y >> 1) * 32 + (x >> 1)] == 1;
+            if (!any)
+                continue;
+            m = L.mean[gi];
+            q = L.var[gi];
+            tb = L.tps_b[gi];
+            cr = L.cross[gi];
+            gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb);
+            L.mean[gi] = m;
+            L.var[gi] = q;
+            L.cross[gi] = cr;
+            L.tps_b[gi] = tb;
+            const float counter = (float)(window_count(qy, L.h) * window_count(qx, L.w));
+            L.value[gi] = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
+        }
+    }
+    __syncthreads();
+    if (tid < g.nbx * g.nby) {
+        int mx = tid % g.nbx, my = tid / g.nbx;
+        if (mx >= 1 && mx <= g.nbx - 2 && my >= 1 && my <= g.nby - 2)
+            L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)] = S.mask[my][mx];
+    }
+    if (tid == 0) {
+        if (ncommit)
+            atomicOr(&flags[iter_idx], 1u);
+        atomicAdd(&stats[iter_idx * 4 + 3], 1u); // tile-phases with records
+        atomicAdd(&stats[iter_idx * 4 + 1], (uint32_t)n_rec);
+        atomicAdd(&stats[iter_idx * 4 + 2], (uint32_t)ncommit);
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+
+void SUF(vm_launch_optimize)(const VmLevelView &L, const VmKParams &P, const uint32_t *tables, int offx,
+                             int offy, uint32_t *flags, uint32_t *stats, int iter_idx, int fixed_work,
+                             int threads, hipStream_t s)
+{
+    dim3 b(threads), g((L.w + VM_PITCH_X - 1) / VM_PITCH_X, (L.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
+    hipLaunchKernelGGL(SUF(k_optimize), g, b, 0, s, L, P, tables, offx, offy, flags, stats, iter_idx,
+                       fixed_work);
+}
+
+// one pass (tile offset) in the SPLIT schedule: 4 phases x (decide, commit)
+void SUF(vm_launch_optimize_split)(const VmLevelView &L, const VmKParams &P, const uint32_t *tables, int offx,
+                                   int offy, int pass, uint32_t *flags, uint32_t *stats, int iter_idx,
+                                   int fixed_work, int threads, int parts, hipStream_t s)
+{
+    const int gx = (L.w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (L.h + VM_PITCH_Y - 1) / VM_PITCH_Y;
+    for (int pi = 0; pi < 2; ++pi)
+        for (int pj = 0; pj < 2; ++pj) {
+            const uint32_t epoch = 1u + (uint32_t)((iter_idx * 4 + pass) * 4 + pi * 2 + pj);
+            hipLaunchKernelGGL(SUF(k_decide), dim3(gx * gy * parts), dim3(threads), 0, s, L, P, tables, offx,
+                               offy, pi, pj, parts, epoch, flags, iter_idx, fixed_work);
+            hipLaunchKernelGGL(SUF(k_commit), dim3(gx, gy), dim3(256), 0, s, L, P, tables, offx, offy, pi, pj,
+                               epoch, flags, stats, iter_idx, fixed_work);
+        }
+}

@@ -105,6 +105,9 @@ class Context(object):
         capi.check(self._L.vm_set_math_mode(self._h, int(mode)))
         self.math_mode = int(mode)
 
+    def set_tuning(self, sweep_mode=0, threads=0, parts=0):
+        capi.check(self._L.vm_set_tuning(self._h, int(sweep_mode), int(threads), int(parts)))
+
     def sync(self):
         capi.check(self._L.vm_ctx_sync(self._h))
 
