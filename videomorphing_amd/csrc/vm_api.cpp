@@ -501,7 +501,9 @@ extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile co
     // workgroup size of the sweep: EXACT relaxes one pixel per lane (256 lanes per
     // tile phase); FAST fans every pixel out over 4..32 lanes, so it takes the
     // largest workgroup the CU offers
-    const int threads = c->sweep_threads ? c->sweep_threads : (exact ? 256 : 1024);
+    // FAST kernels are built for at most 512 threads (256-VGPR budget: the register-cached
+    // window sums must not spill), EXACT ones for up to 1024
+    const int threads = std::min(c->sweep_threads ? c->sweep_threads : (exact ? 256 : 512), exact ? 1024 : 512);
     const int tiles_per_pass = ((l.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
     // SPLIT schedule: workgroups per tile so that a pass roughly fills the 256 CUs
     const int parts = c->sweep_parts ? c->sweep_parts : std::max(1, std::min(8, 256 / tiles_per_pass));
@@ -521,13 +523,13 @@ extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile co
     int batch = 8;
     while (done < cap) {
         int nb = std::min(batch, cap - done);
-        // schedule of this batch.  SPLIT pays 8 launches per pass instead of 1, so it is
-        // used where a pass is short on tiles and long on line searches: the level has
-        // too few tiles to occupy the CUs, and the previous batch still ran >= 24 line
-        // searches per active tile and phase (the first batch of a level is dense).
-        bool split = c->sweep_mode == VM_SWEEP_SPLIT;
-        if (c->sweep_mode == VM_SWEEP_AUTO)
-            split = tiles_per_pass <= 16 && dense_prev >= 24.0;
+        // schedule of this batch.  SPLIT (8 launches per pass, a tile's line searches spread
+        // over several CUs) was measured against TILE on the levels it was meant for -- few
+        // tiles, every pixel active -- and does not win with 512-thread tiles (120x68: 0.87 vs
+        // 0.80 ms per iteration), so AUTO means TILE; SPLIT stays selectable (vm_set_tuning).
+        const bool split = c->sweep_mode == VM_SWEEP_SPLIT;
+        (void)dense_prev;
+        (void)tiles_per_pass;
         VM_HIP(hipEventRecord(c->ev0, s));
         for (int it = done; it < done + nb; ++it)
             for (int k = 0; k < 4; ++k) {

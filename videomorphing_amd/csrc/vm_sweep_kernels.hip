@@ -91,6 +91,7 @@ struct GlbSrc {
 #if VM_EXACT
 // ---- EXACT: literal ssim_change (morph.cu:671-728) + energy_change (:730-761),
 // flag == false; one lane per pixel, neighbours visited in row-major order
+#define VM_SWEEP_T 1024
 #define VM_MIN_FANOUT 1
 #define VM_MAX_FANOUT 1
 struct NbCache {};
@@ -141,8 +142,16 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
 // their sums in registers.  INTERIOR pixels (>= 4 from every border) have 25
 // in-image neighbours with a full window each: count, 1/count and validity
 // become compile-time constants.
+#ifndef VM_SWEEP_T
+#define VM_SWEEP_T 512
+#endif
+#if VM_SWEEP_T >= 1024
 #define VM_SMAX 7
 #define VM_MIN_FANOUT 4
+#else
+#define VM_SMAX 13
+#define VM_MIN_FANOUT 2
+#endif
 #ifndef VM_MAX_FANOUT
 #define VM_MAX_FANOUT 32
 #endif
@@ -151,7 +160,7 @@ struct NbCache {
     float VX[VM_SMAX], VY[VM_SMAX], X[VM_SMAX];     // raw second-moment sums
     float VAL[VM_SMAX];                             // current SSIM value (value - new is summed,
                                                     // as the reference does: 1e-3..1e-6 of the values)
-    float N[VM_SMAX], IN[VM_SMAX], M[VM_SMAX];      // border pixels only: count, 1/count, validity
+    float N[VM_SMAX];                               // border waves only: window count, 0 = no such neighbour
 };
 
 __device__ __forceinline__ float dpp_xor1(float x)
@@ -174,12 +183,12 @@ __device__ __forceinline__ float swz_xor16(float x)
 {
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));
 }
-// sum over the aligned group of Lf lanes (Lf = 4, 8, 16 or 32, uniform in the
+// sum over the aligned group of Lf lanes (Lf = 2, 4, 8, 16 or 32, uniform in the
 // workgroup); every lane of the group ends with the same bits
 __device__ __forceinline__ float group_sum(float x, int Lf)
 {
     x += dpp_xor1(x);
-    x += dpp_xor2(x);
+    if (Lf >= 4) x += dpp_xor2(x);
     if (Lf >= 8) x += dpp_half_mirror(x);
     if (Lf >= 16) x += dpp_mirror(x);
     if (Lf >= 32) x += swz_xor16(x);
@@ -203,9 +212,7 @@ __device__ __forceinline__ void nb_load(NbCache &nb, const VmLevelView &L, const
         if (!INTERIOR) {
             n = ok ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
             in = n == 25.0f ? 0.04f : __builtin_amdgcn_rcpf(n);
-            nb.N[j] = n;
-            nb.IN[j] = in;
-            nb.M[j] = ok ? 1.0f : 0.0f;
+            nb.N[j] = ok ? n : 0.0f; // 1/count is recomputed per evaluation: registers are scarcer than v_rcp
         }
         nb.A[j] = m.x * in;
         nb.B[j] = m.y * in;
@@ -230,7 +237,11 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
     float acc = 0;
 #pragma unroll
     for (int j = 0; j < VM_SMAX; ++j) {
+#ifdef VM_EXP_NOBRANCH
+        if (true) {
+#else
         if (j * Lf < 25) { // uniform in the workgroup
+#endif
             if (INTERIOR) {
                 // the last slot of a lane may lie past the 25th neighbour: it then holds a copy
                 // of the centre neighbour and is masked by the k < 25 test below
@@ -239,10 +250,12 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
                 const float d = nb.VAL[j] - val;
                 acc += ((threadIdx.x & (Lf - 1)) + j * Lf < 25) ? d : 0.0f;
             } else {
-                const float in = nb.IN[j];
+                const bool valid = nb.N[j] != 0.0f;
+                const float n = valid ? nb.N[j] : 25.0f;
+                const float in = n == 25.0f ? 0.04f : __builtin_amdgcn_rcpf(n);
                 const float val = ssim_core(fmaf(dmx, in, nb.A[j]), fmaf(dmy, in, nb.B[j]), nb.VX[j] + dvx,
-                                            nb.VY[j] + dvy, nb.X[j] + dcross, nb.N[j], P.ssim_clamp);
-                acc = fmaf(nb.M[j], nb.VAL[j] - val, acc);
+                                            nb.VY[j] + dvy, nb.X[j] + dcross, n, P.ssim_clamp);
+                acc += valid ? nb.VAL[j] - val : 0.0f;
             }
         }
     }
@@ -539,7 +552,7 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
 
 // ===========================================================================
 // TILE schedule
-__global__ __launch_bounds__(1024) void SUF(k_optimize)(VmLevelView L, VmKParams P,
+__global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(VmLevelView L, VmKParams P,
                                                         const uint32_t *__restrict__ tables, int offx, int offy,
                                                         uint32_t *__restrict__ flags,
                                                         uint32_t *__restrict__ stats, int iter_idx, int fixed_work)
@@ -700,7 +713,7 @@ __global__ __launch_bounds__(1024) void SUF(k_optimize)(VmLevelView L, VmKParams
 // (1: commit, 2: mask hit that did not move), valid only for the current epoch
 // (one epoch per phase, so nothing is ever cleared); rec_step[pixel] = accepted step.
 
-__global__ __launch_bounds__(1024) void SUF(k_decide)(VmLevelView L, VmKParams P,
+__global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(VmLevelView L, VmKParams P,
                                                       const uint32_t *__restrict__ tables, int offx, int offy,
                                                       int pi, int pj, int parts, uint32_t epoch,
                                                       const uint32_t *__restrict__ flags, int iter_idx,
