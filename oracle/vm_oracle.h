@@ -143,6 +143,11 @@ int  vmo_poisson_prepare(uint8_t *rgba_ext, int w, int h, int ex,
                          const uint8_t *other, const float *v, int side,
                          int *type_out);
 
+/* luma pyramid of Pyramid::build (pyramid.cu:203-211, 268-279, 355-364 driving
+ * include/resample): rgb h*w*3 bytes -> lumas of levels 1..nlevels concatenated.
+ * Pinned by tests/golden/pyramid_ref.npz (outputs of the reference's own library). */
+void vmo_luma_pyramid(const uint8_t *rgb, int w, int h, int nlevels, float *out);
+
 /* test hooks: prevent_foldover (morph.cu:872-883) and energy_change (:730-761)
  * evaluated at one pixel of an initialised level */
 float vmo_dbg_foldover(const vmo_level *l, const vmo_params *p, int px, int py, float gx, float gy);

@@ -107,6 +107,8 @@ def lib():
     L.vmo_dbg_foldover.restype = C.c_float
     L.vmo_dbg_energy_change.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_float, C.c_float]
     L.vmo_dbg_energy_change.restype = C.c_float
+    L.vmo_luma_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.vmo_luma_pyramid.restype = None
     L.vmo_set_threads.argtypes = [C.c_int]
     L.vmo_set_threads.restype = None
     L.vmo_get_threads.restype = C.c_int
@@ -261,3 +263,17 @@ def poisson_prepare(ext_rgba, w, h, ex, other_rgba, v, side):
     n = lib().vmo_poisson_prepare(ext.ctypes.data, w, h, ex, other.ctypes.data,
                                   v.ctypes.data, side, typ.ctypes.data)
     return ext, typ, n
+
+
+def luma_pyramid(rgb, nlevels):
+    """list of level lumas (finest first) of the reference's Pyramid::build chain"""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = rgb.shape[:2]
+    sizes = level_sizes(w, h, nlevels)
+    out = np.zeros(sum(a * b for a, b in sizes), dtype=np.float32)
+    lib().vmo_luma_pyramid(rgb.ctypes.data, w, h, nlevels, out.ctypes.data)
+    res, off = [], 0
+    for (a, b) in sizes:
+        res.append(out[off:off + a * b].reshape(b, a))
+        off += a * b
+    return res
