@@ -124,6 +124,11 @@ int  vm_pyramid_levels(vm_pyr *pyr);
 int  vm_level_dims(vm_pyr *pyr, int lvl, int *w, int *h, int *rowstride);
 /* the cudaMemcpy2DToArray uploads of luma in Pyramid::build, pyramid.cu:275-280 */
 int  vm_level_upload_luma(vm_pyr *pyr, int lvl, const float *img0, const float *img1, int pitch);
+/* the image half of Pyramid::build(video0, video1, ..., start_res),
+ * Algorithm/pyramid.cu:166-485, for one pair of RGB8 frames of the level-0 size:
+ * load -> per level scale() (include/resample: cubic B-spline generalized sampling)
+ * -> store_gray, all on the device; fills img0/img1 of every level that holds images */
+int  vm_pyramid_build_rgb(vm_pyr *pyr, const uint8_t *rgb0, const uint8_t *rgb1, int pitch_bytes);
 /* lvl.v.copy_from_host, Algorithm/morph.cu:588 */
 int  vm_level_set_v(vm_pyr *pyr, int lvl, const float *v_xy, int pitch);
 /* the cudaMemcpy2D of CMatchingThread::update_result, MatchingThread.cpp:38-40 */

@@ -27,7 +27,7 @@ SYMBOLS = [
     "vm_last_error", "vm_version", "vm_ctx_create", "vm_ctx_destroy", "vm_ctx_sync",
     "vm_set_params", "vm_get_params", "vm_set_math_mode", "vm_set_tuning", "vm_device_info",
     "vm_pyramid_create", "vm_pyramid_destroy", "vm_pyramid_levels", "vm_level_dims",
-    "vm_level_upload_luma", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
+    "vm_level_upload_luma", "vm_pyramid_build_rgb", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
     "vm_solve", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
     "vm_frame_download_ext", "vm_frame_set_v_from_level", "vm_render_halfway",
@@ -90,6 +90,7 @@ def load():
         "vm_pyramid_levels": [vp],
         "vm_level_dims": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)],
         "vm_level_upload_luma": [vp, i, vp, vp, i],
+        "vm_pyramid_build_rgb": [vp, vp, vp, i],
         "vm_level_set_v": [vp, i, vp, i],
         "vm_level_get_v": [vp, i, vp, i],
         "vm_level_get_field": [vp, i, i, vp],

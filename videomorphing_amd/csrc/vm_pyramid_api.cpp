@@ -1,0 +1,143 @@
+// vm_pyramid_api.cpp -- C-ABI of the device-side pyramid builder: the image half of
+// Pyramid::build (Algorithm/pyramid.cu:166-485) for one frame pair, driving
+// vm_pyramid.hip the way pyramid.cu drives include/resample's scale().
+#include "vm_host.h"
+#include "vm_pyramid.h"
+
+#include <cmath>
+#include <map>
+#include <vector>
+
+namespace {
+
+float bspline3(float r)
+{
+    r = std::fabs(r);
+    if (r < 1.f) return (4.f + r * r * (-6.f + 3.f * r)) / 6.f;
+    if (r < 2.f) return (8.f + r * (-12.f + (6.f - r) * r)) / 6.f;
+    return 0.f;
+}
+int ext_mirror(int i, int n)
+{
+    const int m = 2 * n;
+    i = i >= 0 ? i % m : (m - 1) - ((-i - 1) % m);
+    return i >= n ? m - i - 1 : i;
+}
+
+// the factored inverse of the sampled cubic B-spline with mirror boundary
+// (dlti.cpp:232-257 assembly, :66-93 LU without pivoting, float), as three arrays:
+// [0,n) upper A(j-1? no: A(i,i+1) stored at column i+1), [n,2n) inverse pivots, [2n,3n) lower A(i+1,i)
+std::vector<float> tri_factor(int n)
+{
+    std::vector<float> A((size_t)3 * n, 0.f);
+    auto at = [&](int i, int j) -> float & { return A[(size_t)(i - j + 1) * n + j]; };
+    const float kern[3] = {bspline3(1.f), bspline3(0.f), bspline3(-1.f)};
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k)
+            at(i, ext_mirror(i + k - 1, n)) += kern[k];
+    for (int p = 0; p < n; ++p) {
+        float inv_p = (at(p, p) = 1.f / at(p, p));
+        if (p + 1 < n) {
+            float m = (at(p + 1, p) *= inv_p);
+            at(p + 1, p + 1) -= m * at(p, p + 1);
+        }
+    }
+    return A;
+}
+
+struct Builder {
+    vm_ctx *c;
+    std::map<int, float *> factors; // line length -> device factors
+    float *img = nullptr, *tmp = nullptr;
+    uint8_t *rgb = nullptr;
+    ~Builder()
+    {
+        for (auto &kv : factors) hipFree(kv.second);
+        hipFree(img); hipFree(tmp); hipFree(rgb);
+    }
+    int factor(int n, float **out)
+    {
+        auto it = factors.find(n);
+        if (it == factors.end()) {
+            std::vector<float> A = tri_factor(n);
+            float *d = nullptr;
+            VM_HIP(hipMalloc((void **)&d, A.size() * 4));
+            VM_HIP(hipMemcpyAsync(d, A.data(), A.size() * 4, hipMemcpyHostToDevice, c->stream));
+            VM_HIP(hipStreamSynchronize(c->stream));
+            it = factors.emplace(n, d).first;
+        }
+        *out = it->second;
+        return VM_OK;
+    }
+    // one axis of scale(): src (w x h, 3 planes) -> dst; returns the new size in w, h
+    int axis(float *&src, float *&dst, int &w, int &h, int nout, int ax)
+    {
+        const int nin = ax == 0 ? w : h;
+        const int wout = ax == 0 ? nout : w, hout = ax == 0 ? h : nout;
+        float *A = nullptr;
+        hipStream_t s = c->stream;
+        if (nout < nin) {
+            vm_pyr_launch_down(src, dst, w, h, nout, ax, s);
+            int rc = factor(nout, &A);
+            if (rc != VM_OK) return rc;
+            vm_pyr_launch_tri_solve(dst, A, wout, hout, ax, s);
+        } else {
+            vm_pyr_launch_curve(src, (size_t)3 * w * h, 1, s);
+            int rc = factor(nin, &A);
+            if (rc != VM_OK) return rc;
+            vm_pyr_launch_tri_solve(src, A, w, h, ax, s);
+            vm_pyr_launch_up(src, dst, w, h, nout, ax, s);
+            vm_pyr_launch_curve(dst, (size_t)3 * wout * hout, 0, s);
+        }
+        std::swap(src, dst);
+        w = wout;
+        h = hout;
+        return VM_OK;
+    }
+    // scale(), scale.cpp:225-272
+    int scale(float *&a, float *&b, int &w, int &h, int wout, int hout)
+    {
+        int rc;
+        if (hout * w < wout * h) {
+            if ((rc = axis(a, b, w, h, hout, 1)) != VM_OK) return rc;
+            return axis(a, b, w, h, wout, 0);
+        }
+        if ((rc = axis(a, b, w, h, wout, 0)) != VM_OK) return rc;
+        return axis(a, b, w, h, hout, 1);
+    }
+};
+
+} // namespace
+
+extern "C" int vm_pyramid_build_rgb(vm_pyr *p, const uint8_t *rgb0, const uint8_t *rgb1, int pitch)
+{
+    if (!p || !rgb0 || !rgb1) return vm_fail(VM_E_INVALID, "vm_pyramid_build_rgb: NULL argument");
+    std::lock_guard<std::recursive_mutex> lock(p->ctx->mu);
+    vm_ctx *c = p->ctx;
+    const int w0 = p->lv[0].w, h0 = p->lv[0].h, L = (int)p->lv.size();
+    if (pitch == 0) pitch = 3 * w0;
+    if (pitch < 3 * w0) return vm_fail(VM_E_INVALID, "vm_pyramid_build_rgb: pitch < 3*width");
+    Builder B;
+    B.c = c;
+    const size_t n0 = (size_t)w0 * h0;
+    VM_HIP(hipMalloc((void **)&B.img, n0 * 12));
+    VM_HIP(hipMalloc((void **)&B.tmp, n0 * 12));
+    VM_HIP(hipMalloc((void **)&B.rgb, (size_t)pitch * h0));
+    hipStream_t s = c->stream;
+    const uint8_t *src[2] = {rgb0, rgb1};
+    for (int k = 0; k < 2; ++k) {
+        VM_HIP(hipMemcpyAsync(B.rgb, src[k], (size_t)pitch * h0, hipMemcpyHostToDevice, s));
+        float *a = B.img, *b = B.tmp;
+        int w = w0, h = h0;
+        vm_pyr_launch_load(B.rgb, pitch, a, w, h, s);
+        for (int el = 0; el < L - 1; ++el) { // the coarsest level holds no images (pyramid.cu:329)
+            const vm_level &lv = p->lv[el];
+            int rc = B.scale(a, b, w, h, lv.w, lv.h); // el == 0: same size (pyramid.cu:270-273)
+            if (rc != VM_OK) return rc;
+            vm_pyr_launch_store_gray(a, (float *)(k == 0 ? lv.view.img0 : lv.view.img1), lv.w, lv.h, lv.rs, s);
+        }
+        VM_HIP(hipGetLastError());
+        VM_HIP(hipStreamSynchronize(s)); // B.rgb is reused for the second frame
+    }
+    return VM_OK;
+}

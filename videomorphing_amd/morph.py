@@ -244,6 +244,27 @@ class Pyramid(object):
         return pyr
 
 
+def _pyramid_build_rgb(self, rgb0, rgb1, start_res, nlevels=None):
+    """Pyramid::build for one pair of RGB8 frames with the reference's own image chain
+    (pyramid.cu:203-211, 268-279, 355-364: load, Nehab-Hoppe cubic B-spline scale() per
+    level, store_gray), run on the device (vm_pyramid.hip)."""
+    rgb0 = np.ascontiguousarray(rgb0, dtype=np.uint8)
+    rgb1 = np.ascontiguousarray(rgb1, dtype=np.uint8)
+    h, w = rgb0.shape[:2]
+    assert rgb0.shape == (h, w, 3) and rgb1.shape == rgb0.shape
+    n = max(nlevels if nlevels is not None else synth.num_levels(w, h, start_res), 2)
+    sizes = [(w, h)]
+    for _ in range(n - 1):
+        sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+    self.build_levels(sizes)
+    capi.check(self._L.vm_pyramid_build_rgb(self._h, rgb0.ctypes.data, rgb1.ctypes.data, 0))
+    self._vector = [np.zeros((h, w, 2), dtype=np.float32)]
+    self._qpath = [np.zeros((h, w, 2), dtype=np.float32)]
+
+
+Pyramid.build_rgb = _pyramid_build_rgb
+
+
 class Morph(object):
     """class Morph, morph.h:10-31."""
 
