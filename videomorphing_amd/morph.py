@@ -314,7 +314,9 @@ class Morph(object):
                 self._current_iter += lv.width * lv.height * self._max_iter
                 self.progress[el] = dict(iters=pr.iters, improving=pr.improving,
                                          pixel_iters=pr.pixel_iters, elapsed_ms=pr.elapsed_ms,
-                                         launches=pr.launches, width=lv.width, height=lv.height)
+                                         launches=pr.launches, active_tiles=pr.active_tiles,
+                                         candidates=pr.candidates, commits=pr.commits,
+                                         width=lv.width, height=lv.height)
                 capi.check(L.vm_level_clear(pyr._h, el - 1))
                 self._max_iter /= P.max_iter_drop_factor
             self._current_l -= 1
