@@ -14,8 +14,14 @@ struct VmCgScalars {
 void vm_poisson_launch_crop(uchar4 *dst, const uchar4 *ext, int w, int h, int ex, hipStream_t s);
 void vm_poisson_launch_prepare(uchar4 *ext, uint8_t *type, const uchar4 *other, const float2 *v,
                                int w, int h, int rs, int ex, int sign, hipStream_t s);
-void vm_poisson_launch_setup(const uchar4 *ext, const uint8_t *type, float4 *B, float4 *X,
-                             float4 *R, float4 *P, VmCgScalars *sc, int cw, int ch, hipStream_t s);
+void vm_poisson_launch_setup(const uchar4 *ext, const uint8_t *type, float4 *B, float4 *X, int cw, int ch,
+                             hipStream_t s);
+void vm_poisson_launch_cg_init(const float4 *B, const float4 *X, float4 *R, float4 *P, const uint8_t *type,
+                               VmCgScalars *sc, int cw, int ch, hipStream_t s);
+void vm_poisson_launch_coarsen(const uchar4 *ext, const uint8_t *type, uchar4 *ext_c, uint8_t *type_c, int cw,
+                               int ch, int cw2, int ch2, hipStream_t s);
+void vm_poisson_launch_prolong(const float4 *Xc, const uint8_t *type_c, float4 *X, const uint8_t *type, int cw,
+                               int ch, int cw2, int ch2, hipStream_t s);
 void vm_poisson_launch_iter(float4 *X, float4 *R, float4 *P, float4 *Q, const float4 *B,
                             const uint8_t *type, VmCgScalars *sc, int cw, int ch, hipStream_t s);
 void vm_poisson_launch_paste(uchar4 *ext, const uint8_t *type, const float4 *X, int cw, int ch,

@@ -126,7 +126,7 @@ __device__ __forceinline__ float4 grad(const uchar4 *__restrict__ ext, const uin
 // right-hand side and diagonal, PoissonExt.cpp:214-270; also the initial guess
 __global__ __launch_bounds__(256) void k_setup(const uchar4 *__restrict__ ext,
                                                const uint8_t *__restrict__ type, float4 *B,
-                                               float4 *X, int cw, int ch)
+                                               float4 *X, int cw, int ch, int init_x)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= cw || y >= ch)
@@ -148,6 +148,8 @@ __global__ __launch_bounds__(256) void k_setup(const uchar4 *__restrict__ ext,
     }
     b.w = diag; // the diagonal travels in the spare lane
     B[ii] = b;
+    if (!init_x)
+        return; // X already holds the prolongated coarse solution
     // initial guess: the colour already there (ring and filled pixels), mid grey on holes
     float4 x0 = make_float4(0, 0, 0, 0);
     if (t > 0) {
@@ -334,6 +336,84 @@ __global__ __launch_bounds__(256) void k_crop(uchar4 *dst, const uchar4 *__restr
     dst[(size_t)y * w + x] = ext[(size_t)(y + ex) * (w + 2 * ex) + x + ex];
 }
 
+// nested iteration: the same problem on a 4x coarser canvas gives the fine solve its
+// low frequencies (the outside band is ~0.1 max(W,H) pixels wide, which plain CG has to
+// cross one pixel per iteration).  A coarse pixel is outside (2) if its 4x4 block holds
+// only outside pixels, interior (0) if only interior ones, else an anchor (1) carrying
+// the mean colour of the block's non-outside pixels; outside blocks carry the mean of
+// their real colours (marker if none).
+__global__ __launch_bounds__(256) void k_coarsen(const uchar4 *__restrict__ ext, const uint8_t *__restrict__ type,
+                                                 uchar4 *ext_c, uint8_t *type_c, int cw, int ch, int cw2, int ch2)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw2 || y >= ch2)
+        return;
+    int n_out = 0, n_in = 0, n_ring = 0, n_col = 0, n_anchor = 0;
+    float3 col = make_float3(0, 0, 0), anc = make_float3(0, 0, 0);
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
+            const int fx = 4 * x + i, fy = 4 * y + j;
+            if (fx >= cw || fy >= ch)
+                continue;
+            const size_t ii = (size_t)fy * cw + fx;
+            const uint8_t t = type[ii];
+            const uchar4 c = ext[ii];
+            if (t == 2) {
+                ++n_out;
+                if (!is_marker(c)) { ++n_col; col.x += c.x; col.y += c.y; col.z += c.z; }
+            } else {
+                if (t == 1) ++n_ring; else ++n_in;
+                ++n_anchor; anc.x += c.x; anc.y += c.y; anc.z += c.z;
+            }
+        }
+    uint8_t t = 0;
+    uchar4 o = make_uchar4(255, 0, 255, 0);
+    if (n_out > 0 && n_anchor == 0) {
+        t = 2;
+        if (n_col > 0)
+            o = make_uchar4((uint8_t)(col.x / n_col + 0.5f), (uint8_t)(col.y / n_col + 0.5f), (uint8_t)(col.z / n_col + 0.5f), 0);
+    } else if (n_out > 0 || n_ring > 0) {
+        t = 1;
+        o = make_uchar4((uint8_t)(anc.x / n_anchor + 0.5f), (uint8_t)(anc.y / n_anchor + 0.5f), (uint8_t)(anc.z / n_anchor + 0.5f), 0);
+    } else if (n_anchor > 0) {
+        o = make_uchar4((uint8_t)(anc.x / n_anchor + 0.5f), (uint8_t)(anc.y / n_anchor + 0.5f), (uint8_t)(anc.z / n_anchor + 0.5f), 0);
+    }
+    const size_t k = (size_t)y * cw2 + x;
+    type_c[k] = t;
+    ext_c[k] = o;
+}
+
+// bilinear prolongation of the coarse solution as the fine initial guess
+__global__ __launch_bounds__(256) void k_prolong(const float4 *__restrict__ Xc, const uint8_t *__restrict__ type_c,
+                                                 float4 *X, const uint8_t *__restrict__ type, int cw, int ch,
+                                                 int cw2, int ch2)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= ch)
+        return;
+    const size_t ii = (size_t)y * cw + x;
+    if (type[ii] == 0) { X[ii] = make_float4(0, 0, 0, 0); return; }
+    const float fx = (x + 0.5f) * 0.25f - 0.5f, fy = (y + 0.5f) * 0.25f - 0.5f;
+    const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+    const float a = fx - x0, b = fy - y0;
+    float4 acc = make_float4(0, 0, 0, 0);
+    float wsum = 0;
+    for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i) {
+            const int qx = min(max(x0 + i, 0), cw2 - 1), qy = min(max(y0 + j, 0), ch2 - 1);
+            const size_t k = (size_t)qy * cw2 + qx;
+            if (type_c[k] == 0)
+                continue;
+            const float wgt = (i ? a : 1 - a) * (j ? b : 1 - b);
+            const float4 c = Xc[k];
+            acc.x += wgt * c.x; acc.y += wgt * c.y; acc.z += wgt * c.z;
+            wsum += wgt;
+        }
+    if (wsum > 1e-6f)
+        X[ii] = make_float4(acc.x / wsum, acc.y / wsum, acc.z / wsum, 0);
+    // else: keep the default guess written by k_setup
+}
+
 inline dim3 grid2(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 const dim3 B2(64, 4);
 
@@ -352,11 +432,28 @@ void vm_poisson_launch_prepare(uchar4 *ext, uint8_t *type, const uchar4 *other, 
     hipLaunchKernelGGL(k_fill, grid2(cw, ch), B2, 0, s, ext, type, other, v, w, h, rs, ex, sign);
 }
 
-void vm_poisson_launch_setup(const uchar4 *ext, const uint8_t *type, float4 *B, float4 *X,
-                             float4 *R, float4 *P, VmCgScalars *sc, int cw, int ch, hipStream_t s)
+void vm_poisson_launch_setup(const uchar4 *ext, const uint8_t *type, float4 *B, float4 *X, int cw, int ch,
+                             hipStream_t s)
 {
-    hipLaunchKernelGGL(k_setup, grid2(cw, ch), B2, 0, s, ext, type, B, X, cw, ch);
+    hipLaunchKernelGGL(k_setup, grid2(cw, ch), B2, 0, s, ext, type, B, X, cw, ch, 1);
+}
+
+void vm_poisson_launch_cg_init(const float4 *B, const float4 *X, float4 *R, float4 *P, const uint8_t *type,
+                               VmCgScalars *sc, int cw, int ch, hipStream_t s)
+{
     hipLaunchKernelGGL(k_cg_init, grid2(cw, ch), B2, 0, s, B, X, R, P, type, sc, cw, ch);
+}
+
+void vm_poisson_launch_coarsen(const uchar4 *ext, const uint8_t *type, uchar4 *ext_c, uint8_t *type_c, int cw,
+                               int ch, int cw2, int ch2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_coarsen, grid2(cw2, ch2), B2, 0, s, ext, type, ext_c, type_c, cw, ch, cw2, ch2);
+}
+
+void vm_poisson_launch_prolong(const float4 *Xc, const uint8_t *type_c, float4 *X, const uint8_t *type, int cw,
+                               int ch, int cw2, int ch2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prolong, grid2(cw, ch), B2, 0, s, Xc, type_c, X, type, cw, ch, cw2, ch2);
 }
 
 void vm_poisson_launch_iter(float4 *X, float4 *R, float4 *P, float4 *Q, const float4 *B,
