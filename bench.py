@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent frame pairs solved concurrently per GPU (one HIP stream and one "
                          "host thread each); 1 = one pair at a time")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="frame pairs solved together by the same sweep launches (vm_solve_batch); a step "
+                         "is then one batch.  1 = config[1], one pair per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--size", default=None, help="WxH override (debug only; invalid as a result)")
@@ -103,12 +106,13 @@ def main():
 
     # ---- inputs: K+W independent frame pairs per rank, pyramids resident in HBM ----
     nlev = synth.num_levels(w, h, blk.start_res)
-    npairs = args.steps + args.warmup
+    B = max(1, args.batch)
+    npairs = (args.steps + args.warmup) * B
     pyrs = []
     for k in range(npairs):
         frame = rank * npairs + k
         i0, i1 = synth.make_pair(w, h, frame=frame)
-        p = morph.Pyramid(ctxs[k % nctx])
+        p = morph.Pyramid(ctxs[(k // B) % nctx])
         p.build(i0, i1, blk.start_res, nlevels=nlev)
         pyrs.append(p)
     sizes = [(pyrs[0][el].width, pyrs[0][el].height) for el in range(1, nlev + 1)]
@@ -120,9 +124,30 @@ def main():
         capi.check(L.vm_solve(p._h, blk.max_iter, blk.max_iter_drop_factor, None, 0, None, fixed, prog))
         return prog
 
+    def solve_group(ps, fixed=FIXED):
+        """one step: a batch of B pairs relaxed by the same launches"""
+        if len(ps) == 1:
+            return [solve(ps[0], fixed)]
+        arr = (C.c_void_p * len(ps))(*[p._h for p in ps])
+        prog = (capi.Progress * (len(ps) * (nlev - 1)))()
+        capi.check(L.vm_solve_batch(arr, len(ps), blk.max_iter, blk.max_iter_drop_factor, None, fixed, prog))
+        out = []
+        for i in range(len(ps)):
+            one = (capi.Progress * (nlev - 1))(*[prog[i * (nlev - 1) + k] for k in range(nlev - 1)])
+            if i > 0:          # elapsed/launches are per batch: count them once
+                for k in range(nlev - 1):
+                    one[k].elapsed_ms, one[k].launches = 0.0, 0
+            out.append(one)
+        return out
+
     def run_steps(ps):
         """solve the pyramids; with several contexts, one host thread per context works
         through that context's pyramids (a vm_ctx is single-threaded by contract)"""
+        if B > 1:
+            out = []
+            for g0 in range(0, len(ps), B):
+                out += solve_group(ps[g0:g0 + B])
+            return out
         if nctx == 1:
             return [solve(p) for p in ps]
         from concurrent.futures import ThreadPoolExecutor
@@ -146,10 +171,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run_steps(pyrs[:args.warmup])
+    run_steps(pyrs[:args.warmup * B])
     sync_all()
     t0 = time.perf_counter()
-    progs = run_steps(pyrs[args.warmup:])
+    progs = run_steps(pyrs[args.warmup * B:])
     for c in ctxs:
         c.sync()
     torch.cuda.synchronize()
@@ -190,6 +215,25 @@ def main():
         extras["%s_math_mpix_iters_per_s" % ("exact" if other == capi.MATH_EXACT else "fast")] = round(
             sum(pr[i].pixel_iters for i in range(nlev - 1)) / dt / 1e6, 2)
         ctx.set_math_mode(blk.math_mode)
+        # batched throughput: B independent pairs relaxed by the same launches (the per-GPU
+        # workload of config[2]: 60 pairs over 8 GPUs); frames are reused cyclically
+        if B == 1:
+            base_frames = [synth.make_pair(w, h, frame=1000 + k) for k in range(4)]
+            bt = {}
+            for nb in (8, 32):
+                group = []
+                for k in range(nb):
+                    q = morph.Pyramid(ctx)
+                    q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
+                    group.append(q)
+                solve_group(group)                                    # warm-up
+                ctx.sync(); t1 = time.perf_counter(); pr = solve_group(group); ctx.sync()
+                dt = time.perf_counter() - t1
+                bt["pairs_%d" % nb] = {
+                    "mpix_iters_per_s": round(sum(q2[i].pixel_iters for q2 in pr for i in range(nlev - 1)) / dt / 1e6, 1),
+                    "ms_per_batch": round(dt * 1e3, 1)}
+                del group
+            extras["batched_throughput_fixed_work"] = bt
         # compositor: frames/s of render_halfway with device-resident inputs
         ex = int(0.1 * max(w, h))
         rgb0, rgb1 = synth.make_rgb_pair(w, h)
@@ -199,11 +243,18 @@ def main():
         fr.render_halfway_dev(0.5, 0.5, 1)
         ms = [fr.render_halfway_dev(0.5, 0.1 * k, 1) for k in range(1, 10)]
         extras["render_frames_per_s"] = round(1000.0 / (sum(ms) / len(ms)), 1)
+        # Poisson boundary extension of both sides of that frame (config[4]'s other stage)
+        pe = {}
+        for tol in (1e-4, 1e-5):
+            fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
+            r1, r2 = fr.poisson_extend(1, tol=tol), fr.poisson_extend(2, tol=tol)
+            pe["tol_%g" % tol] = {"ms_per_frame": round(r1[2] + r2[2], 1), "cg_iterations": [r1[0], r2[0]]}
+        extras["poisson_extend_1080p_ex%d" % ex] = pe
         fr.close()
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(np, synth, blk, pyrs[args.warmup])
+        cpu = cpu_baseline(np, synth, blk, pyrs[args.warmup * B:])
 
     if rank == 0:
         avg_launch_us = kern_ms * 1e3 / max(launches, 1)
@@ -223,13 +274,14 @@ def main():
             "ms_per_step": round(el_max / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config[1]: %dx%d frame pair, %d-level pyramid (start_res %d), max_iter %d/level, drop %g, one pair per step per GPU"
-                                   % (w, h, nlev, blk.start_res, int(blk.max_iter), blk.max_iter_drop_factor),
+            "config": {"workload": "config[1]: %dx%d frame pair, %d-level pyramid (start_res %d), max_iter %d/level, drop %g, %s per step per GPU"
+                                   % (w, h, nlev, blk.start_res, int(blk.max_iter), blk.max_iter_drop_factor,
+                                      "one pair" if B == 1 else "a batch of %d independent pairs" % B),
                        "math_mode": "fast" if blk.math_mode == capi.MATH_FAST else "exact",
                        "semantics": "fixed work: every sweep of every level is launched" if FIXED
                                     else "reference: a level stops when no pixel improved",
                        "iters_per_level_fine_to_coarse": iters_per_level[0],
-                       "pairs_in_flight_per_gpu": nctx,
+                       "pairs_in_flight_per_gpu": nctx, "pairs_per_step": B,
                        "parallelism": "independent frame pairs, %d rank(s), 1 RCCL broadcast" % world},
             "roofline": {"bound": "hbm", "kernel": "k_optimize (sweep)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -264,38 +316,45 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(np, synth, blk, gpu_pyr):
+def cpu_baseline(np, synth, blk, gpu_pyrs):
     """The CPU restatement (oracle, OpenMP over tiles) timed on this host on a bounded
-    sample of the same workload: the first sweeps of the finest (1920x1080) level of
-    the solve just timed, started -- like the GPU path -- from the upsampled solution
-    of the 960x540 level."""
+    sample of the same workload: level by level (finest first) of the solves just timed,
+    each level started -- like the GPU path -- from the upsampled solution of the next
+    coarser level and swept until no pixel improves, until about 12 s have been spent."""
     import oracle as O
     threads = effective_cpus()
     O.lib().vmo_set_threads(threads)
     P = O.default_params()
     for f, _ in P._fields_:
         setattr(P, f, getattr(blk.kp, f))
-    w, h = gpu_pyr[1].width, gpu_pyr[1].height
-    frame_imgs = gpu_pyr[1].field("img0"), gpu_pyr[1].field("img1")
-    coarse = O.Level(gpu_pyr[2].width, gpu_pyr[2].height)
-    coarse.field("v")[...] = gpu_pyr[2].v
-    tgt = O.Level(w, h)
-    tgt.set_images(*frame_imgs)
-    tgt.upsample_from(coarse)
-    tgt.init(P.ssim_clamp)
     stats = np.zeros(4)
-    t0 = time.perf_counter()
-    iters = 0
-    while time.perf_counter() - t0 < 12.0 and iters < int(blk.max_iter):
-        imp = tgt.optimize_iter(P, stats)
-        iters += 1
-        if not imp:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": round(w * h * iters / dt / 1e6, 3), "unit": "Mpixel*iters/s",
+    units, spent, parts = 0.0, 0.0, []
+    nlev = gpu_pyrs[0].size() - 1
+    for gp in gpu_pyrs:
+        for el in range(1, nlev - 1):
+            if spent > 12.0:
+                break
+            w, h = gp[el].width, gp[el].height
+            coarse = O.Level(gp[el + 1].width, gp[el + 1].height)
+            coarse.field("v")[...] = gp[el + 1].v
+            tgt = O.Level(w, h)
+            tgt.set_images(gp[el].field("img0"), gp[el].field("img1"))
+            tgt.upsample_from(coarse)
+            tgt.init(P.ssim_clamp)
+            t0 = time.perf_counter()
+            iters = 0
+            while time.perf_counter() - t0 < 8.0 and iters < int(blk.max_iter):
+                imp = tgt.optimize_iter(P, stats)
+                iters += 1
+                if not imp:
+                    break
+            spent += time.perf_counter() - t0
+            units += float(w) * h * iters
+            parts.append("%dx%d:%d" % (w, h, iters))
+    return {"value": round(units / spent / 1e6, 3), "unit": "Mpixel*iters/s",
             "cores": threads, "kind": "port",
-            "sample": "first %d sweeps of the %dx%d level of the same solve (oracle, OpenMP over tiles, "
-                      "%d threads), %.1f s; %.0f energy evaluations" % (iters, w, h, threads, dt, stats[3])}
+            "sample": "reference-semantics sweeps of levels [%s] of the solves just timed (oracle, OpenMP "
+                      "over tiles, %d threads), %.1f s; %.0f energy evaluations" % (", ".join(parts), threads, spent, stats[3])}
 
 
 if __name__ == "__main__":

@@ -160,6 +160,15 @@ int  vm_optimize_level(vm_pyr *pyr, int lvl, float max_iter, volatile const int 
 int  vm_solve(vm_pyr *pyr, float max_iter, float max_iter_drop_factor,
               const vm_constraint *c, int n, volatile const int *run_flag,
               int fixed_work, vm_progress *per_level);
+/* The same two calls for a BATCH of frame pairs that share one context and one geometry
+ * (no constraints): every sweep launch covers all pairs, which is how levels too small to
+ * occupy the GPU are filled -- the natural parallelism of the path is across pairs.
+ * out / per_level: n entries resp. n*(nlevels-1) entries, pair-major; elapsed_ms and
+ * launches are those of the batch.  Each pair converges on its own flags. */
+int  vm_optimize_level_batch(vm_pyr **pyrs, int n, int lvl, float max_iter,
+                             volatile const int *run_flag, int fixed_work, vm_progress *out);
+int  vm_solve_batch(vm_pyr **pyrs, int n, float max_iter, float max_iter_drop_factor,
+                    volatile const int *run_flag, int fixed_work, vm_progress *per_level);
 /* CMatchingThread::update_result + Resize, Algorithm/MatchingThread.cpp:22-100:
  * v of level `lvl` scaled by (W0/W, H0/H) and bilinearly resized to w0 x h0 */
 int  vm_upscale_result(vm_pyr *pyr, int lvl, int w0, int h0, float *v_xy_out, int pitch);

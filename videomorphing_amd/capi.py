@@ -29,7 +29,7 @@ SYMBOLS = [
     "vm_pyramid_create", "vm_pyramid_destroy", "vm_pyramid_levels", "vm_level_dims",
     "vm_level_upload_luma", "vm_pyramid_build_rgb", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
-    "vm_solve", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
+    "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
     "vm_frame_download_ext", "vm_frame_set_v_from_level", "vm_render_halfway",
     "vm_render_halfway_dev", "vm_poisson_extend", "vm_rccl_bcast",
 ]
@@ -100,6 +100,8 @@ def load():
         "vm_init_level": [vp, i, i, i, vp, i],
         "vm_optimize_level": [vp, i, f, vp, i, C.POINTER(Progress)],
         "vm_solve": [vp, f, f, vp, i, vp, i, vp],
+        "vm_optimize_level_batch": [vp, i, i, f, vp, i, vp],
+        "vm_solve_batch": [vp, i, f, f, vp, i, vp],
         "vm_upscale_result": [vp, i, i, i, vp, i],
         "vm_frame_create": [vp, i, i, i, C.POINTER(vp)],
         "vm_frame_upload": [vp, vp, vp, vp, vp],

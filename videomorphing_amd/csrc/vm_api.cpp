@@ -131,6 +131,7 @@ extern "C" void vm_ctx_destroy(vm_ctx *c)
     hipFree(c->stats);
     hipHostFree(c->stats_host);
     hipFree(c->cons_dev);
+    hipFree(c->views);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
@@ -471,118 +472,186 @@ extern "C" int vm_init_level(vm_pyr *p, int lvl, int w0, int h0, const vm_constr
     return VM_OK;
 }
 
-extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile const int *run_flag,
-                                 int fixed_work, vm_progress *out)
+// Morph::optimize_level for a BATCH of frame pairs of identical geometry on one context:
+// every sweep launch covers the same level of all pairs (grid.z = pair), so a level with
+// too few tiles to occupy 256 CUs is filled by the batch instead -- the natural parallelism
+// of the path (independent pairs).  Each pair keeps its own convergence
+// flags: one that stopped improving turns into mask-pruned no-ops while the others go on.
+static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, volatile const int *run_flag,
+                                int fixed_work, vm_progress *out)
 {
-    CHECK_LVL(p, lvl);
-    std::lock_guard<std::recursive_mutex> lock(p->ctx->mu);
-    vm_level &l = p->lv[lvl];
-    vm_ctx *c = p->ctx;
-    if (!l.has_state) return vm_fail(VM_E_STATE, "vm_optimize_level: level %d not initialised", lvl);
+    vm_pyr *p0 = ps[0];
+    vm_ctx *c = p0->ctx;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    vm_level &l0 = p0->lv[lvl];
+    for (int i = 0; i < n; ++i) {
+        if (!ps[i] || ps[i]->ctx != c) return vm_fail(VM_E_INVALID, "batch: pyramids must share one context");
+        if (lvl < 0 || lvl >= (int)ps[i]->lv.size()) return vm_fail(VM_E_INVALID, "batch: level %d out of range", lvl);
+        vm_level &l = ps[i]->lv[lvl];
+        if (l.w != l0.w || l.h != l0.h) return vm_fail(VM_E_INVALID, "batch: pyramids must share their geometry");
+        if (!l.has_state) return vm_fail(VM_E_STATE, "vm_optimize_level: level %d not initialised", lvl);
+    }
     VmKParams P = {c->kp.w_ui, c->kp.w_tps, c->kp.w_ssim, c->kp.ssim_clamp, c->kp.eps, c->kp.bcond};
     // iterations the reference loop would run: do { ... iter++ } while (iter < max_iter && improving)
     int cap = 1;
     while ((float)cap < max_iter) ++cap;
-    if (cap > c->flags_cap) {
+    const size_t words = (size_t)cap * n;
+    if ((size_t)c->flags_cap < words) {
         hipFree(c->flags); hipHostFree(c->flags_host);
         hipFree(c->stats); hipHostFree(c->stats_host);
         c->flags = c->flags_host = c->stats = c->stats_host = nullptr;
         c->flags_cap = 0;
-        VM_HIP(hipMalloc((void **)&c->flags, (size_t)cap * 4));
-        VM_HIP(hipHostMalloc((void **)&c->flags_host, (size_t)cap * 4, hipHostMallocDefault));
-        VM_HIP(hipMalloc((void **)&c->stats, (size_t)cap * 16));
-        VM_HIP(hipHostMalloc((void **)&c->stats_host, (size_t)cap * 16, hipHostMallocDefault));
-        c->flags_cap = cap;
+        VM_HIP(hipMalloc((void **)&c->flags, words * 4));
+        VM_HIP(hipHostMalloc((void **)&c->flags_host, words * 4, hipHostMallocDefault));
+        VM_HIP(hipMalloc((void **)&c->stats, words * 16));
+        VM_HIP(hipHostMalloc((void **)&c->stats_host, words * 16, hipHostMallocDefault));
+        c->flags_cap = (int)words;
+    }
+    if (n > c->views_cap) {
+        hipFree(c->views);
+        c->views = nullptr;
+        c->views_cap = 0;
+        VM_HIP(hipMalloc((void **)&c->views, (size_t)n * sizeof(VmLevelView)));
+        c->views_cap = n;
     }
     hipStream_t s = c->stream;
-    VM_HIP(hipMemsetAsync(c->flags, 0, (size_t)cap * 4, s));
-    VM_HIP(hipMemsetAsync(c->stats, 0, (size_t)cap * 16, s));
+    {
+        std::vector<VmLevelView> hv(n);
+        for (int i = 0; i < n; ++i) hv[i] = ps[i]->lv[lvl].view;
+        VM_HIP(hipMemcpyAsync(c->views, hv.data(), (size_t)n * sizeof(VmLevelView), hipMemcpyHostToDevice, s));
+        VM_HIP(hipStreamSynchronize(s)); // hv is a stack object
+    }
+    VM_HIP(hipMemsetAsync(c->flags, 0, words * 4, s));
+    VM_HIP(hipMemsetAsync(c->stats, 0, words * 16, s));
     const bool exact = c->math_mode == VM_MATH_EXACT;
-    // workgroup size of the sweep: EXACT relaxes one pixel per lane (256 lanes per
-    // tile phase); FAST fans every pixel out over 4..32 lanes, so it takes the
-    // largest workgroup the CU offers
     // FAST kernels are built for at most 512 threads (256-VGPR budget: the register-cached
-    // window sums must not spill), EXACT ones for up to 1024
+    // window sums must not spill), EXACT ones (one pixel per lane) for up to 1024
     const int threads = std::min(c->sweep_threads ? c->sweep_threads : (exact ? 256 : 512), exact ? 1024 : 512);
-    const int tiles_per_pass = ((l.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
+    const int tiles_per_pass = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
     // SPLIT schedule: workgroups per tile so that a pass roughly fills the 256 CUs
-    const int parts = c->sweep_parts ? c->sweep_parts : std::max(1, std::min(8, 256 / tiles_per_pass));
-    if (c->sweep_mode != VM_SWEEP_TILE) // epochs restart with every call: forget old records
-        VM_HIP(hipMemsetAsync(l.view.rec_state, 0, (size_t)l.rs * l.h * 4, s));
-    double st_tiles = 0, st_cand = 0, st_commit = 0;
-    double dense_prev = 1e9; // line searches per active tile and phase in the previous batch
+    const int parts = c->sweep_parts ? c->sweep_parts : std::max(1, std::min(8, 256 / (tiles_per_pass * n)));
+    // SPLIT (8 launches per pass, a tile's line searches spread over several CUs) was measured
+    // against TILE on the levels it was meant for -- few tiles, every pixel active -- and does
+    // not win with 512-thread tiles (120x68: 0.87 vs 0.80 ms per iteration), so AUTO means
+    // TILE; SPLIT stays selectable (vm_set_tuning).
+    const bool split = c->sweep_mode == VM_SWEEP_SPLIT;
+    if (split) // epochs restart with every call: forget old records
+        for (int i = 0; i < n; ++i)
+            VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_state, 0, (size_t)l0.rs * l0.h * 4, s));
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
-    int done = 0, launches = 0, executed = cap, improving = 1;
+    std::vector<int> executed(n, cap), improving(n, 1), stopped(n, 0);
+    std::vector<double> st_tiles(n, 0.0), st_cand(n, 0.0), st_commit(n, 0.0);
+    int done = 0, launches = 0;
     bool cancelled = false;
     float ms = 0;
-    // Iterations are enqueued in batches; each sweep kernel of iteration i exits
-    // at once when iteration i-1 did not improve (device-side flag), so running
-    // past convergence inside a batch costs launch latency only, and the host
-    // reads the flags once per batch instead of once per iteration.  The HIP
-    // events bracket the sweep launches of each batch on the context's stream.
+    // Iterations are enqueued in batches; each sweep kernel of iteration i exits at once (per
+    // pair) when iteration i-1 did not improve (device-side flag), so running past convergence
+    // inside a batch costs launch latency only, and the host reads the flags once per batch
+    // instead of once per iteration.  The HIP events bracket the sweep launches of each batch
+    // on the context's stream.
     int batch = 8;
     while (done < cap) {
-        int nb = std::min(batch, cap - done);
-        // schedule of this batch.  SPLIT (8 launches per pass, a tile's line searches spread
-        // over several CUs) was measured against TILE on the levels it was meant for -- few
-        // tiles, every pixel active -- and does not win with 512-thread tiles (120x68: 0.87 vs
-        // 0.80 ms per iteration), so AUTO means TILE; SPLIT stays selectable (vm_set_tuning).
-        const bool split = c->sweep_mode == VM_SWEEP_SPLIT;
-        (void)dense_prev;
-        (void)tiles_per_pass;
+        const int nb = std::min(batch, cap - done);
         VM_HIP(hipEventRecord(c->ev0, s));
         for (int it = done; it < done + nb; ++it)
             for (int k = 0; k < 4; ++k) {
                 if (split) {
-                    if (exact) vm_launch_optimize_split_exact(l.view, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
-                    else vm_launch_optimize_split_fast(l.view, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
+                    if (exact) vm_launch_optimize_split_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
+                    else vm_launch_optimize_split_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
                     launches += 8;
                 } else {
-                    if (exact) vm_launch_optimize_exact(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
-                    else vm_launch_optimize_fast(l.view, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
+                    if (exact) vm_launch_optimize_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
+                    else vm_launch_optimize_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
                     ++launches;
                 }
             }
         VM_HIP(hipEventRecord(c->ev1, s));
         VM_HIP(hipGetLastError());
-        VM_HIP(hipMemcpyAsync(c->flags_host + done, c->flags + done, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
-        VM_HIP(hipMemcpyAsync(c->stats_host + 4 * done, c->stats + 4 * done, (size_t)nb * 16, hipMemcpyDeviceToHost, s));
-        VM_HIP(hipStreamSynchronize(s));
-        double b_tiles = 0, b_cand = 0;
-        for (int it = done; it < done + nb; ++it) {
-            // [0] tile visits (TILE schedule), [3] tile-phases with records (SPLIT schedule)
-            b_tiles += c->stats_host[4 * it] + 0.25 * c->stats_host[4 * it + 3];
-            b_cand += c->stats_host[4 * it + 1];
-            st_commit += c->stats_host[4 * it + 2];
+        for (int i = 0; i < n; ++i) {
+            VM_HIP(hipMemcpyAsync(c->flags_host + (size_t)i * cap + done, c->flags + (size_t)i * cap + done, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+            VM_HIP(hipMemcpyAsync(c->stats_host + ((size_t)i * cap + done) * 4, c->stats + ((size_t)i * cap + done) * 4, (size_t)nb * 16, hipMemcpyDeviceToHost, s));
         }
-        st_tiles += b_tiles;
-        st_cand += b_cand;
-        dense_prev = b_tiles > 0 ? b_cand / (4.0 * b_tiles) : 0.0;
+        VM_HIP(hipStreamSynchronize(s));
         float bms = 0;
         VM_HIP(hipEventElapsedTime(&bms, c->ev0, c->ev1));
         ms += bms;
-        bool stop = false;
-        for (int it = done; it < done + nb; ++it)
-            if (c->flags_host[it] == 0) {
-                improving = 0;
-                if (!fixed_work) { executed = it + 1; stop = true; break; }
-            } else improving = 1;
+        bool all_stopped = true;
+        for (int i = 0; i < n; ++i) {
+            const uint32_t *fl = c->flags_host + (size_t)i * cap, *st = c->stats_host + (size_t)i * cap * 4;
+            for (int it = done; it < done + nb && !stopped[i]; ++it) {
+                // [0] tile visits (TILE schedule), [3] tile-phases with records (SPLIT schedule)
+                st_tiles[i] += st[4 * it] + 0.25 * st[4 * it + 3];
+                st_cand[i] += st[4 * it + 1];
+                st_commit[i] += st[4 * it + 2];
+                improving[i] = fl[it] != 0;
+                if (!improving[i] && !fixed_work) { executed[i] = it + 1; stopped[i] = 1; }
+            }
+            all_stopped = all_stopped && stopped[i];
+        }
         done += nb;
-        if (stop) break;
-        if (run_flag && !*run_flag) { executed = done; cancelled = true; break; }
+        if (all_stopped) break;
+        if (run_flag && !*run_flag) {
+            for (int i = 0; i < n; ++i) if (!stopped[i]) executed[i] = done;
+            cancelled = true;
+            break;
+        }
         batch = std::min(batch * 2, 64);
     }
-    if (out) {
-        out->iters = executed;
-        out->improving = improving;
-        out->pixel_iters = (double)executed * l.w * l.h;
-        out->elapsed_ms = ms;
-        out->launches = launches;
-        out->active_tiles = st_tiles;
-        out->candidates = st_cand;
-        out->commits = st_commit;
+    for (int i = 0; i < n && out; ++i) {
+        out[i].iters = executed[i];
+        out[i].improving = improving[i];
+        out[i].pixel_iters = (double)executed[i] * l0.w * l0.h;
+        out[i].elapsed_ms = ms;       // of the batch the pair was solved in
+        out[i].launches = launches;   // idem
+        out[i].active_tiles = st_tiles[i];
+        out[i].candidates = st_cand[i];
+        out[i].commits = st_commit[i];
     }
     return cancelled ? vm_fail(VM_E_CANCELLED, "vm_optimize_level: cancelled by run_flag") : VM_OK;
+}
+
+extern "C" int vm_optimize_level(vm_pyr *p, int lvl, float max_iter, volatile const int *run_flag,
+                                 int fixed_work, vm_progress *out)
+{
+    CHECK_LVL(p, lvl);
+    return optimize_level_batch(&p, 1, lvl, max_iter, run_flag, fixed_work, out);
+}
+
+extern "C" int vm_optimize_level_batch(vm_pyr **pyrs, int n, int lvl, float max_iter,
+                                       volatile const int *run_flag, int fixed_work, vm_progress *out)
+{
+    if (!pyrs || n < 1 || !pyrs[0]) return vm_fail(VM_E_INVALID, "vm_optimize_level_batch: empty batch");
+    return optimize_level_batch(pyrs, n, lvl, max_iter, run_flag, fixed_work, out);
+}
+
+// Morph::calculate_halfway_parametrization for a batch of pairs in lockstep
+extern "C" int vm_solve_batch(vm_pyr **pyrs, int n, float max_iter, float drop, volatile const int *run_flag,
+                              int fixed_work, vm_progress *per_level)
+{
+    if (!pyrs || n < 1 || !pyrs[0]) return vm_fail(VM_E_INVALID, "vm_solve_batch: empty batch");
+    if (!(drop > 0)) return vm_fail(VM_E_INVALID, "vm_solve_batch: max_iter_drop_factor must be > 0");
+    std::lock_guard<std::recursive_mutex> lock(pyrs[0]->ctx->mu);
+    const int L = (int)pyrs[0]->lv.size();
+    const int w0 = pyrs[0]->lv[0].w, h0 = pyrs[0]->lv[0].h;
+    int rc;
+    for (int i = 0; i < n; ++i) {
+        if (!pyrs[i] || (int)pyrs[i]->lv.size() != L) return vm_fail(VM_E_INVALID, "vm_solve_batch: pyramids must share their geometry");
+        if ((rc = vm_coarse_solve(pyrs[i], L - 1, w0, h0, nullptr, 0)) != VM_OK) return rc;
+    }
+    float mi = max_iter;
+    std::vector<vm_progress> pr(n);
+    for (int el = L - 2; el >= 0; --el) {
+        if (run_flag && !*run_flag) return vm_fail(VM_E_CANCELLED, "vm_solve_batch: cancelled by run_flag");
+        for (int i = 0; i < n; ++i) {
+            if ((rc = vm_upsample_v(pyrs[i], el, el + 1)) != VM_OK) return rc;
+            if ((rc = vm_init_level(pyrs[i], el, w0, h0, nullptr, 0)) != VM_OK) return rc;
+        }
+        if ((rc = optimize_level_batch(pyrs, n, el, mi, run_flag, fixed_work, pr.data())) != VM_OK) return rc;
+        if (per_level)
+            for (int i = 0; i < n; ++i) per_level[(size_t)i * (L - 1) + el] = pr[i];
+        mi /= drop;
+    }
+    return VM_OK;
 }
 
 extern "C" int vm_solve(vm_pyr *p, float max_iter, float drop, const vm_constraint *cons, int n,

@@ -32,6 +32,8 @@ struct vm_ctx {
     int sweep_mode = 0;              // VM_SWEEP_AUTO / TILE / SPLIT
     int sweep_parts = 0;             // workgroups per tile in the SPLIT schedule, 0 = automatic
     int flags_cap = 0;
+    VmLevelView *views = nullptr;    // device copies of the level views of the current batch
+    int views_cap = 0;
     vm_constraint *cons_dev = nullptr;
     int cons_cap = 0;
 };

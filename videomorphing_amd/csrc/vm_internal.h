@@ -50,15 +50,15 @@ struct VmKParams {
 #define VM_DECL_LAUNCHERS(SUFFIX)                                                             \
     void vm_launch_init_level_##SUFFIX(const VmLevelView &L, float ssim_clamp,                \
                                        const uint32_t *tables, hipStream_t s);                \
-    void vm_launch_optimize_##SUFFIX(const VmLevelView &L, const VmKParams &P,                \
-                                     const uint32_t *tables, int offx, int offy,              \
-                                     uint32_t *flags, uint32_t *stats, int iter_idx,          \
+    void vm_launch_optimize_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w, int h, \
+                                     const VmKParams &P, const uint32_t *tables, int offx,    \
+                                     int offy, uint32_t *flags, uint32_t *stats, int iter_idx,\
                                      int fixed_work, int threads, hipStream_t s);             \
-    void vm_launch_optimize_split_##SUFFIX(const VmLevelView &L, const VmKParams &P,          \
-                                           const uint32_t *tables, int offx, int offy,        \
-                                           int pass, uint32_t *flags, uint32_t *stats,        \
-                                           int iter_idx, int fixed_work, int threads,         \
-                                           int parts, hipStream_t s);                         \
+    void vm_launch_optimize_split_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w, \
+                                           int h, const VmKParams &P, const uint32_t *tables, \
+                                           int offx, int offy, int pass, uint32_t *flags,     \
+                                           uint32_t *stats, int iter_idx, int fixed_work,     \
+                                           int threads, int parts, hipStream_t s);            \
     void vm_launch_upsample_##SUFFIX(float2 *dst, int dw, int dh, int drs, const float2 *src, \
                                      int sw, int sh, int srs, hipStream_t s);                 \
     void vm_launch_splat_##SUFFIX(const VmLevelView &L, int w0, int h0,                       \

@@ -552,13 +552,17 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
 
 // ===========================================================================
 // TILE schedule
-__global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(VmLevelView L, VmKParams P,
-                                                        const uint32_t *__restrict__ tables, int offx, int offy,
-                                                        uint32_t *__restrict__ flags,
+__global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
+                                                        VmKParams P, const uint32_t *__restrict__ tables,
+                                                        int offx, int offy, uint32_t *__restrict__ flags,
                                                         uint32_t *__restrict__ stats, int iter_idx, int fixed_work)
 {
     __shared__ TileLds S;
     const int tid = threadIdx.x, T = blockDim.x;
+    // blockIdx.z = frame pair of the batch: same geometry, own state, own flags
+    const VmLevelView L = views[blockIdx.z];
+    flags += (size_t)blockIdx.z * cap;
+    stats += (size_t)blockIdx.z * cap * 4;
 
     // converged in the previous iteration: nothing left to do (sticky)
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(VmLevelView L, VmK
 // (1: commit, 2: mask hit that did not move), valid only for the current epoch
 // (one epoch per phase, so nothing is ever cleared); rec_step[pixel] = accepted step.
 
-__global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(VmLevelView L, VmKParams P,
+__global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
                                                       const uint32_t *__restrict__ tables, int offx, int offy,
                                                       int pi, int pj, int parts, uint32_t epoch,
                                                       const uint32_t *__restrict__ flags, int iter_idx,
@@ -721,6 +725,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(VmLevelView L, VmKPa
 {
     __shared__ SplitLds S;
     const int tid = threadIdx.x, T = blockDim.x;
+    const VmLevelView L = views[blockIdx.z];
+    flags += (size_t)blockIdx.z * cap;
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
         return;
     const int part = blockIdx.x % parts, tile = blockIdx.x / parts;
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(VmLevelView L, VmKPa
     }
 }
 
-__global__ __launch_bounds__(256) void SUF(k_commit)(VmLevelView L, VmKParams P,
+__global__ __launch_bounds__(256) void SUF(k_commit)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
                                                      const uint32_t *__restrict__ tables, int offx, int offy,
                                                      int pi, int pj, uint32_t epoch,
                                                      uint32_t *__restrict__ flags, uint32_t *__restrict__ stats,
@@ -793,6 +799,9 @@ __global__ __launch_bounds__(256) void SUF(k_commit)(VmLevelView L, VmKParams P,
 {
     __shared__ SplitLds S;
     const int tid = threadIdx.x, T = blockDim.x; // T == 256
+    const VmLevelView L = views[blockIdx.z];
+    flags += (size_t)blockIdx.z * cap;
+    stats += (size_t)blockIdx.z * cap * 4;
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
         return;
     const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
@@ -878,27 +887,30 @@ __global__ __launch_bounds__(256) void SUF(k_commit)(VmLevelView L, VmKParams P,
 // ---------------------------------------------------------------------------
 // launchers
 
-void SUF(vm_launch_optimize)(const VmLevelView &L, const VmKParams &P, const uint32_t *tables, int offx,
-                             int offy, uint32_t *flags, uint32_t *stats, int iter_idx, int fixed_work,
-                             int threads, hipStream_t s)
+// `views`: device array of nbatch level views (frame pairs of one batch, same w x h);
+// flags/stats: nbatch rows of `cap` iterations
+void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
+                             const uint32_t *tables, int offx, int offy, uint32_t *flags, uint32_t *stats,
+                             int iter_idx, int fixed_work, int threads, hipStream_t s)
 {
-    dim3 b(threads), g((L.w + VM_PITCH_X - 1) / VM_PITCH_X, (L.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
-    hipLaunchKernelGGL(SUF(k_optimize), g, b, 0, s, L, P, tables, offx, offy, flags, stats, iter_idx,
+    dim3 b(threads), g((w + VM_PITCH_X - 1) / VM_PITCH_X, (h + VM_PITCH_Y - 1) / VM_PITCH_Y, nbatch);
+    hipLaunchKernelGGL(SUF(k_optimize), g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats, iter_idx,
                        fixed_work);
 }
 
 // one pass (tile offset) in the SPLIT schedule: 4 phases x (decide, commit)
-void SUF(vm_launch_optimize_split)(const VmLevelView &L, const VmKParams &P, const uint32_t *tables, int offx,
-                                   int offy, int pass, uint32_t *flags, uint32_t *stats, int iter_idx,
-                                   int fixed_work, int threads, int parts, hipStream_t s)
+void SUF(vm_launch_optimize_split)(const VmLevelView *views, int nbatch, int cap, int w, int h,
+                                   const VmKParams &P, const uint32_t *tables, int offx, int offy, int pass,
+                                   uint32_t *flags, uint32_t *stats, int iter_idx, int fixed_work, int threads,
+                                   int parts, hipStream_t s)
 {
-    const int gx = (L.w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (L.h + VM_PITCH_Y - 1) / VM_PITCH_Y;
+    const int gx = (w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (h + VM_PITCH_Y - 1) / VM_PITCH_Y;
     for (int pi = 0; pi < 2; ++pi)
         for (int pj = 0; pj < 2; ++pj) {
             const uint32_t epoch = 1u + (uint32_t)((iter_idx * 4 + pass) * 4 + pi * 2 + pj);
-            hipLaunchKernelGGL(SUF(k_decide), dim3(gx * gy * parts), dim3(threads), 0, s, L, P, tables, offx,
-                               offy, pi, pj, parts, epoch, flags, iter_idx, fixed_work);
-            hipLaunchKernelGGL(SUF(k_commit), dim3(gx, gy), dim3(256), 0, s, L, P, tables, offx, offy, pi, pj,
-                               epoch, flags, stats, iter_idx, fixed_work);
+            hipLaunchKernelGGL(SUF(k_decide), dim3(gx * gy * parts, 1, nbatch), dim3(threads), 0, s, views, cap, P,
+                               tables, offx, offy, pi, pj, parts, epoch, flags, iter_idx, fixed_work);
+            hipLaunchKernelGGL(SUF(k_commit), dim3(gx, gy, nbatch), dim3(256), 0, s, views, cap, P, tables, offx,
+                               offy, pi, pj, epoch, flags, stats, iter_idx, fixed_work);
         }
 }

@@ -323,6 +323,28 @@ class Morph(object):
         return True
 
 
+def solve_batch(pyramids, max_iter, max_iter_drop_factor=1.0, fixed_work=False, run_flag=None):
+    """Morph::calculate_halfway_parametrization for a batch of frame pairs (same context,
+    same geometry, no constraints) in lockstep: vm_solve_batch.  Returns one list of
+    per-level progress dicts (finest first) per pair."""
+    n = len(pyramids)
+    L = pyramids[0]._L
+    nl = pyramids[0].size() - 2
+    arr = (C.c_void_p * n)(*[p._h for p in pyramids])
+    prog = (capi.Progress * (n * nl))()
+    flag = C.cast(C.pointer(run_flag), C.c_void_p) if run_flag is not None else None
+    capi.check(L.vm_solve_batch(arr, n, float(max_iter), float(max_iter_drop_factor), flag,
+                                int(bool(fixed_work)), prog))
+    out = []
+    for i in range(n):
+        out.append([dict(iters=prog[i * nl + k].iters, improving=prog[i * nl + k].improving,
+                         pixel_iters=prog[i * nl + k].pixel_iters, elapsed_ms=prog[i * nl + k].elapsed_ms,
+                         launches=prog[i * nl + k].launches, commits=prog[i * nl + k].commits,
+                         candidates=prog[i * nl + k].candidates, active_tiles=prog[i * nl + k].active_tiles)
+                    for k in range(nl)])
+    return out
+
+
 class MatchingThread(object):
     """class CMatchingThread, MatchingThread.h:7-37, on threading.Thread."""
 
