@@ -529,13 +529,16 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     const int threads = std::min(c->sweep_threads ? c->sweep_threads : (exact ? 256 : 512), exact ? 1024 : 512);
     const int tiles_per_pass = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
     // SPLIT schedule: workgroups per tile so that a pass roughly fills the 256 CUs
-    const int parts = c->sweep_parts ? c->sweep_parts : std::max(1, std::min(8, 256 / (tiles_per_pass * n)));
-    // SPLIT (8 launches per pass, a tile's line searches spread over several CUs) was measured
-    // against TILE on the levels it was meant for -- few tiles, every pixel active -- and does
-    // not win with 512-thread tiles (120x68: 0.87 vs 0.80 ms per iteration), so AUTO means
-    // TILE; SPLIT stays selectable (vm_set_tuning).
-    const bool split = c->sweep_mode == VM_SWEEP_SPLIT;
-    if (split) // epochs restart with every call: forget old records
+    const int parts = c->sweep_parts ? c->sweep_parts : std::max(1, std::min(16, 256 / (tiles_per_pass * n)));
+    // Schedule, re-decided per batch of iterations (AUTO): SPLIT spreads a tile's line searches
+    // over several CUs but pays 8 launches per pass instead of 1 -- measured on MI355X it wins
+    // where a pass has few tiles and many line searches (120x68, every pixel active: 0.55 vs
+    // 0.81 ms per iteration; 240x135: 0.53 vs 0.64) and loses 8x on pruned sweeps (no-op
+    // iteration 0.11 vs 0.013 ms).  Both schedules work on the same state in HBM, so the
+    // choice can change from batch to batch.
+    const bool may_split = c->sweep_mode != VM_SWEEP_TILE && tiles_per_pass * n <= 64;
+    double cand_prev = 1e9; // line searches per iteration in the previous batch (first batch: dense)
+    if (may_split) // epochs restart with every call: forget old records
         for (int i = 0; i < n; ++i)
             VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_state, 0, (size_t)l0.rs * l0.h * 4, s));
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
@@ -552,6 +555,7 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     int batch = 8;
     while (done < cap) {
         const int nb = std::min(batch, cap - done);
+        const bool split = c->sweep_mode == VM_SWEEP_SPLIT || (may_split && cand_prev >= 1500.0 * n);
         VM_HIP(hipEventRecord(c->ev0, s));
         for (int it = done; it < done + nb; ++it)
             for (int k = 0; k < 4; ++k) {
@@ -576,18 +580,21 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
         VM_HIP(hipEventElapsedTime(&bms, c->ev0, c->ev1));
         ms += bms;
         bool all_stopped = true;
+        double b_cand = 0;
         for (int i = 0; i < n; ++i) {
             const uint32_t *fl = c->flags_host + (size_t)i * cap, *st = c->stats_host + (size_t)i * cap * 4;
             for (int it = done; it < done + nb && !stopped[i]; ++it) {
                 // [0] tile visits (TILE schedule), [3] tile-phases with records (SPLIT schedule)
                 st_tiles[i] += st[4 * it] + 0.25 * st[4 * it + 3];
                 st_cand[i] += st[4 * it + 1];
+                b_cand += st[4 * it + 1];
                 st_commit[i] += st[4 * it + 2];
                 improving[i] = fl[it] != 0;
                 if (!improving[i] && !fixed_work) { executed[i] = it + 1; stopped[i] = 1; }
             }
             all_stopped = all_stopped && stopped[i];
         }
+        cand_prev = b_cand / nb;
         done += nb;
         if (all_stopped) break;
         if (run_flag && !*run_flag) {

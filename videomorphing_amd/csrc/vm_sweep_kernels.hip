@@ -791,14 +791,14 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
     }
 }
 
-__global__ __launch_bounds__(256) void SUF(k_commit)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
-                                                     const uint32_t *__restrict__ tables, int offx, int offy,
-                                                     int pi, int pj, uint32_t epoch,
-                                                     uint32_t *__restrict__ flags, uint32_t *__restrict__ stats,
-                                                     int iter_idx, int fixed_work)
+__global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
+                                                      const uint32_t *__restrict__ tables, int offx, int offy,
+                                                      int pi, int pj, uint32_t epoch,
+                                                      uint32_t *__restrict__ flags, uint32_t *__restrict__ stats,
+                                                      int iter_idx, int fixed_work)
 {
     __shared__ SplitLds S;
-    const int tid = threadIdx.x, T = blockDim.x; // T == 256
+    const int tid = threadIdx.x, T = blockDim.x;
     const VmLevelView L = views[blockIdx.z];
     flags += (size_t)blockIdx.z * cap;
     stats += (size_t)blockIdx.z * cap * 4;
@@ -807,9 +807,12 @@ __global__ __launch_bounds__(256) void SUF(k_commit)(const VmLevelView *__restri
     const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
     if (ox >= L.w || oy >= L.h)
         return;
-    // the records of this tile's phase pixels
+    // The kernel is a chain of dependent HBM/L2 round trips (records -> own-pixel state ->
+    // taps -> window sums), so everything independent is issued up front: the records of
+    // this tile's phase pixels, the mask words, the stencil table.
+    const MaskGeom g = mask_geom(L, ox, oy);
     int state = 0;
-    {
+    if (tid < 256) {
         const int px = ox + (tid & 31) * 2 + pj, py = oy + (tid >> 5) * 2 + pi;
         if (px < L.w && py < L.h) {
             const uint32_t r = L.rec_state[py * L.rs + px];
@@ -820,19 +823,16 @@ __global__ __launch_bounds__(256) void SUF(k_commit)(const VmLevelView *__restri
             }
         }
         S.d_ok[tid] = state;
-    }
-    const int n_rec = __syncthreads_count(state != 0);
-    if (n_rec == 0)
-        return;
-    const MaskGeom g = mask_geom(L, ox, oy);
-    if (tid < g.nbx * g.nby) {
-        int mx = tid % g.nbx, my = tid / g.nbx;
+    } else if (tid < 256 + g.nbx * g.nby) {
+        const int k = tid - 256, mx = k % g.nbx, my = k / g.nbx;
         S.mask[my][mx] = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)];
     }
     for (int k = tid; k < 625; k += T)
         S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
-    __syncthreads();
-    const bool ok = commit_own(S, L, g, tid, ox, oy, pi, pj);
+    const int n_rec = __syncthreads_count(state != 0);
+    if (n_rec == 0)
+        return;
+    const bool ok = tid < 256 && commit_own(S, L, g, tid, ox, oy, pi, pj);
     const int ncommit = __syncthreads_count(ok);
     if (ncommit) {
         for (int cell = tid; cell < VM_NCELL; cell += T) {
@@ -842,8 +842,6 @@ __global__ __launch_bounds__(256) void SUF(k_commit)(const VmLevelView *__restri
                 continue;
             const int gi = qy * L.rs + qx;
             // cheap pre-test before touching HBM: any committed record in reach?
-            float2 m = make_float2(0, 0), q = m, tb = m;
-            float cr = 0;
             int ylo = max(ry - 2, 0), yhi = min(ry + 2, VM_TILE_H - 1);
             int xlo = max(rx - 2, 0), xhi = min(rx + 2, VM_TILE_W - 1);
             ylo += (ylo & 1) ^ pi;
@@ -854,10 +852,8 @@ __global__ __launch_bounds__(256) void SUF(k_commit)(const VmLevelView *__restri
                     any = any || S.d_ok[(y >> 1) * 32 + (x >> 1)] == 1;
             if (!any)
                 continue;
-            m = L.mean[gi];
-            q = L.var[gi];
-            tb = L.tps_b[gi];
-            cr = L.cross[gi];
+            float2 m = L.mean[gi], q = L.var[gi], tb = L.tps_b[gi];
+            float cr = L.cross[gi];
             gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb);
             L.mean[gi] = m;
             L.var[gi] = q;
@@ -910,7 +906,7 @@ void SUF(vm_launch_optimize_split)(const VmLevelView *views, int nbatch, int cap
             const uint32_t epoch = 1u + (uint32_t)((iter_idx * 4 + pass) * 4 + pi * 2 + pj);
             hipLaunchKernelGGL(SUF(k_decide), dim3(gx * gy * parts, 1, nbatch), dim3(threads), 0, s, views, cap, P,
                                tables, offx, offy, pi, pj, parts, epoch, flags, iter_idx, fixed_work);
-            hipLaunchKernelGGL(SUF(k_commit), dim3(gx, gy, nbatch), dim3(256), 0, s, views, cap, P, tables, offx,
+            hipLaunchKernelGGL(SUF(k_commit), dim3(gx, gy, nbatch), dim3(1024), 0, s, views, cap, P, tables, offx,
                                offy, pi, pj, epoch, flags, stats, iter_idx, fixed_work);
         }
 }
