@@ -111,7 +111,8 @@ static int is_marker(const uint8_t *p) { return p[0] == 255 && p[1] == 0 && p[2]
 /* y = A x for the 5-point system of PoissonExt.cpp:214-312 (matrix-free) */
 static void apply_A(const int *type, const float *diag, int cw, int ch, const double *x, double *y)
 {
-#pragma omp parallel for schedule(static)
+    const int nt = vmo_get_threads(); /* never the machine's logical CPU count: containers cap it */
+#pragma omp parallel for num_threads(nt) schedule(static)
     for (int yy = 0; yy < ch; ++yy)
         for (int xx = 0; xx < cw; ++xx) {
             int ii = yy * cw + xx;

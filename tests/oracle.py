@@ -112,8 +112,22 @@ def lib():
     L.vmo_set_threads.argtypes = [C.c_int]
     L.vmo_set_threads.restype = None
     L.vmo_get_threads.restype = C.c_int
+    L.vmo_set_threads(default_threads())
     _lib = L
     return L
+
+
+def default_threads():
+    """OpenMP threads for the oracle: the CPUs this process may really use (affinity mask capped
+    by the cgroup quota -- a 256-thread team on a 16-CPU quota is ~100x slower), at most 8"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    return max(1, min(n, 8))
 
 
 _FIELDS = {  # name -> (id, channels, dtype)

@@ -1,0 +1,97 @@
+"""End-to-end pipeline of BASELINE config[4] (point constraints + BCOND_BORDER solve ->
+result upscale -> Poisson-extended boundary -> warp/blend render), at a size the oracle
+finishes in seconds, stage by stage against the oracle; plus the same pipeline at 1080p
+checked through properties."""
+import numpy as np
+import pytest
+
+from videomorphing_amd import capi, morph, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gpu(gpu_ctx, w, h, rgb0, rgb1, cons, max_iter, mode):
+    gpu_ctx.set_math_mode(mode)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res, prm.bcond = max_iter, 1.0, 32, capi.BCOND_BORDER
+    for c in cons:
+        prm.add_point_pair(*c[:4], weight=float(c[4]))
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build_rgb(rgb0, rgb1, prm.start_res)
+    t = morph.MatchingThread(prm, pyr)
+    t.start()
+    t.wait()
+    ex = int(0.1 * max(w, h))                       # pyramid.cu:194
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
+    fr.set_v_from_level(pyr, 1)
+    return pyr, fr, ex, t
+
+
+def test_config4_pipeline_against_oracle(gpu_ctx, oracle):
+    w, h = 160, 110
+    rgb0, rgb1 = synth.make_rgb_pair(w, h)
+    cons = synth.make_constraints(w, h, 8)
+    pyr, fr, ex, t = _run_gpu(gpu_ctx, w, h, rgb0, rgb1, cons, 30, capi.MATH_EXACT)
+    v_gpu = pyr._vector[0]
+    # --- solve: same luma pyramid (device builder vs oracle builder agree to 2e-3), so the
+    # oracle is run on the DEVICE's lumas to compare the solver bit for bit
+    nl = pyr.size() - 1
+    imgs = [(pyr[el].field("img0"), pyr[el].field("img1")) for el in range(1, nl)]
+    imgs.append((np.zeros((pyr[nl].height, pyr[nl].width), np.float32),) * 2)
+    P = oracle.default_params(bcond=capi.BCOND_BORDER)
+    lo = oracle.solve(imgs, P, 30, 1.0, cons=cons, threads=8)
+    v_ref = oracle.upscale_result(lo.field("v"), w, h)
+    assert np.array_equal(v_ref.view(np.uint32), v_gpu.view(np.uint32))
+    assert np.abs(v_gpu).max() > 0.3 and t.percentage == pytest.approx(100.0)
+    # the constraint points pull v towards their half-difference
+    c = cons[0]
+    cx, cy = int(round((c[0] + c[2]) / 2)), int(round((c[1] + c[3]) / 2))
+    assert np.abs(v_gpu[cy, cx] - [(c[2] - c[0]) / 2, (c[3] - c[1]) / 2]).max() < 0.6
+    # --- Poisson extension of both sides
+    e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
+    # both sides sample the ORIGINAL other image (CPoissonExt clones the crops first, :26-27)
+    crops = {1: e1[ex:ex + h, ex:ex + w].copy(), 2: e0[ex:ex + h, ex:ex + w].copy()}
+    for side, ext in ((1, e0), (2, e1)):
+        ref, _, _ = oracle.poisson_extend(ext, w, h, ex, crops[side], v_gpu, side, tol=1e-9)
+        fr.poisson_extend(side, tol=1e-6)           # holes far from any anchor need the tight tolerance
+        out = fr.download_ext(side)
+        d = np.abs(out[..., :3].astype(int) - ref[..., :3].astype(int))
+        assert d.max() <= 2 and (d <= 1).mean() > 0.999, (d.max(), (d > 1).mean())
+        (e0, e1)[side - 1][...] = out
+    # --- render three morph times from the device-resident canvases
+    for tt in (0.0, 0.4, 1.0):
+        img = fr.render_halfway(tt, tt, 1)
+        ref = oracle.render_halfway(w, h, ex, tt, tt, 1, e0.astype(np.float32), e1.astype(np.float32),
+                                    v_gpu, np.zeros_like(v_gpu))
+        assert np.array_equal(img, ref)
+    assert np.array_equal(fr.render_halfway(0.0, 0.0, 0)[2:-2, 2:-2] // 64, fr.render_halfway(0.0, 0.0, 1)[2:-2, 2:-2] // 64)
+
+
+def test_config4_pipeline_at_1080p(gpu_ctx):
+    """full size, FAST: runs through, the extension is smooth and opaque-free, the frame at
+    t = 0 / t = 1 reproduces the sources where v is small"""
+    w, h = 1920, 1080
+    rgb0, rgb1 = synth.make_rgb_pair(w, h)
+    cons = synth.make_constraints(w, h, 8)
+    try:
+        pyr, fr, ex, _ = _run_gpu(gpu_ctx, w, h, rgb0, rgb1, cons, 40, capi.MATH_FAST)
+        assert ex == 192
+        v = pyr._vector[0]
+        assert np.isfinite(v).all() and np.abs(v).max() < 60
+        for side in (1, 2):
+            it, rr, ms = fr.poisson_extend(side, tol=1e-4)
+            out = fr.download_ext(side)
+            assert rr <= 1e-4 and out[..., 3].max() == 0
+            src = (rgb0, rgb1)[side - 1]
+            assert np.array_equal(out[ex + 1:ex + h - 1, ex + 1:ex + w - 1, :3], src[1:-1, 1:-1])
+            band = out[:ex, :, :3].astype(np.float32)
+            assert np.abs(np.diff(band, axis=1)).mean() < 4.0          # smooth fill, no marker colour left
+            assert not ((band[..., 0] == 255) & (band[..., 1] == 0) & (band[..., 2] == 255)).any()
+        f0, f1 = fr.render_halfway(0.0, 0.0, 1), fr.render_halfway(1.0, 1.0, 1)
+        assert f0.shape == (h, w, 3)
+        # at t = 0 the frame is image 0 resampled at p - v(p'), p' = p + v: identity up to interpolation
+        assert np.abs(f0.astype(int) - rgb0.astype(int)).mean() < 6.0
+        assert np.abs(f1.astype(int) - rgb1.astype(int)).mean() < 6.0
+    finally:
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
