@@ -32,6 +32,18 @@
 // uses 75 shared + 25 global float atomics per accepted pixel, morph.cu:951-1015).
 #include "vm_morph_common.h"
 
+#ifdef VM_PROF
+// dev-only stage stamps of k_decide (10 ns ticks), wave 0 lane 0 of each workgroup
+__device__ unsigned long long vm_prof_buf[512 * 16];
+#define VM_TS(i) ts[i] = wall_clock64()
+#define VM_TS_ARG , unsigned long long *ts
+#define VM_TS_PASS , ts
+#else
+#define VM_TS(i)
+#define VM_TS_ARG
+#define VM_TS_PASS
+#endif
+
 namespace {
 
 struct TileLds {
@@ -201,6 +213,8 @@ __device__ __forceinline__ void nb_load(NbCache &nb, const VmLevelView &L, const
 {
 #pragma unroll
     for (int j = 0; j < VM_SMAX; ++j) {
+        if (j * Lf >= 25) // uniform in the workgroup: no lane has such a neighbour
+            break;
         const int k = sub + j * Lf;
         const int i = k / 5, jj = k - i * 5;
         const int qx = c.px + jj - 2, qy = c.py + i - 2;
@@ -330,10 +344,11 @@ __device__ __forceinline__ bool pixel_locked(const VmLevelView &L, int bcond, in
 // agree bit for bit.  Returns true and the accepted step when the energy drops.
 template <bool INTERIOR, class Src>
 __device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P, const Src &src,
-                                       const PixelCtx &c, int sub, int Lf, float2 &step)
+                                       const PixelCtx &c, int sub, int Lf, float2 &step VM_TS_ARG)
 {
     NbCache nb;
     nb_load<INTERIOR>(nb, L, src, c, sub, Lf);
+    VM_TS(4);
 #define ENERGY(DX, DY) energy_change<INTERIOR>(L, P, src, nb, c, (DX), (DY), Lf)
     // The energy is evaluated at exactly two places of the instruction stream (not at
     // the reference's seven): the sweep kernels must stay inside the instruction cache.
@@ -350,6 +365,7 @@ __device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P,
     }
     gx = -gx;
     gy = -gy;
+    VM_TS(5);
     const float ng = fsqrt(gx * gx + gy * gy);
     if (ng == 0)
         return false;
@@ -360,6 +376,7 @@ __device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P,
     fover_ring(L, c.px, c.py, -1.0f, -c.v.x, -c.v.y, -gx, -gy, t_min);
     fover_ring(L, c.px, c.py, 1.0f, c.v.x, c.v.y, gx, gy, t_min);
     float cc = fmaxf(t_min - P.eps, 0.0f);
+    VM_TS(6);
     // golden_section_search, morph.cu:885-947: step 0 and 1 evaluate the two initial
     // interior points b and x, later steps shrink the bracket
     const float R = 0.618033989f, C = 1.0f - R;
@@ -401,12 +418,215 @@ __device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P,
         }
     }
 #undef ENERGY
+    VM_TS(7);
     const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
     if (!(fmin < 0))
         return false;
     step = make_float2(gx * tmin, gy * tmin);
     return true;
 }
+
+
+#if !VM_EXACT
+// ---------------------------------------------------------------------------
+// The LEAN line search: exactly 32 lanes per pixel, lane k < 25 owns window neighbour k
+// (one set of sums in registers, no slot loops, no run-time fan-out arithmetic).  It is
+// the schedule of the latency-bound regime -- few candidates, each waiting on ~21
+// dependent energy evaluations -- where the instruction count of ONE evaluation is the
+// time: the two bilinear taps are split over odd/even lanes and exchanged by DPP, the 16
+// fold-over segment tests run on 16 lanes and meet in a min-butterfly.  Same arithmetic
+// per SSIM term as the generic FAST path (ssim_core), so both agree to reduction order.
+struct Nb1 {
+    float A, B, VX, VY, X, VAL, N; // N = window count, 0: lane owns no in-image neighbour
+};
+
+__device__ __forceinline__ float group_min32(float x)
+{
+    x = fminf(x, dpp_xor1(x));
+    x = fminf(x, dpp_xor2(x));
+    x = fminf(x, dpp_half_mirror(x));
+    x = fminf(x, dpp_mirror(x));
+    x = fminf(x, swz_xor16(x));
+    return x;
+}
+
+template <bool INTERIOR, class Src>
+__device__ __forceinline__ void nb1_load(Nb1 &nb, const VmLevelView &L, const Src &src, const PixelCtx &c, int sub)
+{
+    const int i = (sub * 13) >> 6, jj = sub - i * 5; // sub / 5 for sub < 32
+    const int qx = c.px + jj - 2, qy = c.py + i - 2;
+    const bool ok = sub < 25 && (INTERIOR || (qx >= 0 && qx < L.w && qy >= 0 && qy < L.h));
+    float2 m, q;
+    float cr, val;
+    src.load(ok ? i : 2, ok ? jj : 2, m, q, cr, val);
+    float n = 25.0f, in = 0.04f;
+    if (!INTERIOR) {
+        n = ok ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
+        in = n == 25.0f ? 0.04f : __builtin_amdgcn_rcpf(n);
+    }
+    nb.N = ok ? n : 0.0f;
+    nb.A = m.x * in;
+    nb.B = m.y * in;
+    nb.VX = q.x;
+    nb.VY = q.y;
+    nb.X = cr;
+    nb.VAL = val;
+}
+
+// energy_change (morph.cu:730-761) on 32 lanes; also returns the two lumas at the trial point
+template <bool INTERIOR>
+__device__ __forceinline__ float energy32(const VmLevelView &L, const VmKParams &P, const Nb1 &nb,
+                                          const PixelCtx &c, float dx, float dy, int sub, float &lx, float &ly)
+{
+    const float vx = c.v.x + dx, vy = c.v.y + dy;
+    const bool odd = sub & 1;
+    // even lanes sample image 0 at p - v, odd lanes image 1 at p + v (the expressions of the
+    // generic path, so the values agree bit for bit)
+    const float sx = odd ? c.px + vx + 0.5f : c.px - vx + 0.5f;
+    const float sy = odd ? c.py + vy + 0.5f : c.py - vy + 0.5f;
+    const float t = tap(odd ? L.img1 : L.img0, L.w, L.h, L.rs, sx, sy);
+    const float o = dpp_xor1(t);
+    lx = odd ? o : t;
+    ly = odd ? t : o;
+    const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
+    const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
+    const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
+    const float dcross = lx * ly - c.old_luma.x * c.old_luma.y;
+    float acc;
+    if (INTERIOR) {
+        const float val = ssim_core(fmaf(dmx, 0.04f, nb.A), fmaf(dmy, 0.04f, nb.B), nb.VX + dvx, nb.VY + dvy,
+                                    nb.X + dcross, 25.0f, P.ssim_clamp);
+        acc = nb.N != 0.0f ? nb.VAL - val : 0.0f;
+    } else {
+        const bool valid = nb.N != 0.0f;
+        const float n = valid ? nb.N : 25.0f;
+        const float in = n == 25.0f ? 0.04f : __builtin_amdgcn_rcpf(n);
+        const float val = ssim_core(fmaf(dmx, in, nb.A), fmaf(dmy, in, nb.B), nb.VX + dvx, nb.VY + dvy,
+                                    nb.X + dcross, n, P.ssim_clamp);
+        acc = valid ? nb.VAL - val : 0.0f;
+    }
+    const float change = group_sum(acc, 32);
+    const float dd = dx * dx + dy * dy;
+    const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
+    const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
+    return (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
+}
+
+// prevent_foldover (morph.cu:872-883): lane s < 16 tests segment s & 7 of ring s >> 3
+// (ring 0: sign -1 on (-v, -g); ring 1: sign +1 on (v, g)); the bound is the minimum of
+// the 16 crossings (the reference's running minimum up to the rounding of `td < t_min d`)
+__device__ __forceinline__ float fover32(const VmLevelView &L, const PixelCtx &c, float gx, float gy, int sub)
+{
+    const int k = sub & 7, k1 = (k + 1) & 7;
+    const float sgn = (sub & 8) ? 1.0f : -1.0f;
+    const float vx = sgn * c.v.x, vy = sgn * c.v.y;
+    float ex[2], ey[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int kk = e ? k1 : k;
+        // ring offsets (-1,-1) (0,-1) (1,-1) (1,0) (1,1) (0,1) (-1,1) (-1,0), two bits each
+        const int rx = ((0x06A4 >> (2 * kk)) & 3) - 1, ry = ((0x6A40 >> (2 * kk)) & 3) - 1;
+        const int qx = c.px + rx, qy = c.py + ry;
+        float ux = vx, uy = vy;
+        if (qx >= 0 && qx < L.w && qy >= 0 && qy < L.h) {
+            const float2 nv = L.v[qy * L.rs + qx];
+            ux = sgn * nv.x;
+            uy = sgn * nv.y;
+        }
+        ex[e] = ux + (float)(c.px - rx); // `p - off`, as fover_calc_vtx has it
+        ey[e] = uy + (float)(c.py - ry);
+    }
+    float t_min = 10;
+    fover_isec((float)c.px + vx, (float)c.py + vy, sgn * gx, sgn * gy, ex[0], ey[0], ex[1], ey[1], t_min);
+    return group_min32(sub < 16 ? t_min : 10.0f);
+}
+
+// optimize_pixel after the mask test, 32 lanes in lockstep; on success also the lumas at
+// the accepted point (what commit_pixel_motion would sample again)
+template <bool INTERIOR, class Src>
+__device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &P, const Src &src,
+                                         const PixelCtx &c, int sub, float2 &step, float2 &luma VM_TS_ARG)
+{
+    Nb1 nb;
+    nb1_load<INTERIOR>(nb, L, src, c, sub);
+    VM_TS(4);
+    float lx, ly;
+    float gx = 0, gy = 0;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const float sgn = (k & 1) ? -1.0f : 1.0f;
+        const float e = energy32<INTERIOR>(L, P, nb, c, k < 2 ? sgn * P.eps : 0.0f, k < 2 ? 0.0f : sgn * P.eps, sub,
+                                           lx, ly) * sgn;
+        if (k < 2)
+            gx += e;
+        else
+            gy += e;
+    }
+    gx = -gx;
+    gy = -gy;
+    VM_TS(5);
+    const float ng = fsqrt(gx * gx + gy * gy);
+    if (ng == 0)
+        return false;
+    gx = fdiv(gx, ng);
+    gy = fdiv(gy, ng);
+    float cc = fmaxf(fover32(L, c, gx, gy, sub) - P.eps, 0.0f);
+    VM_TS(6);
+    const float R = 0.618033989f, C = 1.0f - R;
+    float a = 0;
+    float b = a * R + cc * C, x = b * R + cc * C;
+    float fb = 0, fx = 0;
+    float2 lb = make_float2(0, 0), lq = make_float2(0, 0); // lumas at b and at x
+#pragma unroll 1
+    for (int s = 0;; ++s) {
+        float t = s == 0 ? b : x;
+        bool lt = false;
+        if (s >= 2) {
+            if (!(cc - a > P.eps))
+                break;
+            lt = fx < fb;
+            if (lt) {
+                a = b;
+                b = x;
+                x = b * R + cc * C;
+            } else {
+                cc = x;
+                x = b * R + a * C;
+            }
+            t = x;
+        }
+        const float f = energy32<INTERIOR>(L, P, nb, c, gx * t, gy * t, sub, lx, ly);
+        const float2 lf = make_float2(lx, ly);
+        if (s == 0) {
+            fb = f;
+            lb = lf;
+        } else if (s == 1) {
+            fx = f;
+            lq = lf;
+        } else if (lt) {
+            fb = fx;
+            lb = lq;
+            fx = f;
+            lq = lf;
+        } else {
+            const float tmp = b;
+            b = x;
+            x = tmp;
+            fx = fb;
+            lq = lb;
+            fb = f;
+            lb = lf;
+        }
+    }
+    VM_TS(7);
+    const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
+    if (!(fmin < 0))
+        return false;
+    step = make_float2(gx * tmin, gy * tmin);
+    luma = fx < fb ? lq : lb;
+    return true;
+}
+#endif
 
 // everything of a pixel that the energy needs besides the window sums
 __device__ __forceinline__ void ctx_load(PixelCtx &c, const VmLevelView &L, const float *s_tps, int px, int py)
@@ -625,6 +845,33 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
             if (n_act > 0) {
                 st_cand += n_act;
                 // ---- 2. line searches on the pre-phase state, L lanes per candidate ----
+#if !VM_EXACT
+                if (n_act * 32 <= T) {
+                    // sparse phase: the lean 32-lane line search
+                    const int li = tid >> 5, sub = tid & 31;
+                    const int slot = S.list[min(li, n_act - 1)];
+                    const int tx = slot & 31, ty = slot >> 5;
+                    const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
+                    const bool wave_interior = __all(li >= n_act || is_interior(L, px, py));
+                    if (li < n_act) {
+                        PixelCtx c;
+                        ctx_load(c, L, S.tps, px, py);
+                        LdsSrc src{&S, (ty * 2 + pi) * VM_HALO_W + (tx * 2 + pj)};
+                        c.tps_b = S.tpsb[src.hc + 2 * VM_HALO_W + 2];
+                        float2 step, luma;
+#ifdef VM_PROF
+                        unsigned long long ts[16];
+#endif
+                        const bool ok = wave_interior ? decide32<true>(L, P, src, c, sub, step, luma VM_TS_PASS)
+                                                      : decide32<false>(L, P, src, c, sub, step, luma VM_TS_PASS);
+                        if (ok && sub == 0) {
+                            S.d_step[slot] = step;
+                            S.d_ok[slot] = 1;
+                        }
+                    }
+                } else
+#endif
+                {
                 int Lf = VM_MIN_FANOUT;
                 while (Lf * 2 <= VM_MAX_FANOUT && Lf * 2 * n_act <= T)
                     Lf *= 2;
@@ -644,13 +891,17 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                         LdsSrc src{&S, (ty * 2 + pi) * VM_HALO_W + (tx * 2 + pj)};
                         c.tps_b = S.tpsb[src.hc + 2 * VM_HALO_W + 2];
                         float2 step;
-                        const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step)
-                                                      : decide<false>(L, P, src, c, sub, Lf, step);
+#ifdef VM_PROF
+                        unsigned long long ts[16];
+#endif
+                        const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step VM_TS_PASS)
+                                                      : decide<false>(L, P, src, c, sub, Lf, step VM_TS_PASS);
                         if (ok && sub == 0) {
                             S.d_step[slot] = step;
                             S.d_ok[slot] = 1;
                         }
                     }
+                }
                 }
             }
             __syncthreads();
@@ -725,6 +976,11 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
 {
     __shared__ SplitLds S;
     const int tid = threadIdx.x, T = blockDim.x;
+#ifdef VM_PROF
+    unsigned long long ts[16];
+    for (int k = 0; k < 16; ++k) ts[k] = 0;
+    VM_TS(0);
+#endif
     const VmLevelView L = views[blockIdx.z];
     flags += (size_t)blockIdx.z * cap;
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
@@ -743,12 +999,19 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
     }
     if (!__syncthreads_or(mymask != 0))
         return;
+    VM_TS(1);
     for (int k = tid; k < 625; k += T)
         S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
     for (int k = tid; k < 225; k += T)
         S.imp[k] = tables[VM_TAB_IMP + k];
     __syncthreads();
+    VM_TS(2);
 
+#ifdef VM_PROF_WARM
+    for (int rep = 0; rep < 2; ++rep) {
+    __syncthreads();
+    VM_TS(2);
+#endif
     // every mask hit of the phase, in slot order: the list is the same in all `parts`
     // workgroups of the tile, entry i belongs to workgroup i % parts
     bool hit = false;
@@ -760,9 +1023,13 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
     const int n_mine = (n_hit - part + parts - 1) / parts;
     if (n_mine <= 0)
         return;
+#if VM_EXACT
     int Lf = VM_MIN_FANOUT;
     while (Lf * 2 <= VM_MAX_FANOUT && Lf * 2 * n_mine <= T)
         Lf *= 2;
+#else
+    const int Lf = 32; // SPLIT is the latency-bound regime: always the lean line search
+#endif
     const int slots = T / Lf;
     const int sub = tid & (Lf - 1), grp = tid / Lf;
     for (int base = 0; base < n_mine; base += slots) {
@@ -775,11 +1042,18 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
             float2 step = make_float2(0, 0);
             if (!pixel_locked(L, P.bcond, px, py)) {
                 PixelCtx c;
+                VM_TS(3);
                 ctx_load(c, L, S.tps, px, py);
                 c.tps_b = L.tps_b[c.idx];
                 GlbSrc src{&L, (py - 2) * L.rs + (px - 2)};
-                const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step)
-                                              : decide<false>(L, P, src, c, sub, Lf, step);
+#if VM_EXACT
+                const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step VM_TS_PASS)
+                                              : decide<false>(L, P, src, c, sub, Lf, step VM_TS_PASS);
+#else
+                float2 luma;
+                const bool ok = wave_interior ? decide32<true>(L, P, src, c, sub, step, luma VM_TS_PASS)
+                                              : decide32<false>(L, P, src, c, sub, step, luma VM_TS_PASS);
+#endif
                 if (ok)
                     state = 1;
             }
@@ -789,6 +1063,17 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
             }
         }
     }
+#ifdef VM_PROF
+    VM_TS(8);
+    if ((tid & 63) == 0 && blockIdx.x < 512 && (tid >> 6) < 1) {
+        ts[9] = (unsigned long long)Lf;
+        ts[10] = (unsigned long long)n_mine;
+        for (int k = 0; k < 16; ++k) vm_prof_buf[blockIdx.x * 16 + k] = ts[k];
+    }
+#endif
+#ifdef VM_PROF_WARM
+    }
+#endif
 }
 
 __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
@@ -882,6 +1167,12 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
 
 // ---------------------------------------------------------------------------
 // launchers
+#if defined(VM_PROF) && !VM_EXACT
+extern "C" int vm_dbg_prof_read(void *dst, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(vm_prof_buf), bytes);
+}
+#endif
 
 // `views`: device array of nbatch level views (frame pairs of one batch, same w x h);
 // flags/stats: nbatch rows of `cap` iterations
