@@ -221,8 +221,8 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
         o_value = off; off += al(n * 4);
         o_uiaxy = off; off += al(n * 4);
         o_imp = off; off += al((size_t)l.imp_rs * l.imp_rows * 4);
-        o_rst = off; off += al(n * 4);
-        o_rsp = off; off += al(n * 8);
+        o_rst = off; off += al(n * 16);
+        o_rsp = off; off += al(n * 16);
     }
     VM_HIP(hipMalloc((void **)&l.slab, off));
     // stream-ordered: the context's stream does not synchronise with the null stream
@@ -241,15 +241,14 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
         V.ui_b = (float2 *)(b + o_uib); V.cross = (float *)(b + o_cross);
         V.value = (float *)(b + o_value); V.ui_axy = (float *)(b + o_uiaxy);
         V.impmask = (uint32_t *)(b + o_imp);
-        V.rec_state = (uint32_t *)(b + o_rst);
-        V.rec_step = (float2 *)(b + o_rsp);
+        V.rec_a = (float4 *)(b + o_rst);
+        V.rec_b = (float4 *)(b + o_rsp);
     } else {
         V.img0 = V.img1 = nullptr;
         V.luma = V.mean = V.var = V.tps_b = V.ui_b = nullptr;
         V.cross = V.value = V.ui_axy = nullptr;
         V.impmask = nullptr;
-        V.rec_state = nullptr;
-        V.rec_step = nullptr;
+        V.rec_a = V.rec_b = nullptr;
     }
     return VM_OK;
 }
@@ -540,7 +539,7 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     double cand_prev = 1e9; // line searches per iteration in the previous batch (first batch: dense)
     if (may_split) // epochs restart with every call: forget old records
         for (int i = 0; i < n; ++i)
-            VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_state, 0, (size_t)l0.rs * l0.h * 4, s));
+            VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_b, 0, (size_t)l0.rs * l0.h * 16, s));
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
     std::vector<int> executed(n, cap), improving(n, 1), stopped(n, 0);
     std::vector<double> st_tiles(n, 0.0), st_cand(n, 0.0), st_commit(n, 0.0);

@@ -30,8 +30,7 @@ struct VmLevelView {
     float *cross, *value, *ui_axy;
     uint32_t *impmask;
     // decision records of the SPLIT sweep schedule (vm_sweep_kernels.hip)
-    uint32_t *rec_state;
-    float2 *rec_step;
+    float4 *rec_a, *rec_b;
 };
 
 struct VmKParams {

@@ -24,8 +24,8 @@
 //  too few tiles to fill 256 CUs, a tile's candidates are divided over K
 //  workgroups (so every pixel gets 32 lanes and the ~21 dependent energy
 //  evaluations of a phase take ~1/6 of the time), decisions go to per-pixel
-//  records in HBM, and a second kernel applies them.  State stays in HBM/L2
-//  between the two (a 120x68 level is 0.6 MB).
+//  records in HBM, and a second kernel folds them into the window sums.  State
+//  stays in HBM/L2 between the two (a 120x68 level is 0.6 MB).
 //
 // Commits are applied by a per-cell gather of the committed pixels' records in a
 // fixed order: deterministic, one owner per cell, no float atomics (the reference
@@ -964,9 +964,15 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
 }
 
 // ===========================================================================
-// SPLIT schedule.  Decision records: rec_state[pixel] = epoch << 2 | state
-// (1: commit, 2: mask hit that did not move), valid only for the current epoch
-// (one epoch per phase, so nothing is ever cleared); rec_step[pixel] = accepted step.
+// SPLIT schedule.  k_decide runs the line searches of one phase and, for an accepted
+// step, writes the pixel's own state at once (v, luma, ui.b: nothing else of the same
+// phase reads them -- the fold-over ring of a pixel has no pixel of its own parity) plus
+// a decision record; k_commit folds the records into the window sums of the cells they
+// reach.  Records, two float4 per pixel:
+//   rec_a = (d mean.x, d mean.y, d var.x, d var.y)
+//   rec_b = (d cross, step.x, step.y, bits(epoch << 2 | state))
+// state 1: commit, 2: mask hit that did not move; valid only for the current epoch (one
+// epoch per phase, so nothing is ever cleared).
 
 __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
                                                       const uint32_t *__restrict__ tables, int offx, int offy,
@@ -991,27 +997,24 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
     if (ox >= L.w || oy >= L.h)
         return;
     const MaskGeom g = mask_geom(L, ox, oy);
+    // the mask words and the two small tables travel together: one round trip
     uint32_t mymask = 0;
     if (tid < g.nbx * g.nby) {
         int mx = tid % g.nbx, my = tid / g.nbx;
         mymask = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)];
         S.mask[my][mx] = mymask;
     }
+    for (int k = tid; k < 225; k += T)
+        S.imp[k] = tables[VM_TAB_IMP + k];
+    if (tid >= 256 && tid < 256 + 25) // ctx_load only needs the centre weight of each border class
+        S.tps[(tid - 256) * 25 + 12] = __uint_as_float(tables[VM_TAB_TPS + (tid - 256) * 25 + 12]);
+    if (T < 512 && tid < 25)
+        S.tps[tid * 25 + 12] = __uint_as_float(tables[VM_TAB_TPS + tid * 25 + 12]);
     if (!__syncthreads_or(mymask != 0))
         return;
     VM_TS(1);
-    for (int k = tid; k < 625; k += T)
-        S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
-    for (int k = tid; k < 225; k += T)
-        S.imp[k] = tables[VM_TAB_IMP + k];
-    __syncthreads();
     VM_TS(2);
 
-#ifdef VM_PROF_WARM
-    for (int rep = 0; rep < 2; ++rep) {
-    __syncthreads();
-    VM_TS(2);
-#endif
     // every mask hit of the phase, in slot order: the list is the same in all `parts`
     // workgroups of the tile, entry i belongs to workgroup i % parts
     bool hit = false;
@@ -1039,9 +1042,10 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
         const bool wave_interior = __all(m >= n_mine || is_interior(L, px, py));
         if (m < n_mine) {
             uint32_t state = 2;
-            float2 step = make_float2(0, 0);
+            float2 step = make_float2(0, 0), luma = make_float2(0, 0);
+            PixelCtx c;
+            c.idx = py * L.rs + px;
             if (!pixel_locked(L, P.bcond, px, py)) {
-                PixelCtx c;
                 VM_TS(3);
                 ctx_load(c, L, S.tps, px, py);
                 c.tps_b = L.tps_b[c.idx];
@@ -1049,8 +1053,12 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
 #if VM_EXACT
                 const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step VM_TS_PASS)
                                               : decide<false>(L, P, src, c, sub, Lf, step VM_TS_PASS);
+                if (ok) { // the lumas commit_pixel_motion samples (morph.cu:997-1003)
+                    const float nvx = c.v.x + step.x, nvy = c.v.y + step.y;
+                    luma.x = tap(L.img0, L.w, L.h, L.rs, px - nvx + 0.5f, py - nvy + 0.5f);
+                    luma.y = tap(L.img1, L.w, L.h, L.rs, px + nvx + 0.5f, py + nvy + 0.5f);
+                }
 #else
-                float2 luma;
                 const bool ok = wave_interior ? decide32<true>(L, P, src, c, sub, step, luma VM_TS_PASS)
                                               : decide32<false>(L, P, src, c, sub, step, luma VM_TS_PASS);
 #endif
@@ -1058,8 +1066,22 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
                     state = 1;
             }
             if (sub == 0) {
-                L.rec_step[py * L.rs + px] = step;
-                L.rec_state[py * L.rs + px] = (epoch << 2) | state;
+                float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
+                if (state == 1) {
+                    // commit_pixel_motion (morph.cu:990-1026), the pixel's own part
+                    const float2 ol = c.old_luma;
+                    ra = make_float4(luma.x - ol.x, luma.y - ol.y, luma.x * luma.x - ol.x * ol.x,
+                                     luma.y * luma.y - ol.y * ol.y);
+                    rb.x = luma.x * luma.y - ol.x * ol.y;
+                    rb.y = step.x;
+                    rb.z = step.y;
+                    L.luma[c.idx] = luma;
+                    L.ui_b[c.idx] = make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy);
+                    L.v[c.idx] = make_float2(c.v.x + step.x, c.v.y + step.y);
+                    L.rec_a[c.idx] = ra;
+                }
+                rb.w = __uint_as_float((epoch << 2) | state);
+                L.rec_b[c.idx] = rb;
             }
         }
     }
@@ -1069,9 +1091,6 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
         ts[9] = (unsigned long long)Lf;
         ts[10] = (unsigned long long)n_mine;
         for (int k = 0; k < 16; ++k) vm_prof_buf[blockIdx.x * 16 + k] = ts[k];
-    }
-#endif
-#ifdef VM_PROF_WARM
     }
 #endif
 }
@@ -1092,20 +1111,30 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
     const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
     if (ox >= L.w || oy >= L.h)
         return;
-    // The kernel is a chain of dependent HBM/L2 round trips (records -> own-pixel state ->
-    // taps -> window sums), so everything independent is issued up front: the records of
-    // this tile's phase pixels, the mask words, the stencil table.
+    // One round trip: the records of this tile's phase pixels, the mask words, the stencil
+    // table and (speculatively) the sums of the two cells each thread may have to update.
     const MaskGeom g = mask_geom(L, ox, oy);
     int state = 0;
+    uint32_t bit = 0;
+    int mcx = 0, mcy = 0;
     if (tid < 256) {
         const int px = ox + (tid & 31) * 2 + pj, py = oy + (tid >> 5) * 2 + pi;
         if (px < L.w && py < L.h) {
-            const uint32_t r = L.rec_state[py * L.rs + px];
+            const float4 rb = L.rec_b[py * L.rs + px];
+            const float4 ra = L.rec_a[py * L.rs + px];
+            const uint32_t r = __float_as_uint(rb.w);
             if ((r >> 2) == epoch) {
                 state = (int)(r & 3u);
-                if (state == 1)
-                    S.d_step[tid] = L.rec_step[py * L.rs + px];
+                if (state == 1) {
+                    S.d_mean[tid] = make_float2(ra.x, ra.y);
+                    S.d_var[tid] = make_float2(ra.z, ra.w);
+                    S.d_cross[tid] = rb.x;
+                    S.d_step[tid] = make_float2(rb.y, rb.z);
+                }
             }
+            mcx = px / 5 - g.bx0;
+            mcy = py / 5 - g.by0;
+            bit = 1u << ((px % 5) + (py % 5) * 5);
         }
         S.d_ok[tid] = state;
     } else if (tid < 256 + g.nbx * g.nby) {
@@ -1114,41 +1143,54 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
     }
     for (int k = tid; k < 625; k += T)
         S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
+    float2 cm[2], cq[2], ctb[2];
+    float ccr[2];
+    int cgi[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int cell = tid + e * 1024;
+        const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2;
+        const int qx = ox + rx, qy = oy + ry;
+        cgi[e] = -1;
+        if (cell < VM_NCELL && qx >= 0 && qx < L.w && qy >= 0 && qy < L.h) {
+            const int gi = qy * L.rs + qx;
+            cgi[e] = gi;
+            cm[e] = L.mean[gi];
+            cq[e] = L.var[gi];
+            ctb[e] = L.tps_b[gi];
+            ccr[e] = L.cross[gi];
+        }
+    }
     const int n_rec = __syncthreads_count(state != 0);
     if (n_rec == 0)
         return;
-    const bool ok = tid < 256 && commit_own(S, L, g, tid, ox, oy, pi, pj);
-    const int ncommit = __syncthreads_count(ok);
+    // the improving mask: a committed pixel sets its bit, a hit that did not move clears it
+    if (state == 1)
+        atomicOr(&S.mask[mcy][mcx], bit);
+    else if (state == 2)
+        atomicAnd(&S.mask[mcy][mcx], ~bit);
+    const int ncommit = __syncthreads_count(state == 1);
     if (ncommit) {
-        for (int cell = tid; cell < VM_NCELL; cell += T) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (cgi[e] < 0)
+                continue;
+            const int cell = tid + e * 1024;
             const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2;
-            const int qx = ox + rx, qy = oy + ry;
-            if (qx < 0 || qx >= L.w || qy < 0 || qy >= L.h)
+            float2 m = cm[e], q = cq[e], tb = ctb[e];
+            float cr = ccr[e];
+            if (!gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb))
                 continue;
-            const int gi = qy * L.rs + qx;
-            // cheap pre-test before touching HBM: any committed record in reach?
-            int ylo = max(ry - 2, 0), yhi = min(ry + 2, VM_TILE_H - 1);
-            int xlo = max(rx - 2, 0), xhi = min(rx + 2, VM_TILE_W - 1);
-            ylo += (ylo & 1) ^ pi;
-            xlo += (xlo & 1) ^ pj;
-            bool any = false;
-            for (int y = ylo; y <= yhi; y += 2)
-                for (int x = xlo; x <= xhi; x += 2)
-                    any = any || S.d_ok[(y >> 1) * 32 + (x >> 1)] == 1;
-            if (!any)
-                continue;
-            float2 m = L.mean[gi], q = L.var[gi], tb = L.tps_b[gi];
-            float cr = L.cross[gi];
-            gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb);
+            const int gi = cgi[e];
             L.mean[gi] = m;
             L.var[gi] = q;
             L.cross[gi] = cr;
             L.tps_b[gi] = tb;
+            const int qx = ox + rx, qy = oy + ry;
             const float counter = (float)(window_count(qy, L.h) * window_count(qx, L.w));
             L.value[gi] = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
         }
     }
-    __syncthreads();
     if (tid < g.nbx * g.nby) {
         int mx = tid % g.nbx, my = tid / g.nbx;
         if (mx >= 1 && mx <= g.nbx - 2 && my >= 1 && my <= g.nby - 2)
