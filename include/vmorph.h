@@ -108,9 +108,12 @@ int  vm_get_params(vm_ctx *ctx, vm_kern_params *p);
 int  vm_set_math_mode(vm_ctx *ctx, int mode);
 /* scheduling of the sweep (results do not depend on it): VM_SWEEP_TILE = one launch
  * per tile-offset pass, one workgroup per tile; VM_SWEEP_SPLIT = two launches per
- * phase, a tile's candidates spread over `parts` workgroups (small levels);
- * VM_SWEEP_AUTO picks per batch of iterations.  threads/parts: 0 = automatic. */
-enum { VM_SWEEP_AUTO = 0, VM_SWEEP_TILE = 1, VM_SWEEP_SPLIT = 2 };
+ * phase (line searches, then the commit), a tile's candidates spread over `parts`
+ * workgroups (small levels); VM_SWEEP_STEP = one launch per phase, the commit of a
+ * phase folded into the next phase's launch (VM_MATH_FAST only; VM_MATH_EXACT runs
+ * SPLIT instead); VM_SWEEP_AUTO picks per batch of iterations.
+ * threads/parts: 0 = automatic. */
+enum { VM_SWEEP_AUTO = 0, VM_SWEEP_TILE = 1, VM_SWEEP_SPLIT = 2, VM_SWEEP_STEP = 3 };
 int  vm_set_tuning(vm_ctx *ctx, int sweep_mode, int threads, int parts);
 /* device facts for reports: name (<=255 chars), CU count, HBM bytes */
 int  vm_device_info(vm_ctx *ctx, char *name256, int *cus, uint64_t *hbm_bytes);

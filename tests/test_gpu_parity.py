@@ -105,6 +105,39 @@ def test_sweep_exact_split_schedule(gpu_ctx, oracle, w, h, parts, threads):
         gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
 
 
+def _state_bits(lvl):
+    return [lvl.field(n).view(np.uint32).copy() for n in ("v", "luma", "mean", "var", "cross", "value", "tps_b", "ui_b", "impmask")]
+
+
+@pytest.mark.parametrize("w,h,bcond,ncons", [(120, 68, capi.BCOND_NONE, 0), (150, 97, capi.BCOND_BORDER, 4), (69, 21, capi.BCOND_CORNER, 0), (333, 47, capi.BCOND_NONE, 3)])
+def test_fast_step_schedule_is_bit_identical_to_split(gpu_ctx, oracle, w, h, bcond, ncons):
+    """FAST: the STEP schedule (one launch per phase, the commit folded into the next phase's
+    launch from a second copy of the sums) must give the bits of the two-kernel SPLIT schedule
+    -- same lean line search, the fold defined by image coordinates -- call after call, with a
+    TILE call in between (all three share the state in HBM)"""
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    cons = synth.make_constraints(w, h, ncons) if ncons else ()
+    out = []
+    try:
+        for sched in (capi.SWEEP_SPLIT, capi.SWEEP_STEP):
+            P = _params(oracle, bcond=bcond)
+            lo, pyr, P = _make_level(gpu_ctx, oracle, w, h, cons=cons, P=P)
+            trace = []
+            for mode, iters in ((sched, 3.0), (capi.SWEEP_TILE, 1.0), (sched, 5.0), (sched, 1.0)):
+                gpu_ctx.set_tuning(mode, 0, 0)
+                pr = capi.Progress()
+                capi.check(pyr._L.vm_optimize_level(pyr._h, 0, iters, None, 1, C.byref(pr)))
+                trace.append((_state_bits(pyr[1]), pr.commits, pr.candidates))
+            out.append(trace)
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    for (sa, ca, na), (sb, cb, nb) in zip(*out):
+        assert ca == cb and ca > 0 and na == nb
+        for a, b in zip(sa, sb):
+            assert np.array_equal(a, b)
+
+
 def test_fast_split_matches_fast_tile_statistically(gpu_ctx, oracle):
     """FAST: the two schedules differ only in lane fan-out (tree-sum order); after 20
     sweeps their fields agree to RMS <= 0.01 px"""

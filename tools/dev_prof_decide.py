@@ -7,7 +7,7 @@ from videomorphing_amd import capi, morph, synth
 
 ctx = morph.Context(0, capi.MATH_FAST)
 ctx.set_params(morph.KernParameters(morph.Parameters()))
-ctx.set_tuning(2, int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ctx.set_tuning(int(os.environ.get("VM_SCHED", "2")), int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 w, h = 1920, 1080
 i0, i1 = synth.make_pair(w, h)
 pyr = morph.Pyramid(ctx); pyr.build(i0, i1, 32)

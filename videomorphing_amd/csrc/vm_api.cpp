@@ -172,7 +172,7 @@ extern "C" int vm_set_math_mode(vm_ctx *c, int mode)
 
 extern "C" int vm_set_tuning(vm_ctx *c, int sweep_mode, int threads, int parts)
 {
-    if (!c || sweep_mode < VM_SWEEP_AUTO || sweep_mode > VM_SWEEP_SPLIT || threads < 0 || parts < 0 ||
+    if (!c || sweep_mode < VM_SWEEP_AUTO || sweep_mode > VM_SWEEP_STEP || threads < 0 || parts < 0 ||
         (threads && (threads % 64 || threads < 256 || threads > 1024)) || parts > 64)
         return vm_fail(VM_E_INVALID, "vm_set_tuning: bad argument");
     c->sweep_mode = sweep_mode;
@@ -208,7 +208,8 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
     size_t off = 0;
     size_t o_v = off; off += al(n * 8);
     size_t o_img0 = off, o_img1 = off, o_luma = off, o_mean = off, o_var = off, o_tpsb = off,
-           o_uib = off, o_cross = off, o_value = off, o_uiaxy = off, o_imp = off, o_rst = off, o_rsp = off;
+           o_uib = off, o_cross = off, o_value = off, o_uiaxy = off, o_imp = off, o_rst = off, o_rsp = off,
+           o_tag = off, o_tag2 = off, o_rst2 = off, o_rsp2 = off, o_mean2 = off, o_var2 = off, o_tpsb2 = off, o_cross2 = off, o_value2 = off, o_imp2 = off;
     if (with_images) {
         o_img0 = off; off += al(n * 4);
         o_img1 = off; off += al(n * 4);
@@ -223,6 +224,16 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
         o_imp = off; off += al((size_t)l.imp_rs * l.imp_rows * 4);
         o_rst = off; off += al(n * 16);
         o_rsp = off; off += al(n * 16);
+        o_tag = off; off += al(n * 4);
+        o_tag2 = off; off += al(n * 4);
+        o_rst2 = off; off += al(n * 16);
+        o_rsp2 = off; off += al(n * 16);
+        o_mean2 = off; off += al(n * 8);
+        o_var2 = off; off += al(n * 8);
+        o_tpsb2 = off; off += al(n * 8);
+        o_cross2 = off; off += al(n * 4);
+        o_value2 = off; off += al(n * 4);
+        o_imp2 = off; off += al((size_t)l.imp_rs * l.imp_rows * 4);
     }
     VM_HIP(hipMalloc((void **)&l.slab, off));
     // stream-ordered: the context's stream does not synchronise with the null stream
@@ -243,12 +254,23 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
         V.impmask = (uint32_t *)(b + o_imp);
         V.rec_a = (float4 *)(b + o_rst);
         V.rec_b = (float4 *)(b + o_rsp);
+        V.rec_tag = (uint32_t *)(b + o_tag);
+        V.rec_tag2 = (uint32_t *)(b + o_tag2);
+        V.rec_a2 = (float4 *)(b + o_rst2); V.rec_b2 = (float4 *)(b + o_rsp2);
+        V.mean2 = (float2 *)(b + o_mean2); V.var2 = (float2 *)(b + o_var2);
+        V.tps_b2 = (float2 *)(b + o_tpsb2); V.cross2 = (float *)(b + o_cross2);
+        V.value2 = (float *)(b + o_value2); V.impmask2 = (uint32_t *)(b + o_imp2);
     } else {
         V.img0 = V.img1 = nullptr;
         V.luma = V.mean = V.var = V.tps_b = V.ui_b = nullptr;
         V.cross = V.value = V.ui_axy = nullptr;
         V.impmask = nullptr;
         V.rec_a = V.rec_b = nullptr;
+        V.rec_tag = V.rec_tag2 = nullptr;
+        V.rec_a2 = V.rec_b2 = nullptr;
+        V.mean2 = V.var2 = V.tps_b2 = nullptr;
+        V.cross2 = V.value2 = nullptr;
+        V.impmask2 = nullptr;
     }
     return VM_OK;
 }
@@ -528,18 +550,25 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     const int threads = std::min(c->sweep_threads ? c->sweep_threads : (exact ? 256 : 512), exact ? 1024 : 512);
     const int tiles_per_pass = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
     // SPLIT schedule: workgroups per tile so that a pass roughly fills the 256 CUs
-    const int parts = c->sweep_parts ? c->sweep_parts : std::max(1, std::min(16, 256 / (tiles_per_pass * n)));
-    // Schedule, re-decided per batch of iterations (AUTO): SPLIT spreads a tile's line searches
-    // over several CUs but pays 8 launches per pass instead of 1 -- measured on MI355X it wins
-    // where a pass has few tiles and many line searches (120x68, every pixel active: 0.55 vs
-    // 0.81 ms per iteration; 240x135: 0.53 vs 0.64) and loses 8x on pruned sweeps (no-op
-    // iteration 0.11 vs 0.013 ms).  Both schedules work on the same state in HBM, so the
-    // choice can change from batch to batch.
+    // (FAST: the lean line search gives every candidate 32 lanes, 16 candidates per workgroup)
+    const int parts = c->sweep_parts ? c->sweep_parts
+                                     : (exact ? std::max(1, std::min(16, 256 / (tiles_per_pass * n))) : 16);
+    // Schedule, re-decided per batch of iterations (AUTO).  TILE: 4 launches per iteration, a
+    // tile's four phases inside one workgroup -- unbeatable when a pass touches nothing (24 us
+    // per converged iteration) or when there are enough tiles to fill the chip.  SPLIT (EXACT)
+    // / STEP (FAST): a tile's line searches spread over `parts` workgroups, 32 / 16 launches
+    // per iteration -- measured on MI355X (FAST, 1080p pyramid): 120x68, every pixel active,
+    // 0.32 (STEP) vs 0.64 ms (TILE) per iteration; 240x135 with 900 line searches per
+    // iteration 0.22 vs 0.36; with 90: 0.24 vs 0.23; converged 0.08 vs 0.024.  All schedules
+    // work on the same state in HBM, so the choice can change from batch to batch.
     const bool may_split = c->sweep_mode != VM_SWEEP_TILE && tiles_per_pass * n <= 64;
     double cand_prev = 1e9; // line searches per iteration in the previous batch (first batch: dense)
     if (may_split) // epochs restart with every call: forget old records
         for (int i = 0; i < n; ++i)
-            VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_b, 0, (size_t)l0.rs * l0.h * 16, s));
+        {
+            VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_tag, 0, (size_t)l0.rs * l0.h * 4, s));
+            VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_tag2, 0, (size_t)l0.rs * l0.h * 4, s));
+        }
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
     std::vector<int> executed(n, cap), improving(n, 1), stopped(n, 0);
     std::vector<double> st_tiles(n, 0.0), st_cand(n, 0.0), st_commit(n, 0.0);
@@ -554,11 +583,25 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     int batch = 8;
     while (done < cap) {
         const int nb = std::min(batch, cap - done);
-        const bool split = c->sweep_mode == VM_SWEEP_SPLIT || (may_split && cand_prev >= 1500.0 * n);
+        const bool split = c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP ||
+                           (may_split && cand_prev >= (exact ? 1500.0 : 200.0) * n);
+        // FAST: the one-launch-per-phase STEP schedule unless the two-kernel SPLIT is forced
+        const bool step = split && !exact && c->sweep_mode != VM_SWEEP_SPLIT;
         VM_HIP(hipEventRecord(c->ev0, s));
+        uint32_t last_epoch = 0;
+        int sb = 0; // step index inside this batch: parity = which copy of the sums is read
         for (int it = done; it < done + nb; ++it)
             for (int k = 0; k < 4; ++k) {
-                if (split) {
+                if (step) {
+                    for (int ph = 0; ph < 4; ++ph, ++sb) {
+                        const uint32_t epoch = 1u + (uint32_t)((it * 4 + k) * 4 + ph);
+                        vm_launch_optimize_step_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1],
+                                                     ph >> 1, ph & 1, epoch, sb == 0 ? 0u : epoch - 1u, sb & 1, 1,
+                                                     c->flags, c->stats, it, fixed_work, threads, parts, s);
+                        last_epoch = epoch;
+                    }
+                    launches += 4;
+                } else if (split) {
                     if (exact) vm_launch_optimize_split_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
                     else vm_launch_optimize_split_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
                     launches += 8;
@@ -568,6 +611,11 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
                     ++launches;
                 }
             }
+        if (step) { // fold the last phase's records in place: copy 0 is complete again
+            vm_launch_optimize_step_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, 0, 0, 0, 0, 0u, last_epoch, 2, 0,
+                                         c->flags, c->stats, done + nb - 1, fixed_work, threads, parts, s);
+            ++launches;
+        }
         VM_HIP(hipEventRecord(c->ev1, s));
         VM_HIP(hipGetLastError());
         for (int i = 0; i < n; ++i) {

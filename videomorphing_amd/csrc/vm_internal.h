@@ -29,8 +29,18 @@ struct VmLevelView {
     float2 *v, *luma, *mean, *var, *tps_b, *ui_b;
     float *cross, *value, *ui_axy;
     uint32_t *impmask;
-    // decision records of the SPLIT sweep schedule (vm_sweep_kernels.hip)
+    // decision records of the SPLIT / STEP sweep schedules (vm_sweep_kernels.hip)
+    uint32_t *rec_tag;
     float4 *rec_a, *rec_b;
+    // STEP writes the records of odd epochs here: a pixel can be decided in two consecutive
+    // phases (last phase of a pass, first of the next), and a step reads the previous
+    // phase's records while it writes its own
+    uint32_t *rec_tag2;
+    float4 *rec_a2, *rec_b2;
+    // second copy of the window sums and the mask for the STEP schedule's ping-pong
+    float2 *mean2, *var2, *tps_b2;
+    float *cross2, *value2;
+    uint32_t *impmask2;
 };
 
 struct VmKParams {
@@ -58,6 +68,13 @@ struct VmKParams {
                                            int offx, int offy, int pass, uint32_t *flags,     \
                                            uint32_t *stats, int iter_idx, int fixed_work,     \
                                            int threads, int parts, hipStream_t s);            \
+    void vm_launch_optimize_step_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w,  \
+                                          int h, const VmKParams &P, const uint32_t *tables,  \
+                                          int offx, int offy, int pi, int pj, uint32_t epoch, \
+                                          uint32_t prev_epoch, int src, int decide,           \
+                                          uint32_t *flags, uint32_t *stats, int iter_idx,     \
+                                          int fixed_work, int threads, int parts,             \
+                                          hipStream_t s);                                     \
     void vm_launch_upsample_##SUFFIX(float2 *dst, int dw, int dh, int drs, const float2 *src, \
                                      int sw, int sh, int srs, hipStream_t s);                 \
     void vm_launch_splat_##SUFFIX(const VmLevelView &L, int w0, int h0,                       \

@@ -450,15 +450,22 @@ __device__ __forceinline__ float group_min32(float x)
     return x;
 }
 
-template <bool INTERIOR, class Src>
-__device__ __forceinline__ void nb1_load(Nb1 &nb, const VmLevelView &L, const Src &src, const PixelCtx &c, int sub)
+// lane `sub` of a pixel's group owns window neighbour (px + sub % 5 - 2, py + sub / 5 - 2)
+template <bool INTERIOR>
+__device__ __forceinline__ bool nb1_cell(const VmLevelView &L, const PixelCtx &c, int sub, int &i, int &jj, int &qx,
+                                         int &qy)
 {
-    const int i = (sub * 13) >> 6, jj = sub - i * 5; // sub / 5 for sub < 32
-    const int qx = c.px + jj - 2, qy = c.py + i - 2;
-    const bool ok = sub < 25 && (INTERIOR || (qx >= 0 && qx < L.w && qy >= 0 && qy < L.h));
-    float2 m, q;
-    float cr, val;
-    src.load(ok ? i : 2, ok ? jj : 2, m, q, cr, val);
+    i = (sub * 13) >> 6; // sub / 5 for sub < 32
+    jj = sub - i * 5;
+    qx = c.px + jj - 2;
+    qy = c.py + i - 2;
+    return sub < 25 && (INTERIOR || (qx >= 0 && qx < L.w && qy >= 0 && qy < L.h));
+}
+
+template <bool INTERIOR>
+__device__ __forceinline__ void nb1_make(Nb1 &nb, const VmLevelView &L, bool ok, int qx, int qy, float2 m, float2 q,
+                                         float cr, float val)
+{
     float n = 25.0f, in = 0.04f;
     if (!INTERIOR) {
         n = ok ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
@@ -471,6 +478,17 @@ __device__ __forceinline__ void nb1_load(Nb1 &nb, const VmLevelView &L, const Sr
     nb.VY = q.y;
     nb.X = cr;
     nb.VAL = val;
+}
+
+template <bool INTERIOR, class Src>
+__device__ __forceinline__ void nb1_load(Nb1 &nb, const VmLevelView &L, const Src &src, const PixelCtx &c, int sub)
+{
+    int i, jj, qx, qy;
+    const bool ok = nb1_cell<INTERIOR>(L, c, sub, i, jj, qx, qy);
+    float2 m, q;
+    float cr, val;
+    src.load(ok ? i : 2, ok ? jj : 2, m, q, cr, val);
+    nb1_make<INTERIOR>(nb, L, ok, qx, qy, m, q, cr, val);
 }
 
 // energy_change (morph.cu:730-761) on 32 lanes; also returns the two lumas at the trial point
@@ -543,12 +561,10 @@ __device__ __forceinline__ float fover32(const VmLevelView &L, const PixelCtx &c
 
 // optimize_pixel after the mask test, 32 lanes in lockstep; on success also the lumas at
 // the accepted point (what commit_pixel_motion would sample again)
-template <bool INTERIOR, class Src>
-__device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &P, const Src &src,
+template <bool INTERIOR>
+__device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &P, const Nb1 &nb,
                                          const PixelCtx &c, int sub, float2 &step, float2 &luma VM_TS_ARG)
 {
-    Nb1 nb;
-    nb1_load<INTERIOR>(nb, L, src, c, sub);
     VM_TS(4);
     float lx, ly;
     float gx = 0, gy = 0;
@@ -862,8 +878,15 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
 #ifdef VM_PROF
                         unsigned long long ts[16];
 #endif
-                        const bool ok = wave_interior ? decide32<true>(L, P, src, c, sub, step, luma VM_TS_PASS)
-                                                      : decide32<false>(L, P, src, c, sub, step, luma VM_TS_PASS);
+                        Nb1 nb;
+                        bool ok;
+                        if (wave_interior) {
+                            nb1_load<true>(nb, L, src, c, sub);
+                            ok = decide32<true>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                        } else {
+                            nb1_load<false>(nb, L, src, c, sub);
+                            ok = decide32<false>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                        }
                         if (ok && sub == 0) {
                             S.d_step[slot] = step;
                             S.d_ok[slot] = 1;
@@ -969,10 +992,9 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
 // phase reads them -- the fold-over ring of a pixel has no pixel of its own parity) plus
 // a decision record; k_commit folds the records into the window sums of the cells they
 // reach.  Records, two float4 per pixel:
-//   rec_a = (d mean.x, d mean.y, d var.x, d var.y)
-//   rec_b = (d cross, step.x, step.y, bits(epoch << 2 | state))
-// state 1: commit, 2: mask hit that did not move; valid only for the current epoch (one
-// epoch per phase, so nothing is ever cleared).
+//   rec_tag = epoch << 2 | state      (state 1: commit, 2: mask hit that did not move)
+//   rec_a = (d mean.x, d mean.y, d var.x, d var.y),  rec_b = (d cross, step.x, step.y, -)
+// valid only for the current epoch (one epoch per phase, so nothing is ever cleared).
 
 __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
                                                       const uint32_t *__restrict__ tables, int offx, int offy,
@@ -1059,8 +1081,15 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
                     luma.y = tap(L.img1, L.w, L.h, L.rs, px + nvx + 0.5f, py + nvy + 0.5f);
                 }
 #else
-                const bool ok = wave_interior ? decide32<true>(L, P, src, c, sub, step, luma VM_TS_PASS)
-                                              : decide32<false>(L, P, src, c, sub, step, luma VM_TS_PASS);
+                Nb1 nb;
+                bool ok;
+                if (wave_interior) {
+                    nb1_load<true>(nb, L, src, c, sub);
+                    ok = decide32<true>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                } else {
+                    nb1_load<false>(nb, L, src, c, sub);
+                    ok = decide32<false>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                }
 #endif
                 if (ok)
                     state = 1;
@@ -1080,8 +1109,9 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
                     L.v[c.idx] = make_float2(c.v.x + step.x, c.v.y + step.y);
                     L.rec_a[c.idx] = ra;
                 }
-                rb.w = __uint_as_float((epoch << 2) | state);
-                L.rec_b[c.idx] = rb;
+                if (state == 1)
+                    L.rec_b[c.idx] = rb;
+                L.rec_tag[c.idx] = (epoch << 2) | state;
             }
         }
     }
@@ -1120,9 +1150,9 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
     if (tid < 256) {
         const int px = ox + (tid & 31) * 2 + pj, py = oy + (tid >> 5) * 2 + pi;
         if (px < L.w && py < L.h) {
+            const uint32_t r = L.rec_tag[py * L.rs + px];
             const float4 rb = L.rec_b[py * L.rs + px];
             const float4 ra = L.rec_a[py * L.rs + px];
-            const uint32_t r = __float_as_uint(rb.w);
             if ((r >> 2) == epoch) {
                 state = (int)(r & 3u);
                 if (state == 1) {
@@ -1205,6 +1235,370 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
     }
 }
 
+
+#if !VM_EXACT
+// ===========================================================================
+// STEP schedule (FAST): ONE launch per phase.  The commit of phase s-1 and the line
+// searches of phase s share a launch: the window sums and the mask live in two copies;
+// a step reads copy `src` (state before the records of phase s-1 were folded in) and
+//  - its FOLD workgroups (one per 64x16 block of the level, geometry-free) write
+//    sums + records(s-1) -> copy `dst`, whole level;
+//  - its DECIDE workgroups (tiles x parts, as k_decide) fold the same records privately,
+//    per lane, into the one window cell the lane owns, run the lean line search and
+//    write the pixel's own state + records(s).
+// Folding is defined by image coordinates only -- a record of epoch s-1 reaches every
+// cell within +-2 of its pixel, row-major order -- which is what gather_cell computes
+// tile-relative; so the STEP schedule is bit-identical to the SPLIT schedule (same
+// arithmetic mode).  A batch of steps ends with a fold-only launch in place on copy 0.
+// staged window of the record tags: the tile +-4 (decide: cells +-2 of a tile pixel, their
+// records +-2 more) or a 64x16 block +-2 (fold); kept as one commit bit per pixel
+#define VM_STEP_BW (VM_TILE_W + 8)
+#define VM_STEP_BH (VM_TILE_H + 8)
+struct StepLds {
+    uint32_t bits[VM_STEP_BH][4]; // bit x of row y: pixel (x0 + x, y0 + y) committed in the last phase
+    int list[256];
+    int wave_cnt[4];
+    float tps[625];
+    uint32_t imp[225];
+    uint32_t mask[6][16];
+    uint32_t n_commit;
+};
+
+// the 25 commit bits of the 5x5 window around cell (qx, qy); (bx0, by0) = origin of the staged window
+__device__ __forceinline__ uint32_t cell_hits(const uint32_t (*bits)[4], int bx0, int by0, int qx, int qy)
+{
+    const int sx = qx - 2 - bx0, sy = qy - 2 - by0;
+    const int wi = sx >> 5, sh = sx & 31;
+    uint32_t hits = 0;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+        const uint32_t lo = bits[sy + dy][wi], hi = bits[sy + dy][wi + 1];
+        hits |= (__funnelshift_r(lo, hi, sh) & 31u) << (5 * dy);
+    }
+    return hits;
+}
+
+// sums of cell (qx, qy) + the committed records flagged in `hits`, row-major (ssim_update,
+// morph.cu:951-988, and the tps.b scatter, :1006-1015, as a gather).  All record loads are
+// issued before the first is used; the slot loops end as soon as no lane of the wave has a
+// record left.
+__device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__restrict__ r_a,
+                                          const float4 *__restrict__ r_b, const float *s_tps, uint32_t hits, int qx,
+                                          int qy, float2 &m, float2 &q, float &cr, float2 &tb)
+{
+    const bool touched = hits != 0;
+    float4 ra[9], rb[9];
+    int bidx[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) // at most 9 pixels of one phase lie in a 5x5 window
+        bidx[k] = -1;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (!__any(hits != 0))
+            break;
+        const int b = hits ? __ffs(hits) - 1 : -1;
+        hits &= hits - 1;
+        bidx[k] = b;
+        const int bb = max(b, 0);
+        const int dy = (bb * 13) >> 6, dx = bb - dy * 5;
+        const int rsafe = b >= 0 ? (qy + dy - 2) * L.rs + (qx + dx - 2) : qy * L.rs + qx;
+        ra[k] = r_a[rsafe];
+        rb[k] = r_b[rsafe];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int b = bidx[k];
+        if (!__any(b >= 0))
+            break;
+        if (b < 0)
+            continue;
+        const int dy = (b * 13) >> 6, dx = b - dy * 5;
+        const int x = qx + dx - 2, y = qy + dy - 2;
+        m.x += ra[k].x;
+        m.y += ra[k].y;
+        q.x += ra[k].z;
+        q.y += ra[k].w;
+        cr += rb[k].x;
+        const float kk = s_tps[(border_class(y, L.h) * 5 + border_class(x, L.w)) * 25 + (4 - dy) * 5 + (4 - dx)];
+        tb.x += rb[k].y * kk;
+        tb.y += rb[k].z * kk;
+    }
+    return touched;
+}
+
+__global__ __launch_bounds__(512) void k_step_fast(const VmLevelView *__restrict__ views, int cap, VmKParams P,
+                                                   const uint32_t *__restrict__ tables, int offx, int offy, int pi,
+                                                   int pj, int parts, uint32_t epoch, uint32_t pe, int srcbuf,
+                                                   int n_fold, uint32_t *__restrict__ flags,
+                                                   uint32_t *__restrict__ stats, int iter_idx, int fixed_work)
+{
+    __shared__ StepLds S;
+    const int tid = threadIdx.x, T = blockDim.x;
+#ifdef VM_PROF
+    unsigned long long ts[16];
+    for (int k = 0; k < 16; ++k) ts[k] = 0;
+    VM_TS(0);
+#endif
+    const VmLevelView L = views[blockIdx.z];
+    flags += (size_t)blockIdx.z * cap;
+    stats += (size_t)blockIdx.z * cap * 4;
+    // copy 0 = the canonical arrays; srcbuf 2 = fold in place on copy 0 (end of a batch)
+    const bool s1 = srcbuf == 1, d1 = srcbuf == 0;
+    const float2 *s_mean = s1 ? L.mean2 : L.mean, *s_var = s1 ? L.var2 : L.var, *s_tpsb = s1 ? L.tps_b2 : L.tps_b;
+    const float *s_cross = s1 ? L.cross2 : L.cross, *s_value = s1 ? L.value2 : L.value;
+    const uint32_t *s_imp = s1 ? L.impmask2 : L.impmask;
+    float2 *d_mean = d1 ? L.mean2 : L.mean, *d_var = d1 ? L.var2 : L.var, *d_tpsb = d1 ? L.tps_b2 : L.tps_b;
+    float *d_cross = d1 ? L.cross2 : L.cross, *d_value = d1 ? L.value2 : L.value;
+    uint32_t *d_imp = d1 ? L.impmask2 : L.impmask;
+    const bool in_place = srcbuf == 2;
+    // records: read the set the previous phase wrote, write the other one
+    const bool r1 = pe & 1u, w1 = epoch & 1u;
+    const uint32_t *r_tag = r1 ? L.rec_tag2 : L.rec_tag;
+    const float4 *r_a = r1 ? L.rec_a2 : L.rec_a, *r_b = r1 ? L.rec_b2 : L.rec_b;
+    uint32_t *w_tag = w1 ? L.rec_tag2 : L.rec_tag;
+    float4 *w_a = w1 ? L.rec_a2 : L.rec_a, *w_b = w1 ? L.rec_b2 : L.rec_b;
+    const uint32_t want = (pe << 2) | 1u;
+
+    for (int k = tid; k < 625; k += T)
+        S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
+    if (tid < VM_STEP_BH * 4)
+        S.bits[tid >> 2][tid & 3] = 0;
+
+    if ((int)blockIdx.x < n_fold) {
+        // ------------------------------------------------------------- FOLD
+        const int nfx = (L.w + 63) / 64;
+        const int x0 = ((int)blockIdx.x % nfx) * 64, y0 = ((int)blockIdx.x / nfx) * 16;
+        const int bx0 = x0 - 2, by0 = y0 - 2; // staged window: 68 x 20
+        uint32_t tg[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int k = tid + e * 512;
+            const int x = bx0 + k % 68, y = by0 + k / 68;
+            tg[e] = (k < 68 * 20 && x >= 0 && x < L.w && y >= 0 && y < L.h) ? r_tag[y * L.rs + x] : 0u;
+        }
+        float2 cm[2], cq[2], ctb[2];
+        float ccr[2], cval[2];
+        int cgi[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int cell = tid + e * 512;
+            const int qx = x0 + (cell & 63), qy = y0 + (cell >> 6);
+            cgi[e] = -1;
+            if (qx < L.w && qy < L.h) {
+                const int gi = qy * L.rs + qx;
+                cgi[e] = gi;
+                cm[e] = s_mean[gi];
+                cq[e] = s_var[gi];
+                ctb[e] = s_tpsb[gi];
+                ccr[e] = s_cross[gi];
+                cval[e] = s_value[gi];
+            }
+        }
+        // mask words, by index range over the padded word array
+        const int nw = L.imp_rs * L.imp_rows, per = (nw + n_fold - 1) / n_fold;
+        const int wi = (int)blockIdx.x * per + tid;
+        if (tid < per && wi < nw) {
+            const int my = wi / L.imp_rs, mx = wi - my * L.imp_rs;
+            uint32_t word = s_imp[wi];
+            if (mx >= 1 && my >= 1 && (mx - 1) * 5 < L.w && (my - 1) * 5 < L.h) {
+                // a committed pixel sets its bit, a hit that did not move clears it
+                uint32_t tw[25];
+#pragma unroll
+                for (int k = 0; k < 25; ++k) {
+                    const int dy = (k * 13) >> 6, dx = k - dy * 5;
+                    const int x = (mx - 1) * 5 + dx, y = (my - 1) * 5 + dy;
+                    tw[k] = (x < L.w && y < L.h) ? r_tag[y * L.rs + x] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 25; ++k)
+                    if ((tw[k] >> 2) == pe) {
+                        if ((tw[k] & 3u) == 1u)
+                            word |= 1u << k;
+                        else if ((tw[k] & 3u) == 2u)
+                            word &= ~(1u << k);
+                    }
+            }
+            d_imp[wi] = word;
+        }
+        __syncthreads(); // bits zeroed
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int k = tid + e * 512;
+            if (tg[e] == want)
+                atomicOr(&S.bits[k / 68][(k % 68) >> 5], 1u << ((k % 68) & 31));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int cell = tid + e * 512;
+            const int qx = x0 + (cell & 63), qy = y0 + (cell >> 6);
+            const bool in = cgi[e] >= 0;
+            float2 m = cm[e], q = cq[e], tb = ctb[e];
+            float cr = ccr[e], val = cval[e];
+            const uint32_t hits = in ? cell_hits(S.bits, bx0, by0, qx, qy) : 0u;
+            const bool touched = fold_cell(L, r_a, r_b, S.tps, hits, in ? qx : 0, in ? qy : 0, m, q, cr, tb);
+            if (!in)
+                continue;
+            if (touched) {
+                const float counter = (float)(window_count(qy, L.h) * window_count(qx, L.w));
+                val = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
+            } else if (in_place) {
+                continue;
+            }
+            const int gi = cgi[e];
+            d_mean[gi] = m;
+            d_var[gi] = q;
+            d_cross[gi] = cr;
+            d_tpsb[gi] = tb;
+            d_value[gi] = val;
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------- DECIDE
+    // converged in the previous iteration: nothing can be a candidate (sticky); the folds go on
+    if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
+        return;
+    const int bid = (int)blockIdx.x - n_fold;
+    const int part = bid % parts, tile = bid / parts;
+    const int gxn = (L.w + VM_PITCH_X - 1) / VM_PITCH_X;
+    const int ox = (tile % gxn) * VM_PITCH_X + offx, oy = (tile / gxn) * VM_PITCH_Y + offy;
+    if (ox >= L.w || oy >= L.h)
+        return;
+    const MaskGeom g = mask_geom(L, ox, oy);
+    const int bx0 = ox - 4, by0 = oy - 4; // staged window: 72 x 24
+    uint32_t tg[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = tid + e * 512;
+        const int x = bx0 + k % VM_STEP_BW, y = by0 + k / VM_STEP_BW;
+        tg[e] = (k < VM_STEP_BW * VM_STEP_BH && x >= 0 && x < L.w && y >= 0 && y < L.h) ? r_tag[y * L.rs + x] : 0u;
+    }
+    if (tid < g.nbx * g.nby)
+        S.mask[tid / g.nbx][tid % g.nbx] = s_imp[(g.by0 + tid / g.nbx + 1) * L.imp_rs + (g.bx0 + tid % g.nbx + 1)];
+    for (int k = tid; k < 225; k += T)
+        S.imp[k] = tables[VM_TAB_IMP + k];
+    if (tid == 0)
+        S.n_commit = 0;
+    __syncthreads();
+    VM_TS(1);
+    // the last phase's records: commit bits for the cell folds, and the mask words -- a committed
+    // pixel sets its bit, a hit that did not move clears it.  (Mask bits further than 2 pixels
+    // from the tile stay unfolded here: mask_hit never looks at them.)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = tid + e * 512;
+        const uint32_t t = tg[e];
+        if ((t >> 2) == pe && (t & 3u) != 0u) {
+            const int sx = k % VM_STEP_BW, sy = k / VM_STEP_BW;
+            const int x = bx0 + sx, y = by0 + sy;
+            const uint32_t bit = 1u << ((x % 5) + (y % 5) * 5);
+            uint32_t *word = &S.mask[y / 5 - g.by0][x / 5 - g.bx0];
+            if ((t & 3u) == 1u) {
+                atomicOr(&S.bits[sy][sx >> 5], 1u << (sx & 31));
+                atomicOr(word, bit);
+            } else {
+                atomicAnd(word, ~bit);
+            }
+        }
+    }
+    __syncthreads();
+    VM_TS(2);
+
+    bool hit = false;
+    if (tid < 256) {
+        const int px = ox + (tid & 31) * 2 + pj, py = oy + (tid >> 5) * 2 + pi;
+        hit = px < L.w && py < L.h && mask_hit(S.mask, S.imp, g, px, py);
+    }
+    const int n_hit = compact256(hit, tid, S.list, S.wave_cnt);
+    const int n_mine = (n_hit - part + parts - 1) / parts;
+    if (n_mine <= 0)
+        return;
+    const int slots = T / 32;
+    const int sub = tid & 31, grp = tid >> 5;
+    uint32_t my_commits = 0;
+    for (int base = 0; base < n_mine; base += slots) {
+        const int mi = base + grp;
+        const int slot = S.list[part + parts * min(mi, n_mine - 1)];
+        const int px = ox + (slot & 31) * 2 + pj, py = oy + (slot >> 5) * 2 + pi;
+        const bool wave_interior = __all(mi >= n_mine || is_interior(L, px, py));
+        const bool live = mi < n_mine && !pixel_locked(L, P.bcond, px, py);
+        uint32_t state = 2;
+        float2 step = make_float2(0, 0), luma = make_float2(0, 0);
+        PixelCtx c;
+        c.px = px;
+        c.py = py;
+        c.idx = py * L.rs + px;
+        VM_TS(3);
+        // every lane takes part in the fold (its slot loops are wave-uniform); idle lanes fold
+        // the pixel's own cell with no records
+        ctx_load(c, L, S.tps, px, py);
+        // the lane's window cell: sums of copy `src` + the records of the last phase
+        int i, jj, qx, qy;
+        const bool okc = wave_interior ? nb1_cell<true>(L, c, sub, i, jj, qx, qy)
+                                       : nb1_cell<false>(L, c, sub, i, jj, qx, qy);
+        const int cx = okc ? qx : px, cy = okc ? qy : py, gi = cy * L.rs + cx;
+        float2 m = s_mean[gi], q = s_var[gi], tb = s_tpsb[gi];
+        float cr = s_cross[gi], val = s_value[gi];
+        const uint32_t hits = live && okc ? cell_hits(S.bits, bx0, by0, cx, cy) : 0u;
+        if (fold_cell(L, r_a, r_b, S.tps, hits, cx, cy, m, q, cr, tb)) {
+            const float counter = (float)(window_count(cy, L.h) * window_count(cx, L.w));
+            val = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
+        }
+        // tps.b of the pixel itself is the folded value of its own cell (lane 12)
+        c.tps_b.x = __shfl(tb.x, 12, 32);
+        c.tps_b.y = __shfl(tb.y, 12, 32);
+        if (live) {
+            Nb1 nb;
+            bool ok;
+            if (wave_interior) {
+                nb1_make<true>(nb, L, okc, qx, qy, m, q, cr, val);
+                ok = decide32<true>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+            } else {
+                nb1_make<false>(nb, L, okc, qx, qy, m, q, cr, val);
+                ok = decide32<false>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+            }
+            if (ok)
+                state = 1;
+        }
+        if (mi < n_mine && sub == 0) {
+            if (state == 1) {
+                const float2 ol = c.old_luma;
+                w_a[c.idx] = make_float4(luma.x - ol.x, luma.y - ol.y, luma.x * luma.x - ol.x * ol.x,
+                                         luma.y * luma.y - ol.y * ol.y);
+                w_b[c.idx] = make_float4(luma.x * luma.y - ol.x * ol.y, step.x, step.y, 0.0f);
+                L.luma[c.idx] = luma;
+                L.ui_b[c.idx] = make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy);
+                L.v[c.idx] = make_float2(c.v.x + step.x, c.v.y + step.y);
+                ++my_commits;
+            }
+            w_tag[c.idx] = (epoch << 2) | state;
+        }
+    }
+    if (my_commits)
+        atomicAdd(&S.n_commit, my_commits);
+#ifdef VM_PROF
+    VM_TS(8);
+    if ((tid & 63) == 0 && bid < 512 && (tid >> 6) < 1) {
+        ts[9] = 32;
+        ts[10] = (unsigned long long)n_mine;
+        for (int k = 0; k < 16; ++k) vm_prof_buf[bid * 16 + k] = ts[k];
+    }
+#endif
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t nc = S.n_commit;
+        if (nc)
+            atomicOr(&flags[iter_idx], 1u);
+        if (part == 0)
+            atomicAdd(&stats[iter_idx * 4 + 3], 1u); // tile-phases with records
+        atomicAdd(&stats[iter_idx * 4 + 1], (uint32_t)n_mine);
+        if (nc)
+            atomicAdd(&stats[iter_idx * 4 + 2], nc);
+    }
+}
+#endif
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -1242,4 +1636,24 @@ void SUF(vm_launch_optimize_split)(const VmLevelView *views, int nbatch, int cap
             hipLaunchKernelGGL(SUF(k_commit), dim3(gx, gy, nbatch), dim3(1024), 0, s, views, cap, P, tables, offx,
                                offy, pi, pj, epoch, flags, stats, iter_idx, fixed_work);
         }
+}
+
+// one phase of the STEP schedule (FAST): fold of the previous phase's records + line
+// searches of this one; decide == 0: the closing fold-only launch of a batch of steps
+void SUF(vm_launch_optimize_step)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
+                                  const uint32_t *tables, int offx, int offy, int pi, int pj, uint32_t epoch,
+                                  uint32_t prev_epoch, int src, int decide, uint32_t *flags, uint32_t *stats,
+                                  int iter_idx, int fixed_work, int threads, int parts, hipStream_t s)
+{
+#if VM_EXACT
+    (void)views; (void)nbatch; (void)cap; (void)w; (void)h; (void)P; (void)tables; (void)offx; (void)offy;
+    (void)pi; (void)pj; (void)epoch; (void)prev_epoch; (void)src; (void)decide; (void)flags; (void)stats;
+    (void)iter_idx; (void)fixed_work; (void)threads; (void)parts; (void)s;
+#else
+    const int gx = (w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (h + VM_PITCH_Y - 1) / VM_PITCH_Y;
+    const int n_fold = ((w + 63) / 64) * ((h + 15) / 16);
+    hipLaunchKernelGGL(k_step_fast, dim3(n_fold + (decide ? gx * gy * parts : 0), 1, nbatch), dim3(512), 0, s, views,
+                       cap, P, tables, offx, offy, pi, pj, parts, epoch, prev_epoch, src, n_fold, flags, stats,
+                       iter_idx, fixed_work);
+#endif
 }
