@@ -491,21 +491,65 @@ __device__ __forceinline__ void nb1_load(Nb1 &nb, const VmLevelView &L, const Sr
     nb1_make<INTERIOR>(nb, L, ok, qx, qy, m, q, cr, val);
 }
 
-// energy_change (morph.cu:730-761) on 32 lanes; also returns the two lumas at the trial point
-template <bool INTERIOR>
-__device__ __forceinline__ float energy32(const VmLevelView &L, const VmKParams &P, const Nb1 &nb,
-                                          const PixelCtx &c, float dx, float dy, int sub, float &lx, float &ly)
+// Per-lane constants of the distributed bilinear taps.  The lanes of a group form 8 quads;
+// even quads sample image 0 at p - v, odd quads image 1 at p + v; lane c of a quad owns
+// corner (c & 1, c >> 1) of the 2x2 texel footprint: one texel load per lane, the quad sum
+// (2 DPP adds) is the tap, the neighbour quad (row_half_mirror) holds the other image's.
+struct TapLane {
+    float sgn;              // -1: p - v, +1: p + v
+    float wxs, wxo, wys, wyo; // corner weight = (wxs a + wxo)(wys b + wyo), a, b = fractions
+    int cx, cy;             // corner
+    int imgoff;             // element offset of the lane's image from img0 (same slab)
+    bool odd;
+};
+
+__device__ __forceinline__ TapLane tap_lane_make(const VmLevelView &L, int sub)
 {
-    const float vx = c.v.x + dx, vy = c.v.y + dy;
-    const bool odd = sub & 1;
-    // even lanes sample image 0 at p - v, odd lanes image 1 at p + v (the expressions of the
-    // generic path, so the values agree bit for bit)
-    const float sx = odd ? c.px + vx + 0.5f : c.px - vx + 0.5f;
-    const float sy = odd ? c.py + vy + 0.5f : c.py - vy + 0.5f;
-    const float t = tap(odd ? L.img1 : L.img0, L.w, L.h, L.rs, sx, sy);
-    const float o = dpp_xor1(t);
-    lx = odd ? o : t;
-    ly = odd ? t : o;
+    TapLane t;
+    t.odd = (sub >> 2) & 1;
+    t.sgn = t.odd ? 1.0f : -1.0f;
+    t.cx = sub & 1;
+    t.cy = (sub >> 1) & 1;
+    t.wxs = t.cx ? 1.0f : -1.0f;
+    t.wxo = t.cx ? 0.0f : 1.0f;
+    t.wys = t.cy ? 1.0f : -1.0f;
+    t.wyo = t.cy ? 0.0f : 1.0f;
+    t.imgoff = t.odd ? (int)(L.img1 - L.img0) : 0;
+    return t;
+}
+
+__device__ __forceinline__ int med3i(int x, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
+}
+
+// tex2D(linear, clamp) of both images at p -+ (vx, vy) (the arithmetic of tap(), the four
+// products summed in quad order)
+__device__ __forceinline__ void taps32(const VmLevelView &L, const TapLane &t, const PixelCtx &c, float vx, float vy,
+                                       float &lx, float &ly)
+{
+    const float xb = fmaf(t.sgn, vx, (float)c.px), yb = fmaf(t.sgn, vy, (float)c.py);
+    float fi = floorf(xb), fj = floorf(yb);
+    const float a = xb - fi, b = yb - fj;
+    fi = __builtin_amdgcn_fmed3f(fi, -1.0f, (float)L.w);
+    fj = __builtin_amdgcn_fmed3f(fj, -1.0f, (float)L.h);
+    const int i = med3i((int)fi + t.cx, 0, L.w - 1), j = med3i((int)fj + t.cy, 0, L.h - 1);
+    const float texel = L.img0[t.imgoff + j * L.rs + i];
+    float r = texel * (fmaf(t.wxs, a, t.wxo) * fmaf(t.wys, b, t.wyo));
+    r += dpp_xor1(r);
+    r += dpp_xor2(r);
+    const float o = dpp_half_mirror(r);
+    lx = t.odd ? o : r;
+    ly = t.odd ? r : o;
+}
+
+// sum over the window of (stored SSIM value - value with the pixel's lumas replaced by
+// lx, ly): ssim_change (morph.cu:671-728) on 32 lanes
+template <bool INTERIOR>
+__device__ __forceinline__ float change32(const VmKParams &P, const Nb1 &nb, const PixelCtx &c, float lx, float ly)
+{
     const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
     const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
     const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
@@ -523,11 +567,7 @@ __device__ __forceinline__ float energy32(const VmLevelView &L, const VmKParams 
                                     nb.X + dcross, n, P.ssim_clamp);
         acc = valid ? nb.VAL - val : 0.0f;
     }
-    const float change = group_sum(acc, 32);
-    const float dd = dx * dx + dy * dy;
-    const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
-    const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
-    return (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
+    return group_sum(acc, 32);
 }
 
 // prevent_foldover (morph.cu:872-883): lane s < 16 tests segment s & 7 of ring s >> 3
@@ -560,19 +600,27 @@ __device__ __forceinline__ float fover32(const VmLevelView &L, const PixelCtx &c
 }
 
 // optimize_pixel after the mask test, 32 lanes in lockstep; on success also the lumas at
-// the accepted point (what commit_pixel_motion would sample again)
+// the accepted point (what commit_pixel_motion would sample again).  The gradient uses the
+// energy as energy_change (morph.cu:730-761) writes it; along the search line d = g t the
+// quadratic terms collapse to t (Q2 t + Q1).
 template <bool INTERIOR>
 __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &P, const Nb1 &nb,
                                          const PixelCtx &c, int sub, float2 &step, float2 &luma VM_TS_ARG)
 {
     VM_TS(4);
+    const TapLane tl = tap_lane_make(L, sub);
     float lx, ly;
     float gx = 0, gy = 0;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         const float sgn = (k & 1) ? -1.0f : 1.0f;
-        const float e = energy32<INTERIOR>(L, P, nb, c, k < 2 ? sgn * P.eps : 0.0f, k < 2 ? 0.0f : sgn * P.eps, sub,
-                                           lx, ly) * sgn;
+        const float dx = k < 2 ? sgn * P.eps : 0.0f, dy = k < 2 ? 0.0f : sgn * P.eps;
+        taps32(L, tl, c, c.v.x + dx, c.v.y + dy, lx, ly);
+        const float change = change32<INTERIOR>(P, nb, c, lx, ly);
+        const float dd = dx * dx + dy * dy;
+        const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
+        const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
+        const float e = ((P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps) * sgn;
         if (k < 2)
             gx += e;
         else
@@ -588,52 +636,48 @@ __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &
     gy = fdiv(gy, ng);
     float cc = fmaxf(fover32(L, c, gx, gy, sub) - P.eps, 0.0f);
     VM_TS(6);
+    // E(t) = WS change(t) + t (Q2 t + Q1)
+    const float gg = gx * gx + gy * gy;
+    const float WS = P.w_ssim * L.inv_wh, WU = P.w_ui * L.inv_wh;
+    const float Q2 = (WU * c.ui_axy + P.w_tps * c.tps_axy) * gg;
+    const float Q1 = WU * (c.ui_b.x * gx + c.ui_b.y * gy) + P.w_tps * (c.tps_b.x * gx + c.tps_b.y * gy);
+#define ELINE(T_, F_, LUM_)                                                            \
+    {                                                                                  \
+        taps32(L, tl, c, fmaf(gx, (T_), c.v.x), fmaf(gy, (T_), c.v.y), lx, ly);        \
+        (F_) = fmaf(WS, change32<INTERIOR>(P, nb, c, lx, ly), (T_) * fmaf(Q2, (T_), Q1)); \
+        (LUM_) = make_float2(lx, ly);                                                  \
+    }
+    // golden_section_search, morph.cu:885-947
     const float R = 0.618033989f, C = 1.0f - R;
     float a = 0;
-    float b = a * R + cc * C, x = b * R + cc * C;
-    float fb = 0, fx = 0;
-    float2 lb = make_float2(0, 0), lq = make_float2(0, 0); // lumas at b and at x
+    float b = cc * C, x = b * R + cc * C;
+    float fb, fx;
+    float2 lb, lq; // lumas at b and at x
+    ELINE(b, fb, lb);
+    ELINE(x, fx, lq);
 #pragma unroll 1
-    for (int s = 0;; ++s) {
-        float t = s == 0 ? b : x;
-        bool lt = false;
-        if (s >= 2) {
-            if (!(cc - a > P.eps))
-                break;
-            lt = fx < fb;
-            if (lt) {
-                a = b;
-                b = x;
-                x = b * R + cc * C;
-            } else {
-                cc = x;
-                x = b * R + a * C;
-            }
-            t = x;
-        }
-        const float f = energy32<INTERIOR>(L, P, nb, c, gx * t, gy * t, sub, lx, ly);
-        const float2 lf = make_float2(lx, ly);
-        if (s == 0) {
-            fb = f;
-            lb = lf;
-        } else if (s == 1) {
-            fx = f;
-            lq = lf;
-        } else if (lt) {
-            fb = fx;
-            lb = lq;
-            fx = f;
-            lq = lf;
-        } else {
-            const float tmp = b;
-            b = x;
-            x = tmp;
-            fx = fb;
-            lq = lb;
-            fb = f;
-            lb = lf;
-        }
+    for (;;) {
+        if (!(cc - a > P.eps))
+            break;
+        const bool lt = fx < fb;
+        // lt: [a, cc] <- [b, cc], b <- x;   else: [a, cc] <- [a, x], x <- b;   one new point
+        const float p = lt ? x : b, qv = lt ? cc : a;
+        a = lt ? b : a;
+        cc = lt ? cc : x;
+        const float xn = p * R + qv * C;
+        float f;
+        float2 lf;
+        ELINE(xn, f, lf);
+        const float ob = b, ofb = fb;
+        const float2 olb = lb;
+        b = lt ? x : xn;
+        x = lt ? xn : ob;
+        fb = lt ? fx : f;
+        fx = lt ? f : ofb;
+        lb = lt ? lq : lf;
+        lq = lt ? lf : olb;
     }
+#undef ELINE
     VM_TS(7);
     const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
     if (!(fmin < 0))
@@ -731,15 +775,22 @@ __device__ __forceinline__ bool commit_own(LdsT &S, const VmLevelView &L, const 
     const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
     const int mcx = px / 5 - g.bx0, mcy = py / 5 - g.by0;
     const uint32_t bit = 1u << ((px % 5) + (py % 5) * 5);
-    if (state != 1) {
+    if (state == 2) {
         atomicAnd(&S.mask[mcy][mcx], ~bit);
         return false;
     }
     const int idx = py * L.rs + px;
     const float2 v = L.v[idx], ol = L.luma[idx], st = S.d_step[tid];
     const float2 newv = make_float2(v.x + st.x, v.y + st.y);
-    const float lx = tap(L.img0, L.w, L.h, L.rs, px - newv.x + 0.5f, py - newv.y + 0.5f);
-    const float ly = tap(L.img1, L.w, L.h, L.rs, px + newv.x + 0.5f, py + newv.y + 0.5f);
+    float lx, ly;
+    if (state == 3) { // the lean line search already sampled them
+        lx = S.d_mean[tid].x;
+        ly = S.d_mean[tid].y;
+        S.d_ok[tid] = 1;
+    } else {
+        lx = tap(L.img0, L.w, L.h, L.rs, px - newv.x + 0.5f, py - newv.y + 0.5f);
+        ly = tap(L.img1, L.w, L.h, L.rs, px + newv.x + 0.5f, py + newv.y + 0.5f);
+    }
     L.luma[idx] = make_float2(lx, ly);
     S.d_mean[tid] = make_float2(lx - ol.x, ly - ol.y);
     S.d_var[tid] = make_float2(lx * lx - ol.x * ol.x, ly * ly - ol.y * ol.y);
@@ -889,7 +940,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                         }
                         if (ok && sub == 0) {
                             S.d_step[slot] = step;
-                            S.d_ok[slot] = 1;
+                            S.d_mean[slot] = luma; // state 3: commit, lumas at the accepted point attached
+                            S.d_ok[slot] = 3;
                         }
                     }
                 } else
