@@ -283,7 +283,7 @@ def main():
                        "iters_per_level_fine_to_coarse": iters_per_level[0],
                        "pairs_in_flight_per_gpu": nctx, "pairs_per_step": B,
                        "parallelism": "independent frame pairs, %d rank(s), 1 RCCL broadcast" % world},
-            "roofline": {"bound": "hbm", "kernel": "sweep kernels (k_optimize | k_decide + k_commit)",
+            "roofline": {"bound": "hbm", "kernel": "sweep kernels (k_optimize | k_step | k_decide + k_commit)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "avg_launch_us": round(avg_launch_us, 2), "launches": launches,

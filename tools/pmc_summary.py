@@ -1,0 +1,54 @@
+"""Summarise rocprofv3 output for profiles/: per-kernel averages of a --kernel-trace --stats run and
+the HBM traffic of the sweep kernels from two --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+  python tools/pmc_summary.py <fetch_dir> <write_dir> <out_csv> <out_json> "<command profiled>"
+"""
+import csv, glob, json, os, sys
+
+SWEEP = ("k_optimize", "k_step", "k_decide", "k_commit")
+
+
+def counters(d, name):
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != name:
+                continue
+            k = r["Kernel_Name"].split("(")[1].split(")")[-1] if False else r["Kernel_Name"]
+            k = k.replace("(anonymous namespace)::", "").split("(")[0]
+            e = out.setdefault(k, [0, 0.0])
+            e[0] += 1
+            e[1] += float(r["Counter_Value"])
+    return out
+
+
+def main():
+    fd, wd, out_csv, out_json, cmd = sys.argv[1:6]
+    F, W = counters(fd, "FETCH_SIZE"), counters(wd, "WRITE_SIZE")
+    rows = []
+    tot_l = tot_f = tot_w = 0
+    for k in sorted(set(F) | set(W)):
+        nf, f = F.get(k, [0, 0.0])
+        nw, w = W.get(k, [0, 0.0])
+        n = max(nf, nw)
+        rows.append((k, n, f / max(nf, 1), w / max(nw, 1)))
+        if any(s in k for s in SWEEP):
+            tot_l += n
+            tot_f += f
+            tot_w += w
+    with open(out_csv, "w") as fo:
+        fo.write("kernel,launches,FETCH_SIZE_KB_per_launch_raw,WRITE_SIZE_KB_per_launch_raw,HBM_bytes_per_launch_corrected\n")
+        for k, n, f, w in rows:
+            fo.write("%s,%d,%.3f,%.3f,%.0f\n" % (k, n, f, w, (2 * f + w) * 1024))
+    fk, wk = tot_f / max(tot_l, 1), tot_w / max(tot_l, 1)
+    json.dump({
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `%s`; all sweep kernels (%s), %d launches" % (cmd, ", ".join(SWEEP), tot_l),
+        "fetch_size_kb_per_launch_raw": fk, "write_size_kb_per_launch_raw": wk,
+        "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
+        "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section; calibrated there for 16 B/lane streams; these kernels read 4-16 B/lane, so the read side is an upper estimate); WRITE_SIZE as reported",
+    }, open(out_json, "w"), indent=1)
+    print(open(out_json).read())
+
+
+if __name__ == "__main__":
+    main()

@@ -9,23 +9,31 @@
 // per candidate pixel an improving-mask test, a finite-difference gradient, the
 // fold-over bound, a golden-section line search and an accept-if-lower commit.
 //
-// How it is computed is CDNA4-first.  Two schedules share every device function:
+// How it is computed is CDNA4-first.  Three schedules share the device functions and
+// the state in HBM (the host may switch between them from batch to batch):
 //
 //  TILE schedule (k_optimize, one launch per pass): one workgroup of T threads
 //  owns one tile; window sums, SSIM values, tps.b and the tile's improving-mask
-//  words live in LDS for the four phases.  Per phase the candidates are compacted
-//  and each gets L = 4..32 consecutive lanes (L = largest power of two <=
-//  T/#candidates) that split the 25 window neighbours, keep their share of the
+//  words live in LDS for the four phases.  Per phase the candidates are compacted;
+//  a DENSE phase gives each L = 2..16 consecutive lanes (L = largest power of two
+//  <= T/#candidates) that split the 25 window neighbours, keep their share of the
 //  sums in registers for the whole line search and combine SSIM terms with DPP
-//  butterflies.  Tiles without a set mask bit return after one 96-word load, so a
-//  pruned level costs almost nothing -- this is the schedule of large levels.
+//  butterflies; a SPARSE phase (<= T/32 candidates) runs the LEAN line search:
+//  32 lanes per pixel, one neighbour per lane, the bilinear taps spread over
+//  quads, a branch-free golden-section loop (~105 instructions per evaluation --
+//  in this regime the instruction count of one evaluation IS the time).  Tiles
+//  without a set mask bit return after one 96-word load, so a pruned level costs
+//  almost nothing -- this is the schedule of large levels.
 //
 //  SPLIT schedule (k_decide + k_commit, two launches per phase): for levels with
-//  too few tiles to fill 256 CUs, a tile's candidates are divided over K
-//  workgroups (so every pixel gets 32 lanes and the ~21 dependent energy
-//  evaluations of a phase take ~1/6 of the time), decisions go to per-pixel
-//  records in HBM, and a second kernel folds them into the window sums.  State
-//  stays in HBM/L2 between the two (a 120x68 level is 0.6 MB).
+//  too few tiles to fill 256 CUs, a tile's candidates are divided over `parts`
+//  workgroups (every pixel gets 32 lanes), decisions go to per-pixel records in
+//  HBM, and a second kernel folds them into the window sums.  The schedule of
+//  EXACT mode on small levels and the reference the STEP schedule is tested against.
+//
+//  STEP schedule (k_step, FAST, one launch per phase): the commit of phase s-1 is
+//  folded into the launch of phase s from a second copy of the sums (ping-pong),
+//  see the comment at k_step.  Bit-identical to SPLIT.
 //
 // Commits are applied by a per-cell gather of the committed pixels' records in a
 // fixed order: deterministic, one owner per cell, no float atomics (the reference
@@ -251,11 +259,7 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
     float acc = 0;
 #pragma unroll
     for (int j = 0; j < VM_SMAX; ++j) {
-#ifdef VM_EXP_NOBRANCH
-        if (true) {
-#else
         if (j * Lf < 25) { // uniform in the workgroup
-#endif
             if (INTERIOR) {
                 // the last slot of a lane may lie past the 25th neighbour: it then holds a copy
                 // of the centre neighbour and is masked by the k < 25 test below
@@ -703,9 +707,6 @@ __device__ __forceinline__ void ctx_load(PixelCtx &c, const VmLevelView &L, cons
 
 __device__ __forceinline__ bool is_interior(const VmLevelView &L, int px, int py)
 {
-#ifdef VM_NO_INTERIOR
-    return false;
-#endif
     return px >= 4 && px < L.w - 4 && py >= 4 && py < L.h - 4;
 }
 
@@ -1378,14 +1379,15 @@ __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__
     return touched;
 }
 
-__global__ __launch_bounds__(512) void k_step_fast(const VmLevelView *__restrict__ views, int cap, VmKParams P,
+template <int T>
+__global__ __launch_bounds__(T) void k_step_fast(const VmLevelView *__restrict__ views, int cap, VmKParams P,
                                                    const uint32_t *__restrict__ tables, int offx, int offy, int pi,
                                                    int pj, int parts, uint32_t epoch, uint32_t pe, int srcbuf,
                                                    int n_fold, uint32_t *__restrict__ flags,
                                                    uint32_t *__restrict__ stats, int iter_idx, int fixed_work)
 {
     __shared__ StepLds S;
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x;
 #ifdef VM_PROF
     unsigned long long ts[16];
     for (int k = 0; k < 16; ++k) ts[k] = 0;
@@ -1421,19 +1423,20 @@ __global__ __launch_bounds__(512) void k_step_fast(const VmLevelView *__restrict
         const int nfx = (L.w + 63) / 64;
         const int x0 = ((int)blockIdx.x % nfx) * 64, y0 = ((int)blockIdx.x / nfx) * 16;
         const int bx0 = x0 - 2, by0 = y0 - 2; // staged window: 68 x 20
-        uint32_t tg[3];
+        constexpr int NTF = (68 * 20 + T - 1) / T, NCF = 1024 / T;
+        uint32_t tg[NTF];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            const int k = tid + e * 512;
+        for (int e = 0; e < NTF; ++e) {
+            const int k = tid + e * T;
             const int x = bx0 + k % 68, y = by0 + k / 68;
             tg[e] = (k < 68 * 20 && x >= 0 && x < L.w && y >= 0 && y < L.h) ? r_tag[y * L.rs + x] : 0u;
         }
-        float2 cm[2], cq[2], ctb[2];
-        float ccr[2], cval[2];
-        int cgi[2];
+        float2 cm[NCF], cq[NCF], ctb[NCF];
+        float ccr[NCF], cval[NCF];
+        int cgi[NCF];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int cell = tid + e * 512;
+        for (int e = 0; e < NCF; ++e) {
+            const int cell = tid + e * T;
             const int qx = x0 + (cell & 63), qy = y0 + (cell >> 6);
             cgi[e] = -1;
             if (qx < L.w && qy < L.h) {
@@ -1474,15 +1477,15 @@ __global__ __launch_bounds__(512) void k_step_fast(const VmLevelView *__restrict
         }
         __syncthreads(); // bits zeroed
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            const int k = tid + e * 512;
+        for (int e = 0; e < NTF; ++e) {
+            const int k = tid + e * T;
             if (tg[e] == want)
                 atomicOr(&S.bits[k / 68][(k % 68) >> 5], 1u << ((k % 68) & 31));
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int cell = tid + e * 512;
+        for (int e = 0; e < NCF; ++e) {
+            const int cell = tid + e * T;
             const int qx = x0 + (cell & 63), qy = y0 + (cell >> 6);
             const bool in = cgi[e] >= 0;
             float2 m = cm[e], q = cq[e], tb = ctb[e];
@@ -1519,10 +1522,11 @@ __global__ __launch_bounds__(512) void k_step_fast(const VmLevelView *__restrict
         return;
     const MaskGeom g = mask_geom(L, ox, oy);
     const int bx0 = ox - 4, by0 = oy - 4; // staged window: 72 x 24
-    uint32_t tg[4];
+    constexpr int NTD = (VM_STEP_BW * VM_STEP_BH + T - 1) / T;
+    uint32_t tg[NTD];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int k = tid + e * 512;
+    for (int e = 0; e < NTD; ++e) {
+        const int k = tid + e * T;
         const int x = bx0 + k % VM_STEP_BW, y = by0 + k / VM_STEP_BW;
         tg[e] = (k < VM_STEP_BW * VM_STEP_BH && x >= 0 && x < L.w && y >= 0 && y < L.h) ? r_tag[y * L.rs + x] : 0u;
     }
@@ -1538,8 +1542,8 @@ __global__ __launch_bounds__(512) void k_step_fast(const VmLevelView *__restrict
     // pixel sets its bit, a hit that did not move clears it.  (Mask bits further than 2 pixels
     // from the tile stay unfolded here: mask_hit never looks at them.)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int k = tid + e * 512;
+    for (int e = 0; e < NTD; ++e) {
+        const int k = tid + e * T;
         const uint32_t t = tg[e];
         if ((t >> 2) == pe && (t & 3u) != 0u) {
             const int sx = k % VM_STEP_BW, sy = k / VM_STEP_BW;
@@ -1704,8 +1708,12 @@ void SUF(vm_launch_optimize_step)(const VmLevelView *views, int nbatch, int cap,
 #else
     const int gx = (w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (h + VM_PITCH_Y - 1) / VM_PITCH_Y;
     const int n_fold = ((w + 63) / 64) * ((h + 15) / 16);
-    hipLaunchKernelGGL(k_step_fast, dim3(n_fold + (decide ? gx * gy * parts : 0), 1, nbatch), dim3(512), 0, s, views,
-                       cap, P, tables, offx, offy, pi, pj, parts, epoch, prev_epoch, src, n_fold, flags, stats,
-                       iter_idx, fixed_work);
+    const dim3 grid(n_fold + (decide ? gx * gy * parts : 0), 1, nbatch);
+    if (threads <= 256)
+        hipLaunchKernelGGL(k_step_fast<256>, grid, dim3(256), 0, s, views, cap, P, tables, offx, offy, pi, pj, parts,
+                           epoch, prev_epoch, src, n_fold, flags, stats, iter_idx, fixed_work);
+    else
+        hipLaunchKernelGGL(k_step_fast<512>, grid, dim3(512), 0, s, views, cap, P, tables, offx, offy, pi, pj, parts,
+                           epoch, prev_epoch, src, n_fold, flags, stats, iter_idx, fixed_work);
 #endif
 }
