@@ -12,13 +12,16 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 _ODIR = os.path.join(_ROOT, "oracle")
-_SO = os.path.join(_ODIR, "_build", "libvm_oracle.so")
+# VM_ORACLE_SO: an alternative build of the oracle (e.g. with -fsanitize=address,undefined)
+_SO = os.environ.get("VM_ORACLE_SO") or os.path.join(_ODIR, "_build", "libvm_oracle.so")
 
 
 def build(force=False):
     srcs = [os.path.join(_ODIR, f) for f in os.listdir(_ODIR) if f.endswith((".c", ".h"))]
     stale = (not os.path.exists(_SO)) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if "VM_ORACLE_SO" in os.environ:
+        return _SO
     if force or stale:
         subprocess.check_call(["make", "-C", _ODIR], stdout=subprocess.DEVNULL)
     return _SO

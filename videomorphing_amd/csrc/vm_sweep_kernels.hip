@@ -63,6 +63,7 @@ struct TileLds {
     int d_ok[256];           // 0: untouched, 1: commit, 2: mask hit that did not move
     int list[256];           // compacted slots
     int wave_cnt[4];
+    uint32_t cbits[8];       // commits of the phase: bit tx of word ty (slot = ty*32 + tx)
     float tps[625];
     uint32_t imp[225];
     uint32_t mask[6][16];    // improving-mask words covering the tile +-1 block
@@ -780,18 +781,16 @@ __device__ __forceinline__ bool commit_own(LdsT &S, const VmLevelView &L, const 
         atomicAnd(&S.mask[mcy][mcx], ~bit);
         return false;
     }
+    if (state == 3) { // the lean line search wrote the pixel's own state and its record already
+        S.d_ok[tid] = 1;
+        atomicOr(&S.mask[mcy][mcx], bit);
+        return true;
+    }
     const int idx = py * L.rs + px;
     const float2 v = L.v[idx], ol = L.luma[idx], st = S.d_step[tid];
     const float2 newv = make_float2(v.x + st.x, v.y + st.y);
-    float lx, ly;
-    if (state == 3) { // the lean line search already sampled them
-        lx = S.d_mean[tid].x;
-        ly = S.d_mean[tid].y;
-        S.d_ok[tid] = 1;
-    } else {
-        lx = tap(L.img0, L.w, L.h, L.rs, px - newv.x + 0.5f, py - newv.y + 0.5f);
-        ly = tap(L.img1, L.w, L.h, L.rs, px + newv.x + 0.5f, py + newv.y + 0.5f);
-    }
+    const float lx = tap(L.img0, L.w, L.h, L.rs, px - newv.x + 0.5f, py - newv.y + 0.5f);
+    const float ly = tap(L.img1, L.w, L.h, L.rs, px + newv.x + 0.5f, py + newv.y + 0.5f);
     L.luma[idx] = make_float2(lx, ly);
     S.d_mean[tid] = make_float2(lx - ol.x, ly - ol.y);
     S.d_var[tid] = make_float2(lx * lx - ol.x * ol.x, ly * ly - ol.y * ol.y);
@@ -846,6 +845,14 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                                                         uint32_t *__restrict__ stats, int iter_idx, int fixed_work)
 {
     __shared__ TileLds S;
+#ifdef VM_PROF
+    unsigned long long tso[16];
+    for (int k = 0; k < 16; ++k) tso[k] = 0;
+    tso[0] = wall_clock64();
+#define VM_TSO(i) tso[i] = wall_clock64()
+#else
+#define VM_TSO(i)
+#endif
     const int tid = threadIdx.x, T = blockDim.x;
     // blockIdx.z = frame pair of the batch: same geometry, own state, own flags
     const VmLevelView L = views[blockIdx.z];
@@ -880,20 +887,43 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
         S.imp[k] = tables[VM_TAB_IMP + k];
 
     // --- LoadSSIM (morph.cu:1214-1234) + the tile's tps.b ---
-    for (int c = tid; c < VM_NCELL; c += T) {
-        int gx = ox - 2 + c % VM_HALO_W, gy = oy - 2 + c / VM_HALO_W;
-        bool in = gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
-        int gi = gy * L.rs + gx;
-        S.mean[c] = in ? L.mean[gi] : make_float2(0, 0);
-        S.var[c] = in ? L.var[gi] : make_float2(0, 0);
-        S.tpsb[c] = in ? L.tps_b[gi] : make_float2(0, 0);
-        S.cross[c] = in ? L.cross[gi] : 0.0f;
-        S.value[c] = in ? L.value[gi] : 0.0f;
+    // (three cells per thread in flight: one HBM/L2 round trip for a 512-thread workgroup)
+    for (int c0 = tid; c0 < VM_NCELL; c0 += 3 * T) {
+        float2 m[3], q[3], tb[3];
+        float cr[3], val[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int c = c0 + e * T;
+            const int gx = ox - 2 + c % VM_HALO_W, gy = oy - 2 + c / VM_HALO_W;
+            const bool in = c < VM_NCELL && gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
+            const int gi = in ? gy * L.rs + gx : 0;
+            m[e] = L.mean[gi];
+            q[e] = L.var[gi];
+            tb[e] = L.tps_b[gi];
+            cr[e] = L.cross[gi];
+            val[e] = L.value[gi];
+            if (!in) {
+                m[e] = q[e] = tb[e] = make_float2(0, 0);
+                cr[e] = val[e] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int c = c0 + e * T;
+            if (c < VM_NCELL) {
+                S.mean[c] = m[e];
+                S.var[c] = q[e];
+                S.tpsb[c] = tb[e];
+                S.cross[c] = cr[e];
+                S.value[c] = val[e];
+            }
+        }
     }
     __syncthreads();
 
     bool improving = false;
     uint32_t st_cand = 0, st_commit = 0;
+    VM_TSO(1);
 
     for (int pi = 0; pi < 2; ++pi) {
         for (int pj = 0; pj < 2; ++pj) {
@@ -909,6 +939,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                 S.d_ok[tid] = state;
             }
             const int n_act = compact256(cand, tid, S.list, S.wave_cnt);
+            VM_TSO(2 + 3 * (pi * 2 + pj));
 
             if (n_act > 0) {
                 st_cand += n_act;
@@ -940,8 +971,16 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                             ok = decide32<false>(L, P, nb, c, sub, step, luma VM_TS_PASS);
                         }
                         if (ok && sub == 0) {
+                            // commit_pixel_motion (morph.cu:990-1026), the pixel's own part, at once:
+                            // nothing else of this phase reads its v, luma or ui.b (state 3)
+                            const float2 ol = c.old_luma;
                             S.d_step[slot] = step;
-                            S.d_mean[slot] = luma; // state 3: commit, lumas at the accepted point attached
+                            S.d_mean[slot] = make_float2(luma.x - ol.x, luma.y - ol.y);
+                            S.d_var[slot] = make_float2(luma.x * luma.x - ol.x * ol.x, luma.y * luma.y - ol.y * ol.y);
+                            S.d_cross[slot] = luma.x * luma.y - ol.x * ol.y;
+                            L.luma[c.idx] = luma;
+                            L.ui_b[c.idx] = make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy);
+                            L.v[c.idx] = make_float2(c.v.x + step.x, c.v.y + step.y);
                             S.d_ok[slot] = 3;
                         }
                     }
@@ -981,9 +1020,17 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                 }
             }
             __syncthreads();
+            VM_TSO(3 + 3 * (pi * 2 + pj));
 
             // ---- 3. commits ----
             const bool ok = tid < 256 && commit_own(S, L, g, tid, ox, oy, pi, pj);
+            {
+                const unsigned long long cb = __ballot(ok);
+                if (tid < 256 && (tid & 63) == 0) {
+                    S.cbits[(tid >> 6) * 2] = (uint32_t)cb;
+                    S.cbits[(tid >> 6) * 2 + 1] = (uint32_t)(cb >> 32);
+                }
+            }
             const int ncommit = __syncthreads_count(ok);
             if (ncommit) {
                 improving = true;
@@ -993,6 +1040,17 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                     const int qx = ox + rx, qy = oy + ry;
                     if (qx < 0 || qx >= L.w || qy < 0 || qy >= L.h)
                         continue;
+                    {
+                        // any committed pixel within +-2?  (three words of the commit bitmap)
+                        const int sy0 = max(ry - 2, 0) >> 1, sy1 = min(ry + 2, VM_TILE_H - 1) >> 1;
+                        const int sx0 = max(rx - 2, 0) >> 1, sx1 = min(rx + 2, VM_TILE_W - 1) >> 1;
+                        const uint32_t colmask = (0xFFFFFFFFu >> (31 - (sx1 - sx0))) << sx0;
+                        uint32_t any = 0;
+                        for (int sy = sy0; sy <= sy1; ++sy)
+                            any |= S.cbits[sy] & colmask;
+                        if (!any)
+                            continue;
+                    }
                     float2 m = S.mean[cell], q = S.var[cell], tb = S.tpsb[cell];
                     float cr = S.cross[cell];
                     if (gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb)) {
@@ -1006,6 +1064,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                 }
             }
             __syncthreads();
+            VM_TSO(4 + 3 * (pi * 2 + pj));
         }
     }
 
@@ -1029,6 +1088,13 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
         if (mx >= 1 && mx <= g.nbx - 2 && my >= 1 && my <= g.nby - 2)
             L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)] = S.mask[my][mx];
     }
+#ifdef VM_PROF
+    VM_TSO(14);
+    if (tid == 0 && st_cand > 0) {
+        tso[15] = st_cand;
+        for (int k = 0; k < 16; ++k) vm_prof_buf[((blockIdx.x + blockIdx.y * gridDim.x) % 512) * 16 + k] = tso[k];
+    }
+#endif
     if (tid == 0) {
         if (improving)
             atomicOr(&flags[iter_idx], 1u);
