@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -132,6 +133,8 @@ extern "C" void vm_ctx_destroy(vm_ctx *c)
     hipHostFree(c->stats_host);
     hipFree(c->cons_dev);
     hipFree(c->views);
+    hipFree(c->iter_dev);
+    for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
@@ -493,6 +496,57 @@ extern "C" int vm_init_level(vm_pyr *p, int lvl, int w0, int h0, const vm_constr
     return VM_OK;
 }
 
+// A hipGraph of VM_GRAPH_ITERS TILE-schedule iterations (4 pass launches + the counter bump each)
+// for the given geometry, instantiated once per context and replayed: pruned sweeps last 2-3 us
+// on the GPU, less than the 4-6 us the host needs per eager launch, so the sweep loop of a
+// converged or nearly converged level is launch-bound without it.  The iteration number is not
+// a kernel argument there but a device counter.  Returns nullptr when graphs are unavailable
+// (VM_NO_GRAPH set, or capture/instantiation failed once): the caller launches eagerly.
+#define VM_GRAPH_ITERS 8
+static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, int cap, int fixed_work, int threads,
+                                  const VmKParams &P)
+{
+    if (c->use_graphs < 0) c->use_graphs = getenv("VM_NO_GRAPH") ? 0 : 1;
+    if (!c->use_graphs) return nullptr;
+    for (auto &g : c->graphs)
+        if (g.exact == exact && g.n == n && g.w == w && g.h == h && g.cap == cap && g.fixed_work == fixed_work &&
+            g.threads == threads && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
+            memcmp(&g.kp, &c->kp, sizeof(c->kp)) == 0)
+            return g.exec;
+    if (!c->iter_dev && hipMalloc((void **)&c->iter_dev, sizeof(int)) != hipSuccess) {
+        c->use_graphs = 0;
+        return nullptr;
+    }
+    const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}};
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        for (int it = 0; it < VM_GRAPH_ITERS; ++it) {
+            for (int k = 0; k < 4; ++k) {
+                if (exact) vm_launch_optimize_exact(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, 0, fixed_work, threads, c->iter_dev, c->stream);
+                else vm_launch_optimize_fast(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, 0, fixed_work, threads, c->iter_dev, c->stream);
+            }
+            if (exact) vm_launch_next_iter_exact(c->iter_dev, 0, 0, c->stream);
+            else vm_launch_next_iter_fast(c->iter_dev, 0, 0, c->stream);
+        }
+        ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && graph;
+    }
+    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    if (!ok) {
+        c->use_graphs = 0;
+        return nullptr;
+    }
+    if (c->graphs.size() >= 64) { // plenty for a pyramid's levels; start over rather than grow
+        for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
+        c->graphs.clear();
+    }
+    c->graphs.push_back({exact, n, w, h, cap, fixed_work, threads, c->views, c->flags, c->stats, c->kp, exec});
+    return exec;
+}
+
 // Morph::optimize_level for a BATCH of frame pairs of identical geometry on one context:
 // every sweep launch covers the same level of all pairs (grid.z = pair), so a level with
 // too few tiles to occupy 256 CUs is filled by the batch instead -- the natural parallelism
@@ -590,7 +644,19 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
         VM_HIP(hipEventRecord(c->ev0, s));
         uint32_t last_epoch = 0;
         int sb = 0; // step index inside this batch: parity = which copy of the sums is read
-        for (int it = done; it < done + nb; ++it)
+        int it0 = done;
+        if (!split && nb >= VM_GRAPH_ITERS) {
+            // TILE batch: whole groups of VM_GRAPH_ITERS iterations are graph replays
+            if (hipGraphExec_t ge = sweep_graph(c, exact, n, l0.w, l0.h, cap, fixed_work, threads, P)) {
+                if (exact) vm_launch_next_iter_exact(c->iter_dev, 1, done, s);
+                else vm_launch_next_iter_fast(c->iter_dev, 1, done, s);
+                for (; it0 + VM_GRAPH_ITERS <= done + nb; it0 += VM_GRAPH_ITERS) {
+                    VM_HIP(hipGraphLaunch(ge, s));
+                    launches += 4 * VM_GRAPH_ITERS;
+                }
+            }
+        }
+        for (int it = it0; it < done + nb; ++it)
             for (int k = 0; k < 4; ++k) {
                 if (step) {
                     for (int ph = 0; ph < 4; ++ph, ++sb) {
@@ -606,8 +672,8 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
                     else vm_launch_optimize_split_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
                     launches += 8;
                 } else {
-                    if (exact) vm_launch_optimize_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
-                    else vm_launch_optimize_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, s);
+                    if (exact) vm_launch_optimize_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, s);
+                    else vm_launch_optimize_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, s);
                     ++launches;
                 }
             }

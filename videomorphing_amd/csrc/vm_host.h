@@ -36,6 +36,17 @@ struct vm_ctx {
     int views_cap = 0;
     vm_constraint *cons_dev = nullptr;
     int cons_cap = 0;
+    // hipGraph replay of launch-bound TILE sweeps (vm_api.cpp): 8 iterations per graph
+    int *iter_dev = nullptr;         // device iteration counter read by the replayed kernels
+    struct SweepGraph {
+        bool exact;
+        int n, w, h, cap, fixed_work, threads;
+        const void *views, *flags, *stats;
+        vm_kern_params kp;
+        hipGraphExec_t exec;
+    };
+    std::vector<SweepGraph> graphs;
+    int use_graphs = -1;             // -1: not decided yet, 0: off (VM_NO_GRAPH or a failed capture), 1: on
 };
 
 struct vm_level {

@@ -842,9 +842,14 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
 __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
                                                         VmKParams P, const uint32_t *__restrict__ tables,
                                                         int offx, int offy, uint32_t *__restrict__ flags,
-                                                        uint32_t *__restrict__ stats, int iter_idx, int fixed_work)
+                                                        uint32_t *__restrict__ stats, int iter_idx, int fixed_work,
+                                                        const int *__restrict__ iter_dev)
 {
     __shared__ TileLds S;
+    // replayed from a hipGraph the launch cannot carry the iteration number: it is read from
+    // a device counter that k_next_iter advances after the four passes
+    if (iter_dev)
+        iter_idx = *iter_dev;
 #ifdef VM_PROF
     unsigned long long tso[16];
     for (int k = 0; k < 16; ++k) tso[k] = 0;
@@ -1721,6 +1726,12 @@ __global__ __launch_bounds__(T) void k_step_fast(const VmLevelView *__restrict__
 }
 #endif
 
+__global__ void SUF(k_next_iter)(int *iter_dev, int set, int value)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        *iter_dev = set ? value : *iter_dev + 1;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -1736,11 +1747,17 @@ extern "C" int vm_dbg_prof_read(void *dst, size_t bytes)
 // flags/stats: nbatch rows of `cap` iterations
 void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
                              const uint32_t *tables, int offx, int offy, uint32_t *flags, uint32_t *stats,
-                             int iter_idx, int fixed_work, int threads, hipStream_t s)
+                             int iter_idx, int fixed_work, int threads, const int *iter_dev, hipStream_t s)
 {
     dim3 b(threads), g((w + VM_PITCH_X - 1) / VM_PITCH_X, (h + VM_PITCH_Y - 1) / VM_PITCH_Y, nbatch);
     hipLaunchKernelGGL(SUF(k_optimize), g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats, iter_idx,
-                       fixed_work);
+                       fixed_work, iter_dev);
+}
+
+// the device iteration counter of graph-replayed sweeps: set it, or advance it by one
+void SUF(vm_launch_next_iter)(int *iter_dev, int set, int value, hipStream_t s)
+{
+    hipLaunchKernelGGL(SUF(k_next_iter), dim3(1), dim3(64), 0, s, iter_dev, set, value);
 }
 
 // one pass (tile offset) in the SPLIT schedule: 4 phases x (decide, commit)
