@@ -27,6 +27,7 @@ UNITS = [
     ("vm_sweep_kernels.hip", "vm_sweep_kernels_fast.o", ["-DVM_EXACT=0", "-ffp-contract=fast"]),
     ("vm_render.hip", "vm_render.o", ["-ffp-contract=off"]),
     ("vm_poisson.hip", "vm_poisson.o", ["-ffp-contract=off"]),
+    ("vm_mg.hip", "vm_mg.o", ["-ffp-contract=fast"]),
     ("vm_pyramid.hip", "vm_pyramid.o", ["-ffp-contract=off"]),
     ("vm_pyramid_api.cpp", "vm_pyramid_api.o", ["-x", "hip"]),
     ("vm_api.cpp", "vm_api.o", ["-x", "hip"]),

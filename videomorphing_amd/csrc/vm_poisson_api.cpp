@@ -2,10 +2,15 @@
 // (CPoissonExt::run body for one side, Algorithm/PoissonExt.cpp:19-41) and the
 // RCCL broadcast helper.
 #include "vm_host.h"
+#include "vm_mg.h"
 #include "vm_poisson.h"
 
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <dlfcn.h>
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -66,17 +71,121 @@ int run_cg(vm_ctx *c, Grid &g, VmCgScalars *sc, float tol, int max_it, int *iter
     *rel = worst;
     return VM_OK;
 }
+// ---------------------------------------------------------------------------
+// multigrid-preconditioned CG (vm_mg.hip)
+
+struct MgHierarchy {
+    std::vector<VmMgLevel> lv;
+    float4 *X = nullptr, *B = nullptr, *R = nullptr, *P = nullptr, *Q = nullptr;
+    VmPcgScalars *sc = nullptr;
+};
+
+// grid sizes: halve (rounding up) until the coarsest grid fits one workgroup
+std::vector<std::pair<int, int>> mg_sizes(int w, int h)
+{
+    std::vector<std::pair<int, int>> v{{w, h}};
+    while ((size_t)v.back().first * v.back().second > 1024)
+        v.push_back({(v.back().first + 1) / 2, (v.back().second + 1) / 2});
+    return v;
+}
+
+size_t mg_bytes(int w, int h)
+{
+    size_t need = al256(sizeof(VmPcgScalars));
+    const auto sz = mg_sizes(w, h);
+    for (size_t l = 0; l < sz.size(); ++l) {
+        const size_t N = (size_t)sz[l].first * sz[l].second;
+        need += 3 * al256(N * 4) + 3 * al256(N * 16); // we, ws, dg + x, b, t
+    }
+    need += 4 * al256((size_t)w * h * 16);             // X, B, P, Q  (R = level 0's b)
+    return need;
+}
+
+char *mg_carve(MgHierarchy &H, int w, int h, char *b)
+{
+    H.sc = (VmPcgScalars *)b; b += al256(sizeof(VmPcgScalars));
+    const auto sz = mg_sizes(w, h);
+    H.lv.resize(sz.size());
+    for (size_t l = 0; l < sz.size(); ++l) {
+        VmMgLevel &L = H.lv[l];
+        L.w = sz[l].first; L.h = sz[l].second;
+        const size_t N = (size_t)L.w * L.h;
+        L.we = (float *)b; b += al256(N * 4);
+        L.ws = (float *)b; b += al256(N * 4);
+        L.dg = (float *)b; b += al256(N * 4);
+        L.x = (float4 *)b; b += al256(N * 16);
+        L.b = (float4 *)b; b += al256(N * 16);
+        L.t = (float4 *)b; b += al256(N * 16);
+    }
+    const size_t N0 = (size_t)w * h;
+    H.X = (float4 *)b; b += al256(N0 * 16);
+    H.B = (float4 *)b; b += al256(N0 * 16);
+    H.P = (float4 *)b; b += al256(N0 * 16);
+    H.Q = (float4 *)b; b += al256(N0 * 16);
+    H.R = H.lv[0].b;
+    return b;
+}
+
+const float kMgOmega = 0.8f;
+const int kMgCoarseSweeps = 40;
+
+// z = M^-1 r: one V(1,1) cycle; level l's right-hand side is lv[l].b, the result ends in lv[l].x
+void mg_vcycle(MgHierarchy &H, size_t l, hipStream_t s)
+{
+    VmMgLevel &F = H.lv[l];
+    if (l + 1 == H.lv.size()) {
+        vm_mg_launch_coarsest(F, kMgOmega, kMgCoarseSweeps, s);
+        return;
+    }
+    vm_mg_launch_jacobi0(F, kMgOmega, s);
+    vm_mg_launch_resid_restrict(F, H.lv[l + 1], s);
+    mg_vcycle(H, l + 1, s);
+    vm_mg_launch_prolong_smooth(F, H.lv[l + 1], kMgOmega, s);
+    std::swap(F.x, F.t);
+}
+
+// PCG from the guess in H.X until the relative residual of every channel is <= tol.
+// The hierarchy's operators (lv[*].we/ws/dg) and H.B must be set.
+int mg_pcg(vm_ctx *c, MgHierarchy &H, float tol, int max_it, int *iters, double *rel)
+{
+    hipStream_t s = c->stream;
+    VmMgLevel &L0 = H.lv[0];
+    VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
+    vm_mg_launch_pcg_init(L0, H.B, H.X, H.R, H.sc, s);
+    VmPcgScalars h;
+    int it = 0;
+    double worst = 0;
+    const int check = 4;
+    while (true) {
+        VM_HIP(hipMemcpyAsync(&h, H.sc, sizeof(h), hipMemcpyDeviceToHost, s));
+        VM_HIP(hipStreamSynchronize(s));
+        worst = 0;
+        for (int k = 0; k < 3; ++k)
+            if (h.bb[k] > 0) worst = std::max(worst, std::sqrt(h.rr[k] / h.bb[k]));
+        if (!(worst == worst)) return vm_fail(VM_E_NUMERIC, "multigrid PCG broke down (NaN)");
+        if (worst <= tol || it >= max_it) break;
+        const int nb = std::min(check, max_it - it);
+        for (int k = 0; k < nb; ++k, ++it) {
+            mg_vcycle(H, 0, s);                                    // z = M^-1 r  (in L0.x)
+            vm_mg_launch_pcg_dot(L0, H.R, L0.x, H.sc, s);          // rz_new = r.z
+            vm_mg_launch_pcg_dir(L0, H.P, L0.x, H.sc, it == 0, s); // p = z + beta p
+            vm_mg_launch_pcg_spmv(L0, H.P, H.Q, H.sc, s);          // q = A p
+            vm_mg_launch_pcg_update(L0, H.X, H.R, H.P, H.Q, H.sc, s);
+        }
+        VM_HIP(hipGetLastError());
+    }
+    *iters = it;
+    *rel = worst;
+    return VM_OK;
+}
 } // namespace
 
-extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, int *iters,
-                                 float *rel_res, float *elapsed_ms)
+// Jacobi-PCG with nested iteration over 4x / 16x coarser canvases: the round-1 solver, kept
+// for A/B measurements (VM_POISSON_SOLVER=jacobi)
+static int poisson_solve_nested(vm_frame *f, int side, float tol, int max_it, int *total_it, double *rel_out)
 {
-    if (!f || (side != 1 && side != 2) || !(tol > 0) || max_it < 1)
-        return vm_fail(VM_E_INVALID, "vm_poisson_extend: bad argument");
     vm_ctx *c = f->ctx;
-    std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipStream_t s = c->stream;
-    // grids: the canvas and 4x / 16x coarser copies while they stay >= 64 pixels wide
     Grid g[3];
     int ng = 1;
     g[0].cw = f->cw; g[0].ch = f->ch;
@@ -101,8 +210,6 @@ extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, i
     g[0].ext = f->ext[side - 1];
     const uchar4 *other = f->crop[side == 1 ? 1 : 0]; // PoissonExt.cpp:54-57
     const int sign = side == 1 ? 1 : -1;
-
-    VM_HIP(hipEventRecord(c->ev0, s));
     vm_poisson_launch_prepare(g[0].ext, g[0].type, other, f->v, f->w, f->h, f->rs, f->ex, sign, s);
     for (int k = 1; k < ng; ++k)
         vm_poisson_launch_coarsen(g[k - 1].ext, g[k - 1].type, g[k].ext, g[k].type, g[k - 1].cw, g[k - 1].ch,
@@ -110,7 +217,7 @@ extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, i
     VM_HIP(hipGetLastError());
     // nested iteration, coarsest grid first; the coarse solves only feed initial guesses,
     // the finest grid is the reference's system and is solved to `tol`
-    int total_it = 0, it = 0;
+    int it = 0;
     double rel = 0;
     for (int k = ng - 1; k >= 0; --k) {
         vm_poisson_launch_setup(g[k].ext, g[k].type, g[k].B, g[k].X, g[k].cw, g[k].ch, s);
@@ -119,9 +226,62 @@ extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, i
                                       g[k + 1].cw, g[k + 1].ch, s);
         int rc = run_cg(c, g[k], sc, k == 0 ? tol : std::max(tol, 1e-4f), k == 0 ? max_it : 4000, &it, &rel);
         if (rc != VM_OK) return rc;
-        if (k == 0) total_it = it;
+        if (k == 0) *total_it = it;
     }
     vm_poisson_launch_paste(g[0].ext, g[0].type, g[0].X, g[0].cw, g[0].ch, s);
+    *rel_out = rel;
+    return VM_OK;
+}
+
+// multigrid-preconditioned CG on the reference's system (the default)
+static int poisson_solve_mg(vm_frame *f, int side, float tol, int max_it, int *total_it, double *rel_out)
+{
+    vm_ctx *c = f->ctx;
+    hipStream_t s = c->stream;
+    const size_t N = (size_t)f->cw * f->ch;
+    const size_t need = al256(N) + mg_bytes(f->cw, f->ch);
+    if (f->pws_bytes < need) {
+        hipFree(f->pws);
+        f->pws = nullptr;
+        f->pws_bytes = 0;
+        VM_HIP(hipMalloc(&f->pws, need));
+        f->pws_bytes = need;
+    }
+    char *b = (char *)f->pws;
+    uint8_t *type = (uint8_t *)b;
+    b += al256(N);
+    MgHierarchy H;
+    mg_carve(H, f->cw, f->ch, b);
+    uchar4 *ext = f->ext[side - 1];
+    const uchar4 *other = f->crop[side == 1 ? 1 : 0]; // PoissonExt.cpp:54-57
+    const int sign = side == 1 ? 1 : -1;
+    vm_poisson_launch_prepare(ext, type, other, f->v, f->w, f->h, f->rs, f->ex, sign, s);
+    vm_poisson_launch_setup(ext, type, H.B, H.X, f->cw, f->ch, s); // right-hand side + initial guess
+    vm_mg_launch_level0_type(type, H.lv[0], s);
+    for (size_t l = 1; l < H.lv.size(); ++l)
+        vm_mg_launch_coarsen(H.lv[l - 1], H.lv[l], s);
+    VM_HIP(hipGetLastError());
+    int rc = mg_pcg(c, H, tol, max_it, total_it, rel_out);
+    if (rc != VM_OK) return rc;
+    vm_poisson_launch_paste(ext, type, H.X, f->cw, f->ch, s);
+    return VM_OK;
+}
+
+extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, int *iters,
+                                 float *rel_res, float *elapsed_ms)
+{
+    if (!f || (side != 1 && side != 2) || !(tol > 0) || max_it < 1)
+        return vm_fail(VM_E_INVALID, "vm_poisson_extend: bad argument");
+    vm_ctx *c = f->ctx;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    hipStream_t s = c->stream;
+    static const bool jacobi = getenv("VM_POISSON_SOLVER") && !strcmp(getenv("VM_POISSON_SOLVER"), "jacobi");
+    VM_HIP(hipEventRecord(c->ev0, s));
+    int total_it = 0;
+    double rel = 0;
+    int rc = jacobi ? poisson_solve_nested(f, side, tol, max_it, &total_it, &rel)
+                    : poisson_solve_mg(f, side, tol, max_it, &total_it, &rel);
+    if (rc != VM_OK) return rc;
     VM_HIP(hipGetLastError());
     VM_HIP(hipEventRecord(c->ev1, s));
     VM_HIP(hipEventSynchronize(c->ev1));
