@@ -250,6 +250,10 @@ def main():
             r1, r2 = fr.poisson_extend(1, tol=tol), fr.poisson_extend(2, tol=tol)
             pe["tol_%g" % tol] = {"ms_per_frame": round(r1[2] + r2[2], 1), "cg_iterations": [r1[0], r2[0]]}
         extras["poisson_extend_1080p_ex%d" % ex] = pe
+        # quadratic motion path of that frame (QuadraticPath.cpp), SURVEY 8(f) rank 4
+        fr.set_v_from_level(p, 1)
+        qp = fr.quadratic_path(tol=1e-5)
+        extras["quadratic_path_1080p"] = {"ms_per_frame": round(qp[2], 1), "pcg_iterations": qp[0], "tol": 1e-5}
         fr.close()
 
     cpu = None

@@ -201,9 +201,19 @@ int  vm_render_halfway_dev(vm_frame *f, float color_fa, float geo_fa, int color_
                            float *elapsed_ms);
 /* CPoissonExt::prepare + poissonExtend for one side (1 or 2) of the frame,
  * Algorithm/PoissonExt.cpp:49-362, on the device-resident canvases: matrix-free
- * preconditioned CG instead of MKL DSS.  iters/rel_res may be NULL. */
+ * multigrid-preconditioned CG instead of MKL DSS.  iters/rel_res may be NULL. */
 int  vm_poisson_extend(vm_frame *f, int side, float tol, int max_it,
                        int *iters, float *rel_res, float *elapsed_ms);
+/* CQuadraticPath::optimize for one frame, Algorithm/QuadraticPath.cpp:24-223
+ * (QuadraticPath.h:14-24): from the frame's halfway field v the per-pixel optimal
+ * Jacobian blend and the Neumann Poisson solve for the quadratic motion path u,
+ * which stays in the frame where vm_render_halfway reads it (the reference's
+ * `_qpath`).  Multigrid-preconditioned CG to the relative residual `tol` instead
+ * of 10 001 plain CG iterations; the zero-mean solution.  iters/rel_res may be NULL. */
+int  vm_frame_quadratic_path(vm_frame *f, float tol, int max_it,
+                             int *iters, float *rel_res, float *elapsed_ms);
+/* the frame's quadratic path (Pyramid::_qpath, Pyramid.h:42), tight (h, w, 2) floats */
+int  vm_frame_download_qpath(vm_frame *f, float *u_xy);
 
 /* ---- multi-GPU ----------------------------------------------------------- */
 /* The shared parameter block every rank needs (KernParameters + iteration

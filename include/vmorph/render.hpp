@@ -43,6 +43,19 @@ public:
         check(vm_poisson_extend(f_, side, tol, max_it, &it, nullptr, nullptr));
         return it;
     }
+    // CQuadraticPath::optimize for this frame (QuadraticPath.cpp:24-223): u stays in the frame
+    int quadratic_path(float tol = 1e-5f, int max_it = 1000)
+    {
+        int it = 0;
+        check(vm_frame_quadratic_path(f_, tol, max_it, &it, nullptr, nullptr));
+        return it;
+    }
+    std::vector<float> download_qpath()
+    {
+        std::vector<float> out((size_t)w_ * h_ * 2);
+        check(vm_frame_download_qpath(f_, out.data()));
+        return out;
+    }
     std::vector<unsigned char> download_ext(int side)
     {
         std::vector<unsigned char> out((size_t)(w_ + 2 * ex_) * (h_ + 2 * ex_) * 4);

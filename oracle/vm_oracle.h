@@ -159,4 +159,9 @@ int  vmo_get_threads(void);
 #ifdef __cplusplus
 }
 #endif
+/* quadratic motion path of one frame (vm_oracle_qpath.c), QuadraticPath.cpp:24-223:
+ * v, u_out: rows*cols*2 floats; jopt_out (optional): rows*cols*4 */
+int vmo_quadratic_path(const float *v, int cols, int rows, double tol, int max_it, float *u_out,
+                       float *jopt_out, double *rel_res);
+
 #endif

@@ -110,6 +110,9 @@ def lib():
     L.vmo_dbg_foldover.restype = C.c_float
     L.vmo_dbg_energy_change.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_float, C.c_float]
     L.vmo_dbg_energy_change.restype = C.c_float
+    L.vmo_quadratic_path.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.POINTER(C.c_double)]
+    L.vmo_quadratic_path.restype = C.c_int
     L.vmo_luma_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.vmo_luma_pyramid.restype = None
     L.vmo_set_threads.argtypes = [C.c_int]
@@ -270,6 +273,17 @@ def poisson_extend(ext_rgba, w, h, ex, other_rgba, v, side, tol=1e-8, max_it=200
     it = lib().vmo_poisson_extend(ext.ctypes.data, w, h, ex, other.ctypes.data,
                                   v.ctypes.data, side, tol, max_it, C.byref(rr))
     return ext, it, rr.value
+
+
+def quadratic_path(v, tol=1e-10, max_it=200000, want_jopt=False):
+    """CQuadraticPath::optimize for one frame: (u, iterations, residual[, j_opt])"""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    h, w = v.shape[:2]
+    u = np.zeros((h, w, 2), dtype=np.float32)
+    jo = np.zeros((h, w, 4), dtype=np.float32)
+    rr = C.c_double(0)
+    it = lib().vmo_quadratic_path(v.ctypes.data, w, h, tol, max_it, u.ctypes.data, jo.ctypes.data, C.byref(rr))
+    return (u, it, rr.value, jo) if want_jopt else (u, it, rr.value)
 
 
 def poisson_prepare(ext_rgba, w, h, ex, other_rgba, v, side):

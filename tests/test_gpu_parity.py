@@ -401,6 +401,30 @@ def test_poisson_extend(gpu_ctx, oracle):
         assert np.array_equal(out[ex + 1:ex + h - 1, ex + 1:ex + w - 1], ext[ex + 1:ex + h - 1, ex + 1:ex + w - 1])
 
 
+@pytest.mark.parametrize("w,h", [(160, 110), (333, 47), (64, 33)])
+def test_quadratic_path(gpu_ctx, oracle, w, h):
+    """CQuadraticPath (QuadraticPath.cpp:24-223): the device's multigrid-PCG solution of the
+    Neumann system agrees with the oracle's double-precision CG to 2e-3 px (both zero-mean),
+    and the renderer consumes it from the frame"""
+    ex = 8
+    e0, e1, _ = _frame_inputs(w, h, ex)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    v = (synth.displacement(w, h) + np.stack([0.8 * np.sin(xx / 9.0) * np.cos(yy / 7.0), 0.6 * np.cos(xx / 11.0 + yy / 5.0)], -1)).astype(np.float32)
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(e0, e1, v, None)
+    it, rr, ms = fr.quadratic_path(tol=1e-6)
+    u = fr.download_qpath()
+    ref, it_o, rr_o = oracle.quadratic_path(v)
+    assert rr <= 1e-6 and it <= 60 and rr_o <= 1e-10
+    assert np.abs(ref).max() > 0.05
+    assert np.abs(u - ref).max() <= 2e-3, np.abs(u - ref).max()
+    assert abs(float(u[..., 0].mean())) < 1e-4 and abs(float(u[..., 1].mean())) < 1e-4
+    out = fr.render_halfway(0.5, 0.5, 1)
+    assert np.array_equal(out, oracle.render_halfway(w, h, ex, 0.5, 0.5, 1, e0.astype(np.float32), e1.astype(np.float32), v, u))
+    fr.upload(None, None, v, None)      # a new upload without a path resets it to zero
+    assert np.all(fr.download_qpath() == 0)
+
+
 def test_errors_are_loud(gpu_ctx, vmlib):
     """error behaviour: bad calls return codes + messages, never crash"""
     pyr = morph.Pyramid(gpu_ctx)

@@ -357,3 +357,39 @@ def test_poisson_against_dense_solve(oracle):
     d = np.abs(ref - got)
     assert d.max() <= 1 and (d > 0).mean() < 0.01       # truncation of x.9999 vs (x+1).0
     assert np.array_equal(out[typ == 0], e0[typ == 0])
+
+
+def test_quadratic_path_closed_forms(oracle):
+    """QuadraticPath.cpp:24-223: (1) v = 0 gives J_opt = I, a zero right-hand side and u = 0;
+    (2) a uniform stretch v = (a x, 0) gives J_opt = diag(sqrt((1-a)(1+a)), 1) everywhere, a
+    right-hand side that lives on the first and last column only, and the linear zero-mean
+    u = ((sqrt(1 - a^2) - 1)(x - mean x), 0); (3) the solution has zero mean and satisfies the
+    5-point Neumann system it was assembled for"""
+    h, w = 24, 40
+    u, it, rr = oracle.quadratic_path(np.zeros((h, w, 2), np.float32))
+    assert it == 0 and np.all(u == 0)
+    a = 0.3
+    v = np.zeros((h, w, 2), np.float32)
+    v[..., 0] = a * np.arange(w, dtype=np.float32)[None, :]
+    u, it, rr, jo = oracle.quadratic_path(v, want_jopt=True)
+    s = np.sqrt((1 - a) * (1 + a))
+    assert np.allclose(jo[..., 0], s, atol=1e-6) and np.allclose(jo[..., 3], 1, atol=1e-6)
+    assert np.allclose(jo[..., 1], 0, atol=1e-6) and np.allclose(jo[..., 2], 0, atol=1e-6)
+    x = np.arange(w) - (w - 1) / 2.0
+    assert rr <= 1e-10 and np.abs(u[..., 0] - (s - 1) * x[None, :]).max() < 2e-5 and np.abs(u[..., 1]).max() < 2e-5
+    # a smooth field: residual of the assembled system, zero mean
+    rng = np.random.RandomState(3)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    v = np.stack([1.5 * np.sin(xx / 7.0) * np.cos(yy / 5.0), 1.2 * np.cos(xx / 9.0 + yy / 11.0)], -1).astype(np.float32)
+    u, it, rr, jo = oracle.quadratic_path(v, want_jopt=True)
+    assert abs(u[..., 0].mean()) < 1e-5 and abs(u[..., 1].mean()) < 1e-5 and np.abs(u).max() > 0.01
+    for c, (jx, jy, one_x, one_y) in enumerate(((0, 1, 1.0, 0.0), (2, 3, 0.0, 1.0))):
+        fx, fy = jo[..., jx] - one_x, jo[..., jy] - one_y      # the field whose divergence drives channel c
+        B = np.zeros((h, w))
+        B[1:, :] += fy[1:, :]; B[:, 1:] += fx[:, 1:]
+        B[:, :-1] -= fx[:, 1:]; B[:-1, :] -= fy[1:, :]
+        U = u[..., c].astype(np.float64)
+        A = np.zeros((h, w))
+        A[1:, :] += U[1:, :] - U[:-1, :]; A[:-1, :] += U[:-1, :] - U[1:, :]
+        A[:, 1:] += U[:, 1:] - U[:, :-1]; A[:, :-1] += U[:, :-1] - U[:, 1:]
+        assert np.abs(A - (B - B.mean())).max() < 1e-4 * max(np.abs(B).max(), 1e-3) + 2e-6

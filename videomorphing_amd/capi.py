@@ -31,7 +31,8 @@ SYMBOLS = [
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
     "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
     "vm_frame_download_ext", "vm_frame_set_v_from_level", "vm_render_halfway",
-    "vm_render_halfway_dev", "vm_poisson_extend", "vm_rccl_bcast",
+    "vm_render_halfway_dev", "vm_poisson_extend", "vm_frame_quadratic_path", "vm_frame_download_qpath",
+    "vm_rccl_bcast",
 ]
 
 
@@ -110,6 +111,8 @@ def load():
         "vm_render_halfway": [vp, f, f, i, vp, i],
         "vm_render_halfway_dev": [vp, f, f, i, C.POINTER(f)],
         "vm_poisson_extend": [vp, i, f, i, C.POINTER(i), C.POINTER(f), C.POINTER(f)],
+        "vm_frame_quadratic_path": [vp, f, i, C.POINTER(i), C.POINTER(f), C.POINTER(f)],
+        "vm_frame_download_qpath": [vp, vp],
         "vm_rccl_bcast": [vp, vp, vp, C.c_uint64, i],
     }
     for name, args in sig.items():

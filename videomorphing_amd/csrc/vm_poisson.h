@@ -27,4 +27,9 @@ void vm_poisson_launch_iter(float4 *X, float4 *R, float4 *P, float4 *Q, const fl
 void vm_poisson_launch_paste(uchar4 *ext, const uint8_t *type, const float4 *X, int cw, int ch,
                              hipStream_t s);
 
+// quadratic motion path (QuadraticPath.cpp:24-223)
+void vm_qpath_launch_rhs(const float2 *v, int rs, int w, int h, float4 *B, float4 *X, hipStream_t s);
+void vm_qpath_launch_sum(const float4 *X, int w, int h, double *sums, hipStream_t s);
+void vm_qpath_launch_shift(float4 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s);
+
 #endif

@@ -417,6 +417,88 @@ __global__ __launch_bounds__(256) void k_prolong(const float4 *__restrict__ Xc, 
 inline dim3 grid2(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 const dim3 B2(64, 4);
 
+
+// ---------------------------------------------------------------------------
+// quadratic motion path, CQuadraticPath::optimize (QuadraticPath.cpp:24-223)
+
+// optimal Jacobian of pixel (x, y), :37-109: J0 = I - grad v, J1 = I + grad v (backward
+// differences, forward on the first row / column); per column: average the directions,
+// geometric mean of the lengths.  jo = (j00, j01, j10, j11) in the reference's index order.
+__device__ __forceinline__ void qp_jopt(const float2 *__restrict__ v, int rs, int x, int y, float *jo)
+{
+    const float2 c = v[(size_t)y * rs + x];
+    float2 dx, dy;
+    if (x == 0) { const float2 n = v[(size_t)y * rs + x + 1]; dx = make_float2(n.x - c.x, n.y - c.y); }
+    else { const float2 n = v[(size_t)y * rs + x - 1]; dx = make_float2(c.x - n.x, c.y - n.y); }
+    if (y == 0) { const float2 n = v[(size_t)(y + 1) * rs + x]; dy = make_float2(n.x - c.x, n.y - c.y); }
+    else { const float2 n = v[(size_t)(y - 1) * rs + x]; dy = make_float2(c.x - n.x, c.y - n.y); }
+    float j0[4], j1[4];
+    j0[0] = 1.0f - dx.x; j0[2] = -dx.y; j1[0] = 1.0f + dx.x; j1[2] = dx.y;
+    j0[1] = -dy.x; j0[3] = 1.0f - dy.y; j1[1] = dy.x; j1[3] = 1.0f + dy.y;
+    const float la0 = sqrtf(j0[0] * j0[0] + j0[2] * j0[2]), lb0 = sqrtf(j0[1] * j0[1] + j0[3] * j0[3]);
+    const float la1 = sqrtf(j1[0] * j1[0] + j1[2] * j1[2]), lb1 = sqrtf(j1[1] * j1[1] + j1[3] * j1[3]);
+    float nj[4];
+    nj[0] = j0[0] / la0 + j1[0] / la1;
+    nj[2] = j0[2] / la0 + j1[2] / la1;
+    nj[1] = j0[1] / lb0 + j1[1] / lb1;
+    nj[3] = j0[3] / lb0 + j1[3] / lb1;
+    float la = sqrtf(nj[0] * nj[0] + nj[2] * nj[2]), lb = sqrtf(nj[1] * nj[1] + nj[3] * nj[3]);
+    nj[0] /= la; nj[2] /= la; nj[1] /= lb; nj[3] /= lb;
+    la = sqrtf(la0 * la1);
+    lb = sqrtf(lb0 * lb1);
+    jo[0] = nj[0] * la; jo[2] = nj[2] * la; jo[1] = nj[1] * lb; jo[3] = nj[3] * lb;
+}
+
+// right-hand sides, :137-170, both channels in one float4 (bx, by, 0, 0); X = 0
+__global__ __launch_bounds__(256) void k_qp_rhs(const float2 *__restrict__ v, int rs, int w, int h, float4 *B,
+                                                float4 *X)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h)
+        return;
+    float jc[4], je[4], js[4];
+    qp_jopt(v, rs, x, y, jc);
+    float bx = 0, by = 0;
+    if (y - 1 >= 0) { bx += jc[1]; by += jc[3] - 1.0f; }
+    if (x - 1 >= 0) { bx += jc[0] - 1.0f; by += jc[2]; }
+    if (x + 1 < w) { qp_jopt(v, rs, x + 1, y, je); bx -= je[0] - 1.0f; by -= je[2]; }
+    if (y + 1 < h) { qp_jopt(v, rs, x, y + 1, js); bx -= js[1]; by -= js[3] - 1.0f; }
+    const size_t ii = (size_t)y * w + x;
+    B[ii] = make_float4(bx, by, 0, 0);
+    X[ii] = make_float4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_qp_sum(const float4 *__restrict__ X, int w, int h, double *dst)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    double a = 0, b = 0;
+    if (x < w && y < h) {
+        const float4 v = X[(size_t)y * w + x];
+        a = v.x;
+        b = v.y;
+    }
+    block_sum3(a, b, 0.0, dst);
+}
+
+// B -= mean(B) (the float sums leave the right-hand side a hair off the range of the singular
+// operator), or u = X - mean(X) (CG from zero converges to the zero-mean solution)
+__global__ __launch_bounds__(256) void k_qp_shift(float4 *X, int w, int h, const double *__restrict__ sums,
+                                                  float2 *u, int rs)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h)
+        return;
+    const double n = (double)w * h;
+    const size_t ii = (size_t)y * w + x;
+    float4 v = X[ii];
+    v.x = (float)((double)v.x - sums[0] / n);
+    v.y = (float)((double)v.y - sums[1] / n);
+    if (u)
+        u[(size_t)y * rs + x] = make_float2(v.x, v.y);
+    else
+        X[ii] = v;
+}
+
 } // namespace
 
 void vm_poisson_launch_crop(uchar4 *dst, const uchar4 *ext, int w, int h, int ex, hipStream_t s)
@@ -469,4 +551,21 @@ void vm_poisson_launch_paste(uchar4 *ext, const uint8_t *type, const float4 *X, 
                              hipStream_t s)
 {
     hipLaunchKernelGGL(k_paste, grid2(cw, ch), B2, 0, s, ext, type, X, cw, ch);
+}
+
+void vm_qpath_launch_rhs(const float2 *v, int rs, int w, int h, float4 *B, float4 *X, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_qp_rhs, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, v, rs, w, h, B, X);
+}
+
+// sums[0..2] += column sums of X (sums must be zeroed by the caller)
+void vm_qpath_launch_sum(const float4 *X, int w, int h, double *sums, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_qp_sum, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums);
+}
+
+// u == nullptr: X -= mean in place; else u = X - mean
+void vm_qpath_launch_shift(float4 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_qp_shift, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, u, rs);
 }

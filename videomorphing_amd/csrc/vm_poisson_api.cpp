@@ -295,6 +295,69 @@ extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, i
     return VM_OK;
 }
 
+// CQuadraticPath::optimize for the frame's halfway field (QuadraticPath.cpp:24-223): u goes
+// to the frame's quadratic-path buffer, where vm_render_halfway reads it
+extern "C" int vm_frame_quadratic_path(vm_frame *f, float tol, int max_it, int *iters, float *rel_res,
+                                       float *elapsed_ms)
+{
+    if (!f || !(tol > 0) || max_it < 1)
+        return vm_fail(VM_E_INVALID, "vm_frame_quadratic_path: bad argument");
+    if (f->w < 2 || f->h < 2)
+        return vm_fail(VM_E_INVALID, "vm_frame_quadratic_path: needs a frame of at least 2x2 pixels");
+    vm_ctx *c = f->ctx;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    hipStream_t s = c->stream;
+    const size_t need = mg_bytes(f->w, f->h);
+    if (f->pws_bytes < need) {
+        hipFree(f->pws);
+        f->pws = nullptr;
+        f->pws_bytes = 0;
+        VM_HIP(hipMalloc(&f->pws, need));
+        f->pws_bytes = need;
+    }
+    MgHierarchy H;
+    mg_carve(H, f->w, f->h, (char *)f->pws);
+    VM_HIP(hipEventRecord(c->ev0, s));
+    vm_qpath_launch_rhs(f->v, f->rs, f->w, f->h, H.B, H.X, s);
+    // project the right-hand side onto the range of the singular operator
+    double *sums = H.sc->pq;
+    VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
+    vm_qpath_launch_sum(H.B, f->w, f->h, sums, s);
+    vm_qpath_launch_shift(H.B, f->w, f->h, sums, nullptr, 0, s);
+    vm_mg_launch_level0_full(H.lv[0], s);
+    for (size_t l = 1; l < H.lv.size(); ++l)
+        vm_mg_launch_coarsen(H.lv[l - 1], H.lv[l], s);
+    VM_HIP(hipGetLastError());
+    int it = 0;
+    double rel = 0;
+    int rc = mg_pcg(c, H, tol, max_it, &it, &rel);
+    if (rc != VM_OK) return rc;
+    VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
+    vm_qpath_launch_sum(H.X, f->w, f->h, sums, s);
+    vm_qpath_launch_shift(H.X, f->w, f->h, sums, f->u, f->rs, s);
+    VM_HIP(hipGetLastError());
+    VM_HIP(hipEventRecord(c->ev1, s));
+    VM_HIP(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    VM_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (iters) *iters = it;
+    if (rel_res) *rel_res = (float)rel;
+    if (elapsed_ms) *elapsed_ms = ms;
+    if (rel > tol)
+        return vm_fail(VM_E_NUMERIC, "vm_frame_quadratic_path: residual %.3g after %d iterations (tol %.3g)", rel, it, (double)tol);
+    return VM_OK;
+}
+
+// the frame's quadratic path, tight (h, w, 2) floats
+extern "C" int vm_frame_download_qpath(vm_frame *f, float *u_xy)
+{
+    if (!f || !u_xy) return vm_fail(VM_E_INVALID, "vm_frame_download_qpath: bad argument");
+    hipStream_t s = f->ctx->stream;
+    VM_HIP(hipMemcpy2DAsync(u_xy, (size_t)f->w * 8, f->u, (size_t)f->rs * 8, (size_t)f->w * 8, f->h, hipMemcpyDeviceToHost, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}
+
 // RCCL is resolved at first use so that the library loads (and the CPU-side
 // tests run) on hosts without a usable librccl.
 extern "C" int vm_rccl_bcast(vm_ctx *c, void *comm, void *dev_buf, uint64_t bytes, int root)

@@ -455,6 +455,18 @@ class Frame(object):
         capi.check(self._L.vm_render_halfway_dev(self._h, color_fa, geo_fa, color_from, C.byref(ms)))
         return ms.value
 
+    def quadratic_path(self, tol=1e-5, max_it=1000):
+        """CQuadraticPath::optimize for this frame's v (QuadraticPath.cpp:24-223); the result
+        stays in the frame for render_halfway.  Returns (iterations, residual, ms)."""
+        it, rr, ms = C.c_int(0), C.c_float(0), C.c_float(0)
+        capi.check(self._L.vm_frame_quadratic_path(self._h, float(tol), int(max_it), C.byref(it), C.byref(rr), C.byref(ms)))
+        return it.value, rr.value, ms.value
+
+    def download_qpath(self):
+        out = np.empty((self.h, self.w, 2), dtype=np.float32)
+        capi.check(self._L.vm_frame_download_qpath(self._h, out.ctypes.data))
+        return out
+
     def poisson_extend(self, side, tol=1e-5, max_it=20000):
         """CPoissonExt::prepare + poissonExtend for one side (PoissonExt.cpp:19-41)."""
         it, rr, ms = C.c_int(0), C.c_float(0), C.c_float(0)
