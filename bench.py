@@ -252,8 +252,12 @@ def main():
         extras["poisson_extend_1080p_ex%d" % ex] = pe
         # quadratic motion path of that frame (QuadraticPath.cpp), SURVEY 8(f) rank 4
         fr.set_v_from_level(p, 1)
-        qp = fr.quadratic_path(tol=1e-5)
-        extras["quadratic_path_1080p"] = {"ms_per_frame": round(qp[2], 1), "pcg_iterations": qp[0], "tol": 1e-5}
+        try:
+            qp = fr.quadratic_path(tol=1e-4)
+            extras["quadratic_path_1080p"] = {"ms_per_frame": round(qp[2], 1), "pcg_iterations": qp[0], "tol": 1e-4,
+                                              "residual": float("%.3g" % qp[1])}
+        except capi.VmError as e:        # e.g. a folded v: the blend of the Jacobians is 0/0 there
+            extras["quadratic_path_1080p"] = {"error": str(e)[-120:]}
         fr.close()
 
     cpu = None

@@ -44,7 +44,7 @@ public:
         return it;
     }
     // CQuadraticPath::optimize for this frame (QuadraticPath.cpp:24-223): u stays in the frame
-    int quadratic_path(float tol = 1e-5f, int max_it = 1000)
+    int quadratic_path(float tol = 1e-4f, int max_it = 200)
     {
         int it = 0;
         check(vm_frame_quadratic_path(f_, tol, max_it, &it, nullptr, nullptr));

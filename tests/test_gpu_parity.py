@@ -425,6 +425,31 @@ def test_quadratic_path(gpu_ctx, oracle, w, h):
     assert np.all(fr.download_qpath() == 0)
 
 
+def test_quadratic_path_at_precision_floor(gpu_ctx, oracle):
+    """a smooth field on a larger frame: |u| >> |rhs|, float32 PCG bottoms out near 1e-5 and
+    would drift if continued -- the solver returns its best iterate: an unattainable tolerance
+    is reported loudly, 1e-4 succeeds and stays within 0.02 px of the oracle"""
+    w, h, ex = 480, 270, 8
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    v = (synth.displacement(w, h) + np.stack([0.8 * np.sin(xx / 9.0), 0.6 * np.cos(yy / 5.0)], -1)).astype(np.float32)
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(None, None, v, None)
+    with pytest.raises(capi.VmError):
+        fr.quadratic_path(tol=1e-9, max_it=200)
+    it, rr, ms = fr.quadratic_path(tol=1e-4, max_it=200)
+    assert rr <= 1e-4 and it <= 40
+    ref, it_o, rr_o = oracle.quadratic_path(v, tol=1e-9)
+    u = fr.download_qpath()
+    assert np.abs(u - ref).max() <= 0.02, np.abs(u - ref).max()
+    # a folded field: columns of I - grad v and I + grad v anti-parallel -> 0/0 in the blend
+    # (QuadraticPath.cpp:96-101); the reference propagates the NaN, here it is an error
+    vf = np.zeros((h, w, 2), np.float32)
+    vf[..., 0] = 2.0 * np.arange(w, dtype=np.float32)[None, :]      # dv_x/dx = 2: J0 col = (-1, 0), J1 col = (3, 0)
+    fr.upload(None, None, vf, None)
+    with pytest.raises(capi.VmError, match="not finite"):
+        fr.quadratic_path(tol=1e-4)
+
+
 def test_errors_are_loud(gpu_ctx, vmlib):
     """error behaviour: bad calls return codes + messages, never crash"""
     pyr = morph.Pyramid(gpu_ctx)

@@ -77,6 +77,7 @@ int run_cg(vm_ctx *c, Grid &g, VmCgScalars *sc, float tol, int max_it, int *iter
 struct MgHierarchy {
     std::vector<VmMgLevel> lv;
     float4 *X = nullptr, *B = nullptr, *R = nullptr, *P = nullptr, *Q = nullptr;
+    float4 *Xbest = nullptr; // the iterate with the smallest residual seen so far
     VmPcgScalars *sc = nullptr;
 };
 
@@ -97,7 +98,7 @@ size_t mg_bytes(int w, int h)
         const size_t N = (size_t)sz[l].first * sz[l].second;
         need += 3 * al256(N * 4) + 3 * al256(N * 16); // we, ws, dg + x, b, t
     }
-    need += 4 * al256((size_t)w * h * 16);             // X, B, P, Q  (R = level 0's b)
+    need += 5 * al256((size_t)w * h * 16);             // X, B, P, Q, Xbest  (R = level 0's b)
     return need;
 }
 
@@ -122,6 +123,7 @@ char *mg_carve(MgHierarchy &H, int w, int h, char *b)
     H.B = (float4 *)b; b += al256(N0 * 16);
     H.P = (float4 *)b; b += al256(N0 * 16);
     H.Q = (float4 *)b; b += al256(N0 * 16);
+    H.Xbest = (float4 *)b; b += al256(N0 * 16);
     H.R = H.lv[0].b;
     return b;
 }
@@ -145,25 +147,41 @@ void mg_vcycle(MgHierarchy &H, size_t l, hipStream_t s)
 }
 
 // PCG from the guess in H.X until the relative residual of every channel is <= tol.
-// The hierarchy's operators (lv[*].we/ws/dg) and H.B must be set.
+// The hierarchy's operators (lv[*].we/ws/dg) and H.B must be set.  The residual is the
+// recursively updated one; in float32 it can pass below what the stored iterate attains and
+// the iteration then drifts (notably on the singular Neumann system, where |x| >> |b|), so
+// the best iterate seen at the checks is kept and returned, and the loop ends when the
+// residual has not improved for three checks or has grown 1000-fold.
 int mg_pcg(vm_ctx *c, MgHierarchy &H, float tol, int max_it, int *iters, double *rel)
 {
     hipStream_t s = c->stream;
     VmMgLevel &L0 = H.lv[0];
+    const size_t bytes = (size_t)L0.w * L0.h * sizeof(float4);
     VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
     vm_mg_launch_pcg_init(L0, H.B, H.X, H.R, H.sc, s);
     VmPcgScalars h;
-    int it = 0;
-    double worst = 0;
+    int it = 0, best_it = 0, stale = 0;
+    double worst = 0, best = 1e300;
     const int check = 4;
     while (true) {
         VM_HIP(hipMemcpyAsync(&h, H.sc, sizeof(h), hipMemcpyDeviceToHost, s));
         VM_HIP(hipStreamSynchronize(s));
         worst = 0;
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k) {
+            if (!(h.bb[k] == h.bb[k]) || !(h.rr[k] == h.rr[k]) || std::isinf(h.bb[k]) || std::isinf(h.rr[k]))
+                return vm_fail(VM_E_NUMERIC, it == 0 ? "multigrid PCG: the right-hand side is not finite"
+                                                     : "multigrid PCG broke down (NaN)");
             if (h.bb[k] > 0) worst = std::max(worst, std::sqrt(h.rr[k] / h.bb[k]));
-        if (!(worst == worst)) return vm_fail(VM_E_NUMERIC, "multigrid PCG broke down (NaN)");
-        if (worst <= tol || it >= max_it) break;
+        }
+        if (worst < best) {
+            best = worst;
+            best_it = it;
+            stale = 0;
+            VM_HIP(hipMemcpyAsync(H.Xbest, H.X, bytes, hipMemcpyDeviceToDevice, s));
+        } else {
+            ++stale;
+        }
+        if (worst <= tol || it >= max_it || stale >= 3 || worst > 1e3 * best) break;
         const int nb = std::min(check, max_it - it);
         for (int k = 0; k < nb; ++k, ++it) {
             mg_vcycle(H, 0, s);                                    // z = M^-1 r  (in L0.x)
@@ -174,8 +192,10 @@ int mg_pcg(vm_ctx *c, MgHierarchy &H, float tol, int max_it, int *iters, double 
         }
         VM_HIP(hipGetLastError());
     }
-    *iters = it;
-    *rel = worst;
+    if (best_it != it)
+        VM_HIP(hipMemcpyAsync(H.X, H.Xbest, bytes, hipMemcpyDeviceToDevice, s));
+    *iters = best_it;
+    *rel = best;
     return VM_OK;
 }
 } // namespace

@@ -455,7 +455,7 @@ class Frame(object):
         capi.check(self._L.vm_render_halfway_dev(self._h, color_fa, geo_fa, color_from, C.byref(ms)))
         return ms.value
 
-    def quadratic_path(self, tol=1e-5, max_it=1000):
+    def quadratic_path(self, tol=1e-4, max_it=200):
         """CQuadraticPath::optimize for this frame's v (QuadraticPath.cpp:24-223); the result
         stays in the frame for render_halfway.  Returns (iterations, residual, ms)."""
         it, rr, ms = C.c_int(0), C.c_float(0), C.c_float(0)
