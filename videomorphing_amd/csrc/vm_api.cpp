@@ -504,13 +504,13 @@ extern "C" int vm_init_level(vm_pyr *p, int lvl, int w0, int h0, const vm_constr
 // (VM_NO_GRAPH set, or capture/instantiation failed once): the caller launches eagerly.
 #define VM_GRAPH_ITERS 8
 static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, int cap, int fixed_work, int threads,
-                                  const VmKParams &P)
+                                  int dense, const VmKParams &P)
 {
     if (c->use_graphs < 0) c->use_graphs = getenv("VM_NO_GRAPH") ? 0 : 1;
     if (!c->use_graphs) return nullptr;
     for (auto &g : c->graphs)
         if (g.exact == exact && g.n == n && g.w == w && g.h == h && g.cap == cap && g.fixed_work == fixed_work &&
-            g.threads == threads && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
+            g.threads == threads && g.dense == dense && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
             memcmp(&g.kp, &c->kp, sizeof(c->kp)) == 0)
             return g.exec;
     if (!c->iter_dev && hipMalloc((void **)&c->iter_dev, sizeof(int)) != hipSuccess) {
@@ -524,8 +524,8 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
     if (ok) {
         for (int it = 0; it < VM_GRAPH_ITERS; ++it) {
             for (int k = 0; k < 4; ++k) {
-                if (exact) vm_launch_optimize_exact(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, 0, fixed_work, threads, c->iter_dev, c->stream);
-                else vm_launch_optimize_fast(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, 0, fixed_work, threads, c->iter_dev, c->stream);
+                if (exact) vm_launch_optimize_exact(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, 0, fixed_work, threads, c->iter_dev, dense, c->stream);
+                else vm_launch_optimize_fast(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, 0, fixed_work, threads, c->iter_dev, dense, c->stream);
             }
             if (exact) vm_launch_next_iter_exact(c->iter_dev, 0, 0, c->stream);
             else vm_launch_next_iter_fast(c->iter_dev, 0, 0, c->stream);
@@ -543,7 +543,7 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
         for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
         c->graphs.clear();
     }
-    c->graphs.push_back({exact, n, w, h, cap, fixed_work, threads, c->views, c->flags, c->stats, c->kp, exec});
+    c->graphs.push_back({exact, n, w, h, cap, fixed_work, threads, dense, c->views, c->flags, c->stats, c->kp, exec});
     return exec;
 }
 
@@ -634,20 +634,23 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     // inside a batch costs launch latency only, and the host reads the flags once per batch
     // instead of once per iteration.  The HIP events bracket the sweep launches of each batch
     // on the context's stream.
-    int batch = 8;
+    int batch = 2; // a short first batch: the schedule of the rest depends on what it finds
     while (done < cap) {
         const int nb = std::min(batch, cap - done);
         const bool split = c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP ||
                            (may_split && cand_prev >= (exact ? 1500.0 : 200.0) * n);
         // FAST: the one-launch-per-phase STEP schedule unless the two-kernel SPLIT is forced
         const bool step = split && !exact && c->sweep_mode != VM_SWEEP_SPLIT;
+        // TILE (FAST): the register-light kernel variant once fewer than a tenth of the pixels
+        // are searched per iteration (after the first sweep of a level, typically)
+        const int dense = exact || getenv("VM_TILE_DENSE") || cand_prev >= 0.1 * l0.w * l0.h * n;
         VM_HIP(hipEventRecord(c->ev0, s));
         uint32_t last_epoch = 0;
         int sb = 0; // step index inside this batch: parity = which copy of the sums is read
         int it0 = done;
         if (!split && nb >= VM_GRAPH_ITERS) {
             // TILE batch: whole groups of VM_GRAPH_ITERS iterations are graph replays
-            if (hipGraphExec_t ge = sweep_graph(c, exact, n, l0.w, l0.h, cap, fixed_work, threads, P)) {
+            if (hipGraphExec_t ge = sweep_graph(c, exact, n, l0.w, l0.h, cap, fixed_work, threads, dense, P)) {
                 if (exact) vm_launch_next_iter_exact(c->iter_dev, 1, done, s);
                 else vm_launch_next_iter_fast(c->iter_dev, 1, done, s);
                 for (; it0 + VM_GRAPH_ITERS <= done + nb; it0 += VM_GRAPH_ITERS) {
@@ -672,8 +675,8 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
                     else vm_launch_optimize_split_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
                     launches += 8;
                 } else {
-                    if (exact) vm_launch_optimize_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, s);
-                    else vm_launch_optimize_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, s);
+                    if (exact) vm_launch_optimize_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, s);
+                    else vm_launch_optimize_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, s);
                     ++launches;
                 }
             }
@@ -715,7 +718,7 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
             cancelled = true;
             break;
         }
-        batch = std::min(batch * 2, 64);
+        batch = std::min(batch * 4, 64);
     }
     for (int i = 0; i < n && out; ++i) {
         out[i].iters = executed[i];

@@ -40,7 +40,7 @@ struct vm_ctx {
     int *iter_dev = nullptr;         // device iteration counter read by the replayed kernels
     struct SweepGraph {
         bool exact;
-        int n, w, h, cap, fixed_work, threads;
+        int n, w, h, cap, fixed_work, threads, dense;
         const void *views, *flags, *stats;
         vm_kern_params kp;
         hipGraphExec_t exec;

@@ -839,6 +839,10 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
 
 // ===========================================================================
 // TILE schedule
+// DENSE = false (FAST only): the variant for pruned sweeps -- every phase runs the lean line
+// search, 16 candidates per round; without the dense path the kernel needs ~100 instead of
+// 256 VGPRs, which is what a launch of mostly no-op workgroups pays for.
+template <bool DENSE>
 __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
                                                         VmKParams P, const uint32_t *__restrict__ tables,
                                                         int offx, int offy, uint32_t *__restrict__ flags,
@@ -950,9 +954,10 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                 st_cand += n_act;
                 // ---- 2. line searches on the pre-phase state, L lanes per candidate ----
 #if !VM_EXACT
-                if (n_act * 32 <= T) {
+                if (!DENSE || n_act * 32 <= T) {
                     // sparse phase: the lean 32-lane line search
-                    const int li = tid >> 5, sub = tid & 31;
+                    for (int base = 0; base < n_act; base += T / 32) {
+                    const int li = base + (tid >> 5), sub = tid & 31;
                     const int slot = S.list[min(li, n_act - 1)];
                     const int tx = slot & 31, ty = slot >> 5;
                     const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
@@ -989,9 +994,10 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                             S.d_ok[slot] = 3;
                         }
                     }
+                    }
                 } else
 #endif
-                {
+                if (DENSE) {
                 int Lf = VM_MIN_FANOUT;
                 while (Lf * 2 <= VM_MAX_FANOUT && Lf * 2 * n_act <= T)
                     Lf *= 2;
@@ -1747,10 +1753,19 @@ extern "C" int vm_dbg_prof_read(void *dst, size_t bytes)
 // flags/stats: nbatch rows of `cap` iterations
 void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
                              const uint32_t *tables, int offx, int offy, uint32_t *flags, uint32_t *stats,
-                             int iter_idx, int fixed_work, int threads, const int *iter_dev, hipStream_t s)
+                             int iter_idx, int fixed_work, int threads, const int *iter_dev, int dense,
+                             hipStream_t s)
 {
     dim3 b(threads), g((w + VM_PITCH_X - 1) / VM_PITCH_X, (h + VM_PITCH_Y - 1) / VM_PITCH_Y, nbatch);
-    hipLaunchKernelGGL(SUF(k_optimize), g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats, iter_idx,
+#if !VM_EXACT
+    if (!dense) {
+        hipLaunchKernelGGL(SUF(k_optimize)<false>, g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats,
+                           iter_idx, fixed_work, iter_dev);
+        return;
+    }
+#endif
+    (void)dense;
+    hipLaunchKernelGGL(SUF(k_optimize)<true>, g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats, iter_idx,
                        fixed_work, iter_dev);
 }
 
