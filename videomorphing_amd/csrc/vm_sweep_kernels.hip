@@ -715,17 +715,18 @@ __device__ __forceinline__ bool is_interior(const VmLevelView &L, int px, int py
 struct MaskGeom {
     int bx0, by0, nbx, nby;
 };
-__device__ __forceinline__ MaskGeom mask_geom(const VmLevelView &L, int ox, int oy)
+__device__ __forceinline__ MaskGeom mask_geom(int w, int h, int ox, int oy)
 {
     MaskGeom g;
     g.bx0 = ox / 5 - 1;
     g.by0 = oy / 5 - 1;
-    const int bx1 = min(ox + VM_TILE_W - 1, L.w - 1) / 5 + 1;
-    const int by1 = min(oy + VM_TILE_H - 1, L.h - 1) / 5 + 1;
+    const int bx1 = min(ox + VM_TILE_W - 1, w - 1) / 5 + 1;
+    const int by1 = min(oy + VM_TILE_H - 1, h - 1) / 5 + 1;
     g.nbx = bx1 - g.bx0 + 1; // <= 16
     g.nby = by1 - g.by0 + 1; // <= 6
     return g;
 }
+__device__ __forceinline__ MaskGeom mask_geom(const VmLevelView &L, int ox, int oy) { return mask_geom(L.w, L.h, ox, oy); }
 
 // get_improve_mask_idx, morph.cu:621-646, on the LDS copy of the mask words
 __device__ __forceinline__ bool mask_hit(const uint32_t (*mask)[16], const uint32_t *imp, const MaskGeom &g,
@@ -847,7 +848,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                                                         VmKParams P, const uint32_t *__restrict__ tables,
                                                         int offx, int offy, uint32_t *__restrict__ flags,
                                                         uint32_t *__restrict__ stats, int iter_idx, int fixed_work,
-                                                        const int *__restrict__ iter_dev)
+                                                        const int *__restrict__ iter_dev,
+                                                        const uint32_t *__restrict__ imp0, int imp_rs0, int w0, int h0)
 {
     __shared__ TileLds S;
     // replayed from a hipGraph the launch cannot carry the iteration number: it is read from
@@ -872,16 +874,20 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
         return;
 
+    // (single pair: geometry and mask pointer also travel as launch arguments, so that the mask
+    // test of a pruned tile does not wait for the view to arrive first)
+    const uint32_t *impmask = imp0 ? imp0 : L.impmask;
+    const int lw = imp0 ? w0 : L.w, lh = imp0 ? h0 : L.h, imp_rs = imp0 ? imp_rs0 : L.imp_rs;
     const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
-    if (ox >= L.w || oy >= L.h)
+    if (ox >= lw || oy >= lh)
         return;
 
     // --- improving-mask words of the tile and its ring of neighbour blocks ---
-    const MaskGeom g = mask_geom(L, ox, oy);
+    const MaskGeom g = mask_geom(lw, lh, ox, oy);
     uint32_t mymask = 0;
     if (tid < g.nbx * g.nby) {
         int mx = tid % g.nbx, my = tid / g.nbx;
-        mymask = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)];
+        mymask = impmask[(g.by0 + my + 1) * imp_rs + (g.bx0 + mx + 1)];
         S.mask[my][mx] = mymask;
     }
     // tile-level early out: no set bit anywhere near the tile means no pixel of it is a
@@ -1754,19 +1760,21 @@ extern "C" int vm_dbg_prof_read(void *dst, size_t bytes)
 void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
                              const uint32_t *tables, int offx, int offy, uint32_t *flags, uint32_t *stats,
                              int iter_idx, int fixed_work, int threads, const int *iter_dev, int dense,
-                             hipStream_t s)
+                             const uint32_t *imp0, int imp_rs0, hipStream_t s)
 {
     dim3 b(threads), g((w + VM_PITCH_X - 1) / VM_PITCH_X, (h + VM_PITCH_Y - 1) / VM_PITCH_Y, nbatch);
+    if (nbatch != 1)
+        imp0 = nullptr; // a batch: every pair has its own mask, reached through its view
 #if !VM_EXACT
     if (!dense) {
         hipLaunchKernelGGL(SUF(k_optimize)<false>, g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats,
-                           iter_idx, fixed_work, iter_dev);
+                           iter_idx, fixed_work, iter_dev, imp0, imp_rs0, w, h);
         return;
     }
 #endif
     (void)dense;
     hipLaunchKernelGGL(SUF(k_optimize)<true>, g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats, iter_idx,
-                       fixed_work, iter_dev);
+                       fixed_work, iter_dev, imp0, imp_rs0, w, h);
 }
 
 // the device iteration counter of graph-replayed sweeps: set it, or advance it by one
