@@ -245,6 +245,7 @@ def main():
         extras["render_frames_per_s"] = round(1000.0 / (sum(ms) / len(ms)), 1)
         # Poisson boundary extension of both sides of that frame (config[4]'s other stage)
         pe = {}
+        fr.poisson_extend(1, tol=1e-3)      # the workspace is allocated on first use: not timed
         for tol in (1e-4, 1e-5):
             fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
             r1, r2 = fr.poisson_extend(1, tol=tol), fr.poisson_extend(2, tol=tol)

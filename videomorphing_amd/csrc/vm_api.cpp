@@ -496,7 +496,7 @@ extern "C" int vm_init_level(vm_pyr *p, int lvl, int w0, int h0, const vm_constr
     return VM_OK;
 }
 
-// A hipGraph of VM_GRAPH_ITERS TILE-schedule iterations (4 pass launches + the counter bump each)
+// A hipGraph of VM_GRAPH_ITERS TILE-schedule iterations (4 pass launches each, one counter bump)
 // for the given geometry, instantiated once per context and replayed: pruned sweeps last 2-3 us
 // on the GPU, less than the 4-6 us the host needs per eager launch, so the sweep loop of a
 // converged or nearly converged level is launch-bound without it.  The iteration number is not
@@ -524,12 +524,12 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
     if (ok) {
         for (int it = 0; it < VM_GRAPH_ITERS; ++it) {
             for (int k = 0; k < 4; ++k) {
-                if (exact) vm_launch_optimize_exact(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, 0, fixed_work, threads, c->iter_dev, dense, imp0, imp_rs0, c->stream);
-                else vm_launch_optimize_fast(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, 0, fixed_work, threads, c->iter_dev, dense, imp0, imp_rs0, c->stream);
+                if (exact) vm_launch_optimize_exact(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, c->iter_dev, dense, imp0, imp_rs0, c->stream);
+                else vm_launch_optimize_fast(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, c->iter_dev, dense, imp0, imp_rs0, c->stream);
             }
-            if (exact) vm_launch_next_iter_exact(c->iter_dev, 0, 0, c->stream);
-            else vm_launch_next_iter_fast(c->iter_dev, 0, 0, c->stream);
         }
+        if (exact) vm_launch_next_iter_exact(c->iter_dev, 0, VM_GRAPH_ITERS, c->stream);
+        else vm_launch_next_iter_fast(c->iter_dev, 0, VM_GRAPH_ITERS, c->stream);
         ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && graph;
     }
     if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;

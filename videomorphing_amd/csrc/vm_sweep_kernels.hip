@@ -852,10 +852,10 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView 
                                                         const uint32_t *__restrict__ imp0, int imp_rs0, int w0, int h0)
 {
     __shared__ TileLds S;
-    // replayed from a hipGraph the launch cannot carry the iteration number: it is read from
-    // a device counter that k_next_iter advances after the four passes
+    // replayed from a hipGraph the launch can only carry the iteration's position inside the
+    // graph: the base comes from a device counter that k_next_iter advances once per replay
     if (iter_dev)
-        iter_idx = *iter_dev;
+        iter_idx += *iter_dev;
 #ifdef VM_PROF
     unsigned long long tso[16];
     for (int k = 0; k < 16; ++k) tso[k] = 0;
@@ -1741,7 +1741,7 @@ __global__ __launch_bounds__(T) void k_step_fast(const VmLevelView *__restrict__
 __global__ void SUF(k_next_iter)(int *iter_dev, int set, int value)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0)
-        *iter_dev = set ? value : *iter_dev + 1;
+        *iter_dev = set ? value : *iter_dev + value;
 }
 
 } // namespace
@@ -1777,7 +1777,7 @@ void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int 
                        fixed_work, iter_dev, imp0, imp_rs0, w, h);
 }
 
-// the device iteration counter of graph-replayed sweeps: set it, or advance it by one
+// the device iteration counter of graph-replayed sweeps: set it to, or advance it by, `value`
 void SUF(vm_launch_next_iter)(int *iter_dev, int set, int value, hipStream_t s)
 {
     hipLaunchKernelGGL(SUF(k_next_iter), dim3(1), dim3(64), 0, s, iter_dev, set, value);
