@@ -395,7 +395,7 @@ void vm_mg_launch_coarsen(const VmMgLevel &F, const VmMgLevel &C, hipStream_t s)
     hipLaunchKernelGGL(k_coarsen, grid2(C.w, C.h), blk2, 0, s, F, C);
     // screening -> diagonal; C.t is free at set-up time and serves as the output buffer
     hipLaunchKernelGGL(k_diag, grid2(C.w, C.h), blk2, 0, s, C, (float *)C.t);
-    hipMemcpyAsync(C.dg, C.t, (size_t)C.w * C.h * sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(C.dg, C.t, (size_t)C.w * C.h * sizeof(float), hipMemcpyDeviceToDevice, s);
 }
 
 void vm_mg_launch_jacobi0(const VmMgLevel &L, float omega, hipStream_t s)

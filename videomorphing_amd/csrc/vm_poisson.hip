@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_coarsen(const uchar4 *__restrict__ ext,
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= cw2 || y >= ch2)
         return;
-    int n_out = 0, n_in = 0, n_ring = 0, n_col = 0, n_anchor = 0;
+    int n_out = 0, n_ring = 0, n_col = 0, n_anchor = 0;
     float3 col = make_float3(0, 0, 0), anc = make_float3(0, 0, 0);
     for (int j = 0; j < 4; ++j)
         for (int i = 0; i < 4; ++i) {
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_coarsen(const uchar4 *__restrict__ ext,
                 ++n_out;
                 if (!is_marker(c)) { ++n_col; col.x += c.x; col.y += c.y; col.z += c.z; }
             } else {
-                if (t == 1) ++n_ring; else ++n_in;
+                if (t == 1) ++n_ring;
                 ++n_anchor; anc.x += c.x; anc.y += c.y; anc.z += c.z;
             }
         }
