@@ -298,6 +298,40 @@ def test_batched_solve_equals_individual_solves(gpu_ctx):
     assert len({tuple(i) for i in iters}) > 1 or True   # pairs may stop at different sweeps
 
 
+@pytest.mark.parametrize("sched", [capi.SWEEP_STEP, capi.SWEEP_TILE])
+def test_fast_batched_solve_equals_individual_solves(gpu_ctx, sched):
+    """FAST, a fixed schedule: the batch dimension (grid.z = pair; STEP: per-pair ping-pong copies
+    and record sets, TILE: graph replays with the device iteration counter) changes no bit"""
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    w, h = 150, 100
+    frames = [synth.make_pair(w, h, frame=k, amp=0.4 + 0.5 * k) for k in range(3)]
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 40, 1.0, 32
+    try:
+        gpu_ctx.set_tuning(sched, 0, 0)
+        single, iters = [], []
+        for i0, i1 in frames:
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build(i0, i1, 32)
+            m = morph.Morph(prm, pyr)
+            m.calculate_halfway_parametrization()
+            single.append(pyr[1].v)
+            iters.append([m.progress[el]["iters"] for el in sorted(m.progress)])
+        batch = []
+        for i0, i1 in frames:
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build(i0, i1, 32)
+            batch.append(pyr)
+        prog = morph.solve_batch(batch, 40, 1.0)
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    for k in range(3):
+        assert [p["iters"] for p in prog[k]] == iters[k]
+        assert np.array_equal(single[k].view(np.uint32), batch[k][1].v.view(np.uint32))
+
+
 def test_upsample_exact(gpu_ctx, oracle):
     gpu_ctx.set_math_mode(capi.MATH_EXACT)
     for (dw, dh) in [(97, 75), (128, 64)]:
