@@ -143,3 +143,36 @@ def test_schedules_agree_exactly_at_1080p(gpu_ctx):
     assert out[0][3] == out[1][3] > 10000
     for a, b in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_step_schedule_is_bit_identical_to_split_on_a_long_run(gpu_ctx):
+    """FAST, the 240x135 level of a 1080p pyramid, 120 fixed-work iterations (1920 phase
+    launches, from the dense start down to a handful of candidates): STEP = SPLIT bit for bit,
+    and both satisfy the window-sum invariants (every commit the level ever made)"""
+    w, h = 240, 135
+    i0, i1 = synth.make_pair(w, h)
+    v0 = (0.9 * synth.displacement(w, h) + 0.05 * np.random.RandomState(2).randn(h, w, 2)).astype(np.float32)
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    out = []
+    try:
+        for mode in (capi.SWEEP_SPLIT, capi.SWEEP_STEP):
+            gpu_ctx.set_tuning(mode, 0, 0)
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build_levels([(w, h), (120, 68)])
+            pyr.upload_luma(1, i0, i1)
+            pyr[1].v = v0
+            capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+            pr = capi.Progress()
+            capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 120.0, None, 1, C.byref(pr)))
+            lv = pyr[1]
+            out.append(([lv.field(n).copy() for n in ("v", "luma", "mean", "var", "cross", "value", "tps_b", "impmask")], pr.commits))
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    assert out[0][1] == out[1][1] > 50000
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    v, luma, mean, var, cross = out[1][0][:5]
+    assert np.abs(_box5(luma) - mean).max() < 2e-2 * 25 and np.abs(_box5(luma ** 2) - var).max() < 4.0 * 25
+    assert np.abs(_box5(luma[..., 0] * luma[..., 1]) - cross).max() < 4.0 * 25
