@@ -259,6 +259,30 @@ def main():
                                               "residual": float("%.3g" % qp[1])}
         except capi.VmError as e:        # e.g. a folded v: the blend of the Jacobians is 0/0 there
             extras["quadratic_path_1080p"] = {"error": str(e)[-120:]}
+        # config[4]'s whole pipeline on one GPU: 8 frame pairs solved as a batch (reference
+        # semantics), then per frame v upscale -> Poisson extension of both sides -> 9 rendered
+        # in-between frames; canvases uploaded once per frame (PCIe included)
+        if B == 1:
+            group = []
+            for k in range(8):
+                q = morph.Pyramid(ctx)
+                q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
+                group.append(q)
+            e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
+            ctx.sync(); t1 = time.perf_counter()
+            morph.solve_batch(group, blk.max_iter, blk.max_iter_drop_factor, fixed_work=False)
+            t_solve = time.perf_counter() - t1
+            for q in group:
+                fr.upload(e0, e1, None, None)
+                fr.set_v_from_level(q, 1)
+                fr.poisson_extend(1, tol=1e-5)
+                fr.poisson_extend(2, tol=1e-5)
+                for k in range(1, 10):
+                    fr.render_halfway_dev(0.1 * k, 0.1 * k, 1)
+            ctx.sync(); dt = time.perf_counter() - t1
+            extras["pipeline_config4_8_pairs"] = {"ms_per_pair": round(dt * 1e3 / 8, 1), "solve_ms_per_pair": round(t_solve * 1e3 / 8, 1),
+                                                  "rendered_frames_per_s": round(8 * 9 / dt, 1)}
+            del group
         fr.close()
 
     cpu = None
