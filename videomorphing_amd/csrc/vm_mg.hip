@@ -233,7 +233,11 @@ __global__ __launch_bounds__(1024) void k_coarsest(VmMgLevel L, float omega, int
 }
 
 // ---------------------------------------------------------------------------
-// PCG on level 0
+// PCG on level 0.  The kernels with a dot product give each thread VM_PCG_ROWS rows of the
+// 64x4 footprint: every block ends in three same-address double atomics, which the L2
+// serialises at ~5 ns each -- with one footprint per block (13 k blocks on the 1080p canvas)
+// that alone took 65 us per kernel, more than the streaming.
+#define VM_PCG_ROWS 16
 
 // block reduction of three doubles, then one double atomic per block and channel
 __device__ __forceinline__ void block_sum3(double a, double b, double c, double *dst)
@@ -259,19 +263,22 @@ __device__ __forceinline__ void block_sum3(double a, double b, double c, double 
 __global__ __launch_bounds__(256) void k_pcg_init(VmMgLevel L, const float4 *__restrict__ B,
                                                   const float4 *__restrict__ X, float4 *R, VmPcgScalars *sc)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int x = blockIdx.x * 64 + threadIdx.x;
     double bb[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
-    if (x < L.w && y < L.h) {
-        const size_t ii = (size_t)y * L.w + x;
-        const float dg = L.dg[ii];
-        float4 r = make_float4(0, 0, 0, 0);
-        if (dg > 0) {
-            const float4 b = B[ii], ax = mg_apply(L, X, x, y, ii, dg);
-            r = make_float4(b.x - ax.x, b.y - ax.y, b.z - ax.z, 0);
-            bb[0] = (double)b.x * b.x; bb[1] = (double)b.y * b.y; bb[2] = (double)b.z * b.z;
-            rr[0] = (double)r.x * r.x; rr[1] = (double)r.y * r.y; rr[2] = (double)r.z * r.z;
+    for (int k = 0; k < VM_PCG_ROWS; ++k) {
+        const int y = (blockIdx.y * VM_PCG_ROWS + k) * 4 + threadIdx.y;
+        if (x < L.w && y < L.h) {
+            const size_t ii = (size_t)y * L.w + x;
+            const float dg = L.dg[ii];
+            float4 r = make_float4(0, 0, 0, 0);
+            if (dg > 0) {
+                const float4 b = B[ii], ax = mg_apply(L, X, x, y, ii, dg);
+                r = make_float4(b.x - ax.x, b.y - ax.y, b.z - ax.z, 0);
+                bb[0] += (double)b.x * b.x; bb[1] += (double)b.y * b.y; bb[2] += (double)b.z * b.z;
+                rr[0] += (double)r.x * r.x; rr[1] += (double)r.y * r.y; rr[2] += (double)r.z * r.z;
+            }
+            R[ii] = r;
         }
-        R[ii] = r;
     }
     block_sum3(bb[0], bb[1], bb[2], sc->bb);
     block_sum3(rr[0], rr[1], rr[2], sc->rr);
@@ -281,15 +288,18 @@ __global__ __launch_bounds__(256) void k_pcg_init(VmMgLevel L, const float4 *__r
 __global__ __launch_bounds__(256) void k_pcg_spmv(VmMgLevel L, const float4 *__restrict__ P, float4 *Q,
                                                   VmPcgScalars *sc)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int x = blockIdx.x * 64 + threadIdx.x;
     double pq[3] = {0, 0, 0};
-    if (x < L.w && y < L.h) {
-        const size_t ii = (size_t)y * L.w + x;
-        const float dg = L.dg[ii];
-        if (dg > 0) {
-            const float4 q = mg_apply(L, P, x, y, ii, dg), p = P[ii];
-            Q[ii] = q;
-            pq[0] = (double)p.x * q.x; pq[1] = (double)p.y * q.y; pq[2] = (double)p.z * q.z;
+    for (int k = 0; k < VM_PCG_ROWS; ++k) {
+        const int y = (blockIdx.y * VM_PCG_ROWS + k) * 4 + threadIdx.y;
+        if (x < L.w && y < L.h) {
+            const size_t ii = (size_t)y * L.w + x;
+            const float dg = L.dg[ii];
+            if (dg > 0) {
+                const float4 q = mg_apply(L, P, x, y, ii, dg), p = P[ii];
+                Q[ii] = q;
+                pq[0] += (double)p.x * q.x; pq[1] += (double)p.y * q.y; pq[2] += (double)p.z * q.z;
+            }
         }
     }
     block_sum3(pq[0], pq[1], pq[2], sc->pq);
@@ -299,22 +309,25 @@ __global__ __launch_bounds__(256) void k_pcg_spmv(VmMgLevel L, const float4 *__r
 __global__ __launch_bounds__(256) void k_pcg_update(VmMgLevel L, float4 *X, float4 *R, const float4 *__restrict__ P,
                                                     const float4 *__restrict__ Q, VmPcgScalars *sc)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int x = blockIdx.x * 64 + threadIdx.x;
     double rr[3] = {0, 0, 0};
-    if (x < L.w && y < L.h) {
-        const size_t ii = (size_t)y * L.w + x;
-        if (L.dg[ii] > 0) {
-            float al[3];
+    float al[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                al[c] = sc->pq[c] > 0 ? (float)(sc->rz[c] / sc->pq[c]) : 0.0f;
-            const float4 p = P[ii], q = Q[ii];
-            float4 xx = X[ii], r = R[ii];
-            xx.x += al[0] * p.x; xx.y += al[1] * p.y; xx.z += al[2] * p.z;
-            r.x -= al[0] * q.x; r.y -= al[1] * q.y; r.z -= al[2] * q.z;
-            X[ii] = xx;
-            R[ii] = r;
-            rr[0] = (double)r.x * r.x; rr[1] = (double)r.y * r.y; rr[2] = (double)r.z * r.z;
+    for (int c = 0; c < 3; ++c)
+        al[c] = sc->pq[c] > 0 ? (float)(sc->rz[c] / sc->pq[c]) : 0.0f;
+    for (int k = 0; k < VM_PCG_ROWS; ++k) {
+        const int y = (blockIdx.y * VM_PCG_ROWS + k) * 4 + threadIdx.y;
+        if (x < L.w && y < L.h) {
+            const size_t ii = (size_t)y * L.w + x;
+            if (L.dg[ii] > 0) {
+                const float4 p = P[ii], q = Q[ii];
+                float4 xx = X[ii], r = R[ii];
+                xx.x += al[0] * p.x; xx.y += al[1] * p.y; xx.z += al[2] * p.z;
+                r.x -= al[0] * q.x; r.y -= al[1] * q.y; r.z -= al[2] * q.z;
+                X[ii] = xx;
+                R[ii] = r;
+                rr[0] += (double)r.x * r.x; rr[1] += (double)r.y * r.y; rr[2] += (double)r.z * r.z;
+            }
         }
     }
     block_sum3(rr[0], rr[1], rr[2], sc->rr);
@@ -324,13 +337,16 @@ __global__ __launch_bounds__(256) void k_pcg_update(VmMgLevel L, float4 *X, floa
 __global__ __launch_bounds__(256) void k_pcg_dot(VmMgLevel L, const float4 *__restrict__ R,
                                                  const float4 *__restrict__ Z, VmPcgScalars *sc)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int x = blockIdx.x * 64 + threadIdx.x;
     double rz[3] = {0, 0, 0};
-    if (x < L.w && y < L.h) {
-        const size_t ii = (size_t)y * L.w + x;
-        if (L.dg[ii] > 0) {
-            const float4 r = R[ii], z = Z[ii];
-            rz[0] = (double)r.x * z.x; rz[1] = (double)r.y * z.y; rz[2] = (double)r.z * z.z;
+    for (int k = 0; k < VM_PCG_ROWS; ++k) {
+        const int y = (blockIdx.y * VM_PCG_ROWS + k) * 4 + threadIdx.y;
+        if (x < L.w && y < L.h) {
+            const size_t ii = (size_t)y * L.w + x;
+            if (L.dg[ii] > 0) {
+                const float4 r = R[ii], z = Z[ii];
+                rz[0] += (double)r.x * z.x; rz[1] += (double)r.y * z.y; rz[2] += (double)r.z * z.z;
+            }
         }
     }
     block_sum3(rz[0], rz[1], rz[2], sc->rz_new);
@@ -376,6 +392,7 @@ __global__ void k_pcg_clear_rr(VmPcgScalars *sc)
 }
 
 dim3 grid2(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
+dim3 grid_pcg(int w, int h) { return dim3((w + 63) / 64, (h + 4 * VM_PCG_ROWS - 1) / (4 * VM_PCG_ROWS)); }
 const dim3 blk2(64, 4);
 
 } // namespace
@@ -421,24 +438,24 @@ void vm_mg_launch_coarsest(const VmMgLevel &L, float omega, int sweeps, hipStrea
 void vm_mg_launch_pcg_init(const VmMgLevel &L, const float4 *B, const float4 *X, float4 *R, VmPcgScalars *sc,
                            hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pcg_init, grid2(L.w, L.h), blk2, 0, s, L, B, X, R, sc);
+    hipLaunchKernelGGL(k_pcg_init, grid_pcg(L.w, L.h), blk2, 0, s, L, B, X, R, sc);
 }
 
 void vm_mg_launch_pcg_spmv(const VmMgLevel &L, const float4 *P, float4 *Q, VmPcgScalars *sc, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pcg_spmv, grid2(L.w, L.h), blk2, 0, s, L, P, Q, sc);
+    hipLaunchKernelGGL(k_pcg_spmv, grid_pcg(L.w, L.h), blk2, 0, s, L, P, Q, sc);
 }
 
 void vm_mg_launch_pcg_update(const VmMgLevel &L, float4 *X, float4 *R, const float4 *P, const float4 *Q,
                              VmPcgScalars *sc, hipStream_t s)
 {
     hipLaunchKernelGGL(k_pcg_clear_rr, dim3(1), dim3(64), 0, s, sc);
-    hipLaunchKernelGGL(k_pcg_update, grid2(L.w, L.h), blk2, 0, s, L, X, R, P, Q, sc);
+    hipLaunchKernelGGL(k_pcg_update, grid_pcg(L.w, L.h), blk2, 0, s, L, X, R, P, Q, sc);
 }
 
 void vm_mg_launch_pcg_dot(const VmMgLevel &L, const float4 *R, const float4 *Z, VmPcgScalars *sc, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pcg_dot, grid2(L.w, L.h), blk2, 0, s, L, R, Z, sc);
+    hipLaunchKernelGGL(k_pcg_dot, grid_pcg(L.w, L.h), blk2, 0, s, L, R, Z, sc);
 }
 
 void vm_mg_launch_pcg_dir(const VmMgLevel &L, float4 *P, const float4 *Z, VmPcgScalars *sc, int first,
