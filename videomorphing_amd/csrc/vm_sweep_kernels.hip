@@ -1416,49 +1416,52 @@ __device__ __forceinline__ uint32_t cell_hits(const uint32_t (*bits)[4], int bx0
 }
 
 // sums of cell (qx, qy) + the committed records flagged in `hits`, row-major (ssim_update,
-// morph.cu:951-988, and the tps.b scatter, :1006-1015, as a gather).  All record loads are
-// issued before the first is used; the slot loops end as soon as no lane of the wave has a
-// record left.
+// morph.cu:951-988, and the tps.b scatter, :1006-1015, as a gather).  The (at most 9) records
+// are fetched in two batches of 5 and 4 -- all loads of a batch are issued before the first is
+// used, and a batch is skipped when no lane of the wave has a record left; one batch of 9 would
+// cost 72 VGPRs and with them a workgroup per CU.
 __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__restrict__ r_a,
                                           const float4 *__restrict__ r_b, const float *s_tps, uint32_t hits, int qx,
                                           int qy, float2 &m, float2 &q, float &cr, float2 &tb)
 {
     const bool touched = hits != 0;
-    float4 ra[9], rb[9];
-    int bidx[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) // at most 9 pixels of one phase lie in a 5x5 window
-        bidx[k] = -1;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int half = 0; half < 2; ++half) {
         if (!__any(hits != 0))
             break;
-        const int b = hits ? __ffs(hits) - 1 : -1;
-        hits &= hits - 1;
-        bidx[k] = b;
-        const int bb = max(b, 0);
-        const int dy = (bb * 13) >> 6, dx = bb - dy * 5;
-        const int rsafe = b >= 0 ? (qy + dy - 2) * L.rs + (qx + dx - 2) : qy * L.rs + qx;
-        ra[k] = r_a[rsafe];
-        rb[k] = r_b[rsafe];
-    }
+        float4 ra[5], rb[5];
+        int bidx[5];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int b = bidx[k];
-        if (!__any(b >= 0))
-            break;
-        if (b < 0)
-            continue;
-        const int dy = (b * 13) >> 6, dx = b - dy * 5;
-        const int x = qx + dx - 2, y = qy + dy - 2;
-        m.x += ra[k].x;
-        m.y += ra[k].y;
-        q.x += ra[k].z;
-        q.y += ra[k].w;
-        cr += rb[k].x;
-        const float kk = s_tps[(border_class(y, L.h) * 5 + border_class(x, L.w)) * 25 + (4 - dy) * 5 + (4 - dx)];
-        tb.x += rb[k].y * kk;
-        tb.y += rb[k].z * kk;
+        for (int k = 0; k < 5; ++k) {
+            if (half == 1 && k == 4) { // 5 + 4: at most 9 pixels of one phase lie in a 5x5 window
+                bidx[k] = -1;
+                continue;
+            }
+            const int b = hits ? __ffs(hits) - 1 : -1;
+            hits &= hits - 1;
+            bidx[k] = b;
+            const int bb = max(b, 0);
+            const int dy = (bb * 13) >> 6, dx = bb - dy * 5;
+            const int rsafe = b >= 0 ? (qy + dy - 2) * L.rs + (qx + dx - 2) : qy * L.rs + qx;
+            ra[k] = r_a[rsafe];
+            rb[k] = r_b[rsafe];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int b = bidx[k];
+            if (b < 0)
+                continue;
+            const int dy = (b * 13) >> 6, dx = b - dy * 5;
+            const int x = qx + dx - 2, y = qy + dy - 2;
+            m.x += ra[k].x;
+            m.y += ra[k].y;
+            q.x += ra[k].z;
+            q.y += ra[k].w;
+            cr += rb[k].x;
+            const float kk = s_tps[(border_class(y, L.h) * 5 + border_class(x, L.w)) * 25 + (4 - dy) * 5 + (4 - dx)];
+            tb.x += rb[k].y * kk;
+            tb.y += rb[k].z * kk;
+        }
     }
     return touched;
 }
