@@ -845,7 +845,7 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
 // search, 16 candidates per round; without the dense path the kernel needs 134 instead of
 // 256 VGPRs (measured: pruned sweeps 5-8 % faster).
 template <bool DENSE>
-__global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
+__global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENSE ? 1 : 4))) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
                                                         VmKParams P, const uint32_t *__restrict__ tables,
                                                         int offx, int offy, uint32_t *__restrict__ flags,
                                                         uint32_t *__restrict__ stats, int iter_idx, int fixed_work,
