@@ -1,0 +1,66 @@
+"""Randomised parity: level sizes, boundary conditions, constraint counts and iteration counts
+drawn from a seeded generator (ragged sizes, single-tile levels, tiles cut by the border)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from videomorphing_amd import capi, morph, synth
+import test_gpu_parity as T
+
+pytestmark = pytest.mark.gpu
+
+STATE = ("v", "luma", "mean", "var", "cross", "value", "tps_b", "ui_b", "impmask")
+
+
+def _draw(rng, wmax, hmax):
+    w, h = int(rng.randint(10, wmax)), int(rng.randint(10, hmax))
+    ncons = int(rng.randint(0, 4))
+    cons = synth.make_constraints(w, h, ncons) if ncons and min(w, h) > 40 else ()
+    return w, h, int(rng.randint(0, 3)), cons
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_exact_sweeps_equal_the_oracle_on_random_levels(gpu_ctx, oracle, seed):
+    """EXACT, TILE and SPLIT schedules, 1-3 sweeps: every state array bit-identical to the oracle"""
+    rng = np.random.RandomState(seed)
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    try:
+        for trial in range(8):
+            w, h, bcond, cons = _draw(rng, 300, 120)
+            iters = int(rng.randint(1, 4))
+            for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT):
+                P = T._params(oracle, bcond=bcond)
+                lo, pyr, P = T._make_level(gpu_ctx, oracle, w, h, cons=cons, P=P, seed=trial)
+                for _ in range(iters):
+                    lo.optimize_iter(P)
+                gpu_ctx.set_tuning(sched, 0, 0)
+                capi.check(pyr._L.vm_optimize_level(pyr._h, 0, float(iters), None, 1, None))
+                T._assert_state_equal(lo, pyr[1])
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fast_step_equals_split_on_random_levels(gpu_ctx, oracle, seed):
+    """FAST: the one-launch-per-phase STEP schedule against the two-kernel SPLIT schedule, bitwise"""
+    rng = np.random.RandomState(seed)
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    try:
+        for trial in range(12):
+            w, h, bcond, cons = _draw(rng, 420, 160)
+            iters = float(rng.randint(1, 7))
+            res = []
+            for sched in (capi.SWEEP_SPLIT, capi.SWEEP_STEP):
+                P = T._params(oracle, bcond=bcond)
+                lo, pyr, P = T._make_level(gpu_ctx, oracle, w, h, cons=cons, P=P, seed=trial)
+                gpu_ctx.set_tuning(sched, 0, 0)
+                pr = capi.Progress()
+                capi.check(pyr._L.vm_optimize_level(pyr._h, 0, iters, None, 1, C.byref(pr)))
+                res.append(([pyr[1].field(n).copy() for n in STATE], pr.commits))
+            assert res[0][1] == res[1][1], (w, h, bcond, iters)
+            for n, a, b in zip(STATE, res[0][0], res[1][0]):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, w, h, bcond, iters)
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
