@@ -207,3 +207,13 @@ def test_fast_solve_tracks_exact_at_1080p(gpu_ctx):
     d = synth.displacement(w, h)
     err = [np.sqrt(((out[k] - d) ** 2).sum(-1).mean()) for k in (capi.MATH_EXACT, capi.MATH_FAST)]
     assert abs(err[0] - err[1]) < 0.05, err
+    # the rendered halfway frame from either field: >= 99 % of the bytes within 2 levels
+    ex = int(0.1 * max(w, h))
+    rgb0, rgb1 = synth.make_rgb_pair(w, h)
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    frames = []
+    for k in (capi.MATH_EXACT, capi.MATH_FAST):
+        fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), out[k], None)
+        frames.append(fr.render_halfway(0.5, 0.5, 1).astype(np.int32))
+    dpx = np.abs(frames[0] - frames[1])
+    assert (dpx <= 2).mean() >= 0.99 and dpx.mean() < 0.5, ((dpx <= 2).mean(), dpx.mean())
