@@ -199,8 +199,15 @@ extern "C" int vm_device_info(vm_ctx *c, char *name256, int *cus, uint64_t *hbm)
 static void level_free(vm_level &l)
 {
     hipFree(l.slab);
-    l.slab = nullptr;
+    hipFree(l.ws);
+    l.slab = l.ws = nullptr;
     l.has_state = false;
+    VmLevelView &V = l.view;
+    V.rec_a = V.rec_b = V.rec_a2 = V.rec_b2 = nullptr;
+    V.rec_tag = V.rec_tag2 = nullptr;
+    V.mean2 = V.var2 = V.tps_b2 = nullptr;
+    V.cross2 = V.value2 = nullptr;
+    V.impmask2 = nullptr;
 }
 
 // one slab per level: every array starts on a 256-byte boundary
@@ -211,8 +218,7 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
     size_t off = 0;
     size_t o_v = off; off += al(n * 8);
     size_t o_img0 = off, o_img1 = off, o_luma = off, o_mean = off, o_var = off, o_tpsb = off,
-           o_uib = off, o_cross = off, o_value = off, o_uiaxy = off, o_imp = off, o_rst = off, o_rsp = off,
-           o_tag = off, o_tag2 = off, o_rst2 = off, o_rsp2 = off, o_mean2 = off, o_var2 = off, o_tpsb2 = off, o_cross2 = off, o_value2 = off, o_imp2 = off;
+           o_uib = off, o_cross = off, o_value = off, o_uiaxy = off, o_imp = off;
     if (with_images) {
         o_img0 = off; off += al(n * 4);
         o_img1 = off; off += al(n * 4);
@@ -225,18 +231,6 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
         o_value = off; off += al(n * 4);
         o_uiaxy = off; off += al(n * 4);
         o_imp = off; off += al((size_t)l.imp_rs * l.imp_rows * 4);
-        o_rst = off; off += al(n * 16);
-        o_rsp = off; off += al(n * 16);
-        o_tag = off; off += al(n * 4);
-        o_tag2 = off; off += al(n * 4);
-        o_rst2 = off; off += al(n * 16);
-        o_rsp2 = off; off += al(n * 16);
-        o_mean2 = off; off += al(n * 8);
-        o_var2 = off; off += al(n * 8);
-        o_tpsb2 = off; off += al(n * 8);
-        o_cross2 = off; off += al(n * 4);
-        o_value2 = off; off += al(n * 4);
-        o_imp2 = off; off += al((size_t)l.imp_rs * l.imp_rows * 4);
     }
     VM_HIP(hipMalloc((void **)&l.slab, off));
     // stream-ordered: the context's stream does not synchronise with the null stream
@@ -255,26 +249,45 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
         V.ui_b = (float2 *)(b + o_uib); V.cross = (float *)(b + o_cross);
         V.value = (float *)(b + o_value); V.ui_axy = (float *)(b + o_uiaxy);
         V.impmask = (uint32_t *)(b + o_imp);
-        V.rec_a = (float4 *)(b + o_rst);
-        V.rec_b = (float4 *)(b + o_rsp);
-        V.rec_tag = (uint32_t *)(b + o_tag);
-        V.rec_tag2 = (uint32_t *)(b + o_tag2);
-        V.rec_a2 = (float4 *)(b + o_rst2); V.rec_b2 = (float4 *)(b + o_rsp2);
-        V.mean2 = (float2 *)(b + o_mean2); V.var2 = (float2 *)(b + o_var2);
-        V.tps_b2 = (float2 *)(b + o_tpsb2); V.cross2 = (float *)(b + o_cross2);
-        V.value2 = (float *)(b + o_value2); V.impmask2 = (uint32_t *)(b + o_imp2);
     } else {
         V.img0 = V.img1 = nullptr;
         V.luma = V.mean = V.var = V.tps_b = V.ui_b = nullptr;
         V.cross = V.value = V.ui_axy = nullptr;
         V.impmask = nullptr;
-        V.rec_a = V.rec_b = nullptr;
-        V.rec_tag = V.rec_tag2 = nullptr;
-        V.rec_a2 = V.rec_b2 = nullptr;
-        V.mean2 = V.var2 = V.tps_b2 = nullptr;
-        V.cross2 = V.value2 = nullptr;
-        V.impmask2 = nullptr;
     }
+    V.rec_a = V.rec_b = V.rec_a2 = V.rec_b2 = nullptr;
+    V.rec_tag = V.rec_tag2 = nullptr;
+    V.mean2 = V.var2 = V.tps_b2 = nullptr;
+    V.cross2 = V.value2 = nullptr;
+    V.impmask2 = nullptr;
+    return VM_OK;
+}
+
+// The workspace of the SPLIT / STEP schedules (two record sets, the second copy of the sums
+// and of the mask: 104 B per pixel against 72 B of solver state) is allocated the first time
+// a level is swept with one of them -- in practice the small levels only.
+static int level_ensure_ws(vm_ctx *c, vm_level &l)
+{
+    if (l.ws) return VM_OK;
+    const size_t n = (size_t)l.rs * l.h, nimp = (size_t)l.imp_rs * l.imp_rows;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t total = 2 * al(n * 4) + 4 * al(n * 16) + 3 * al(n * 8) + 2 * al(n * 4) + al(nimp * 4);
+    VM_HIP(hipMalloc((void **)&l.ws, total));
+    VM_HIP(hipMemsetAsync(l.ws, 0, total, c->stream));
+    char *b = (char *)l.ws;
+    VmLevelView &V = l.view;
+    V.rec_tag = (uint32_t *)b; b += al(n * 4);
+    V.rec_tag2 = (uint32_t *)b; b += al(n * 4);
+    V.rec_a = (float4 *)b; b += al(n * 16);
+    V.rec_b = (float4 *)b; b += al(n * 16);
+    V.rec_a2 = (float4 *)b; b += al(n * 16);
+    V.rec_b2 = (float4 *)b; b += al(n * 16);
+    V.mean2 = (float2 *)b; b += al(n * 8);
+    V.var2 = (float2 *)b; b += al(n * 8);
+    V.tps_b2 = (float2 *)b; b += al(n * 8);
+    V.cross2 = (float *)b; b += al(n * 4);
+    V.value2 = (float *)b; b += al(n * 4);
+    V.impmask2 = (uint32_t *)b;
     return VM_OK;
 }
 
@@ -591,6 +604,15 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     }
     hipStream_t s = c->stream;
     {
+        // levels that may run the SPLIT / STEP schedules need their workspace before the views
+        // are copied to the device
+        const int tiles0 = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
+        if (c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP ||
+            (c->sweep_mode == VM_SWEEP_AUTO && tiles0 * n <= 64))
+            for (int i = 0; i < n; ++i) {
+                int rc = level_ensure_ws(c, ps[i]->lv[lvl]);
+                if (rc != VM_OK) return rc;
+            }
         std::vector<VmLevelView> hv(n);
         for (int i = 0; i < n; ++i) hv[i] = ps[i]->lv[lvl].view;
         VM_HIP(hipMemcpyAsync(c->views, hv.data(), (size_t)n * sizeof(VmLevelView), hipMemcpyHostToDevice, s));
@@ -617,7 +639,7 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     // work on the same state in HBM, so the choice can change from batch to batch.
     const bool may_split = c->sweep_mode != VM_SWEEP_TILE && tiles_per_pass * n <= 64;
     double cand_prev = 1e9; // line searches per iteration in the previous batch (first batch: dense)
-    if (may_split) // epochs restart with every call: forget old records
+    if (may_split || c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP) // epochs restart with every call: forget old records
         for (int i = 0; i < n; ++i)
         {
             VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_tag, 0, (size_t)l0.rs * l0.h * 4, s));

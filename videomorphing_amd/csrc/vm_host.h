@@ -54,6 +54,7 @@ struct vm_level {
     int w = 0, h = 0, rs = 0, imp_rs = 0, imp_rows = 0;
     void *slab = nullptr;
     size_t slab_bytes = 0;
+    void *ws = nullptr;              // SPLIT / STEP workspace, allocated on first use (vm_api.cpp)
     bool has_state = false;
     VmLevelView view{};
 };
