@@ -517,13 +517,13 @@ extern "C" int vm_init_level(vm_pyr *p, int lvl, int w0, int h0, const vm_constr
 // (VM_NO_GRAPH set, or capture/instantiation failed once): the caller launches eagerly.
 #define VM_GRAPH_ITERS 8
 static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, int cap, int fixed_work, int threads,
-                                  int dense, const uint32_t *imp0, int imp_rs0, const VmKParams &P)
+                                  int dense, const VmKParams &P)
 {
     if (c->use_graphs < 0) c->use_graphs = getenv("VM_NO_GRAPH") ? 0 : 1;
     if (!c->use_graphs) return nullptr;
     for (auto &g : c->graphs)
         if (g.exact == exact && g.n == n && g.w == w && g.h == h && g.cap == cap && g.fixed_work == fixed_work &&
-            g.threads == threads && g.dense == dense && g.imp0 == imp0 && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
+            g.threads == threads && g.dense == dense && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
             memcmp(&g.kp, &c->kp, sizeof(c->kp)) == 0)
             return g.exec;
     if (!c->iter_dev && hipMalloc((void **)&c->iter_dev, sizeof(int)) != hipSuccess) {
@@ -537,8 +537,8 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
     if (ok) {
         for (int it = 0; it < VM_GRAPH_ITERS; ++it) {
             for (int k = 0; k < 4; ++k) {
-                if (exact) vm_launch_optimize_exact(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, c->iter_dev, dense, imp0, imp_rs0, c->stream);
-                else vm_launch_optimize_fast(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, c->iter_dev, dense, imp0, imp_rs0, c->stream);
+                if (exact) vm_launch_optimize_exact(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, c->iter_dev, dense, c->stream);
+                else vm_launch_optimize_fast(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, c->iter_dev, dense, c->stream);
             }
         }
         if (exact) vm_launch_next_iter_exact(c->iter_dev, 0, VM_GRAPH_ITERS, c->stream);
@@ -556,7 +556,7 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
         for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
         c->graphs.clear();
     }
-    c->graphs.push_back({exact, n, w, h, cap, fixed_work, threads, dense, imp0, c->views, c->flags, c->stats, c->kp, exec});
+    c->graphs.push_back({exact, n, w, h, cap, fixed_work, threads, dense, c->views, c->flags, c->stats, c->kp, exec});
     return exec;
 }
 
@@ -646,7 +646,6 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
             VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_tag2, 0, (size_t)l0.rs * l0.h * 4, s));
         }
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
-    const uint32_t *imp0 = n == 1 ? l0.view.impmask : nullptr; // the mask test's shortcut past the view
     std::vector<int> executed(n, cap), improving(n, 1), stopped(n, 0);
     std::vector<double> st_tiles(n, 0.0), st_cand(n, 0.0), st_commit(n, 0.0);
     int done = 0, launches = 0;
@@ -673,7 +672,7 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
         int it0 = done;
         if (!split && nb >= VM_GRAPH_ITERS) {
             // TILE batch: whole groups of VM_GRAPH_ITERS iterations are graph replays
-            if (hipGraphExec_t ge = sweep_graph(c, exact, n, l0.w, l0.h, cap, fixed_work, threads, dense, imp0, l0.imp_rs, P)) {
+            if (hipGraphExec_t ge = sweep_graph(c, exact, n, l0.w, l0.h, cap, fixed_work, threads, dense, P)) {
                 if (exact) vm_launch_next_iter_exact(c->iter_dev, 1, done, s);
                 else vm_launch_next_iter_fast(c->iter_dev, 1, done, s);
                 for (; it0 + VM_GRAPH_ITERS <= done + nb; it0 += VM_GRAPH_ITERS) {
@@ -698,8 +697,8 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
                     else vm_launch_optimize_split_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
                     launches += 8;
                 } else {
-                    if (exact) vm_launch_optimize_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, imp0, l0.imp_rs, s);
-                    else vm_launch_optimize_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, imp0, l0.imp_rs, s);
+                    if (exact) vm_launch_optimize_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, s);
+                    else vm_launch_optimize_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, s);
                     ++launches;
                 }
             }

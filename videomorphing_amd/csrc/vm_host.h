@@ -41,7 +41,6 @@ struct vm_ctx {
     struct SweepGraph {
         bool exact;
         int n, w, h, cap, fixed_work, threads, dense;
-        const void *imp0;
         const void *views, *flags, *stats;
         vm_kern_params kp;
         hipGraphExec_t exec;

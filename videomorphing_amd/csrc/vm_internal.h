@@ -63,8 +63,7 @@ struct VmKParams {
                                      const VmKParams &P, const uint32_t *tables, int offx,    \
                                      int offy, uint32_t *flags, uint32_t *stats, int iter_idx,\
                                      int fixed_work, int threads, const int *iter_dev,        \
-                                     int dense, const uint32_t *imp0, int imp_rs0,            \
-                                     hipStream_t s);                                          \
+                                     int dense, hipStream_t s);                               \
     void vm_launch_next_iter_##SUFFIX(int *iter_dev, int set, int value, hipStream_t s);      \
     void vm_launch_optimize_split_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w, \
                                            int h, const VmKParams &P, const uint32_t *tables, \

@@ -849,8 +849,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
                                                         VmKParams P, const uint32_t *__restrict__ tables,
                                                         int offx, int offy, uint32_t *__restrict__ flags,
                                                         uint32_t *__restrict__ stats, int iter_idx, int fixed_work,
-                                                        const int *__restrict__ iter_dev,
-                                                        const uint32_t *__restrict__ imp0, int imp_rs0, int w0, int h0)
+                                                        const int *__restrict__ iter_dev)
 {
     __shared__ TileLds S;
     // replayed from a hipGraph the launch can only carry the iteration's position inside the
@@ -875,20 +874,16 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
         return;
 
-    // (single pair: geometry and mask pointer also travel as launch arguments, so that the mask
-    // test of a pruned tile does not wait for the view to arrive first)
-    const uint32_t *impmask = imp0 ? imp0 : L.impmask;
-    const int lw = imp0 ? w0 : L.w, lh = imp0 ? h0 : L.h, imp_rs = imp0 ? imp_rs0 : L.imp_rs;
     const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
-    if (ox >= lw || oy >= lh)
+    if (ox >= L.w || oy >= L.h)
         return;
 
     // --- improving-mask words of the tile and its ring of neighbour blocks ---
-    const MaskGeom g = mask_geom(lw, lh, ox, oy);
+    const MaskGeom g = mask_geom(L, ox, oy);
     uint32_t mymask = 0;
     if (tid < g.nbx * g.nby) {
         int mx = tid % g.nbx, my = tid / g.nbx;
-        mymask = impmask[(g.by0 + my + 1) * imp_rs + (g.bx0 + mx + 1)];
+        mymask = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)];
         S.mask[my][mx] = mymask;
     }
     // tile-level early out: no set bit anywhere near the tile means no pixel of it is a
@@ -1764,21 +1759,19 @@ extern "C" int vm_dbg_prof_read(void *dst, size_t bytes)
 void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
                              const uint32_t *tables, int offx, int offy, uint32_t *flags, uint32_t *stats,
                              int iter_idx, int fixed_work, int threads, const int *iter_dev, int dense,
-                             const uint32_t *imp0, int imp_rs0, hipStream_t s)
+                             hipStream_t s)
 {
     dim3 b(threads), g((w + VM_PITCH_X - 1) / VM_PITCH_X, (h + VM_PITCH_Y - 1) / VM_PITCH_Y, nbatch);
-    if (nbatch != 1)
-        imp0 = nullptr; // a batch: every pair has its own mask, reached through its view
 #if !VM_EXACT
     if (!dense) {
         hipLaunchKernelGGL(SUF(k_optimize)<false>, g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats,
-                           iter_idx, fixed_work, iter_dev, imp0, imp_rs0, w, h);
+                           iter_idx, fixed_work, iter_dev);
         return;
     }
 #endif
     (void)dense;
     hipLaunchKernelGGL(SUF(k_optimize)<true>, g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats, iter_idx,
-                       fixed_work, iter_dev, imp0, imp_rs0, w, h);
+                       fixed_work, iter_dev);
 }
 
 // the device iteration counter of graph-replayed sweeps: set it to, or advance it by, `value`
