@@ -14,10 +14,14 @@ STATE = ("v", "luma", "mean", "var", "cross", "value", "tps_b", "ui_b", "impmask
 
 
 def _draw(rng, wmax, hmax):
+    """size, kernel parameters (boundary condition, weights over three decades, clamp, eps), constraints"""
     w, h = int(rng.randint(10, wmax)), int(rng.randint(10, hmax))
     ncons = int(rng.randint(0, 4))
     cons = synth.make_constraints(w, h, ncons) if ncons and min(w, h) > 40 else ()
-    return w, h, int(rng.randint(0, 3)), cons
+    kw = dict(bcond=int(rng.randint(0, 3)), w_tps=float(10 ** rng.uniform(-3, 0)), w_ssim=float(10 ** rng.uniform(0, 3)),
+              w_ui=float(10 ** rng.uniform(3, 6)), ssim_clamp=float(rng.choice([0.0, 0.0, 0.3])),
+              eps=float(rng.choice([0.01, 0.01, 0.003, 0.03])))
+    return w, h, kw, cons
 
 
 @pytest.mark.parametrize("seed", [11, 12])
@@ -27,10 +31,10 @@ def test_exact_sweeps_equal_the_oracle_on_random_levels(gpu_ctx, oracle, seed):
     gpu_ctx.set_math_mode(capi.MATH_EXACT)
     try:
         for trial in range(8):
-            w, h, bcond, cons = _draw(rng, 300, 120)
+            w, h, kw, cons = _draw(rng, 300, 120)
             iters = int(rng.randint(1, 4))
             for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT):
-                P = T._params(oracle, bcond=bcond)
+                P = T._params(oracle, **kw)
                 lo, pyr, P = T._make_level(gpu_ctx, oracle, w, h, cons=cons, P=P, seed=trial)
                 for _ in range(iters):
                     lo.optimize_iter(P)
@@ -48,19 +52,19 @@ def test_fast_step_equals_split_on_random_levels(gpu_ctx, oracle, seed):
     gpu_ctx.set_math_mode(capi.MATH_FAST)
     try:
         for trial in range(12):
-            w, h, bcond, cons = _draw(rng, 420, 160)
+            w, h, kw, cons = _draw(rng, 420, 160)
             iters = float(rng.randint(1, 7))
             res = []
             for sched in (capi.SWEEP_SPLIT, capi.SWEEP_STEP):
-                P = T._params(oracle, bcond=bcond)
+                P = T._params(oracle, **kw)
                 lo, pyr, P = T._make_level(gpu_ctx, oracle, w, h, cons=cons, P=P, seed=trial)
                 gpu_ctx.set_tuning(sched, 0, 0)
                 pr = capi.Progress()
                 capi.check(pyr._L.vm_optimize_level(pyr._h, 0, iters, None, 1, C.byref(pr)))
                 res.append(([pyr[1].field(n).copy() for n in STATE], pr.commits))
-            assert res[0][1] == res[1][1], (w, h, bcond, iters)
+            assert res[0][1] == res[1][1], (w, h, kw, iters)
             for n, a, b in zip(STATE, res[0][0], res[1][0]):
-                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, w, h, bcond, iters)
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, w, h, kw, iters)
     finally:
         gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
         gpu_ctx.set_math_mode(capi.MATH_EXACT)
