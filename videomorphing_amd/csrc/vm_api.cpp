@@ -623,12 +623,11 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     const bool exact = c->math_mode == VM_MATH_EXACT;
     // FAST kernels are built for at most 512 threads (256-VGPR budget: the register-cached
     // window sums must not spill), EXACT ones (one pixel per lane) for up to 1024
-    const int threads = std::min(c->sweep_threads ? c->sweep_threads : (exact ? 256 : 512), exact ? 1024 : 512);
+    const int threads = std::min(c->sweep_threads ? c->sweep_threads : 512, exact ? 1024 : 512);
     const int tiles_per_pass = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
     // SPLIT schedule: workgroups per tile so that a pass roughly fills the 256 CUs
     // (FAST: the lean line search gives every candidate 32 lanes, 16 candidates per workgroup)
-    const int parts = c->sweep_parts ? c->sweep_parts
-                                     : (exact ? std::max(1, std::min(16, 256 / (tiles_per_pass * n))) : 16);
+    const int parts = c->sweep_parts ? c->sweep_parts : 16;
     // Schedule, re-decided per batch of iterations (AUTO).  TILE: 4 launches per iteration, a
     // tile's four phases inside one workgroup -- unbeatable when a pass touches nothing (24 us
     // per converged iteration) or when there are enough tiles to fill the chip.  SPLIT (EXACT)

@@ -111,7 +111,8 @@ struct GlbSrc {
 
 #if VM_EXACT
 // ---- EXACT: literal ssim_change (morph.cu:671-728) + energy_change (:730-761),
-// flag == false; one lane per pixel, neighbours visited in row-major order
+// flag == false; one lane per pixel, neighbours visited in row-major order (dense
+// phases; sparse phases and the SPLIT schedule use energy_x32 below: same bits)
 #define VM_SWEEP_T 1024
 #define VM_MIN_FANOUT 1
 #define VM_MAX_FANOUT 1
@@ -347,14 +348,12 @@ __device__ __forceinline__ bool pixel_locked(const VmLevelView &L, int bcond, in
 // optimize_pixel (morph.cu:1030-1083) after the mask test: gradient, fold-over bound,
 // golden-section search.  All L lanes of the pixel's group run it in lockstep and
 // agree bit for bit.  Returns true and the accepted step when the energy drops.
-template <bool INTERIOR, class Src>
-__device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P, const Src &src,
-                                       const PixelCtx &c, int sub, int Lf, float2 &step VM_TS_ARG)
+template <class Energy>
+__device__ __forceinline__ bool decide_with(const VmLevelView &L, const VmKParams &P, const PixelCtx &c,
+                                            const Energy &energy, float2 &step VM_TS_ARG)
 {
-    NbCache nb;
-    nb_load<INTERIOR>(nb, L, src, c, sub, Lf);
     VM_TS(4);
-#define ENERGY(DX, DY) energy_change<INTERIOR>(L, P, src, nb, c, (DX), (DY), Lf)
+#define ENERGY(DX, DY) energy((DX), (DY))
     // The energy is evaluated at exactly two places of the instruction stream (not at
     // the reference's seven): the sweep kernels must stay inside the instruction cache.
     // compute_gradient, morph.cu:763-778: g = -(E(+eps x) - E(-eps x), E(+eps y) - E(-eps y))
@@ -431,6 +430,82 @@ __device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P,
     return true;
 }
 
+// one lane (EXACT) or L lanes (FAST dense path) per pixel
+template <bool INTERIOR, class Src>
+__device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P, const Src &src,
+                                       const PixelCtx &c, int sub, int Lf, float2 &step VM_TS_ARG)
+{
+    NbCache nb;
+    nb_load<INTERIOR>(nb, L, src, c, sub, Lf);
+    return decide_with(
+        L, P, c, [&](float dx, float dy) { return energy_change<INTERIOR>(L, P, src, nb, c, dx, dy, Lf); },
+        step VM_TS_PASS);
+}
+
+#if VM_EXACT
+// ---------------------------------------------------------------------------
+// EXACT on 32 lanes per pixel, still bit-identical to the one-lane evaluation: lane k < 25
+// computes the SSIM term of window neighbour k (the expensive part: IEEE divisions and square
+// roots), every lane then adds the 25 differences in the reference's row-major order -- the
+// terms of neighbours outside the image are +0, and x + (+0) == x for every x the running
+// sum can hold (it starts at +0 and can never become -0) -- so all lanes end with the bits the
+// sequential loop produces.  Taps, quadratic terms, fold-over test and the golden-section
+// control run redundantly on every lane, exactly as written for one lane.
+struct NbX {
+    float2 m, q;
+    float cr, val, counter;
+    bool ok;
+};
+
+template <class Src>
+__device__ __forceinline__ void nbx_load(NbX &nb, const VmLevelView &L, const Src &src, const PixelCtx &c, int sub)
+{
+    const int i = (sub * 13) >> 6, jj = sub - i * 5; // sub / 5, sub % 5 for sub < 32
+    const int qx = c.px + jj - 2, qy = c.py + i - 2;
+    nb.ok = sub < 25 && qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
+    src.load(nb.ok ? i : 2, nb.ok ? jj : 2, nb.m, nb.q, nb.cr, nb.val);
+    nb.counter = nb.ok ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
+}
+
+__device__ __forceinline__ float energy_x32(const VmLevelView &L, const VmKParams &P, const NbX &nb,
+                                            const PixelCtx &c, float dx, float dy)
+{
+    const float vx = c.v.x + dx, vy = c.v.y + dy;
+    const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - vx + 0.5f, c.py - vy + 0.5f);
+    const float ly = tap(L.img1, L.w, L.h, L.rs, c.px + vx + 0.5f, c.py + vy + 0.5f);
+    const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
+    const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
+    const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
+    const float dcross = lx * ly - c.old_luma.x * c.old_luma.y;
+    float d = 0.0f;
+    if (nb.ok) {
+        const float ns = ssim_value(nb.m.x + dmx, nb.m.y + dmy, nb.q.x + dvx, nb.q.y + dvy, nb.cr + dcross,
+                                    nb.counter, P.ssim_clamp);
+        d = nb.val - ns;
+    }
+    float change = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k)
+        change += __shfl(d, k, 32);
+    float v_tps = c.tps_axy * (dx * dx + dy * dy);
+    v_tps += c.tps_b.x * dx;
+    v_tps += c.tps_b.y * dy;
+    float v_ui = c.ui_axy * (dx * dx + dy * dy);
+    v_ui += c.ui_b.x * dx;
+    v_ui += c.ui_b.y * dy;
+    return (P.w_ui * v_ui + P.w_ssim * change + 0.0f) * L.inv_wh + P.w_tps * v_tps;
+}
+
+template <class Src>
+__device__ __forceinline__ bool decide_x32(const VmLevelView &L, const VmKParams &P, const Src &src,
+                                           const PixelCtx &c, int sub, float2 &step VM_TS_ARG)
+{
+    NbX nb;
+    nbx_load(nb, L, src, c, sub);
+    return decide_with(
+        L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step VM_TS_PASS);
+}
+#endif
 
 #if !VM_EXACT
 // ---------------------------------------------------------------------------
@@ -998,6 +1073,30 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
                     }
                     }
                 } else
+#else
+                if (n_act * 32 <= 4 * T) {
+                    // up to four rounds of T / 32 candidates on 32 lanes each (decide_x32)
+                    for (int base = 0; base < n_act; base += T / 32) {
+                        const int li = base + (tid >> 5), sub = tid & 31;
+                        const int slot = S.list[min(li, n_act - 1)];
+                        const int tx = slot & 31, ty = slot >> 5;
+                        const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
+                        if (li < n_act) {
+                            PixelCtx c;
+                            ctx_load(c, L, S.tps, px, py);
+                            LdsSrc src{&S, (ty * 2 + pi) * VM_HALO_W + (tx * 2 + pj)};
+                            c.tps_b = S.tpsb[src.hc + 2 * VM_HALO_W + 2];
+                            float2 step;
+#ifdef VM_PROF
+                            unsigned long long ts[16];
+#endif
+                            if (decide_x32(L, P, src, c, sub, step VM_TS_PASS) && sub == 0) {
+                                S.d_step[slot] = step;
+                                S.d_ok[slot] = 1;
+                            }
+                        }
+                    }
+                } else
 #endif
                 if (DENSE) {
                 int Lf = VM_MIN_FANOUT;
@@ -1180,13 +1279,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
     const int n_mine = (n_hit - part + parts - 1) / parts;
     if (n_mine <= 0)
         return;
-#if VM_EXACT
-    int Lf = VM_MIN_FANOUT;
-    while (Lf * 2 <= VM_MAX_FANOUT && Lf * 2 * n_mine <= T)
-        Lf *= 2;
-#else
-    const int Lf = 32; // SPLIT is the latency-bound regime: always the lean line search
-#endif
+    const int Lf = 32; // SPLIT is the latency-bound regime: always 32 lanes per candidate
     const int slots = T / Lf;
     const int sub = tid & (Lf - 1), grp = tid / Lf;
     for (int base = 0; base < n_mine; base += slots) {
@@ -1205,8 +1298,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
                 c.tps_b = L.tps_b[c.idx];
                 GlbSrc src{&L, (py - 2) * L.rs + (px - 2)};
 #if VM_EXACT
-                const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step VM_TS_PASS)
-                                              : decide<false>(L, P, src, c, sub, Lf, step VM_TS_PASS);
+                (void)wave_interior;
+                const bool ok = decide_x32(L, P, src, c, sub, step VM_TS_PASS);
                 if (ok) { // the lumas commit_pixel_motion samples (morph.cu:997-1003)
                     const float nvx = c.v.x + step.x, nvy = c.v.y + step.y;
                     luma.x = tap(L.img0, L.w, L.h, L.rs, px - nvx + 0.5f, py - nvy + 0.5f);
