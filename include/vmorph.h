@@ -110,8 +110,8 @@ int  vm_set_math_mode(vm_ctx *ctx, int mode);
  * per tile-offset pass, one workgroup per tile; VM_SWEEP_SPLIT = two launches per
  * phase (line searches, then the commit), a tile's candidates spread over `parts`
  * workgroups (small levels); VM_SWEEP_STEP = one launch per phase, the commit of a
- * phase folded into the next phase's launch (VM_MATH_FAST only; VM_MATH_EXACT runs
- * SPLIT instead); VM_SWEEP_AUTO picks per batch of iterations.
+ * phase folded into the next phase's launch; VM_SWEEP_AUTO picks per batch of
+ * iterations.
  * threads/parts: 0 = automatic. */
 enum { VM_SWEEP_AUTO = 0, VM_SWEEP_TILE = 1, VM_SWEEP_SPLIT = 2, VM_SWEEP_STEP = 3 };
 int  vm_set_tuning(vm_ctx *ctx, int sweep_mode, int threads, int parts);

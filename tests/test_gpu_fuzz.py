@@ -26,14 +26,14 @@ def _draw(rng, wmax, hmax):
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_exact_sweeps_equal_the_oracle_on_random_levels(gpu_ctx, oracle, seed):
-    """EXACT, TILE and SPLIT schedules, 1-3 sweeps: every state array bit-identical to the oracle"""
+    """EXACT, TILE / SPLIT / STEP schedules, 1-3 sweeps: every state array bit-identical to the oracle"""
     rng = np.random.RandomState(seed)
     gpu_ctx.set_math_mode(capi.MATH_EXACT)
     try:
         for trial in range(8):
             w, h, kw, cons = _draw(rng, 300, 120)
             iters = int(rng.randint(1, 4))
-            for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT):
+            for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP):
                 P = T._params(oracle, **kw)
                 lo, pyr, P = T._make_level(gpu_ctx, oracle, w, h, cons=cons, P=P, seed=trial)
                 for _ in range(iters):

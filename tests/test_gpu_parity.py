@@ -87,14 +87,14 @@ def test_sweep_exact(gpu_ctx, oracle, w, h, iters):
 @pytest.mark.parametrize("w,h,parts,threads", [(96, 64, 8, 1024), (150, 97, 3, 256), (69, 21, 1, 512), (200, 40, 5, 1024)])
 def test_sweep_exact_split_schedule(gpu_ctx, oracle, w, h, parts, threads):
     """the SPLIT schedule (decide/commit kernels, a tile's candidates spread over `parts`
-    workgroups) gives the same bits as the oracle, and mixing schedules between calls
-    is seamless (both work on the same state in HBM)"""
+    workgroups) and the STEP schedule (one launch per phase) give the same bits as the oracle,
+    and mixing schedules between calls is seamless (all work on the same state in HBM)"""
     gpu_ctx.set_math_mode(capi.MATH_EXACT)
     cons = synth.make_constraints(w, h, 4)
     P = _params(oracle, bcond=capi.BCOND_BORDER)
     lo, pyr, P = _make_level(gpu_ctx, oracle, w, h, cons=cons, P=P)
     try:
-        for it, mode in enumerate([capi.SWEEP_SPLIT, capi.SWEEP_SPLIT, capi.SWEEP_TILE, capi.SWEEP_SPLIT]):
+        for it, mode in enumerate([capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_TILE, capi.SWEEP_STEP, capi.SWEEP_SPLIT]):
             gpu_ctx.set_tuning(mode, threads, parts)
             imp_o = lo.optimize_iter(P)
             pr = capi.Progress()

@@ -18,7 +18,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
     cons = synth.make_constraints(w, h, ncons) if ncons and min(w, h) > 40 else ()
     kw = dict(w_tps=float(10 ** rng.uniform(-3, 0)), w_ssim=float(10 ** rng.uniform(0, 3)), w_ui=float(10 ** rng.uniform(3, 6)),
               ssim_clamp=float(rng.choice([0.0, 0.0, 0.3])), eps=float(rng.choice([0.01, 0.01, 0.003, 0.03])))
-    for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT):
+    for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP):
         P = T._params(O, bcond=bcond, **kw)
         lo, pyr, P = T._make_level(ctx, O, w, h, cons=cons, P=P, seed=trial)
         for _ in range(iters):

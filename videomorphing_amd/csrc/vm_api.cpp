@@ -659,9 +659,9 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     while (done < cap) {
         const int nb = std::min(batch, cap - done);
         const bool split = c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP ||
-                           (may_split && cand_prev >= (exact ? 1500.0 : 200.0) * n);
-        // FAST: the one-launch-per-phase STEP schedule unless the two-kernel SPLIT is forced
-        const bool step = split && !exact && c->sweep_mode != VM_SWEEP_SPLIT;
+                           (may_split && cand_prev >= 200.0 * n);
+        // the one-launch-per-phase STEP schedule unless the two-kernel SPLIT is forced
+        const bool step = split && c->sweep_mode != VM_SWEEP_SPLIT;
         // TILE (FAST): the register-light kernel variant once fewer than a tenth of the pixels
         // are searched per iteration (after the first sweep of a level, typically)
         const int dense = exact || getenv("VM_TILE_DENSE") || cand_prev >= 0.1 * l0.w * l0.h * n;
@@ -685,9 +685,9 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
                 if (step) {
                     for (int ph = 0; ph < 4; ++ph, ++sb) {
                         const uint32_t epoch = 1u + (uint32_t)((it * 4 + k) * 4 + ph);
-                        vm_launch_optimize_step_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1],
-                                                     ph >> 1, ph & 1, epoch, sb == 0 ? 0u : epoch - 1u, sb & 1, 1,
-                                                     c->flags, c->stats, it, fixed_work, threads, parts, s);
+                        (exact ? vm_launch_optimize_step_exact : vm_launch_optimize_step_fast)(
+                            c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], ph >> 1, ph & 1, epoch,
+                            sb == 0 ? 0u : epoch - 1u, sb & 1, 1, c->flags, c->stats, it, fixed_work, threads, parts, s);
                         last_epoch = epoch;
                     }
                     launches += 4;
@@ -702,8 +702,9 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
                 }
             }
         if (step) { // fold the last phase's records in place: copy 0 is complete again
-            vm_launch_optimize_step_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, 0, 0, 0, 0, 0u, last_epoch, 2, 0,
-                                         c->flags, c->stats, done + nb - 1, fixed_work, threads, parts, s);
+            (exact ? vm_launch_optimize_step_exact : vm_launch_optimize_step_fast)(
+                c->views, n, cap, l0.w, l0.h, P, c->tables, 0, 0, 0, 0, 0u, last_epoch, 2, 0, c->flags, c->stats,
+                done + nb - 1, fixed_work, threads, parts, s);
             ++launches;
         }
         VM_HIP(hipEventRecord(c->ev1, s));

@@ -28,10 +28,10 @@
 //  SPLIT schedule (k_decide + k_commit, two launches per phase): for levels with
 //  too few tiles to fill 256 CUs, a tile's candidates are divided over `parts`
 //  workgroups (every pixel gets 32 lanes), decisions go to per-pixel records in
-//  HBM, and a second kernel folds them into the window sums.  The schedule of
-//  EXACT mode on small levels and the reference the STEP schedule is tested against.
+//  HBM, and a second kernel folds them into the window sums.  The reference the
+//  STEP schedule is tested against.
 //
-//  STEP schedule (k_step, FAST, one launch per phase): the commit of phase s-1 is
+//  STEP schedule (k_step, one launch per phase): the commit of phase s-1 is
 //  folded into the launch of phase s from a second copy of the sums (ping-pong),
 //  see the comment at k_step.  Bit-identical to SPLIT.
 //
@@ -1461,15 +1461,14 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
 }
 
 
-#if !VM_EXACT
 // ===========================================================================
-// STEP schedule (FAST): ONE launch per phase.  The commit of phase s-1 and the line
+// STEP schedule: ONE launch per phase.  The commit of phase s-1 and the line
 // searches of phase s share a launch: the window sums and the mask live in two copies;
 // a step reads copy `src` (state before the records of phase s-1 were folded in) and
 //  - its FOLD workgroups (one per 64x16 block of the level, geometry-free) write
 //    sums + records(s-1) -> copy `dst`, whole level;
 //  - its DECIDE workgroups (tiles x parts, as k_decide) fold the same records privately,
-//    per lane, into the one window cell the lane owns, run the lean line search and
+//    per lane, into the one window cell the lane owns, run the 32-lane line search and
 //    write the pixel's own state + records(s).
 // Folding is defined by image coordinates only -- a record of epoch s-1 reaches every
 // cell within +-2 of its pixel, row-major order -- which is what gather_cell computes
@@ -1555,7 +1554,7 @@ __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__
 }
 
 template <int T>
-__global__ __launch_bounds__(T) void k_step_fast(const VmLevelView *__restrict__ views, int cap, VmKParams P,
+__global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
                                                    const uint32_t *__restrict__ tables, int offx, int offy, int pi,
                                                    int pj, int parts, uint32_t epoch, uint32_t pe, int srcbuf,
                                                    int n_fold, uint32_t *__restrict__ flags,
@@ -1765,9 +1764,9 @@ __global__ __launch_bounds__(T) void k_step_fast(const VmLevelView *__restrict__
         // the pixel's own cell with no records
         ctx_load(c, L, S.tps, px, py);
         // the lane's window cell: sums of copy `src` + the records of the last phase
-        int i, jj, qx, qy;
-        const bool okc = wave_interior ? nb1_cell<true>(L, c, sub, i, jj, qx, qy)
-                                       : nb1_cell<false>(L, c, sub, i, jj, qx, qy);
+        const int i = (sub * 13) >> 6, jj = sub - i * 5; // lane sub < 25 owns neighbour (sub % 5 - 2, sub / 5 - 2)
+        const int qx = px + jj - 2, qy = py + i - 2;
+        const bool okc = sub < 25 && qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
         const int cx = okc ? qx : px, cy = okc ? qy : py, gi = cy * L.rs + cx;
         float2 m = s_mean[gi], q = s_var[gi], tb = s_tpsb[gi];
         float cr = s_cross[gi], val = s_value[gi];
@@ -1780,8 +1779,25 @@ __global__ __launch_bounds__(T) void k_step_fast(const VmLevelView *__restrict__
         c.tps_b.x = __shfl(tb.x, 12, 32);
         c.tps_b.y = __shfl(tb.y, 12, 32);
         if (live) {
-            Nb1 nb;
             bool ok;
+#if VM_EXACT
+            (void)wave_interior;
+            NbX nb;
+            nb.ok = okc;
+            nb.m = m;
+            nb.q = q;
+            nb.cr = cr;
+            nb.val = val;
+            nb.counter = okc ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
+            ok = decide_with(
+                L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step VM_TS_PASS);
+            if (ok) { // the lumas commit_pixel_motion samples (morph.cu:997-1003)
+                const float nvx = c.v.x + step.x, nvy = c.v.y + step.y;
+                luma.x = tap(L.img0, L.w, L.h, L.rs, px - nvx + 0.5f, py - nvy + 0.5f);
+                luma.y = tap(L.img1, L.w, L.h, L.rs, px + nvx + 0.5f, py + nvy + 0.5f);
+            }
+#else
+            Nb1 nb;
             if (wave_interior) {
                 nb1_make<true>(nb, L, okc, qx, qy, m, q, cr, val);
                 ok = decide32<true>(L, P, nb, c, sub, step, luma VM_TS_PASS);
@@ -1789,6 +1805,7 @@ __global__ __launch_bounds__(T) void k_step_fast(const VmLevelView *__restrict__
                 nb1_make<false>(nb, L, okc, qx, qy, m, q, cr, val);
                 ok = decide32<false>(L, P, nb, c, sub, step, luma VM_TS_PASS);
             }
+#endif
             if (ok)
                 state = 1;
         }
@@ -1828,7 +1845,6 @@ __global__ __launch_bounds__(T) void k_step_fast(const VmLevelView *__restrict__
             atomicAdd(&stats[iter_idx * 4 + 2], nc);
     }
 }
-#endif
 
 __global__ void SUF(k_next_iter)(int *iter_dev, int set, int value)
 {
@@ -1890,26 +1906,20 @@ void SUF(vm_launch_optimize_split)(const VmLevelView *views, int nbatch, int cap
         }
 }
 
-// one phase of the STEP schedule (FAST): fold of the previous phase's records + line
+// one phase of the STEP schedule: fold of the previous phase's records + line
 // searches of this one; decide == 0: the closing fold-only launch of a batch of steps
 void SUF(vm_launch_optimize_step)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
                                   const uint32_t *tables, int offx, int offy, int pi, int pj, uint32_t epoch,
                                   uint32_t prev_epoch, int src, int decide, uint32_t *flags, uint32_t *stats,
                                   int iter_idx, int fixed_work, int threads, int parts, hipStream_t s)
 {
-#if VM_EXACT
-    (void)views; (void)nbatch; (void)cap; (void)w; (void)h; (void)P; (void)tables; (void)offx; (void)offy;
-    (void)pi; (void)pj; (void)epoch; (void)prev_epoch; (void)src; (void)decide; (void)flags; (void)stats;
-    (void)iter_idx; (void)fixed_work; (void)threads; (void)parts; (void)s;
-#else
     const int gx = (w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (h + VM_PITCH_Y - 1) / VM_PITCH_Y;
     const int n_fold = ((w + 63) / 64) * ((h + 15) / 16);
     const dim3 grid(n_fold + (decide ? gx * gy * parts : 0), 1, nbatch);
     if (threads <= 256)
-        hipLaunchKernelGGL(k_step_fast<256>, grid, dim3(256), 0, s, views, cap, P, tables, offx, offy, pi, pj, parts,
+        hipLaunchKernelGGL(SUF(k_step)<256>, grid, dim3(256), 0, s, views, cap, P, tables, offx, offy, pi, pj, parts,
                            epoch, prev_epoch, src, n_fold, flags, stats, iter_idx, fixed_work);
     else
-        hipLaunchKernelGGL(k_step_fast<512>, grid, dim3(512), 0, s, views, cap, P, tables, offx, offy, pi, pj, parts,
+        hipLaunchKernelGGL(SUF(k_step)<512>, grid, dim3(512), 0, s, views, cap, P, tables, offx, offy, pi, pj, parts,
                            epoch, prev_epoch, src, n_fold, flags, stats, iter_idx, fixed_work);
-#endif
 }
