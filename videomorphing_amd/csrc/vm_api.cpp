@@ -622,16 +622,16 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     VM_HIP(hipMemsetAsync(c->stats, 0, words * 16, s));
     const bool exact = c->math_mode == VM_MATH_EXACT;
     // FAST kernels are built for at most 512 threads (256-VGPR budget: the register-cached
-    // window sums must not spill), EXACT ones (one pixel per lane) for up to 1024
+    // window sums must not spill), EXACT ones for up to 1024
     const int threads = std::min(c->sweep_threads ? c->sweep_threads : 512, exact ? 1024 : 512);
     const int tiles_per_pass = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
-    // SPLIT schedule: workgroups per tile so that a pass roughly fills the 256 CUs
-    // (FAST: the lean line search gives every candidate 32 lanes, 16 candidates per workgroup)
+    // SPLIT / STEP schedules: workgroups per tile (every candidate gets 32 lanes, 16 candidates
+    // per 512-thread workgroup)
     const int parts = c->sweep_parts ? c->sweep_parts : 16;
     // Schedule, re-decided per batch of iterations (AUTO).  TILE: 4 launches per iteration, a
     // tile's four phases inside one workgroup -- unbeatable when a pass touches nothing (24 us
-    // per converged iteration) or when there are enough tiles to fill the chip.  SPLIT (EXACT)
-    // / STEP (FAST): a tile's line searches spread over `parts` workgroups, 32 / 16 launches
+    // per converged iteration) or when there are enough tiles to fill the chip.  STEP (SPLIT
+    // when forced): a tile's line searches spread over `parts` workgroups, 16 (32) launches
     // per iteration -- measured on MI355X (FAST, 1080p pyramid): 120x68, every pixel active,
     // 0.32 (STEP) vs 0.64 ms (TILE) per iteration; 240x135 with 900 line searches per
     // iteration 0.22 vs 0.36; with 90: 0.24 vs 0.23; converged 0.08 vs 0.024.  All schedules
@@ -662,7 +662,7 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
                            (may_split && cand_prev >= 200.0 * n);
         // the one-launch-per-phase STEP schedule unless the two-kernel SPLIT is forced
         const bool step = split && c->sweep_mode != VM_SWEEP_SPLIT;
-        // TILE (FAST): the register-light kernel variant once fewer than a tenth of the pixels
+        // TILE, FAST arithmetic: the register-light kernel variant once fewer than a tenth of the pixels
         // are searched per iteration (after the first sweep of a level, typically)
         const int dense = exact || getenv("VM_TILE_DENSE") || cand_prev >= 0.1 * l0.w * l0.h * n;
         VM_HIP(hipEventRecord(c->ev0, s));
