@@ -471,8 +471,13 @@ __device__ __forceinline__ float energy_x32(const VmLevelView &L, const VmKParam
                                             const PixelCtx &c, float dx, float dy)
 {
     const float vx = c.v.x + dx, vy = c.v.y + dy;
-    const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - vx + 0.5f, c.py - vy + 0.5f);
-    const float ly = tap(L.img1, L.w, L.h, L.rs, c.px + vx + 0.5f, c.py + vy + 0.5f);
+    // one tap per lane (even lanes: image 0 at p - v, odd lanes: image 1 at p + v), swapped with
+    // the neighbour lane: each value is produced by the expression the one-lane code uses
+    const bool odd = threadIdx.x & 1;
+    const float t = tap(odd ? L.img1 : L.img0, L.w, L.h, L.rs, odd ? c.px + vx + 0.5f : c.px - vx + 0.5f,
+                        odd ? c.py + vy + 0.5f : c.py - vy + 0.5f);
+    const float o = __shfl_xor(t, 1);
+    const float lx = odd ? o : t, ly = odd ? t : o;
     const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
     const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
     const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
