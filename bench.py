@@ -1,24 +1,33 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the halfway-domain morph solver.
 
-Metric (BASELINE.json): Mpixel*iters/s of the halfway optimizer on a 1080p frame
-pair, 6-level pyramid (start_res 32), 500 iterations per level (config[1]).
+Metric (BASELINE.json): Mpixel*iters/s of the halfway optimizer.
 
-A "step" = one complete coarse-to-fine solve (vm_solve: coarse solve, then per
-level upsample + init + sweeps) of ONE synthetic 1080p frame pair whose pyramid
-is already resident in HBM.  value = sum over levels of W*H*iterations executed
-(the reference's own progress unit, morph.cu:1389) divided by wall time, summed
-over all ranks.  Independent frame pairs shard across GPUs with no data-path
-collective (weak scaling: K pairs per GPU); the only collective is one RCCL
-broadcast of the shared parameter block.
+  --config 1  (default at N = 1) config[1]: ONE 1920x1080 frame pair, 6-level pyramid
+              (start_res 32), 500 iterations per level.  A step = one complete
+              coarse-to-fine solve (vm_solve) of one pair whose pyramid is resident in HBM;
+              every step solves a different frame of the synthetic video.
+  --config 2  (default at N > 1) config[2]: 60 independent 1080p frame pairs sharded over
+              the ranks (static block distribution, videomorphing_amd.dist.shard_pairs); a
+              step = every rank solves ITS pairs as batches (vm_solve_batch: all pairs of a
+              batch relaxed by the same launches).  Total work is fixed: strong scaling.
+  --config 3  config[3]: one 3840x2160 pair, 7-level pyramid, otherwise as config 1.
+
+value = sum over levels of W*H*iterations (the reference's own progress unit,
+morph.cu:1389) over all ranks / max-over-ranks wall time.  No collective sits on the data
+path; the only exchanges are one RCCL broadcast of the parameter block and one all-gather of
+two scalars per rank for the report.
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+With N > 1 and no torch.distributed environment the script starts its N ranks itself (as
+child processes, before anything touches the GPU); under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it is one rank.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,9 +36,15 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-W, H, START_RES, MAX_ITER, DROP = 1920, 1080, 32, 500.0, 1.0
+START_RES, MAX_ITER, DROP = 32, 500.0, 1.0
+CONFIG_SIZE = {1: (1920, 1080), 2: (1920, 1080), 3: (3840, 2160)}
 ALG_BYTES_PER_VISIT = 100.0      # 76 B read + 24 B written per pixel-visit
+FLOP_PER_EVAL = 25 * 45 + 2 * 30  # 25 ssim() of ~45 flop-eq + 2 bilinear taps of ~30
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_FLOPS = 157e12         # MI355X_MICROARCH.md: f32 vector peak
+SCHED = ("k_optimize<true> (TILE schedule, dense kernel)", "k_optimize<false> (TILE schedule, lean kernel for pruned sweeps)",
+         "k_step (STEP schedule, one launch per phase)")
+SCHED_PMC = ("k_optimize_fast<true>", "k_optimize_fast<false>", "k_step_fast<512>")
 
 
 def tile_visits(w, h):
@@ -47,44 +62,68 @@ def tile_visits(w, h):
     return tot
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="BASELINE.json config index; 0 = 1 on one GPU, 2 on several")
+    ap.add_argument("--pairs", type=int, default=60, help="config 2: frame pairs of the whole job")
+    ap.add_argument("--max-batch", type=int, default=32, help="config 2: most pairs relaxed by one launch")
     ap.add_argument("--math", default="fast", choices=["fast", "exact"])
     ap.add_argument("--semantics", default="fixed", choices=["fixed", "reference"],
                     help="fixed: every level runs its max_iter sweeps (BASELINE config: 500 iters/level); "
                          "reference: a level stops when no pixel improved (morph.cu:1390)")
     ap.add_argument("--inflight", type=int, default=1,
-                    help="independent frame pairs solved concurrently per GPU (one HIP stream and one "
-                         "host thread each); 1 = one pair at a time")
+                    help="config 1/3: independent pairs solved concurrently per GPU (one HIP stream and one "
+                         "host thread each)")
     ap.add_argument("--batch", type=int, default=1,
-                    help="frame pairs solved together by the same sweep launches (vm_solve_batch); a step "
-                         "is then one batch.  1 = config[1], one pair per step")
+                    help="config 1/3: pairs solved together by the same sweep launches; a step is then one batch")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the two collectives: nccl = RCCL over xGMI (the product path); "
+                         "gloo lets a box with fewer GPUs than ranks exercise the N > 1 code (ranks then share devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--size", default=None, help="WxH override (debug only; invalid as a result)")
-    args = ap.parse_args()
+    ap.add_argument("--size", default=None, help="WxH override (development only)")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    # ---- N > 1 asked for from a plain invocation: become the launcher (no GPU call, no torch) ----
+    from videomorphing_amd import launch
+    if launch.needs_launch(args.gpus):
+        sys.exit(launch.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    w, h = W, H
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node equal to --gpus" % (args.gpus, world))
+    config = args.config or (1 if world == 1 else 2)
+    w, h = CONFIG_SIZE[config]
     if args.size:
         w, h = [int(x) for x in args.size.lower().split("x")]
 
     import numpy as np
     import torch
     import torch.distributed as dist
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())    # test mode: ranks may share a device
     torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=coll_dev)
+        else:
+            dist.init_process_group("gloo")
 
     from videomorphing_amd import capi, morph, synth
+    from videomorphing_amd import dist as vdist
 
     # ---- the shared parameter block: rank 0 decides, one RCCL broadcast ----
-    from videomorphing_amd import dist as vdist
     blk = capi.ParamBlock()
     if rank == 0:
         P = morph.Parameters()
@@ -94,30 +133,48 @@ def main():
     raw = vdist.pack_block(blk)
     if world > 1:
         # backend "nccl" is RCCL on ROCm (xGMI within the node)
-        raw = vdist.broadcast_block(raw, torch.device("cuda", local_rank))
+        raw = vdist.broadcast_block(raw, coll_dev)
     blk, _cons = vdist.unpack_block(raw)
 
-    nctx = max(1, args.inflight)
+    nctx = max(1, args.inflight) if config != 2 else 1
     ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(nctx)]
     for c in ctxs:
         c.set_params(blk.kp)
     ctx = ctxs[0]
     L = capi.load()
-
-    # ---- inputs: K+W independent frame pairs per rank, pyramids resident in HBM ----
     nlev = synth.num_levels(w, h, blk.start_res)
-    B = max(1, args.batch)
-    npairs = (args.steps + args.warmup) * B
-    pyrs = []
-    for k in range(npairs):
-        frame = rank * npairs + k
-        i0, i1 = synth.make_pair(w, h, frame=frame)
-        p = morph.Pyramid(ctxs[(k // B) % nctx])
-        p.build(i0, i1, blk.start_res, nlevels=nlev)
-        pyrs.append(p)
-    sizes = [(pyrs[0][el].width, pyrs[0][el].height) for el in range(1, nlev + 1)]
-
     FIXED = 1 if args.semantics == "fixed" else 0
+
+    # ---- inputs: pyramids resident in HBM before the timed region ----
+    def frames(ids):
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(8, max(1, len(ids)))) as ex:   # numpy releases the GIL
+            return list(ex.map(lambda f: synth.make_pair(w, h, frame=f), ids))
+
+    def pyramid(c, imgs):
+        p = morph.Pyramid(c)
+        p.build(imgs[0], imgs[1], blk.start_res, nlevels=nlev)
+        return p
+
+    distinct_frames = None
+    if config == 2:
+        mine = vdist.shard_pairs(args.pairs, world, rank)
+        distinct = mine[:8]                       # 8 distinct frames per rank, reused cyclically
+        distinct_frames = len(distinct)
+        imgs = frames(distinct)
+        pyrs = [pyramid(ctx, imgs[k % len(imgs)]) for k in range(len(mine))]
+        B = max(1, min(args.max_batch, len(mine)))
+        nb = (len(mine) + B - 1) // B
+        B = (len(mine) + nb - 1) // nb            # even batches: 60 pairs on one GPU = 2 x 30
+        step_sets = [pyrs] * (args.steps + args.warmup)       # every step re-solves the rank's shard
+    else:
+        B = max(1, args.batch)
+        npairs = (args.steps + args.warmup) * B
+        ids = [rank * npairs + k for k in range(npairs)]
+        imgs = frames(ids)
+        pyrs = [pyramid(ctxs[(k // B) % nctx], imgs[k]) for k in range(npairs)]
+        step_sets = [pyrs[s * B:(s + 1) * B] for s in range(args.steps + args.warmup)]
+    sizes = [(pyrs[0][el].width, pyrs[0][el].height) for el in range(1, nlev + 1)]
 
     def solve(p, fixed=FIXED):
         prog = (capi.Progress * (nlev - 1))()
@@ -125,7 +182,7 @@ def main():
         return prog
 
     def solve_group(ps, fixed=FIXED):
-        """one step: a batch of B pairs relaxed by the same launches"""
+        """a batch of pairs relaxed by the same launches"""
         if len(ps) == 1:
             return [solve(ps[0], fixed)]
         arr = (C.c_void_p * len(ps))(*[p._h for p in ps])
@@ -137,31 +194,44 @@ def main():
             if i > 0:          # elapsed/launches are per batch: count them once
                 for k in range(nlev - 1):
                     one[k].elapsed_ms, one[k].launches = 0.0, 0
+                    for j in range(3):
+                        one[k].sched_ms[j], one[k].sched_launches[j] = 0.0, 0
             out.append(one)
         return out
 
-    def run_steps(ps):
-        """solve the pyramids; with several contexts, one host thread per context works
-        through that context's pyramids (a vm_ctx is single-threaded by contract)"""
-        if B > 1:
+    def run_step(ps):
+        """one step; with several contexts, one host thread per context (a vm_ctx is
+        single-threaded by contract)"""
+        if B > 1 or config == 2:
             out = []
             for g0 in range(0, len(ps), B):
                 out += solve_group(ps[g0:g0 + B])
             return out
-        if nctx == 1:
-            return [solve(p) for p in ps]
-        from concurrent.futures import ThreadPoolExecutor
-        groups = {}
-        for i, p in enumerate(ps):
-            groups.setdefault(id(p._ctx), []).append((i, p))
-        out = [None] * len(ps)
+        return [solve(p) for p in ps]
 
-        def work(items):
-            for i, p in items:
-                out[i] = solve(p)
-        with ThreadPoolExecutor(max_workers=len(groups)) as ex:   # ctypes calls release the GIL
-            list(ex.map(work, groups.values()))
-        return out
+    def run_steps(sets):
+        if nctx > 1 and B == 1 and config != 2:
+            from concurrent.futures import ThreadPoolExecutor
+            flat = [p for ps in sets for p in ps]
+            groups = {}
+            for i, p in enumerate(flat):
+                groups.setdefault(id(p._ctx), []).append((i, p))
+            out = [None] * len(flat)
+
+            def work(items):
+                for i, p in items:
+                    out[i] = solve(p)
+            with ThreadPoolExecutor(max_workers=len(groups)) as ex:   # ctypes calls release the GIL
+                list(ex.map(work, groups.values()))
+            return out, []
+        out, per_step = [], []
+        for ps in sets:
+            t1 = time.perf_counter()
+            out += run_step(ps)
+            for c in ctxs:
+                c.sync()
+            per_step.append((time.perf_counter() - t1) * 1e3)
+        return out, per_step
 
     def sync_all():
         for c in ctxs:
@@ -171,164 +241,247 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run_steps(pyrs[:args.warmup * B])
+    run_steps(step_sets[:args.warmup])
     sync_all()
     t0 = time.perf_counter()
-    progs = run_steps(pyrs[args.warmup * B:])
+    progs, step_ms = run_steps(step_sets[args.warmup:])
     for c in ctxs:
         c.sync()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     sync_all()
 
-    pix_iters = sum(pr[i].pixel_iters for pr in progs for i in range(nlev - 1))
-    kern_ms = sum(pr[i].elapsed_ms for pr in progs for i in range(nlev - 1))
-    launches = sum(pr[i].launches for pr in progs for i in range(nlev - 1))
-    alg_bytes = 0.0
-    for pr in progs:
-        for i in range(nlev - 1):
-            # launches enqueued past convergence exit at once: count executed iterations only
-            alg_bytes += pr[i].iters * tile_visits(*sizes[i]) * ALG_BYTES_PER_VISIT
-    iters_per_level = [[pr[i].iters for i in range(nlev - 1)] for pr in progs]
-    activity = {"active_tile_visits": sum(pr[i].active_tiles for pr in progs for i in range(nlev - 1)) / len(progs),
-                "line_searches": sum(pr[i].candidates for pr in progs for i in range(nlev - 1)) / len(progs),
-                "commits": sum(pr[i].commits for pr in progs for i in range(nlev - 1)) / len(progs),
-                "pixel_visits": sum(pr[i].iters * tile_visits(*sizes[i]) for pr in progs for i in range(nlev - 1)) / len(progs)}
-
+    R = range(nlev - 1)
+    pix_iters = sum(pr[i].pixel_iters for pr in progs for i in R)
     if world > 1:
-        el_max, pix_total = vdist.reduce_report(el, pix_iters, torch.device("cuda", local_rank))
+        el_max, pix_total = vdist.reduce_report(el, pix_iters, coll_dev)
     else:
         el_max, pix_total = el, pix_iters
 
     extras = {}
-    if rank == 0 and not args.no_extras:
-        # the other stopping rule and the other arithmetic mode, one solve each
-        p = pyrs[0]
-        ctx.sync(); t1 = time.perf_counter(); pr = solve(p, fixed=1 - FIXED); ctx.sync(); dt = time.perf_counter() - t1
-        extras["%s_semantics" % ("reference" if FIXED else "fixed")] = {
-            "mpix_iters_per_s": round(sum(pr[i].pixel_iters for i in range(nlev - 1)) / dt / 1e6, 2),
-            "ms_per_solve": round(dt * 1e3, 2),
-            "iters_per_level_fine_to_coarse": [pr[i].iters for i in range(nlev - 1)]}
-        other = capi.MATH_EXACT if blk.math_mode == capi.MATH_FAST else capi.MATH_FAST
-        ctx.set_math_mode(other)
-        ctx.sync(); t1 = time.perf_counter(); pr = solve(p); ctx.sync(); dt = time.perf_counter() - t1
-        extras["%s_math_mpix_iters_per_s" % ("exact" if other == capi.MATH_EXACT else "fast")] = round(
-            sum(pr[i].pixel_iters for i in range(nlev - 1)) / dt / 1e6, 2)
-        ctx.set_math_mode(blk.math_mode)
-        # batched throughput: B independent pairs relaxed by the same launches (the per-GPU
-        # workload of config[2]: 60 pairs over 8 GPUs); frames are reused cyclically
-        if B == 1:
-            base_frames = [synth.make_pair(w, h, frame=1000 + k) for k in range(4)]
-            bt = {}
-            for nb in (8, 32):
-                group = []
-                for k in range(nb):
-                    q = morph.Pyramid(ctx)
-                    q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
-                    group.append(q)
-                solve_group(group)                                    # warm-up
-                ctx.sync(); t1 = time.perf_counter(); pr = solve_group(group); ctx.sync()
-                dt = time.perf_counter() - t1
-                bt["pairs_%d" % nb] = {
-                    "mpix_iters_per_s": round(sum(q2[i].pixel_iters for q2 in pr for i in range(nlev - 1)) / dt / 1e6, 1),
-                    "ms_per_batch": round(dt * 1e3, 1)}
-                del group
-            extras["batched_throughput_fixed_work"] = bt
-        # compositor: frames/s of render_halfway with device-resident inputs
-        ex = int(0.1 * max(w, h))
-        rgb0, rgb1 = synth.make_rgb_pair(w, h)
-        fr = morph.Frame(ctx, w, h, ex)
-        fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
-        fr.set_v_from_level(p, 1)
-        fr.render_halfway_dev(0.5, 0.5, 1)
-        ms = [fr.render_halfway_dev(0.5, 0.1 * k, 1) for k in range(1, 10)]
-        extras["render_frames_per_s"] = round(1000.0 / (sum(ms) / len(ms)), 1)
-        # Poisson boundary extension of both sides of that frame (config[4]'s other stage)
-        pe = {}
-        fr.poisson_extend(1, tol=1e-3)      # the workspace is allocated on first use: not timed
-        for tol in (1e-4, 1e-5):
-            fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
-            r1, r2 = fr.poisson_extend(1, tol=tol), fr.poisson_extend(2, tol=tol)
-            pe["tol_%g" % tol] = {"ms_per_frame": round(r1[2] + r2[2], 1), "cg_iterations": [r1[0], r2[0]]}
-        extras["poisson_extend_1080p_ex%d" % ex] = pe
-        # quadratic motion path of that frame (QuadraticPath.cpp), SURVEY 8(f) rank 4
-        fr.set_v_from_level(p, 1)
-        try:
-            qp = fr.quadratic_path(tol=1e-4)
-            extras["quadratic_path_1080p"] = {"ms_per_frame": round(qp[2], 1), "pcg_iterations": qp[0], "tol": 1e-4,
-                                              "residual": float("%.3g" % qp[1])}
-        except capi.VmError as e:        # e.g. a folded v: the blend of the Jacobians is 0/0 there
-            extras["quadratic_path_1080p"] = {"error": str(e)[-120:]}
-        # config[4]'s whole pipeline on one GPU: 8 frame pairs solved as a batch (reference
-        # semantics), then per frame v upscale -> Poisson extension of both sides -> 9 rendered
-        # in-between frames; canvases uploaded once per frame (PCIe included)
-        if B == 1:
-            group = []
-            for k in range(8):
-                q = morph.Pyramid(ctx)
-                q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
-                group.append(q)
-            e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
-            ctx.sync(); t1 = time.perf_counter()
-            morph.solve_batch(group, blk.max_iter, blk.max_iter_drop_factor, fixed_work=False)
-            t_solve = time.perf_counter() - t1
-            for q in group:
-                fr.upload(e0, e1, None, None)
-                fr.set_v_from_level(q, 1)
-                fr.poisson_extend(1, tol=1e-5)
-                fr.poisson_extend(2, tol=1e-5)
-                for k in range(1, 10):
-                    fr.render_halfway_dev(0.1 * k, 0.1 * k, 1)
-            ctx.sync(); dt = time.perf_counter() - t1
-            extras["pipeline_config4_8_pairs"] = {"ms_per_pair": round(dt * 1e3 / 8, 1), "solve_ms_per_pair": round(t_solve * 1e3 / 8, 1),
-                                                  "rendered_frames_per_s": round(8 * 9 / dt, 1)}
-            del group
-        fr.close()
+    if rank == 0 and not args.no_extras and config != 2:
+        extras = run_extras(args, np, capi, morph, synth, L, blk, ctx, pyrs[0], w, h, nlev, FIXED, B, solve, solve_group)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(np, synth, blk, pyrs[args.warmup * B:])
+        cpu = cpu_baseline(np, capi, L, blk, pyrs[0], nlev)
 
     if rank == 0:
-        avg_launch_us = kern_ms * 1e3 / max(launches, 1)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "Mpixel*iters/s (halfway optimizer, 1080p pair, 6-level pyramid, 500 iters/level)",
-            "value": round(pix_total / el_max / 1e6, 2),
-            "unit": "Mpixel*iters/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(el_max / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config[1]: %dx%d frame pair, %d-level pyramid (start_res %d), max_iter %d/level, drop %g, %s per step per GPU"
-                                   % (w, h, nlev, blk.start_res, int(blk.max_iter), blk.max_iter_drop_factor,
-                                      "one pair" if B == 1 else "a batch of %d independent pairs" % B),
-                       "math_mode": "fast" if blk.math_mode == capi.MATH_FAST else "exact",
-                       "semantics": "fixed work: every sweep of every level is launched" if FIXED
-                                    else "reference: a level stops when no pixel improved",
-                       "iters_per_level_fine_to_coarse": iters_per_level[0],
-                       "pairs_in_flight_per_gpu": nctx, "pairs_per_step": B,
-                       "parallelism": "independent frame pairs, %d rank(s), 1 RCCL broadcast" % world},
-            "roofline": {"bound": "hbm", "kernel": "sweep kernels (k_optimize | k_step | k_decide + k_commit)",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "avg_launch_us": round(avg_launch_us, 2), "launches": launches,
-                         "alg_bytes_per_pixel_visit": ALG_BYTES_PER_VISIT},
-            "cpu_baseline": cpu,
-        }
-        out["activity_per_solve"] = {k: round(v) for k, v in activity.items()}
+        out = report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, progs, step_ms, el_max, pix_total,
+                     cpu, distinct_frames, len(pyrs) if config == 2 else None)
         out.update(extras)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, progs, step_ms, el_max, pix_total, cpu,
+           distinct_frames, pairs_this_rank):
+    R = range(nlev - 1)
+    nsolve = max(len(progs), 1)
+    kern_ms = sum(pr[i].elapsed_ms for pr in progs for i in R)
+    launches = sum(pr[i].launches for pr in progs for i in R)
+    # ---- algorithmic bytes: 100 B per pixel-visit; NOMINAL counts every visit of
+    # every executed iteration, EXECUTED only the tile visits the improving mask did not skip
+    alg_nominal = sum(pr[i].iters * tile_visits(*sizes[i]) * ALG_BYTES_PER_VISIT for pr in progs for i in R)
+    pixel_visits = sum(pr[i].iters * tile_visits(*sizes[i]) for pr in progs for i in R)
+    active_tiles = sum(pr[i].active_tiles for pr in progs for i in R)
+    line_searches = sum(pr[i].candidates for pr in progs for i in R)
+    commits = sum(pr[i].commits for pr in progs for i in R)
+    evals = sum(pr[i].evaluations for pr in progs for i in R)
+    alg_executed = active_tiles * 64 * 16 * ALG_BYTES_PER_VISIT
+    achieved = alg_nominal / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # ---- HBM traffic per launch from the PMC passes of the committed profile (not of this run:
+    # counters need rocprofv3)
+    traffic, traffic_src, pmc_k = None, None, {}
+    for name in ("traffic_latest.json",):
+        tp = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/%s (%s)" % (name, tj.get("source", "")[:160])
+                pmc_k = tj.get("per_kernel", {}) or {}
+            except Exception:
+                traffic = None
+    # ---- per kernel: launches, average duration (HIP events around each batch of launches on
+    # the context's stream), algorithmic bytes per launch, nominal and real fraction of HBM peak
+    per_kernel = []
+    for k in range(3):
+        ms = sum(pr[i].sched_ms[k] for pr in progs for i in R)
+        n = sum(pr[i].sched_launches[k] for pr in progs for i in R)
+        if n == 0:
+            continue
+        # one TILE launch = one pass over the level (a quarter of an iteration's visits) of every
+        # pair of the batch; one STEP launch = one phase of one pass (a sixteenth)
+        share = 16.0 if k == 2 else 4.0
+        nbytes = 0.0
+        for pr_i, pr in enumerate(progs):
+            for i in R:
+                if pr[i].sched_launches[k]:
+                    # launches are recorded once per batch (first pair); the batch's other pairs add their visits
+                    nbytes += pr[i].sched_launches[k] * tile_visits(*sizes[i]) / share * ALG_BYTES_PER_VISIT * B
+        avg_us = ms * 1e3 / n
+        ent = {"kernel": SCHED[k], "launches": n, "avg_us": round(avg_us, 2), "share_of_sweep_time": round(ms / max(kern_ms, 1e-9), 3),
+               "alg_bytes_per_launch": round(nbytes / n), "nominal_GBs": round(nbytes / n / (avg_us * 1e-6) / 1e9, 2),
+               "nominal_frac": round(nbytes / n / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
+        pb = pmc_k.get(SCHED_PMC[k])
+        if pb is not None:
+            ent["pmc_bytes_per_launch"] = round(pb)
+            ent["real_GBs"] = round(pb / (avg_us * 1e-6) / 1e9, 2)
+            ent["real_frac"] = round(pb / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+            ent["traffic_over_algorithmic"] = round(pb / max(nbytes / n, 1.0), 2)
+        per_kernel.append(ent)
+    avg_launch_us = kern_ms * 1e3 / max(launches, 1)
+    hbm_real_frac = (traffic / (avg_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and launches) else None
+    steps = args.steps
+    out = {
+        "metric": "Mpixel*iters/s (halfway optimizer, 1080p pair, 6-level pyramid, 500 iters/level)" if config != 3 else
+                  "Mpixel*iters/s (halfway optimizer, 3840x2160 pair, 7-level pyramid, 500 iters/level)",
+        "value": round(pix_total / el_max / 1e6, 2),
+        "unit": "Mpixel*iters/s",
+        "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": round(el_max / steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "strong" if config == 2 else "weak", "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic" if config != 2 else "synthetic (%d distinct frames per rank, reused cyclically over its pairs)" % distinct_frames,
+        "config": {"workload": workload_name(config, w, h, nlev, blk, B, args, world, pairs_this_rank),
+                   "math_mode": "fast" if blk.math_mode == capi.MATH_FAST else "exact",
+                   "semantics": "fixed work: every sweep of every level is launched" if FIXED
+                                else "reference: a level stops when no pixel improved",
+                   "iters_per_level_fine_to_coarse": [progs[0][i].iters for i in R],
+                   "pairs_in_flight_per_gpu": nctx, "pairs_per_launch": B,
+                   "parallelism": "independent frame pairs, %d rank(s), 1 RCCL broadcast + 1 all-gather of the report" % world},
+        "roofline": {"bound": "hbm", "kernel": "sweep kernels (k_optimize | k_step); per_kernel splits them",
+                     # SURVEY 8(d)'s figure: NOMINAL algorithmic bytes (every pixel-visit of every executed
+                     # iteration, whether or not the improving mask skipped its tile) / HIP-event time
+                     "achieved": round(achieved, 2), "achieved_is": "nominal algorithmic rate (SURVEY 8(d)), not DRAM throughput",
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "achieved_executed": round(alg_executed / (kern_ms * 1e-3) / 1e9, 2) if kern_ms > 0 else None,
+                     "frac_executed": round(alg_executed / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kern_ms > 0 else None,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "hbm_real_frac": round(hbm_real_frac, 5) if hbm_real_frac is not None else None,
+                     "avg_launch_us": round(avg_launch_us, 2), "launches": launches,
+                     "alg_bytes_per_pixel_visit": ALG_BYTES_PER_VISIT,
+                     "valu_frac": round(evals * FLOP_PER_EVAL / (kern_ms * 1e-3) / VALU_PEAK_FLOPS, 5) if kern_ms > 0 else None,
+                     "flop_per_evaluation": FLOP_PER_EVAL,
+                     "active_pixel_ratio": round(line_searches / max(pixel_visits, 1), 6),
+                     "per_kernel": per_kernel},
+        "cpu_baseline": cpu,
+        "activity_per_solve": {"active_tile_visits": round(active_tiles / nsolve), "line_searches": round(line_searches / nsolve),
+                               "energy_evaluations": round(evals / nsolve), "commits": round(commits / nsolve),
+                               "pixel_visits": round(pixel_visits / nsolve)},
+    }
+    if step_ms:
+        ms = sorted(step_ms)
+        out["step_ms"] = {"each": [round(x, 2) for x in step_ms], "min": round(ms[0], 2), "median": round(statistics.median(ms), 2),
+                          "max": round(ms[-1], 2),
+                          "note": "every step is a different frame of the synthetic video; whether the finest level converges or "
+                                  "keeps exchanging rounding-level moves differs per frame" if config != 2 else "every step re-solves the rank's pairs"}
+        med = statistics.median(ms)
+        # the same units per step (fixed work), the median step instead of the mean
+        out["value_median_step"] = round(pix_total / world / len(step_ms) / (med * 1e-3) / 1e6 * world, 2) if FIXED else None
+    return out
+
+
+def workload_name(config, w, h, nlev, blk, B, args, world, pairs_this_rank):
+    base = "%dx%d frame pair, %d-level pyramid (start_res %d), max_iter %d/level, drop %g" % (
+        w, h, nlev, blk.start_res, int(blk.max_iter), blk.max_iter_drop_factor)
+    if config == 2:
+        return ("config[2]: %d independent %s; sharded over %d rank(s) (rank 0: %d pairs), solved per rank in batches of <= %d "
+                "pairs per launch; one step = the whole job" % (args.pairs, base, world, pairs_this_rank, B))
+    return "config[%d]: %s, %s per step per GPU" % (config, base, "one pair" if B == 1 else "a batch of %d independent pairs" % B)
+
+
+def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, B, solve, solve_group):
+    """context numbers beside the headline (rank 0, one GPU): the other stopping rule, the other
+    arithmetic, batched throughput, compositor stages"""
+    extras = {}
+    R = range(nlev - 1)
+    ctx.sync(); t1 = time.perf_counter(); pr = solve(p, fixed=1 - FIXED); ctx.sync(); dt = time.perf_counter() - t1
+    extras["%s_semantics" % ("reference" if FIXED else "fixed")] = {
+        "mpix_iters_per_s": round(sum(pr[i].pixel_iters for i in R) / dt / 1e6, 2),
+        "ms_per_solve": round(dt * 1e3, 2),
+        "iters_per_level_fine_to_coarse": [pr[i].iters for i in R]}
+    other = capi.MATH_EXACT if blk.math_mode == capi.MATH_FAST else capi.MATH_FAST
+    ctx.set_math_mode(other)
+    ctx.sync(); t1 = time.perf_counter(); pr = solve(p); ctx.sync(); dt = time.perf_counter() - t1
+    extras["%s_math_mpix_iters_per_s" % ("exact" if other == capi.MATH_EXACT else "fast")] = round(
+        sum(pr[i].pixel_iters for i in R) / dt / 1e6, 2)
+    ctx.set_math_mode(blk.math_mode)
+    if w * h > 1920 * 1080:
+        return extras
+    # batched throughput: B independent pairs relaxed by the same launches (the per-GPU workload
+    # of config[2]); 4 distinct frames reused cyclically
+    base_frames = [synth.make_pair(w, h, frame=1000 + k) for k in range(4)]
+    if B == 1:
+        bt = {}
+        for nb in (8, 32):
+            group = []
+            for k in range(nb):
+                q = morph.Pyramid(ctx)
+                q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
+                group.append(q)
+            solve_group(group)                                    # warm-up
+            ctx.sync(); t1 = time.perf_counter(); pr = solve_group(group); ctx.sync()
+            dt = time.perf_counter() - t1
+            bt["pairs_%d" % nb] = {
+                "mpix_iters_per_s": round(sum(q2[i].pixel_iters for q2 in pr for i in R) / dt / 1e6, 1),
+                "ms_per_batch": round(dt * 1e3, 1)}
+            del group
+        extras["batched_throughput_fixed_work"] = bt
+    # compositor: frames/s of render_halfway with device-resident inputs
+    ex = int(0.1 * max(w, h))
+    rgb0, rgb1 = synth.make_rgb_pair(w, h)
+    fr = morph.Frame(ctx, w, h, ex)
+    fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
+    fr.set_v_from_level(p, 1)
+    fr.render_halfway_dev(0.5, 0.5, 1)
+    ms = [fr.render_halfway_dev(0.5, 0.1 * k, 1) for k in range(1, 10)]
+    extras["render_frames_per_s"] = round(1000.0 / (sum(ms) / len(ms)), 1)
+    # Poisson boundary extension of both sides of that frame (config[4]'s other stage)
+    pe = {}
+    fr.poisson_extend(1, tol=1e-3)      # the workspace is allocated on first use: not timed
+    for tol in (1e-4, 1e-5):
+        fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
+        r1, r2 = fr.poisson_extend(1, tol=tol), fr.poisson_extend(2, tol=tol)
+        pe["tol_%g" % tol] = {"ms_per_frame": round(r1[2] + r2[2], 1), "cg_iterations": [r1[0], r2[0]]}
+    extras["poisson_extend_1080p_ex%d" % ex] = pe
+    # quadratic motion path of that frame (QuadraticPath.cpp), SURVEY 8(f) rank 4
+    fr.set_v_from_level(p, 1)
+    try:
+        qp = fr.quadratic_path(tol=1e-4)
+        extras["quadratic_path_1080p"] = {"ms_per_frame": round(qp[2], 1), "pcg_iterations": qp[0], "tol": 1e-4,
+                                          "residual": float("%.3g" % qp[1])}
+    except capi.VmError as e:        # e.g. a folded v: the blend of the Jacobians is 0/0 there
+        extras["quadratic_path_1080p"] = {"error": str(e)[-120:]}
+    # config[4]'s whole pipeline on one GPU: 8 frame pairs solved as a batch (reference
+    # semantics), then per frame v upscale -> Poisson extension of both sides -> 9 rendered
+    # in-between frames; canvases uploaded once per frame (PCIe included)
+    if B == 1:
+        group = []
+        for k in range(8):
+            q = morph.Pyramid(ctx)
+            q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
+            group.append(q)
+        e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
+        ctx.sync(); t1 = time.perf_counter()
+        morph.solve_batch(group, blk.max_iter, blk.max_iter_drop_factor, fixed_work=False)
+        t_solve = time.perf_counter() - t1
+        for q in group:
+            fr.upload(e0, e1, None, None)
+            fr.set_v_from_level(q, 1)
+            fr.poisson_extend(1, tol=1e-5)
+            fr.poisson_extend(2, tol=1e-5)
+            for k in range(1, 10):
+                fr.render_halfway_dev(0.1 * k, 0.1 * k, 1)
+        ctx.sync(); dt = time.perf_counter() - t1
+        extras["pipeline_config4_8_pairs"] = {"ms_per_pair": round(dt * 1e3 / 8, 1), "solve_ms_per_pair": round(t_solve * 1e3 / 8, 1),
+                                              "rendered_frames_per_s": round(8 * 9 / dt, 1)}
+        del group
+    fr.close()
+    return extras
 
 
 def effective_cpus():
@@ -349,45 +502,57 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(np, synth, blk, gpu_pyrs):
-    """The CPU restatement (oracle, OpenMP over tiles) timed on this host on a bounded
-    sample of the same workload: level by level (finest first) of the solves just timed,
-    each level started -- like the GPU path -- from the upsampled solution of the next
-    coarser level and swept until no pixel improves, until about 12 s have been spent."""
+def cpu_baseline(np, capi, L, blk, gp, nlev):
+    """The CPU restatement (oracle, OpenMP over tiles) timed on this host on a bounded sample
+    of the same workload, and the GPU timed on the IDENTICAL sample beside it: every level of
+    the solve just timed (coarsest first, incl. the 120x68 one), each started -- like the
+    solver does -- from the upsampled solution of the next coarser level and swept with
+    reference semantics (stop when no pixel improved) for at most max_iter iterations or 8 s
+    of CPU time; the GPU then runs exactly the iterations the CPU ran, from the same start."""
     import oracle as O
     threads = effective_cpus()
     O.lib().vmo_set_threads(threads)
     P = O.default_params()
     for f, _ in P._fields_:
-        setattr(P, f, getattr(blk.kp, f))
+        if hasattr(blk.kp, f):
+            setattr(P, f, getattr(blk.kp, f))
     stats = np.zeros(4)
-    units, spent, parts = 0.0, 0.0, []
-    nlev = gpu_pyrs[0].size() - 1
-    for gp in gpu_pyrs:
-        for el in range(1, nlev - 1):
-            if spent > 12.0:
+    units, spent, gpu_ms, parts = 0.0, 0.0, 0.0, []
+    for el in range(nlev - 1, 0, -1):       # el = python-side level index, nlev = coarsest (host-solved)
+        if spent > 20.0:
+            break
+        w, h = gp[el].width, gp[el].height
+        coarse = O.Level(gp[el + 1].width, gp[el + 1].height)
+        coarse.field("v")[...] = gp[el + 1].v
+        tgt = O.Level(w, h)
+        tgt.set_images(gp[el].field("img0"), gp[el].field("img1"))
+        tgt.upsample_from(coarse)
+        tgt.init(P.ssim_clamp)
+        t0 = time.perf_counter()
+        iters = 0
+        while time.perf_counter() - t0 < 8.0 and iters < int(blk.max_iter):
+            imp = tgt.optimize_iter(P, stats)
+            iters += 1
+            if not imp:
                 break
-            w, h = gp[el].width, gp[el].height
-            coarse = O.Level(gp[el + 1].width, gp[el + 1].height)
-            coarse.field("v")[...] = gp[el + 1].v
-            tgt = O.Level(w, h)
-            tgt.set_images(gp[el].field("img0"), gp[el].field("img1"))
-            tgt.upsample_from(coarse)
-            tgt.init(P.ssim_clamp)
-            t0 = time.perf_counter()
-            iters = 0
-            while time.perf_counter() - t0 < 8.0 and iters < int(blk.max_iter):
-                imp = tgt.optimize_iter(P, stats)
-                iters += 1
-                if not imp:
-                    break
-            spent += time.perf_counter() - t0
-            units += float(w) * h * iters
-            parts.append("%dx%d:%d" % (w, h, iters))
+        spent += time.perf_counter() - t0
+        units += float(w) * h * iters
+        parts.append("%dx%d:%d" % (w, h, iters))
+        # the GPU on the same sample: same start, reference semantics, the CPU's iteration count
+        capi.check(L.vm_upsample_v(gp._h, el - 1, el))
+        capi.check(L.vm_init_level(gp._h, el - 1, gp[1].width, gp[1].height, None, 0))
+        pr = capi.Progress()
+        t1 = time.perf_counter()
+        capi.check(L.vm_optimize_level(gp._h, el - 1, float(iters), None, 0, C.byref(pr)))
+        gpu_ms += (time.perf_counter() - t1) * 1e3
     return {"value": round(units / spent / 1e6, 3), "unit": "Mpixel*iters/s",
             "cores": threads, "kind": "port",
-            "sample": "reference-semantics sweeps of levels [%s] of the solves just timed (oracle, OpenMP "
-                      "over tiles, %d threads), %.1f s; %.0f energy evaluations" % (", ".join(parts), threads, spent, stats[3])}
+            "sample": "reference-semantics sweeps of levels [%s] (coarse to fine, each from the upsampled coarser solution) of the "
+                      "first timed pair (oracle, OpenMP over tiles, %d threads), %.1f s; %.0f energy evaluations" % (
+                          ", ".join(parts), threads, spent, stats[3]),
+            "gpu_same_sample": {"value": round(units / (gpu_ms * 1e-3) / 1e6, 2), "unit": "Mpixel*iters/s", "ms": round(gpu_ms, 2),
+                                "note": "the HIP path on the identical sample: same levels, same starts, same iteration counts "
+                                        "(wall time incl. launches and flag read-backs)"}}
 
 
 if __name__ == "__main__":

@@ -85,6 +85,12 @@ typedef struct {
     double active_tiles;   /* tile visits that were not skipped by the mask     */
     double candidates;     /* pixel visits that ran the line search             */
     double commits;        /* accepted moves                                    */
+    double evaluations;    /* energy evaluations executed (each: 2 bilinear taps
+                              + 25 SSIM terms, morph.cu:671-761)                 */
+    /* HIP-event time and launch count of the sweep kernels per schedule:
+     * [0] TILE, dense kernel; [1] TILE, lean kernel (pruned sweeps); [2] STEP / SPLIT */
+    float  sched_ms[3];
+    int    sched_launches[3];
 } vm_progress;
 
 /* device-state arrays a test or a UI may read back (vm_level_get_field) */

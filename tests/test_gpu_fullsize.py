@@ -217,3 +217,61 @@ def test_fast_solve_tracks_exact_at_1080p(gpu_ctx):
         frames.append(fr.render_halfway(0.5, 0.5, 1).astype(np.int32))
     dpx = np.abs(frames[0] - frames[1])
     assert (dpx <= 2).mean() >= 0.99 and dpx.mean() < 0.5, ((dpx <= 2).mean(), dpx.mean())
+
+
+def _window_sum_invariants(lv, i0, i1):
+    """mean/var/cross are the 5x5 box sums of the stored lumas; lumas are the images at p -/+ v"""
+    h, w = i0.shape
+    v, luma = lv.v, lv.field("luma")
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    assert np.abs(_bilinear(i0, xx - v[..., 0], yy - v[..., 1]) - luma[..., 0]).max() < 2e-2
+    assert np.abs(_bilinear(i1, xx + v[..., 0], yy + v[..., 1]) - luma[..., 1]).max() < 2e-2
+    mean, var, cross = lv.field("mean"), lv.field("var"), lv.field("cross")
+    assert np.abs(_box5(luma) - mean).max() < 0.05
+    assert np.abs(_box5(luma.astype(np.float64) ** 2) - var).max() < 8.0
+    assert np.abs(_box5(luma[..., 0].astype(np.float64) * luma[..., 1]) - cross).max() < 8.0
+    tb = lv.field("tps_b")[2:-2, 2:-2]
+    assert np.abs(_tps_apply(v) - tb).max() < 5e-3 * max(1.0, np.abs(tb).max())
+
+
+@pytest.mark.parametrize("mode,sched", [(capi.MATH_FAST, capi.SWEEP_TILE), (capi.MATH_EXACT, capi.SWEEP_AUTO)])
+def test_config2_batch_of_8_pairs_at_1080p_equals_individual_solves(gpu_ctx, mode, sched):
+    """config[2]'s per-GPU unit at full size: 8 frame pairs of 1920x1080 (6 levels), solved by ONE
+    vm_solve_batch (all pairs relaxed by the same launches, reference semantics per pair), end
+    bit-identical to the 8 pairs solved one at a time, with the same per-level iteration counts;
+    the state of a batched pair satisfies the window-sum invariants.  FAST is compared under one
+    fixed schedule (its schedules differ in summation order); EXACT under the automatic choice --
+    which picks different schedules for a batch and for a single pair -- because every EXACT
+    schedule is bit-identical to the oracle."""
+    gpu_ctx.set_math_mode(mode)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    w, h, sweeps = 1920, 1080, 40
+    frames = [synth.make_pair(w, h, frame=k) for k in range(4)]
+    try:
+        gpu_ctx.set_tuning(sched, 0, 0)
+        prm = morph.Parameters()
+        prm.max_iter, prm.max_iter_drop_factor, prm.start_res = sweeps, 1.0, 32
+        single, iters = [], []
+        for k in range(4):                  # pairs 4..7 repeat frames 0..3: solved once
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build(frames[k][0], frames[k][1], 32)
+            m = morph.Morph(prm, pyr)
+            m.calculate_halfway_parametrization()
+            single.append(pyr[1].v)
+            iters.append([m.progress[el]["iters"] for el in sorted(m.progress)])
+            del pyr
+        batch = []
+        for k in range(8):
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build(frames[k % 4][0], frames[k % 4][1], 32)
+            batch.append(pyr)
+        assert batch[0].size() == 7
+        prog = morph.solve_batch(batch, sweeps, 1.0)
+        for k in range(8):
+            assert [p["iters"] for p in prog[k]] == iters[k % 4], k
+            assert np.array_equal(single[k % 4].view(np.uint32), batch[k][1].v.view(np.uint32)), k
+        assert np.abs(single[0]).max() > 5.0          # the solve moved: ~19 px of displacement at 1080p
+        _window_sum_invariants(batch[5][1], *frames[1])
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)

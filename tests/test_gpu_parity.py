@@ -295,7 +295,9 @@ def test_batched_solve_equals_individual_solves(gpu_ctx):
     for k in range(3):
         assert [p["iters"] for p in prog[k]] == iters[k]
         assert np.array_equal(single[k].view(np.uint32), batch[k][1].v.view(np.uint32))
-    assert len({tuple(i) for i in iters}) > 1 or True   # pairs may stop at different sweeps
+    # the three displacement amplitudes make the pairs stop at different sweeps: the batch keeps
+    # one convergence flag per pair
+    assert len({tuple(i) for i in iters}) > 1, iters
 
 
 @pytest.mark.parametrize("sched", [capi.SWEEP_STEP, capi.SWEEP_TILE])
@@ -511,3 +513,62 @@ def test_cancellation(gpu_ctx, oracle):
     m = morph.Morph(prm, pyr, flag)
     assert m.calculate_halfway_parametrization() is True
     assert m.progress == {}  # no level ran
+
+
+def test_max_iter_is_validated_not_looped_on(gpu_ctx):
+    """a non-finite or absurd max_iter is a caller error (VM_E_INVALID), not a 2^31-step
+    loop or an unbounded allocation; 0 and negatives mean one sweep (do { } while, morph.cu:1378-1390)"""
+    w, h = 64, 48
+    i0, i1 = synth.make_pair(w, h)
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build(i0, i1, 16)
+    L = pyr._L
+    capi.check(L.vm_coarse_solve(pyr._h, pyr.size() - 2, w, h, None, 0))
+    capi.check(L.vm_upsample_v(pyr._h, 0, 1))
+    capi.check(L.vm_init_level(pyr._h, 0, w, h, None, 0))
+    pr = capi.Progress()
+    for bad in (float("inf"), float("nan"), 3e9):
+        rc = L.vm_optimize_level(pyr._h, 0, bad, None, 0, C.byref(pr))
+        assert rc == capi.VM_E_INVALID, (bad, rc)
+        assert b"max_iter" in L.vm_last_error()
+    for one in (0.0, -5.0, 0.25, 1.0):
+        capi.check(L.vm_init_level(pyr._h, 0, w, h, None, 0))
+        capi.check(L.vm_optimize_level(pyr._h, 0, one, None, 1, C.byref(pr)))
+        assert pr.iters == 1
+    capi.check(L.vm_init_level(pyr._h, 0, w, h, None, 0))
+    capi.check(L.vm_optimize_level(pyr._h, 0, 2.5, None, 1, C.byref(pr)))
+    assert pr.iters == 3 and pr.evaluations >= 6 * pr.candidates > 0     # >= 4 gradient + 2 bracket evaluations each
+
+
+def test_context_driven_from_fresh_threads(gpu_ctx):
+    """The API is driven from worker threads (MatchingThread, thread pools); HIP's current
+    device is per thread, so every entry point selects the context's device itself.  On a
+    multi-GPU box this runs on the LAST device from threads whose current device is 0."""
+    import threading
+    import torch
+    dev = torch.cuda.device_count() - 1
+    ctx = morph.Context(dev, capi.MATH_EXACT)
+    ctx.set_params(morph.KernParameters(morph.Parameters()))
+    w, h = 96, 64
+    i0, i1 = synth.make_pair(w, h)
+    out, err = {}, []
+
+    def work(tag):
+        try:
+            pyr = morph.Pyramid(ctx)           # allocates on the context's device from this thread
+            pyr.build(i0, i1, 16)
+            prm = morph.Parameters()
+            prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 6, 1.0, 16
+            morph.Morph(prm, pyr).calculate_halfway_parametrization()
+            out[tag] = pyr[1].v
+        except Exception as e:                  # noqa
+            err.append(e)
+    for tag in ("a", "b"):
+        t = threading.Thread(target=work, args=(tag,))
+        t.start()
+        t.join()
+    assert not err, err
+    work("main")
+    assert np.array_equal(out["a"], out["main"]) and np.array_equal(out["b"], out["main"])
+    assert np.abs(out["main"]).max() > 0
+    ctx.close()

@@ -41,7 +41,12 @@ def main():
         for k, n, f, w in rows:
             fo.write("%s,%d,%.3f,%.3f,%.0f\n" % (k, n, f, w, (2 * f + w) * 1024))
     fk, wk = tot_f / max(tot_l, 1), tot_w / max(tot_l, 1)
+    per_kernel = {}
+    for k, n, f, w in rows:
+        name = k.replace("void ", "").strip()
+        per_kernel[name] = (2 * f + w) * 1024
     json.dump({
+        "per_kernel": per_kernel,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `%s`; all sweep kernels (%s), %d launches" % (cmd, ", ".join(SWEEP), tot_l),
         "fetch_size_kb_per_launch_raw": fk, "write_size_kb_per_launch_raw": wk,
         "hbm_bytes_per_launch": (2 * fk + wk) * 1024,

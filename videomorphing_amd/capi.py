@@ -51,7 +51,8 @@ class Constraint(C.Structure):
 class Progress(C.Structure):
     _fields_ = [("iters", C.c_int), ("improving", C.c_int), ("pixel_iters", C.c_double),
                 ("elapsed_ms", C.c_float), ("launches", C.c_int),
-                ("active_tiles", C.c_double), ("candidates", C.c_double), ("commits", C.c_double)]
+                ("active_tiles", C.c_double), ("candidates", C.c_double), ("commits", C.c_double),
+                ("evaluations", C.c_double), ("sched_ms", C.c_float * 3), ("sched_launches", C.c_int * 3)]
 
 
 class ParamBlock(C.Structure):

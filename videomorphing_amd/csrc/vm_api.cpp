@@ -88,6 +88,8 @@ static void build_tables(uint32_t *tab)
 }
 
 // ---------------------------------------------------------------------------
+static void ctx_free(vm_ctx *c);
+
 extern "C" int vm_ctx_create(int device, vm_ctx **out)
 {
     if (!out) return vm_fail(VM_E_INVALID, "vm_ctx_create: out is NULL");
@@ -99,33 +101,35 @@ extern "C" int vm_ctx_create(int device, vm_ctx **out)
                        hipGetErrorString(e));
     if (device < 0 || device >= ndev)
         return vm_fail(VM_E_INVALID, "vm_ctx_create: device %d out of range (0..%d)", device, ndev - 1);
-    VM_HIP(hipSetDevice(device));
     vm_ctx *c = new vm_ctx();
     c->device = device;
+    VM_ON_DEVICE(c);
     c->math_mode = VM_MATH_EXACT;
     c->kp = {10.0f, 1e5f, 0.05f, 100.0f, 0.0f, 0.01f, VM_BCOND_NONE}; // UI/MdiEditor.cpp:131-140
-    hipError_t e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e2 != hipSuccess) { delete c; return vm_fail(VM_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e2)); }
-    VM_HIP(hipEventCreate(&c->ev0));
-    VM_HIP(hipEventCreate(&c->ev1));
+    // a context that cannot be completed is torn down again: nothing leaks on the error paths
     uint32_t tab[VM_TAB_WORDS];
     build_tables(tab);
-    VM_HIP(hipMalloc((void **)&c->tables, sizeof(tab)));
-    VM_HIP(hipMemcpy(c->tables, tab, sizeof(tab), hipMemcpyHostToDevice));
     c->flags_cap = 4096;
-    VM_HIP(hipMalloc((void **)&c->flags, c->flags_cap * sizeof(uint32_t)));
-    VM_HIP(hipHostMalloc((void **)&c->flags_host, c->flags_cap * sizeof(uint32_t), hipHostMallocDefault));
-    VM_HIP(hipMalloc((void **)&c->stats, c->flags_cap * 4 * sizeof(uint32_t)));
-    VM_HIP(hipHostMalloc((void **)&c->stats_host, c->flags_cap * 4 * sizeof(uint32_t), hipHostMallocDefault));
+    hipError_t e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e2 == hipSuccess) e2 = hipEventCreate(&c->ev0);
+    if (e2 == hipSuccess) e2 = hipEventCreate(&c->ev1);
+    if (e2 == hipSuccess) e2 = hipMalloc((void **)&c->tables, sizeof(tab));
+    if (e2 == hipSuccess) e2 = hipMemcpy(c->tables, tab, sizeof(tab), hipMemcpyHostToDevice);
+    if (e2 == hipSuccess) e2 = hipMalloc((void **)&c->flags, c->flags_cap * sizeof(uint32_t));
+    if (e2 == hipSuccess) e2 = hipHostMalloc((void **)&c->flags_host, c->flags_cap * sizeof(uint32_t), hipHostMallocDefault);
+    if (e2 == hipSuccess) e2 = hipMalloc((void **)&c->stats, c->flags_cap * VM_STAT_WORDS * sizeof(uint32_t));
+    if (e2 == hipSuccess) e2 = hipHostMalloc((void **)&c->stats_host, c->flags_cap * VM_STAT_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e2 != hipSuccess) {
+        ctx_free(c);
+        return vm_fail(VM_E_DEVICE, "vm_ctx_create: %s", hipGetErrorString(e2));
+    }
     *out = c;
     return VM_OK;
 }
 
-extern "C" void vm_ctx_destroy(vm_ctx *c)
+static void ctx_free(vm_ctx *c)
 {
-    if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->tables);
     hipFree(c->flags);
     hipHostFree(c->flags_host);
@@ -135,15 +139,24 @@ extern "C" void vm_ctx_destroy(vm_ctx *c)
     hipFree(c->views);
     hipFree(c->iter_dev);
     for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
-    hipEventDestroy(c->ev0);
-    hipEventDestroy(c->ev1);
-    hipStreamDestroy(c->stream);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    (void)hipGetLastError();
     delete c;
+}
+
+extern "C" void vm_ctx_destroy(vm_ctx *c)
+{
+    if (!c) return;
+    VM_ON_DEVICE(c);
+    ctx_free(c);
 }
 
 extern "C" int vm_ctx_sync(vm_ctx *c)
 {
     if (!c) return vm_fail(VM_E_INVALID, "ctx is NULL");
+    VM_ON_DEVICE(c);
     VM_HIP(hipStreamSynchronize(c->stream));
     return VM_OK;
 }
@@ -196,7 +209,7 @@ extern "C" int vm_device_info(vm_ctx *c, char *name256, int *cus, uint64_t *hbm)
 }
 
 // ---------------------------------------------------------------------------
-static void level_free(vm_level &l)
+void vm_level_free(vm_level &l)
 {
     hipFree(l.slab);
     hipFree(l.ws);
@@ -208,10 +221,12 @@ static void level_free(vm_level &l)
     V.mean2 = V.var2 = V.tps_b2 = nullptr;
     V.cross2 = V.value2 = nullptr;
     V.impmask2 = nullptr;
+    V.temp_ref = nullptr;
+    V.temp_mask = nullptr;
 }
 
 // one slab per level: every array starts on a 256-byte boundary
-static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
+int vm_level_alloc(vm_ctx *c, vm_level &l, bool with_images)
 {
     size_t n = (size_t)l.rs * l.h;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -260,6 +275,9 @@ static int level_alloc(vm_ctx *c, vm_level &l, bool with_images)
     V.mean2 = V.var2 = V.tps_b2 = nullptr;
     V.cross2 = V.value2 = nullptr;
     V.impmask2 = nullptr;
+    V.temp_ref = nullptr;
+    V.temp_mask = nullptr;
+    V.factor_d = 1.0f;
     return VM_OK;
 }
 
@@ -298,7 +316,7 @@ extern "C" int vm_pyramid_create(vm_ctx *c, int nlevels, const int *w, const int
     for (int i = 0; i < nlevels; ++i)
         if (w[i] < 5 || h[i] < 5)
             return vm_fail(VM_E_INVALID, "vm_pyramid_create: level %d is %dx%d (min 5x5)", i, w[i], h[i]);
-    VM_HIP(hipSetDevice(c->device));
+    VM_ON_DEVICE(c);
     vm_pyr *p = new vm_pyr();
     p->ctx = c;
     p->lv.resize(nlevels);
@@ -308,7 +326,7 @@ extern "C" int vm_pyramid_create(vm_ctx *c, int nlevels, const int *w, const int
         l.rs = (w[i] + 31) / 32 * 32;               // pyramid.cu:535
         l.imp_rs = (w[i] + 4) / 5 + 2;              // pyramid.cu:538
         l.imp_rows = (h[i] + 4) / 5 + 2;            // pyramid.cu:539
-        int rc = level_alloc(c, l, i != nlevels - 1);
+        int rc = vm_level_alloc(c, l, i != nlevels - 1);
         if (rc != VM_OK) { vm_pyramid_destroy(p); return rc; }
     }
     *out = p;
@@ -318,9 +336,9 @@ extern "C" int vm_pyramid_create(vm_ctx *c, int nlevels, const int *w, const int
 extern "C" void vm_pyramid_destroy(vm_pyr *p)
 {
     if (!p) return;
-    hipSetDevice(p->ctx->device);
+    VM_ON_DEVICE(p->ctx);
     hipStreamSynchronize(p->ctx->stream);
-    for (auto &l : p->lv) level_free(l);
+    for (auto &l : p->lv) vm_level_free(l);
     delete p;
 }
 
@@ -329,7 +347,8 @@ extern "C" int vm_pyramid_levels(vm_pyr *p) { return p ? (int)p->lv.size() : 0; 
 #define CHECK_LVL(p, lvl)                                                        \
     if (!(p)) return vm_fail(VM_E_INVALID, "%s: pyramid is NULL", __func__);     \
     if ((lvl) < 0 || (lvl) >= (int)(p)->lv.size())                               \
-        return vm_fail(VM_E_INVALID, "%s: level %d out of range", __func__, (lvl));
+        return vm_fail(VM_E_INVALID, "%s: level %d out of range", __func__, (lvl)); \
+    VM_ON_DEVICE((p)->ctx);
 
 extern "C" int vm_level_dims(vm_pyr *p, int lvl, int *w, int *h, int *rs)
 {
@@ -475,24 +494,33 @@ extern "C" int vm_coarse_solve(vm_pyr *p, int lvl, int w0, int h0, const vm_cons
     return vm_level_set_v(p, lvl, v.data(), 0);
 }
 
+// upsample(PyramidLevel&dest, PyramidLevel&orig) for one page, upsample.cu:260-286
+int vm_level_upsample(vm_ctx *c, vm_level &d, const vm_level &s)
+{
+    if (c->math_mode == VM_MATH_EXACT)
+        vm_launch_upsample_exact(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, c->stream);
+    else
+        vm_launch_upsample_fast(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, c->stream);
+    VM_HIP(hipGetLastError());
+    return VM_OK;
+}
+
 extern "C" int vm_upsample_v(vm_pyr *p, int dst, int src)
 {
     CHECK_LVL(p, dst);
     CHECK_LVL(p, src);
-    vm_level &d = p->lv[dst], &s = p->lv[src];
-    if (p->ctx->math_mode == VM_MATH_EXACT)
-        vm_launch_upsample_exact(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, p->ctx->stream);
-    else
-        vm_launch_upsample_fast(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, p->ctx->stream);
-    VM_HIP(hipGetLastError());
-    return VM_OK;
+    return vm_level_upsample(p->ctx, p->lv[dst], p->lv[src]);
 }
 
 extern "C" int vm_init_level(vm_pyr *p, int lvl, int w0, int h0, const vm_constraint *cons, int n)
 {
     CHECK_LVL(p, lvl);
-    vm_level &l = p->lv[lvl];
-    vm_ctx *c = p->ctx;
+    return vm_level_init(p->ctx, p->lv[lvl], w0, h0, cons, n);
+}
+
+// Morph::initialize_level for one page, morph.cu:264-390
+int vm_level_init(vm_ctx *c, vm_level &l, int w0, int h0, const vm_constraint *cons, int n)
+{
     if (!l.view.img0) return vm_fail(VM_E_STATE, "vm_init_level: the coarsest level is solved by vm_coarse_solve");
     if (n < 0 || (n > 0 && !cons)) return vm_fail(VM_E_INVALID, "vm_init_level: constraints");
     int rc = upload_constraints(c, cons, n);
@@ -570,19 +598,45 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
 {
     vm_pyr *p0 = ps[0];
     vm_ctx *c = p0->ctx;
-    std::lock_guard<std::recursive_mutex> lock(c->mu);
-    vm_level &l0 = p0->lv[lvl];
+    std::vector<vm_level *> lv(n);
     for (int i = 0; i < n; ++i) {
         if (!ps[i] || ps[i]->ctx != c) return vm_fail(VM_E_INVALID, "batch: pyramids must share one context");
         if (lvl < 0 || lvl >= (int)ps[i]->lv.size()) return vm_fail(VM_E_INVALID, "batch: level %d out of range", lvl);
-        vm_level &l = ps[i]->lv[lvl];
-        if (l.w != l0.w || l.h != l0.h) return vm_fail(VM_E_INVALID, "batch: pyramids must share their geometry");
-        if (!l.has_state) return vm_fail(VM_E_STATE, "vm_optimize_level: level %d not initialised", lvl);
+        lv[i] = &ps[i]->lv[lvl];
     }
-    VmKParams P = {c->kp.w_ui, c->kp.w_tps, c->kp.w_ssim, c->kp.ssim_clamp, c->kp.eps, c->kp.bcond};
-    // iterations the reference loop would run: do { ... iter++ } while (iter < max_iter && improving)
+    return vm_optimize_levels(c, lv.data(), n, max_iter, run_flag, fixed_work, out);
+}
+
+// The iteration count of `do { ... iter++; } while (iter < _max_iter && ...)` (morph.cu:1378-1390)
+// for the float _max_iter of morph.h:20: max(1, ceil(max_iter)).  Not finite, or beyond 2^20
+// iterations, is a caller error (the flag and counter arrays are sized by it).
+int vm_iteration_cap(float max_iter, int *cap)
+{
+    if (!std::isfinite(max_iter)) return vm_fail(VM_E_INVALID, "max_iter must be finite (got %g)", (double)max_iter);
+    if (max_iter > (float)(1 << 20)) return vm_fail(VM_E_INVALID, "max_iter %g exceeds the limit of %d iterations per level", (double)max_iter, 1 << 20);
+    *cap = std::max(1, (int)std::ceil(max_iter));
+    return VM_OK;
+}
+
+// The same level (one page) of n frame pairs -- or n pages of a video that do not depend on
+// each other -- relaxed by the same launches.
+int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile const int *run_flag,
+                       int fixed_work, vm_progress *out)
+{
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    VM_ON_DEVICE(c);
+    vm_level &l0 = *lv[0];
+    for (int i = 0; i < n; ++i) {
+        vm_level &l = *lv[i];
+        if (l.w != l0.w || l.h != l0.h) return vm_fail(VM_E_INVALID, "batch: pyramids must share their geometry");
+        if (!l.has_state) return vm_fail(VM_E_STATE, "vm_optimize_level: level not initialised");
+        if ((l.view.temp_mask != nullptr) != (l0.view.temp_mask != nullptr))
+            return vm_fail(VM_E_INVALID, "batch: pages with and without the temporal term cannot share a launch");
+    }
+    VmKParams P = {c->kp.w_ui, c->kp.w_tps, c->kp.w_ssim, c->kp.ssim_clamp, c->kp.eps, c->kp.bcond, c->kp.w_temp};
     int cap = 1;
-    while ((float)cap < max_iter) ++cap;
+    int rc0 = vm_iteration_cap(max_iter, &cap);
+    if (rc0 != VM_OK) return rc0;
     const size_t words = (size_t)cap * n;
     if ((size_t)c->flags_cap < words) {
         hipFree(c->flags); hipHostFree(c->flags_host);
@@ -591,8 +645,8 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
         c->flags_cap = 0;
         VM_HIP(hipMalloc((void **)&c->flags, words * 4));
         VM_HIP(hipHostMalloc((void **)&c->flags_host, words * 4, hipHostMallocDefault));
-        VM_HIP(hipMalloc((void **)&c->stats, words * 16));
-        VM_HIP(hipHostMalloc((void **)&c->stats_host, words * 16, hipHostMallocDefault));
+        VM_HIP(hipMalloc((void **)&c->stats, words * 4 * VM_STAT_WORDS));
+        VM_HIP(hipHostMalloc((void **)&c->stats_host, words * 4 * VM_STAT_WORDS, hipHostMallocDefault));
         c->flags_cap = (int)words;
     }
     if (n > c->views_cap) {
@@ -610,16 +664,16 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
         if (c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP ||
             (c->sweep_mode == VM_SWEEP_AUTO && tiles0 * n <= 64))
             for (int i = 0; i < n; ++i) {
-                int rc = level_ensure_ws(c, ps[i]->lv[lvl]);
+                int rc = level_ensure_ws(c, *lv[i]);
                 if (rc != VM_OK) return rc;
             }
         std::vector<VmLevelView> hv(n);
-        for (int i = 0; i < n; ++i) hv[i] = ps[i]->lv[lvl].view;
+        for (int i = 0; i < n; ++i) hv[i] = lv[i]->view;
         VM_HIP(hipMemcpyAsync(c->views, hv.data(), (size_t)n * sizeof(VmLevelView), hipMemcpyHostToDevice, s));
         VM_HIP(hipStreamSynchronize(s)); // hv is a stack object
     }
     VM_HIP(hipMemsetAsync(c->flags, 0, words * 4, s));
-    VM_HIP(hipMemsetAsync(c->stats, 0, words * 16, s));
+    VM_HIP(hipMemsetAsync(c->stats, 0, words * 4 * VM_STAT_WORDS, s));
     const bool exact = c->math_mode == VM_MATH_EXACT;
     // FAST kernels are built for at most 512 threads (256-VGPR budget: the register-cached
     // window sums must not spill), EXACT ones for up to 1024
@@ -641,15 +695,18 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
     if (may_split || c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP) // epochs restart with every call: forget old records
         for (int i = 0; i < n; ++i)
         {
-            VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_tag, 0, (size_t)l0.rs * l0.h * 4, s));
-            VM_HIP(hipMemsetAsync(ps[i]->lv[lvl].view.rec_tag2, 0, (size_t)l0.rs * l0.h * 4, s));
+            VM_HIP(hipMemsetAsync(lv[i]->view.rec_tag, 0, (size_t)l0.rs * l0.h * 4, s));
+            VM_HIP(hipMemsetAsync(lv[i]->view.rec_tag2, 0, (size_t)l0.rs * l0.h * 4, s));
         }
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
     std::vector<int> executed(n, cap), improving(n, 1), stopped(n, 0);
-    std::vector<double> st_tiles(n, 0.0), st_cand(n, 0.0), st_commit(n, 0.0);
+    std::vector<double> st_tiles(n, 0.0), st_cand(n, 0.0), st_commit(n, 0.0), st_eval(n, 0.0);
     int done = 0, launches = 0;
     bool cancelled = false;
     float ms = 0;
+    float sched_ms[3] = {0, 0, 0}; // [0] TILE dense kernel, [1] TILE lean kernel, [2] STEP / SPLIT
+    int sched_launches[3] = {0, 0, 0};
+    static const bool force_dense = getenv("VM_TILE_DENSE") != nullptr; // dev switch
     // Iterations are enqueued in batches; each sweep kernel of iteration i exits at once (per
     // pair) when iteration i-1 did not improve (device-side flag), so running past convergence
     // inside a batch costs launch latency only, and the host reads the flags once per batch
@@ -664,7 +721,9 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
         const bool step = split && c->sweep_mode != VM_SWEEP_SPLIT;
         // TILE, FAST arithmetic: the register-light kernel variant once fewer than a tenth of the pixels
         // are searched per iteration (after the first sweep of a level, typically)
-        const int dense = exact || getenv("VM_TILE_DENSE") || cand_prev >= 0.1 * l0.w * l0.h * n;
+        const int dense = exact || force_dense || cand_prev >= 0.1 * l0.w * l0.h * n;
+        const int sched = split ? 2 : (dense ? 0 : 1);
+        const int launches_before = launches;
         VM_HIP(hipEventRecord(c->ev0, s));
         uint32_t last_epoch = 0;
         int sb = 0; // step index inside this batch: parity = which copy of the sums is read
@@ -711,22 +770,26 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
         VM_HIP(hipGetLastError());
         for (int i = 0; i < n; ++i) {
             VM_HIP(hipMemcpyAsync(c->flags_host + (size_t)i * cap + done, c->flags + (size_t)i * cap + done, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
-            VM_HIP(hipMemcpyAsync(c->stats_host + ((size_t)i * cap + done) * 4, c->stats + ((size_t)i * cap + done) * 4, (size_t)nb * 16, hipMemcpyDeviceToHost, s));
+            VM_HIP(hipMemcpyAsync(c->stats_host + ((size_t)i * cap + done) * VM_STAT_WORDS, c->stats + ((size_t)i * cap + done) * VM_STAT_WORDS,
+                                  (size_t)nb * 4 * VM_STAT_WORDS, hipMemcpyDeviceToHost, s));
         }
         VM_HIP(hipStreamSynchronize(s));
         float bms = 0;
         VM_HIP(hipEventElapsedTime(&bms, c->ev0, c->ev1));
         ms += bms;
+        sched_ms[sched] += bms;
+        sched_launches[sched] += launches - launches_before;
         bool all_stopped = true;
         double b_cand = 0;
         for (int i = 0; i < n; ++i) {
-            const uint32_t *fl = c->flags_host + (size_t)i * cap, *st = c->stats_host + (size_t)i * cap * 4;
+            const uint32_t *fl = c->flags_host + (size_t)i * cap, *st = c->stats_host + (size_t)i * cap * VM_STAT_WORDS;
             for (int it = done; it < done + nb && !stopped[i]; ++it) {
                 // [0] tile visits (TILE schedule), [3] tile-phases with records (SPLIT schedule)
-                st_tiles[i] += st[4 * it] + 0.25 * st[4 * it + 3];
-                st_cand[i] += st[4 * it + 1];
-                b_cand += st[4 * it + 1];
-                st_commit[i] += st[4 * it + 2];
+                st_tiles[i] += st[VM_STAT_WORDS * it] + 0.25 * st[VM_STAT_WORDS * it + 3];
+                st_cand[i] += st[VM_STAT_WORDS * it + 1];
+                b_cand += st[VM_STAT_WORDS * it + 1];
+                st_commit[i] += st[VM_STAT_WORDS * it + 2];
+                st_eval[i] += st[VM_STAT_WORDS * it + 4];
                 improving[i] = fl[it] != 0;
                 if (!improving[i] && !fixed_work) { executed[i] = it + 1; stopped[i] = 1; }
             }
@@ -751,6 +814,11 @@ static int optimize_level_batch(vm_pyr **ps, int n, int lvl, float max_iter, vol
         out[i].active_tiles = st_tiles[i];
         out[i].candidates = st_cand[i];
         out[i].commits = st_commit[i];
+        out[i].evaluations = st_eval[i];
+        for (int k = 0; k < 3; ++k) { // of the batch, like elapsed_ms
+            out[i].sched_ms[k] = sched_ms[k];
+            out[i].sched_launches[k] = sched_launches[k];
+        }
     }
     return cancelled ? vm_fail(VM_E_CANCELLED, "vm_optimize_level: cancelled by run_flag") : VM_OK;
 }

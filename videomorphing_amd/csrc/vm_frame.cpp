@@ -10,7 +10,7 @@ extern "C" int vm_frame_create(vm_ctx *c, int w, int h, int ex, vm_frame **out)
 {
     if (!c || !out || w < 1 || h < 1 || ex < 0)
         return vm_fail(VM_E_INVALID, "vm_frame_create: bad argument");
-    VM_HIP(hipSetDevice(c->device));
+    VM_ON_DEVICE(c);
     vm_frame *f = new vm_frame();
     f->ctx = c;
     f->w = w; f->h = h; f->ex = ex;
@@ -36,7 +36,7 @@ extern "C" int vm_frame_create(vm_ctx *c, int w, int h, int ex, vm_frame **out)
 extern "C" void vm_frame_destroy(vm_frame *f)
 {
     if (!f) return;
-    hipSetDevice(f->ctx->device);
+    VM_ON_DEVICE(f->ctx);
     hipStreamSynchronize(f->ctx->stream);
     hipFree(f->ext[0]); hipFree(f->ext[1]);
     hipFree(f->crop[0]); hipFree(f->crop[1]);
@@ -48,6 +48,7 @@ extern "C" int vm_frame_upload(vm_frame *f, const uint8_t *e0, const uint8_t *e1
                                const float *q)
 {
     if (!f) return vm_fail(VM_E_INVALID, "vm_frame_upload: frame is NULL");
+    VM_ON_DEVICE(f->ctx);
     hipStream_t s = f->ctx->stream;
     size_t nc = (size_t)f->cw * f->ch * 4;
     const uint8_t *e[2] = {e0, e1};
@@ -68,6 +69,7 @@ extern "C" int vm_frame_download_ext(vm_frame *f, int side, uint8_t *ext)
 {
     if (!f || !ext || (side != 1 && side != 2))
         return vm_fail(VM_E_INVALID, "vm_frame_download_ext: bad argument");
+    VM_ON_DEVICE(f->ctx);
     hipStream_t s = f->ctx->stream;
     VM_HIP(hipMemcpyAsync(ext, f->ext[side - 1], (size_t)f->cw * f->ch * 4, hipMemcpyDeviceToHost, s));
     VM_HIP(hipStreamSynchronize(s));
@@ -79,6 +81,7 @@ extern "C" int vm_frame_set_v_from_level(vm_frame *f, vm_pyr *p, int lvl)
     if (!f || !p || lvl < 0 || lvl >= (int)p->lv.size())
         return vm_fail(VM_E_INVALID, "vm_frame_set_v_from_level: bad argument");
     if (p->ctx != f->ctx) return vm_fail(VM_E_INVALID, "frame and pyramid belong to different contexts");
+    VM_ON_DEVICE(f->ctx);
     vm_level &l = p->lv[lvl];
     vm_launch_upscale(f->v, f->w, f->h, f->rs, l.view.v, l.w, l.h, l.rs, f->ctx->stream);
     VM_HIP(hipGetLastError());
@@ -91,6 +94,7 @@ extern "C" int vm_upscale_result(vm_pyr *p, int lvl, int w0, int h0, float *out,
         return vm_fail(VM_E_INVALID, "vm_upscale_result: bad argument");
     if (pitch == 0) pitch = 2 * w0;
     if (pitch < 2 * w0) return vm_fail(VM_E_INVALID, "vm_upscale_result: pitch < 2*w0");
+    VM_ON_DEVICE(p->ctx);
     vm_level &l = p->lv[lvl];
     hipStream_t s = p->ctx->stream;
     float2 *tmp = nullptr;
@@ -110,6 +114,7 @@ static int render_dev(vm_frame *f, float color_fa, float geo_fa, int color_from,
     if (!f) return vm_fail(VM_E_INVALID, "vm_render_halfway: frame is NULL");
     if (color_from < 0 || color_from > 2) return vm_fail(VM_E_INVALID, "vm_render_halfway: color_from %d", color_from);
     vm_ctx *c = f->ctx;
+    VM_ON_DEVICE(c);
     if (ms) VM_HIP(hipEventRecord(c->ev0, c->stream));
     vm_launch_render(f->out, f->w * 3, f->w, f->h, f->rs, f->ex, color_fa, geo_fa, color_from,
                      f->ext[0], f->ext[1], f->v, f->u, c->stream);
@@ -135,6 +140,7 @@ extern "C" int vm_render_halfway(vm_frame *f, float color_fa, float geo_fa, int 
     if (rc != VM_OK) return rc;
     if (pitch == 0) pitch = f->w * 3;
     if (pitch < f->w * 3) return vm_fail(VM_E_INVALID, "vm_render_halfway: pitch < 3*w");
+    VM_ON_DEVICE(f->ctx);
     hipStream_t s = f->ctx->stream;
     VM_HIP(hipMemcpy2DAsync(rgb, pitch, f->out, (size_t)f->w * 3, (size_t)f->w * 3, f->h, hipMemcpyDeviceToHost, s));
     VM_HIP(hipStreamSynchronize(s));

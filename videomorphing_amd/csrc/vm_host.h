@@ -16,6 +16,29 @@ int vm_fail(int code, const char *fmt, ...);
                            hipGetErrorString(e_));                                         \
     } while (0)
 
+// HIP's current device belongs to the calling host thread, and the API is driven from worker
+// threads (MatchingThread, thread pools): every entry point that allocates or launches makes
+// the context's device current first and restores the caller's device on return.
+struct VmDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit VmDeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess || prev != dev)
+            switched = hipSetDevice(dev) == hipSuccess && prev >= 0;
+    }
+    ~VmDeviceGuard()
+    {
+        if (switched)
+            (void)hipSetDevice(prev);
+    }
+    VmDeviceGuard(const VmDeviceGuard &) = delete;
+    VmDeviceGuard &operator=(const VmDeviceGuard &) = delete;
+};
+#define VM_CAT2(a, b) a##b
+#define VM_CAT(a, b) VM_CAT2(a, b)
+#define VM_ON_DEVICE(ctx) VmDeviceGuard VM_CAT(vm_device_guard_, __LINE__)((ctx)->device)
+
 struct vm_ctx {
     std::recursive_mutex mu;         // a context is single-threaded by contract; this makes misuse safe
     int device = 0;
@@ -74,6 +97,16 @@ struct vm_frame {
     void *pws = nullptr;
     size_t pws_bytes = 0;
 };
+
+// level-wise pieces of the solver shared by the frame-pair API (vm_api.cpp) and the video
+// API (vm_video.cpp); a "level" here is one page of one pyramid level
+int vm_level_alloc(vm_ctx *c, vm_level &l, bool with_images);
+void vm_level_free(vm_level &l);
+int vm_level_upsample(vm_ctx *c, vm_level &dst, const vm_level &src);
+int vm_level_init(vm_ctx *c, vm_level &l, int w0, int h0, const vm_constraint *cons, int n);
+int vm_iteration_cap(float max_iter, int *cap);
+int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile const int *run_flag,
+                       int fixed_work, vm_progress *out);
 
 // Morph::cpu_optimize_level (morph.cu:419-590) on the host: v_out is a tight
 // (h, w, 2) array

@@ -41,12 +41,26 @@ struct VmLevelView {
     float2 *mean2, *var2, *tps_b2;
     float *cross2, *value2;
     uint32_t *impmask2;
+    // temporal coherence term of a video page (energy_change with flag == true,
+    // morph.cu:752-759): the halfway field advected from the neighbouring page
+    // (lvl.temp.ref), its splat weight (lvl.temp.mask) and the level's factor_d.
+    // temp_mask == nullptr <=> flag == false (the middle page, and every frame pair
+    // solved on its own).
+    const float2 *temp_ref;
+    const float *temp_mask;
+    float factor_d;
 };
 
 struct VmKParams {
     float w_ui, w_tps, w_ssim, ssim_clamp, eps;
     int bcond;
+    float w_temp;
 };
+
+// per-iteration activity counters of the sweep kernels (uint32 words per iteration):
+// [0] tile visits that were not skipped (TILE), [1] line searches, [2] commits,
+// [3] tile-phases with records (SPLIT / STEP), [4] energy evaluations
+#define VM_STAT_WORDS 8
 
 // constant tables living in one device buffer: 625 floats (thin-plate stencil
 // per border class) followed by 225 uint32 (improving-mask window bits)

@@ -293,6 +293,7 @@ extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, i
     if (!f || (side != 1 && side != 2) || !(tol > 0) || max_it < 1)
         return vm_fail(VM_E_INVALID, "vm_poisson_extend: bad argument");
     vm_ctx *c = f->ctx;
+    VM_ON_DEVICE(c);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipStream_t s = c->stream;
     static const bool jacobi = getenv("VM_POISSON_SOLVER") && !strcmp(getenv("VM_POISSON_SOLVER"), "jacobi");
@@ -325,6 +326,7 @@ extern "C" int vm_frame_quadratic_path(vm_frame *f, float tol, int max_it, int *
     if (f->w < 2 || f->h < 2)
         return vm_fail(VM_E_INVALID, "vm_frame_quadratic_path: needs a frame of at least 2x2 pixels");
     vm_ctx *c = f->ctx;
+    VM_ON_DEVICE(c);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipStream_t s = c->stream;
     const size_t need = mg_bytes(f->w, f->h);
@@ -372,6 +374,7 @@ extern "C" int vm_frame_quadratic_path(vm_frame *f, float tol, int max_it, int *
 extern "C" int vm_frame_download_qpath(vm_frame *f, float *u_xy)
 {
     if (!f || !u_xy) return vm_fail(VM_E_INVALID, "vm_frame_download_qpath: bad argument");
+    VM_ON_DEVICE(f->ctx);
     hipStream_t s = f->ctx->stream;
     VM_HIP(hipMemcpy2DAsync(u_xy, (size_t)f->w * 8, f->u, (size_t)f->rs * 8, (size_t)f->w * 8, f->h, hipMemcpyDeviceToHost, s));
     VM_HIP(hipStreamSynchronize(s));
@@ -383,6 +386,7 @@ extern "C" int vm_frame_download_qpath(vm_frame *f, float *u_xy)
 extern "C" int vm_rccl_bcast(vm_ctx *c, void *comm, void *dev_buf, uint64_t bytes, int root)
 {
     if (!c || !comm || !dev_buf) return vm_fail(VM_E_INVALID, "vm_rccl_bcast: NULL argument");
+    VM_ON_DEVICE(c);
     typedef int (*bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
     static bcast_fn fn = nullptr;
     if (!fn) {

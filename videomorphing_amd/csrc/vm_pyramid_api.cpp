@@ -114,6 +114,7 @@ extern "C" int vm_pyramid_build_rgb(vm_pyr *p, const uint8_t *rgb0, const uint8_
     if (!p || !rgb0 || !rgb1) return vm_fail(VM_E_INVALID, "vm_pyramid_build_rgb: NULL argument");
     std::lock_guard<std::recursive_mutex> lock(p->ctx->mu);
     vm_ctx *c = p->ctx;
+    VM_ON_DEVICE(c);
     const int w0 = p->lv[0].w, h0 = p->lv[0].h, L = (int)p->lv.size();
     if (pitch == 0) pitch = 3 * w0;
     if (pitch < 3 * w0) return vm_fail(VM_E_INVALID, "vm_pyramid_build_rgb: pitch < 3*width");

@@ -67,6 +67,7 @@ struct TileLds {
     float tps[625];
     uint32_t imp[225];
     uint32_t mask[6][16];    // improving-mask words covering the tile +-1 block
+    uint32_t n_eval;         // energy evaluations of the workgroup (one count per candidate)
 };
 
 // the LDS of the SPLIT kernels: no window sums
@@ -79,6 +80,7 @@ struct SplitLds {
     float tps[625];
     uint32_t imp[225];
     uint32_t mask[6][16];
+    uint32_t n_eval;
 };
 
 struct PixelCtx {
@@ -87,7 +89,19 @@ struct PixelCtx {
     float2 v, old_luma;
     float tps_axy, ui_axy;
     float2 tps_b, ui_b;
+    // temporal term (flag == true only): reference vector and splat weight of the pixel
+    float2 tref;
+    float tmask;
 };
+
+// v_temp of energy_change (morph.cu:752-756): the change of |v - ref|_1 under the move d
+__device__ __forceinline__ float temp_change(const PixelCtx &c, float dx, float dy)
+{
+    float v_temp = 0.0f;
+    v_temp += fabsf(c.v.x + dx - c.tref.x) - fabsf(c.v.x - c.tref.x);
+    v_temp += fabsf(c.v.y + dy - c.tref.y) - fabsf(c.v.y - c.tref.y);
+    return v_temp;
+}
 
 // where the 5x5 window sums of a pixel come from
 struct LdsSrc {
@@ -156,7 +170,9 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
     float v_ui = c.ui_axy * (dx * dx + dy * dy);
     v_ui += c.ui_b.x * dx;
     v_ui += c.ui_b.y * dy;
-    return (P.w_ui * v_ui + P.w_ssim * change + 0.0f) * L.inv_wh + P.w_tps * v_tps;
+    // flag == false: v_temp = 0 and the mask is 0, the term is +0 (morph.cu:752-759)
+    const float t = L.temp_mask ? P.w_temp * temp_change(c, dx, dy) * c.tmask * L.factor_d : 0.0f;
+    return (P.w_ui * v_ui + P.w_ssim * change + t) * L.inv_wh + P.w_tps * v_tps;
 }
 #else
 // ---- FAST: the same energy, evaluated by L lanes per pixel.  Lane `sub` owns the
@@ -283,7 +299,10 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
     const float dd = dx * dx + dy * dy;
     const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
     const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
-    return (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
+    float e = P.w_ui * v_ui + P.w_ssim * change;
+    if (L.temp_mask) // uniform in the launch
+        e = fmaf(P.w_temp * c.tmask * L.factor_d, temp_change(c, dx, dy), e);
+    return e * L.inv_wh + P.w_tps * v_tps;
 }
 #endif
 
@@ -350,10 +369,10 @@ __device__ __forceinline__ bool pixel_locked(const VmLevelView &L, int bcond, in
 // agree bit for bit.  Returns true and the accepted step when the energy drops.
 template <class Energy>
 __device__ __forceinline__ bool decide_with(const VmLevelView &L, const VmKParams &P, const PixelCtx &c,
-                                            const Energy &energy, float2 &step VM_TS_ARG)
+                                            const Energy &energy, float2 &step, uint32_t &n_eval VM_TS_ARG)
 {
     VM_TS(4);
-#define ENERGY(DX, DY) energy((DX), (DY))
+#define ENERGY(DX, DY) (++n_eval, energy((DX), (DY)))
     // The energy is evaluated at exactly two places of the instruction stream (not at
     // the reference's seven): the sweep kernels must stay inside the instruction cache.
     // compute_gradient, morph.cu:763-778: g = -(E(+eps x) - E(-eps x), E(+eps y) - E(-eps y))
@@ -433,13 +452,13 @@ __device__ __forceinline__ bool decide_with(const VmLevelView &L, const VmKParam
 // one lane (EXACT) or L lanes (FAST dense path) per pixel
 template <bool INTERIOR, class Src>
 __device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P, const Src &src,
-                                       const PixelCtx &c, int sub, int Lf, float2 &step VM_TS_ARG)
+                                       const PixelCtx &c, int sub, int Lf, float2 &step, uint32_t &n_eval VM_TS_ARG)
 {
     NbCache nb;
     nb_load<INTERIOR>(nb, L, src, c, sub, Lf);
     return decide_with(
         L, P, c, [&](float dx, float dy) { return energy_change<INTERIOR>(L, P, src, nb, c, dx, dy, Lf); },
-        step VM_TS_PASS);
+        step, n_eval VM_TS_PASS);
 }
 
 #if VM_EXACT
@@ -498,17 +517,18 @@ __device__ __forceinline__ float energy_x32(const VmLevelView &L, const VmKParam
     float v_ui = c.ui_axy * (dx * dx + dy * dy);
     v_ui += c.ui_b.x * dx;
     v_ui += c.ui_b.y * dy;
-    return (P.w_ui * v_ui + P.w_ssim * change + 0.0f) * L.inv_wh + P.w_tps * v_tps;
+    const float tt = L.temp_mask ? P.w_temp * temp_change(c, dx, dy) * c.tmask * L.factor_d : 0.0f;
+    return (P.w_ui * v_ui + P.w_ssim * change + tt) * L.inv_wh + P.w_tps * v_tps;
 }
 
 template <class Src>
 __device__ __forceinline__ bool decide_x32(const VmLevelView &L, const VmKParams &P, const Src &src,
-                                           const PixelCtx &c, int sub, float2 &step VM_TS_ARG)
+                                           const PixelCtx &c, int sub, float2 &step, uint32_t &n_eval VM_TS_ARG)
 {
     NbX nb;
     nbx_load(nb, L, src, c, sub);
     return decide_with(
-        L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step VM_TS_PASS);
+        L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step, n_eval VM_TS_PASS);
 }
 #endif
 
@@ -691,9 +711,13 @@ __device__ __forceinline__ float fover32(const VmLevelView &L, const PixelCtx &c
 // quadratic terms collapse to t (Q2 t + Q1).
 template <bool INTERIOR>
 __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &P, const Nb1 &nb,
-                                         const PixelCtx &c, int sub, float2 &step, float2 &luma VM_TS_ARG)
+                                         const PixelCtx &c, int sub, float2 &step, float2 &luma,
+                                         uint32_t &n_eval VM_TS_ARG)
 {
     VM_TS(4);
+    n_eval += 4;
+    const bool has_temp = L.temp_mask != nullptr; // uniform in the launch
+    const float WT = has_temp ? P.w_temp * c.tmask * L.factor_d * L.inv_wh : 0.0f;
     const TapLane tl = tap_lane_make(L, sub);
     float lx, ly;
     float gx = 0, gy = 0;
@@ -706,7 +730,10 @@ __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &
         const float dd = dx * dx + dy * dy;
         const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
         const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
-        const float e = ((P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps) * sgn;
+        float e = (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
+        if (has_temp)
+            e = fmaf(WT, temp_change(c, dx, dy), e);
+        e *= sgn;
         if (k < 2)
             gx += e;
         else
@@ -727,10 +754,16 @@ __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &
     const float WS = P.w_ssim * L.inv_wh, WU = P.w_ui * L.inv_wh;
     const float Q2 = (WU * c.ui_axy + P.w_tps * c.tps_axy) * gg;
     const float Q1 = WU * (c.ui_b.x * gx + c.ui_b.y * gy) + P.w_tps * (c.tps_b.x * gx + c.tps_b.y * gy);
+    // temporal term along the line: WT (|v + g t - ref|_1 - |v - ref|_1)
+    const float T0 = fabsf(c.v.x - c.tref.x) + fabsf(c.v.y - c.tref.y);
 #define ELINE(T_, F_, LUM_)                                                            \
     {                                                                                  \
-        taps32(L, tl, c, fmaf(gx, (T_), c.v.x), fmaf(gy, (T_), c.v.y), lx, ly);        \
+        const float nvx_ = fmaf(gx, (T_), c.v.x), nvy_ = fmaf(gy, (T_), c.v.y);        \
+        ++n_eval;                                                                      \
+        taps32(L, tl, c, nvx_, nvy_, lx, ly);                                          \
         (F_) = fmaf(WS, change32<INTERIOR>(P, nb, c, lx, ly), (T_) * fmaf(Q2, (T_), Q1)); \
+        if (has_temp)                                                                  \
+            (F_) = fmaf(WT, (fabsf(nvx_ - c.tref.x) + fabsf(nvy_ - c.tref.y)) - T0, (F_)); \
         (LUM_) = make_float2(lx, ly);                                                  \
     }
     // golden_section_search, morph.cu:885-947
@@ -785,6 +818,12 @@ __device__ __forceinline__ void ctx_load(PixelCtx &c, const VmLevelView &L, cons
     c.ui_axy = L.ui_axy[c.idx];
     c.ui_b = L.ui_b[c.idx];
     c.tps_axy = s_tps[(border_class(py, L.h) * 5 + border_class(px, L.w)) * 25 + 12] / 2;
+    c.tref = make_float2(0, 0);
+    c.tmask = 0.0f;
+    if (L.temp_mask) { // uniform in the launch
+        c.tref = L.temp_ref[c.idx];
+        c.tmask = L.temp_mask[c.idx];
+    }
 }
 
 __device__ __forceinline__ bool is_interior(const VmLevelView &L, int px, int py)
@@ -948,7 +987,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
     // blockIdx.z = frame pair of the batch: same geometry, own state, own flags
     const VmLevelView L = views[blockIdx.z];
     flags += (size_t)blockIdx.z * cap;
-    stats += (size_t)blockIdx.z * cap * 4;
+    stats += (size_t)blockIdx.z * cap * VM_STAT_WORDS;
 
     // converged in the previous iteration: nothing left to do (sticky)
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
@@ -976,6 +1015,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
         S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
     for (int k = tid; k < 225; k += T)
         S.imp[k] = tables[VM_TAB_IMP + k];
+    if (tid == 0)
+        S.n_eval = 0;
 
     // --- LoadSSIM (morph.cu:1214-1234) + the tile's tps.b ---
     // (three cells per thread in flight: one HBM/L2 round trip for a 512-thread workgroup)
@@ -1055,13 +1096,16 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
 #endif
                         Nb1 nb;
                         bool ok;
+                        uint32_t n_eval = 0;
                         if (wave_interior) {
                             nb1_load<true>(nb, L, src, c, sub);
-                            ok = decide32<true>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                            ok = decide32<true>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
                         } else {
                             nb1_load<false>(nb, L, src, c, sub);
-                            ok = decide32<false>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                            ok = decide32<false>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
                         }
+                        if (sub == 0)
+                            atomicAdd(&S.n_eval, n_eval);
                         if (ok && sub == 0) {
                             // commit_pixel_motion (morph.cu:990-1026), the pixel's own part, at once:
                             // nothing else of this phase reads its v, luma or ui.b (state 3)
@@ -1095,7 +1139,11 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
 #ifdef VM_PROF
                             unsigned long long ts[16];
 #endif
-                            if (decide_x32(L, P, src, c, sub, step VM_TS_PASS) && sub == 0) {
+                            uint32_t n_eval = 0;
+                            const bool ok = decide_x32(L, P, src, c, sub, step, n_eval VM_TS_PASS);
+                            if (sub == 0)
+                                atomicAdd(&S.n_eval, n_eval);
+                            if (ok && sub == 0) {
                                 S.d_step[slot] = step;
                                 S.d_ok[slot] = 1;
                             }
@@ -1126,8 +1174,11 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
 #ifdef VM_PROF
                         unsigned long long ts[16];
 #endif
-                        const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step VM_TS_PASS)
-                                                      : decide<false>(L, P, src, c, sub, Lf, step VM_TS_PASS);
+                        uint32_t n_eval = 0;
+                        const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS)
+                                                      : decide<false>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS);
+                        if (sub == 0)
+                            atomicAdd(&S.n_eval, n_eval);
                         if (ok && sub == 0) {
                             S.d_step[slot] = step;
                             S.d_ok[slot] = 1;
@@ -1216,9 +1267,10 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
         if (improving)
             atomicOr(&flags[iter_idx], 1u);
         // per-iteration activity counters: active tiles, line searches, commits
-        atomicAdd(&stats[iter_idx * 4 + 0], 1u);
-        atomicAdd(&stats[iter_idx * 4 + 1], st_cand);
-        atomicAdd(&stats[iter_idx * 4 + 2], st_commit);
+        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 0], 1u);
+        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 1], st_cand);
+        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 2], st_commit);
+        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 4], S.n_eval);
     }
 }
 
@@ -1235,7 +1287,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
 __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
                                                       const uint32_t *__restrict__ tables, int offx, int offy,
                                                       int pi, int pj, int parts, uint32_t epoch,
-                                                      const uint32_t *__restrict__ flags, int iter_idx,
+                                                      const uint32_t *__restrict__ flags,
+                                                      uint32_t *__restrict__ stats, int iter_idx,
                                                       int fixed_work)
 {
     __shared__ SplitLds S;
@@ -1247,6 +1300,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
 #endif
     const VmLevelView L = views[blockIdx.z];
     flags += (size_t)blockIdx.z * cap;
+    stats += (size_t)blockIdx.z * cap * VM_STAT_WORDS;
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
         return;
     const int part = blockIdx.x % parts, tile = blockIdx.x / parts;
@@ -1268,6 +1322,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
         S.tps[(tid - 256) * 25 + 12] = __uint_as_float(tables[VM_TAB_TPS + (tid - 256) * 25 + 12]);
     if (T < 512 && tid < 25)
         S.tps[tid * 25 + 12] = __uint_as_float(tables[VM_TAB_TPS + tid * 25 + 12]);
+    if (tid == 0)
+        S.n_eval = 0;
     if (!__syncthreads_or(mymask != 0))
         return;
     VM_TS(1);
@@ -1294,6 +1350,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
         const bool wave_interior = __all(m >= n_mine || is_interior(L, px, py));
         if (m < n_mine) {
             uint32_t state = 2;
+            uint32_t n_eval = 0;
             float2 step = make_float2(0, 0), luma = make_float2(0, 0);
             PixelCtx c;
             c.idx = py * L.rs + px;
@@ -1304,7 +1361,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
                 GlbSrc src{&L, (py - 2) * L.rs + (px - 2)};
 #if VM_EXACT
                 (void)wave_interior;
-                const bool ok = decide_x32(L, P, src, c, sub, step VM_TS_PASS);
+                const bool ok = decide_x32(L, P, src, c, sub, step, n_eval VM_TS_PASS);
                 if (ok) { // the lumas commit_pixel_motion samples (morph.cu:997-1003)
                     const float nvx = c.v.x + step.x, nvy = c.v.y + step.y;
                     luma.x = tap(L.img0, L.w, L.h, L.rs, px - nvx + 0.5f, py - nvy + 0.5f);
@@ -1315,16 +1372,18 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
                 bool ok;
                 if (wave_interior) {
                     nb1_load<true>(nb, L, src, c, sub);
-                    ok = decide32<true>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                    ok = decide32<true>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
                 } else {
                     nb1_load<false>(nb, L, src, c, sub);
-                    ok = decide32<false>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                    ok = decide32<false>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
                 }
 #endif
                 if (ok)
                     state = 1;
             }
             if (sub == 0) {
+                if (n_eval)
+                    atomicAdd(&S.n_eval, n_eval);
                 float4 ra = make_float4(0, 0, 0, 0), rb = make_float4(0, 0, 0, 0);
                 if (state == 1) {
                     // commit_pixel_motion (morph.cu:990-1026), the pixel's own part
@@ -1345,6 +1404,9 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
             }
         }
     }
+    __syncthreads();
+    if (tid == 0 && S.n_eval)
+        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 4], S.n_eval);
 #ifdef VM_PROF
     VM_TS(8);
     if ((tid & 63) == 0 && blockIdx.x < 512 && (tid >> 6) < 1) {
@@ -1365,7 +1427,7 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
     const int tid = threadIdx.x, T = blockDim.x;
     const VmLevelView L = views[blockIdx.z];
     flags += (size_t)blockIdx.z * cap;
-    stats += (size_t)blockIdx.z * cap * 4;
+    stats += (size_t)blockIdx.z * cap * VM_STAT_WORDS;
     if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
         return;
     const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
@@ -1459,9 +1521,9 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
     if (tid == 0) {
         if (ncommit)
             atomicOr(&flags[iter_idx], 1u);
-        atomicAdd(&stats[iter_idx * 4 + 3], 1u); // tile-phases with records
-        atomicAdd(&stats[iter_idx * 4 + 1], (uint32_t)n_rec);
-        atomicAdd(&stats[iter_idx * 4 + 2], (uint32_t)ncommit);
+        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 3], 1u); // tile-phases with records
+        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 1], (uint32_t)n_rec);
+        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 2], (uint32_t)ncommit);
     }
 }
 
@@ -1491,6 +1553,7 @@ struct StepLds {
     uint32_t imp[225];
     uint32_t mask[6][16];
     uint32_t n_commit;
+    uint32_t n_eval;
 };
 
 // the 25 commit bits of the 5x5 window around cell (qx, qy); (bx0, by0) = origin of the staged window
@@ -1574,7 +1637,7 @@ __global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__
 #endif
     const VmLevelView L = views[blockIdx.z];
     flags += (size_t)blockIdx.z * cap;
-    stats += (size_t)blockIdx.z * cap * 4;
+    stats += (size_t)blockIdx.z * cap * VM_STAT_WORDS;
     // copy 0 = the canonical arrays; srcbuf 2 = fold in place on copy 0 (end of a batch)
     const bool s1 = srcbuf == 1, d1 = srcbuf == 0;
     const float2 *s_mean = s1 ? L.mean2 : L.mean, *s_var = s1 ? L.var2 : L.var, *s_tpsb = s1 ? L.tps_b2 : L.tps_b;
@@ -1713,8 +1776,10 @@ __global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__
         S.mask[tid / g.nbx][tid % g.nbx] = s_imp[(g.by0 + tid / g.nbx + 1) * L.imp_rs + (g.bx0 + tid % g.nbx + 1)];
     for (int k = tid; k < 225; k += T)
         S.imp[k] = tables[VM_TAB_IMP + k];
-    if (tid == 0)
+    if (tid == 0) {
         S.n_commit = 0;
+        S.n_eval = 0;
+    }
     __syncthreads();
     VM_TS(1);
     // the last phase's records: commit bits for the cell folds, and the mask words -- a committed
@@ -1759,6 +1824,7 @@ __global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__
         const bool wave_interior = __all(mi >= n_mine || is_interior(L, px, py));
         const bool live = mi < n_mine && !pixel_locked(L, P.bcond, px, py);
         uint32_t state = 2;
+        uint32_t n_eval = 0;
         float2 step = make_float2(0, 0), luma = make_float2(0, 0);
         PixelCtx c;
         c.px = px;
@@ -1795,7 +1861,7 @@ __global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__
             nb.val = val;
             nb.counter = okc ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
             ok = decide_with(
-                L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step VM_TS_PASS);
+                L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step, n_eval VM_TS_PASS);
             if (ok) { // the lumas commit_pixel_motion samples (morph.cu:997-1003)
                 const float nvx = c.v.x + step.x, nvy = c.v.y + step.y;
                 luma.x = tap(L.img0, L.w, L.h, L.rs, px - nvx + 0.5f, py - nvy + 0.5f);
@@ -1805,16 +1871,18 @@ __global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__
             Nb1 nb;
             if (wave_interior) {
                 nb1_make<true>(nb, L, okc, qx, qy, m, q, cr, val);
-                ok = decide32<true>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                ok = decide32<true>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
             } else {
                 nb1_make<false>(nb, L, okc, qx, qy, m, q, cr, val);
-                ok = decide32<false>(L, P, nb, c, sub, step, luma VM_TS_PASS);
+                ok = decide32<false>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
             }
 #endif
             if (ok)
                 state = 1;
         }
         if (mi < n_mine && sub == 0) {
+            if (n_eval)
+                atomicAdd(&S.n_eval, n_eval);
             if (state == 1) {
                 const float2 ol = c.old_luma;
                 w_a[c.idx] = make_float4(luma.x - ol.x, luma.y - ol.y, luma.x * luma.x - ol.x * ol.x,
@@ -1844,10 +1912,12 @@ __global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__
         if (nc)
             atomicOr(&flags[iter_idx], 1u);
         if (part == 0)
-            atomicAdd(&stats[iter_idx * 4 + 3], 1u); // tile-phases with records
-        atomicAdd(&stats[iter_idx * 4 + 1], (uint32_t)n_mine);
+            atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 3], 1u); // tile-phases with records
+        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 1], (uint32_t)n_mine);
         if (nc)
-            atomicAdd(&stats[iter_idx * 4 + 2], nc);
+            atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 2], nc);
+        if (S.n_eval)
+            atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 4], S.n_eval);
     }
 }
 
@@ -1905,7 +1975,7 @@ void SUF(vm_launch_optimize_split)(const VmLevelView *views, int nbatch, int cap
         for (int pj = 0; pj < 2; ++pj) {
             const uint32_t epoch = 1u + (uint32_t)((iter_idx * 4 + pass) * 4 + pi * 2 + pj);
             hipLaunchKernelGGL(SUF(k_decide), dim3(gx * gy * parts, 1, nbatch), dim3(threads), 0, s, views, cap, P,
-                               tables, offx, offy, pi, pj, parts, epoch, flags, iter_idx, fixed_work);
+                               tables, offx, offy, pi, pj, parts, epoch, flags, stats, iter_idx, fixed_work);
             hipLaunchKernelGGL(SUF(k_commit), dim3(gx, gy, nbatch), dim3(1024), 0, s, views, cap, P, tables, offx,
                                offy, pi, pj, epoch, flags, stats, iter_idx, fixed_work);
         }

@@ -39,27 +39,38 @@ def unpack_block(raw):
     return blk, cons
 
 
-def broadcast_block(raw, device, max_constraints=256):
-    """Rank 0's packed block to every rank (fixed-size buffer so that all ranks post
-    the same collective).  Returns the uint8 array every rank now agrees on."""
+MAX_BLOCK_BYTES = 1 << 24
+
+
+def broadcast_block(raw, device):
+    """Rank 0's packed block to every rank: a fixed 8-byte header (the payload size) first,
+    then a payload of exactly that size, so every rank posts the same two collectives whatever
+    rank 0 holds.  A block that is too large is refused on ALL ranks (the header is
+    broadcast before anybody can raise), never truncated.  Returns the uint8 array every rank
+    now agrees on."""
     import torch
     import torch.distributed as dist
-    cap = C.sizeof(capi.ParamBlock) + 20 * max_constraints
-    buf = np.zeros(cap, dtype=np.uint8)
+    n = int(np.asarray(raw).size) if dist.get_rank() == 0 else 0
+    head = torch.tensor([n], dtype=torch.int64, device=device)
+    dist.broadcast(head, src=0)
+    n = int(head.item())
+    if n < C.sizeof(capi.ParamBlock) or n > MAX_BLOCK_BYTES:
+        raise ValueError("parameter block of %d bytes (expected %d..%d)" % (n, C.sizeof(capi.ParamBlock), MAX_BLOCK_BYTES))
+    buf = np.zeros(n, dtype=np.uint8)
     if dist.get_rank() == 0:
-        assert raw.size <= cap
-        buf[:raw.size] = raw
+        buf[:] = np.ascontiguousarray(raw, dtype=np.uint8).ravel()
     t = torch.from_numpy(buf).to(device)
     dist.broadcast(t, src=0)
     return t.cpu().numpy()
 
 
 def reduce_report(elapsed, units, device):
-    """(max over ranks of elapsed, sum over ranks of units)."""
+    """(max over ranks of elapsed, sum over ranks of units): one all-gather of two scalars
+    per rank."""
     import torch
     import torch.distributed as dist
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    tsum = torch.tensor([units], dtype=torch.float64, device=device)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-    return tmax.item(), tsum.item()
+    mine = torch.tensor([elapsed, units], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    vals = torch.stack(every).cpu().numpy()
+    return float(vals[:, 0].max()), float(vals[:, 1].sum())

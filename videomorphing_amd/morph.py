@@ -316,6 +316,7 @@ class Morph(object):
                                          pixel_iters=pr.pixel_iters, elapsed_ms=pr.elapsed_ms,
                                          launches=pr.launches, active_tiles=pr.active_tiles,
                                          candidates=pr.candidates, commits=pr.commits,
+                                         evaluations=pr.evaluations,
                                          width=lv.width, height=lv.height)
                 capi.check(L.vm_level_clear(pyr._h, el - 1))
                 self._max_iter /= P.max_iter_drop_factor
@@ -340,7 +341,8 @@ def solve_batch(pyramids, max_iter, max_iter_drop_factor=1.0, fixed_work=False, 
         out.append([dict(iters=prog[i * nl + k].iters, improving=prog[i * nl + k].improving,
                          pixel_iters=prog[i * nl + k].pixel_iters, elapsed_ms=prog[i * nl + k].elapsed_ms,
                          launches=prog[i * nl + k].launches, commits=prog[i * nl + k].commits,
-                         candidates=prog[i * nl + k].candidates, active_tiles=prog[i * nl + k].active_tiles)
+                         candidates=prog[i * nl + k].candidates, active_tiles=prog[i * nl + k].active_tiles,
+                         evaluations=prog[i * nl + k].evaluations)
                     for k in range(nl)])
     return out
 
