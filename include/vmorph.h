@@ -97,7 +97,10 @@ typedef struct {
 enum {
     VM_F_IMG0 = 0, VM_F_IMG1, VM_F_V, VM_F_LUMA, VM_F_MEAN, VM_F_VAR, VM_F_CROSS,
     VM_F_VALUE, VM_F_COUNTER, VM_F_TPS_AXY, VM_F_TPS_B, VM_F_UI_AXY, VM_F_UI_B,
-    VM_F_IMPMASK
+    VM_F_IMPMASK,
+    /* pages of a video (vm_video_get_field): lvl.temp.ref (float2), lvl.temp.mask, the four
+     * flow fields of the page (float2) */
+    VM_F_TEMP_REF, VM_F_TEMP_MASK, VM_F_FLOW_F0, VM_F_FLOW_F1, VM_F_FLOW_B0, VM_F_FLOW_B1
 };
 
 const char *vm_last_error(void);
@@ -181,6 +184,69 @@ int  vm_solve_batch(vm_pyr **pyrs, int n, float max_iter, float max_iter_drop_fa
 /* CMatchingThread::update_result + Resize, Algorithm/MatchingThread.cpp:22-100:
  * v of level `lvl` scaled by (W0/W, H0/H) and bilinearly resized to w0 x h0 */
 int  vm_upscale_result(vm_pyr *pyr, int lvl, int w0, int h0, float *v_xy_out, int pitch);
+
+/* ---- video pairs: the temporal coherence path ------------------------------ */
+/* The reference couples the frames of a video: class Pyramid with
+ * depth > 1 -- per level `depth` pages (Algorithm/Pyramid.h:52-98) and four optical-flow
+ * fields per page (f0/f1: forward flow of video 0/1 from frame t to t+1, b0/b1: backward,
+ * Pyramid.h:85-90) -- and Morph::optimize_level solves the middle page first, then two
+ * chains outward, each page tied to its solved neighbour by w_temp |v - ref|_1
+ * (Algorithm/morph.cu:752-759, 1394-1439), ref being the neighbour's field advected along
+ * the flows (initialize_temp, Algorithm/upsample.cu:214-258).  vm_video is that object; a
+ * page is the same device state as a frame pair and is swept by the same kernels. */
+typedef struct vm_video vm_video;
+/* a connected point pair with the frame it belongs to (Conp::p.z, parameters.h:22-26) */
+typedef struct {
+    float lx, ly, rx, ry;
+    float weight;
+    int   frame;
+} vm_video_constraint;
+/* Pyramid::append_new per level with its depth (pyramid.cu:220-240, 462-477).  Level 0 is
+ * the finest; the last level holds only v.  d[l] = pages of level l (not growing with l);
+ * factor_t[l] (may be NULL: 2 where the depth shrank) = temporal stride level l was built
+ * with (pyramid.cu:468); depth0 = frames of the video (the placeholder level's depth). */
+int  vm_video_create(vm_ctx *ctx, int nlevels, const int *w, const int *h, const int *d,
+                     const int *factor_t, int depth0, vm_video **out);
+void vm_video_destroy(vm_video *v);
+int  vm_video_levels(vm_video *v);
+int  vm_video_level_dims(vm_video *v, int lvl, int *w, int *h, int *depth, float *factor_d);
+/* the uploads of Pyramid::build for one page: lumas (pyramid.cu:275-280) and the four flow
+ * fields, tight or pitched (h, w, 2) floats (pyramid.cu:323-326, 452-455); NULL = keep */
+int  vm_video_upload_luma(vm_video *v, int lvl, int page, const float *img0, const float *img1, int pitch);
+int  vm_video_upload_flows(vm_video *v, int lvl, int page, const float *f0, const float *f1,
+                           const float *b0, const float *b1, int pitch);
+/* Pyramid::build(video0, video1, f0, f1, b0, b1, start_res), pyramid.cu:166-485, on the
+ * device: the image half for one frame (its luma pyramid goes to every page that shows it),
+ * and the flow half for the whole video (scale, x size ratio, temporal concatenation where
+ * the depth halves): f0[t].. = tight (h0, w0, 2) float arrays of the depth0 frames */
+int  vm_video_build_rgb(vm_video *v, int frame, const uint8_t *rgb0, const uint8_t *rgb1, int pitch_bytes);
+int  vm_video_build_flows(vm_video *v, const float *const *f0, const float *const *f1,
+                          const float *const *b0, const float *const *b1);
+int  vm_video_set_v(vm_video *v, int lvl, int page, const float *v_xy, int pitch);
+int  vm_video_get_v(vm_video *v, int lvl, int page, float *v_xy, int pitch);
+int  vm_video_get_field(vm_video *v, int lvl, int page, int field, void *host);
+/* Morph::cpu_optimize_level for every page of the coarsest level, morph.cu:419-590 */
+int  vm_video_coarse_solve(vm_video *v, const vm_video_constraint *c, int n);
+/* upsample(pyr[dst], pyr[dst+1]), upsample.cu:260-340: the spatial upsample of every coarse
+ * page and, where the depth doubles, the in-between pages splatted from their two
+ * neighbours along the flows, smoothed and hole-filled (temp_ref, interpolate_temp_ref,
+ * smooth, fill_zeros_x; fill_zeros_y has no effect on the result) */
+int  vm_video_upsample(vm_video *v, int dst_lvl);
+/* Morph::initialize_level for every page, morph.cu:264-390 */
+int  vm_video_init_level(vm_video *v, int lvl, const vm_video_constraint *c, int n);
+/* initialize_temp(lvl, page, dir), upsample.cu:214-258: temp.ref / temp.mask of `page` from
+ * page + dir (dir = -1: along its forward flows, +1: backward); the page is then swept
+ * with flag == true */
+int  vm_video_initialize_temp(vm_video *v, int lvl, int page, int dir);
+/* Morph::optimize_level, morph.cu:1353-1441: middle page, then both chains (step k of the two
+ * chains shares its launches).  out (may be NULL): depth entries, index = page. */
+int  vm_video_optimize_level(vm_video *v, int lvl, float max_iter, volatile const int *run_flag,
+                             int fixed_work, vm_progress *out);
+/* Morph::calculate_halfway_parametrization, morph.cu:150-168.  per_page (may be NULL): for
+ * every level with images (finest first) its depth entries. */
+int  vm_video_solve(vm_video *v, float max_iter, float max_iter_drop_factor,
+                    const vm_video_constraint *c, int n, volatile const int *run_flag,
+                    int fixed_work, vm_progress *per_page);
 
 /* ---- compositor ---------------------------------------------------------- */
 typedef struct vm_frame vm_frame;

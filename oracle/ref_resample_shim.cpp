@@ -48,3 +48,36 @@ extern "C" int ref_luma_pyramid(const float *rgb_0_255, int w, int h, int nlevel
     delete ext;
     return 0;
 }
+
+// The flow half of Pyramid::build (Algorithm/pyramid.cu:284-321, 375-404) for ONE flow field:
+// image::load(rgba, data, w, h, rowstride, -50, 50) -> scale() -> image::store(data, rgba,
+// rowstride, -50, 50) of the reference's own library, then the x (wout/w, hout/h) rescale the
+// caller applies there when the size shrinks.  flow: h*w*2 floats, out: hout*wout*2.
+namespace image {
+int load(image::rgba<float> *rgba, float *data, int w, int h, int rowstride, float min, float max);
+int store(float *data, const image::rgba<float> &rgba, int rowstride, float min, float max);
+}
+
+extern "C" int ref_flow_scale(const float *flow, int w, int h, int wout, int hout, float *out)
+{
+    kernel::base *pre = new kernel::generalized(new kernel::discrete::delta,
+                                                new kernel::discrete::sampled(new kernel::generating::bspline3),
+                                                new kernel::generating::bspline3);
+    kernel::discrete::base *delta = new kernel::discrete::delta;
+    extension::base *ext = new extension::mirror;
+    image::rgba<float> temp;
+    std::vector<float> data(flow, flow + (size_t)w * h * 2);
+    image::load(&temp, data.data(), w, h, w, -50, 50);
+    scale(hout, wout, pre, delta, delta, ext, &temp, &temp);
+    image::store(out, temp, wout, -50, 50);
+    const float ratiox = (float)wout / (float)w, ratioy = (float)hout / (float)h;
+    if (ratiox < 1 || ratioy < 1)
+        for (size_t p = 0; p < (size_t)wout * hout; ++p) {
+            out[2 * p] *= ratiox;
+            out[2 * p + 1] *= ratioy;
+        }
+    delete pre;
+    delete delta;
+    delete ext;
+    return 0;
+}

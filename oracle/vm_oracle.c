@@ -263,6 +263,10 @@ vmo_level *vmo_level_create(int w, int h)
     l->ui_axy = (float *)calloc(n, sizeof(float));
     l->ui_b = (float *)calloc(2 * n, sizeof(float));
     l->impmask = (uint32_t *)calloc((size_t)l->imp_rs * l->imp_rows, sizeof(uint32_t));
+    l->temp_ref = (float *)calloc(2 * n, sizeof(float));
+    l->temp_mask = (float *)calloc(n, sizeof(float));
+    l->factor_d = 1.0f; /* pyramid.cu:541 */
+    l->flag = 0;
     return l;
 }
 
@@ -274,7 +278,15 @@ void vmo_level_destroy(vmo_level *l)
     free(l->var); free(l->cross); free(l->value); free(l->counter);
     free(l->tps_axy); free(l->tps_b); free(l->ui_axy); free(l->ui_b);
     free(l->impmask);
+    free(l->temp_ref); free(l->temp_mask);
     free(l);
+}
+
+/* the page's temporal state: `flag` of kernel_optimize_level, factor_d of its level */
+void vmo_level_set_temporal(vmo_level *l, int flag, float factor_d)
+{
+    l->flag = flag;
+    l->factor_d = factor_d;
 }
 
 void *vmo_level_field(vmo_level *l, int f)
@@ -294,6 +306,8 @@ void *vmo_level_field(vmo_level *l, int f)
     case VMO_F_UI_AXY: return l->ui_axy;
     case VMO_F_UI_B: return l->ui_b;
     case VMO_F_IMPMASK: return l->impmask;
+    case VMO_F_TEMP_REF: return l->temp_ref;
+    case VMO_F_TEMP_MASK: return l->temp_mask;
     }
     return 0;
 }
@@ -458,8 +472,8 @@ static float ssim_change(const vmo_level *l, const vmo_params *P, int px, int py
     return change;
 }
 
-/* energy_change, morph.cu:730-761 (flag == false: single frame pair, the
- * temporal term multiplies out to +0) */
+/* energy_change, morph.cu:730-761.  flag == false (a single frame pair, the middle page of a
+ * video level): v_temp = 0 and lvl.temp.mask = 0, the temporal term multiplies out to +0 */
 static float energy_change(const vmo_level *l, const vmo_params *P, int px, int py,
                            float vx, float vy, float olx, float oly,
                            float dx, float dy, sweep_stats *st)
@@ -474,7 +488,12 @@ static float energy_change(const vmo_level *l, const vmo_params *P, int px, int 
     v_ui += l->ui_b[2 * idx] * dx;
     v_ui += l->ui_b[2 * idx + 1] * dy;
     float v_temp = 0.0f;
-    return (P->w_ui * v_ui + P->w_ssim * v_ssim + P->w_temp * v_temp * 0.0f * 1.0f) * l->inv_wh
+    if (l->flag) {
+        v_temp += fabsf(vx + dx - l->temp_ref[2 * idx]) - fabsf(vx - l->temp_ref[2 * idx]);
+        v_temp += fabsf(vy + dy - l->temp_ref[2 * idx + 1]) - fabsf(vy - l->temp_ref[2 * idx + 1]);
+    }
+    const float mask = l->flag ? l->temp_mask[idx] : 0.0f;
+    return (P->w_ui * v_ui + P->w_ssim * v_ssim + P->w_temp * v_temp * mask * l->factor_d) * l->inv_wh
            + P->w_tps * v_tps;
 }
 
@@ -653,6 +672,9 @@ float vmo_dbg_energy_change(const vmo_level *l, const vmo_params *P, int px, int
  * state, commits applied in row-major order of the committing pixels
  * (commit_pixel_motion :990-1026, ssim_update :951-988), then the SSIM value
  * of every tile+halo cell recomputed (UpdateSSIM :1258-1279). */
+static int g_commit_reversed = 0;
+void vmo_set_commit_order(int reversed) { g_commit_reversed = reversed != 0; }
+
 static int optimize_tile(vmo_level *l, const vmo_params *P, int ox, int oy, sweep_stats *st)
 {
     const int w = l->w, h = l->h;
@@ -665,8 +687,8 @@ static int optimize_tile(vmo_level *l, const vmo_params *P, int ox, int oy, swee
                 for (int tx = 0; tx < OPT_BW; ++tx)
                     optimize_pixel(l, P, ox + tx * 2 + j, oy + ty * 2 + i, &dec[nd++], st);
             /* __syncthreads(); commits (row-major: ty outer, tx inner) */
-            for (int k = 0; k < nd; ++k) {
-                decision *d = &dec[k];
+            for (int kk = 0; kk < nd; ++kk) {
+                decision *d = &dec[g_commit_reversed ? nd - 1 - kk : kk];
                 if (d->ok) {
                     int px = d->px, py = d->py, idx = py * w + px;
                     float lx = vmo_tex2d(l->img0, w, h, px - d->nvx + 0.5f, py - d->nvy + 0.5f);
@@ -792,6 +814,14 @@ static void band_add(double *ab, int kd, int n, int i, int j, double val)
 int vmo_coarse_solve(vmo_level *l, int w0, int h0, const vmo_params *P,
                      const vmo_constraint *c, int ncon)
 {
+    return vmo_coarse_solve_page(l, w0, h0, P, c, ncon, 1);
+}
+
+/* one page of a level of `depth` pages: BCOND_BORDER adds the border diagonal `depth` times
+ * (the `for(int t=0;t<d;t++)` of morph.cu:536-560 sits inside the per-page loop) */
+int vmo_coarse_solve_page(vmo_level *l, int w0, int h0, const vmo_params *P,
+                          const vmo_constraint *c, int ncon, int depth)
+{
     const int w = l->w, h = l->h, n = w * h, kd = 2 * w;
     const double wt = (double)P->w_tps * 2.0;
     double *ab = (double *)calloc((size_t)(kd + 1) * n, sizeof(double));
@@ -833,12 +863,13 @@ int vmo_coarse_solve(vmo_level *l, int w0, int h0, const vmo_params *P,
                     any_rhs = 1;
                 }
     }
-    /* boundary condition, morph.cu:507-562 (depth 1: BCOND_BORDER adds once) */
+    /* boundary condition, morph.cu:507-562 */
     double bd = (double)(P->w_ui * l->inv_wh);
     if (P->bcond == VMO_BCOND_CORNER) {
         int idx[4] = {0, (h - 1) * w, (h - 1) * w + (w - 1), w - 1};
         for (int k = 0; k < 4; ++k) A_(idx[k], idx[k], bd);
     } else if (P->bcond == VMO_BCOND_BORDER) {
+        bd *= depth;
         for (int x = 0; x < w; ++x) { A_(x, x, bd); A_((h - 1) * w + x, (h - 1) * w + x, bd); }
         for (int y = 1; y < h - 1; ++y) { A_(y * w, y * w, bd); A_(y * w + w - 1, y * w + w - 1, bd); }
     }

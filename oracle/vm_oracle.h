@@ -70,13 +70,17 @@ typedef struct {
     float *tps_axy, *tps_b;       /* w*h, 2*w*h */
     float *ui_axy, *ui_b;         /* w*h, 2*w*h */
     uint32_t *impmask;            /* imp_rs*imp_rows */
+    /* temporal coherence (a page of a video level; upsample.cu:190-258, morph.cu:752-759) */
+    float *temp_ref, *temp_mask;  /* 2*w*h, w*h: lvl.temp.ref / lvl.temp.mask of this page */
+    float factor_d;               /* Pyramid.h:65, pyramid.cu:470-477 */
+    int   flag;                   /* the `flag` argument of kernel_optimize_level for this page */
 } vmo_level;
 
 /* field ids for vmo_level_field() */
 enum {
     VMO_F_IMG0 = 0, VMO_F_IMG1, VMO_F_V, VMO_F_LUMA, VMO_F_MEAN, VMO_F_VAR,
     VMO_F_CROSS, VMO_F_VALUE, VMO_F_COUNTER, VMO_F_TPS_AXY, VMO_F_TPS_B,
-    VMO_F_UI_AXY, VMO_F_UI_B, VMO_F_IMPMASK
+    VMO_F_UI_AXY, VMO_F_UI_B, VMO_F_IMPMASK, VMO_F_TEMP_REF, VMO_F_TEMP_MASK
 };
 
 /* --- small pieces --------------------------------------------------------- */
@@ -94,6 +98,7 @@ void  vmo_improvmask_stencil(uint32_t *out225);              /* stencils.cpp:90-
 vmo_level *vmo_level_create(int w, int h);
 void       vmo_level_destroy(vmo_level *l);
 void      *vmo_level_field(vmo_level *l, int field);
+void       vmo_level_set_temporal(vmo_level *l, int flag, float factor_d);
 
 /* --- hot path ------------------------------------------------------------- */
 /* kernel_initialize_level + init_improving_mask, morph.cu:173-260 (+ the
@@ -116,6 +121,8 @@ void vmo_upsample_v(vmo_level *dst, const vmo_level *src);
 /* Morph::cpu_optimize_level, morph.cu:419-590 (banded solve, see .c) */
 int  vmo_coarse_solve(vmo_level *l, int w0, int h0, const vmo_params *p,
                       const vmo_constraint *c, int n);
+int  vmo_coarse_solve_page(vmo_level *l, int w0, int h0, const vmo_params *p,
+                           const vmo_constraint *c, int n, int depth);
 /* total energy of the current field (diagnostic, derived from the terms of
  * morph.cu:730-761): returns E_ssim, E_tps, E_ui in out3 */
 void vmo_energy(const vmo_level *l, const vmo_params *p, double *out3);
@@ -152,6 +159,43 @@ void vmo_luma_pyramid(const uint8_t *rgb, int w, int h, int nlevels, float *out)
  * evaluated at one pixel of an initialised level */
 float vmo_dbg_foldover(const vmo_level *l, const vmo_params *p, int px, int py, float gx, float gy);
 float vmo_dbg_energy_change(const vmo_level *l, const vmo_params *p, int px, int py, float dx, float dy);
+
+/* --- temporal coherence path (vm_oracle_temporal.c) ------------------------------------- */
+/* A video level is `depth` pages (vmo_level objects of one size) plus four flow fields per
+ * page (f0/f1: forward flow of video 0/1 from frame t to t+1, b0/b1: backward), tight
+ * h*w*2 floats.  The host control flow (Morph::optimize_level's page chains, upsample()'s
+ * page loop) lives in tests/oracle.py; these are the kernels.
+ *
+ * ORDER NOTE: temp_ref scatters with float atomicAdd in an unspecified order
+ * (upsample.cu:57-58), so the reference's own result is not reproducible bit for bit.
+ * Here -- and in the HIP path -- each contribution (computed in float exactly as the
+ * reference writes it) is accumulated in 64-bit fixed point (value * 2^32, round to nearest
+ * even): order-independent, hence comparable bit for bit.  The deviation from any float
+ * summation order is below one float ulp of the sum. */
+/* temp_ref, upsample.cu:28-62: splat of v_prev advected by the mean of the two flows into
+ * acc (3 int64 per pixel: v.x, v.y, weight; caller zero-fills).  ssim may be NULL. */
+void vmo_temp_splat(int w, int h, const float *v_prev, const float *f0, const float *f1,
+                    const float *ssim, int64_t *acc);
+/* fixed point -> float, then interpolate_temp_ref (upsample.cu:64-77) */
+void vmo_temp_normalise(int w, int h, const int64_t *acc, float *v_cur, float *weight);
+/* initialize_temp, upsample.cu:214-258: dst's temp.ref / temp.mask from the neighbouring
+ * page `src` (its v and ssim.value) advected by src's flows (fa, fb = f0, f1 of src for
+ * dir < 0; b0, b1 of src for dir > 0); sets dst->flag = 1 */
+void vmo_initialize_temp(vmo_level *dst, const vmo_level *src, const float *fa, const float *fb);
+/* the temporal half of upsample(), upsample.cu:297-338, for one in-between page: splat of the
+ * previous page (its f0, f1) and of the next page (its b0, b1), normalise, smooth (:80-111),
+ * fill_zeros_x (:115-151); fill_zeros_y (:153-189) only touches the discarded weight array */
+void vmo_temporal_fill(int w, int h, const float *v_prev, const float *f0_prev, const float *f1_prev,
+                       const float *v_next, const float *b0_next, const float *b1_next, float *v_out);
+/* flow half of Pyramid::build (pyramid.cu:284-321, 375-404): one flow field through
+ * load(-50, 50) -> scale() -> store(-50, 50), then x (wout/w, hout/h) when the size shrinks */
+void vmo_flow_scale(const float *flow, int w, int h, int wout, int hout, float *out);
+/* temporal concatenation (pyramid.cu:406-442): f(p) += BiLinear(f_next, p + f(p)) */
+void vmo_flow_concat(float *f, const float *f_next, int w, int h);
+/* order in which the commits of a phase are applied (the reference leaves it to atomics):
+ * 0 = row-major over the committing pixels (the oracle's definition), 1 = reversed -- an
+ * equally legal order, used to measure how far two legal trajectories drift apart */
+void vmo_set_commit_order(int reversed);
 
 void vmo_set_threads(int n);   /* OpenMP threads for the timed CPU baseline */
 int  vmo_get_threads(void);

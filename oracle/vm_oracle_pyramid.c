@@ -219,3 +219,75 @@ void vmo_luma_pyramid(const uint8_t *rgb, int w, int h, int nlevels, float *out)
     }
     free(img);
 }
+
+/* ------------------------------------------------------------------------- */
+/* Flow half of Pyramid::build, Algorithm/pyramid.cu:284-321 (level 1) and
+ * :375-404 (coarser levels): image::load(min = -50, max = 50) (image.cpp:33-54:
+ * (f - min) / (max - min) through srgbuncurve into the r and g planes, b = 1),
+ * scale(), image::store(min, max) (image.cpp:72-85: clamp, srgbcurve, x (max - min)
+ * + min), then x (wout/w, hout/h) when either ratio is below one (:306-321). */
+void vmo_flow_scale(const float *flow, int w, int h, int wout, int hout, float *out)
+{
+    const int w_in = w, h_in = h;
+    const size_t n = (size_t)w * h;
+    float *img = (float *)malloc(sizeof(float) * 3 * n);
+    const float mn = -50.f, mx = 50.f;
+    const float tof = 1.f / (mx - mn);
+    for (size_t p = 0; p < n; ++p) {
+        img[p] = srgbuncurve((flow[2 * p] - mn) * tof);
+        img[n + p] = srgbuncurve((flow[2 * p + 1] - mn) * tof);
+        img[2 * n + p] = 1.0f;
+    }
+    img = scale_image(img, &w, &h, wout, hout);
+    const size_t m = (size_t)w * h;
+    const float ratiox = (float)wout / (float)w_in, ratioy = (float)hout / (float)h_in;
+    for (size_t p = 0; p < m; ++p)
+        for (int k = 0; k < 2; ++k) {
+            float v = img[k * m + p];
+            v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+            float f = srgbcurve(v) * (mx - mn) + mn;
+            if (ratiox < 1 || ratioy < 1)
+                f *= k == 0 ? ratiox : ratioy;
+            out[2 * p + k] = f;
+        }
+    free(img);
+}
+
+/* Pyramid::BiLinear<cv::Vec2f>, pyramid.cu:486-522 */
+static void bilinear_f2(const float *img, int cols, int rows, float px, float py, float *o)
+{
+    int x[2], y[2];
+    x[0] = (int)floorf(px);
+    y[0] = (int)floorf(py);
+    x[1] = (int)ceilf(px);
+    y[1] = (int)ceilf(py);
+    const float u = px - x[0], v = py - y[0];
+    float val[2][2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            int tx = x[i], ty = y[j];
+            tx = tx < 0 ? 0 : tx;
+            tx = tx > cols - 1 ? cols - 1 : tx;
+            ty = ty < 0 ? 0 : ty;
+            ty = ty > rows - 1 ? rows - 1 : ty;
+            val[i][j][0] = img[2 * (ty * cols + tx)];
+            val[i][j][1] = img[2 * (ty * cols + tx) + 1];
+        }
+    for (int k = 0; k < 2; ++k)
+        o[k] = val[0][0][k] * (1 - u) * (1 - v) + val[0][1][k] * (1 - u) * v + val[1][0][k] * u * (1 - v) +
+               val[1][1][k] * u * v;
+}
+
+/* the temporal concatenation of two consecutive flows, pyramid.cu:406-442:
+ * f(p) += BiLinear(f_next, p + f(p)) */
+void vmo_flow_concat(float *f, const float *f_next, int w, int h)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float *p = f + 2 * ((size_t)y * w + x);
+            float o[2];
+            bilinear_f2(f_next, w, h, (float)x + p[0], (float)y + p[1], o);
+            p[0] += o[0];
+            p[1] += o[1];
+        }
+}

@@ -92,6 +92,9 @@ def lib():
     L.vmo_coarse_solve.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params),
                                    C.c_void_p, C.c_int]
     L.vmo_coarse_solve.restype = C.c_int
+    L.vmo_coarse_solve_page.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params),
+                                        C.c_void_p, C.c_int, C.c_int]
+    L.vmo_coarse_solve_page.restype = C.c_int
     L.vmo_energy.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p]
     L.vmo_energy.restype = None
     L.vmo_render_halfway.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -115,6 +118,22 @@ def lib():
     L.vmo_quadratic_path.restype = C.c_int
     L.vmo_luma_pyramid.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.vmo_luma_pyramid.restype = None
+    L.vmo_level_set_temporal.argtypes = [C.c_void_p, C.c_int, C.c_float]
+    L.vmo_level_set_temporal.restype = None
+    L.vmo_temp_splat.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vmo_temp_splat.restype = None
+    L.vmo_temp_normalise.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vmo_temp_normalise.restype = None
+    L.vmo_initialize_temp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vmo_initialize_temp.restype = None
+    L.vmo_temporal_fill.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7
+    L.vmo_temporal_fill.restype = None
+    L.vmo_flow_scale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.vmo_flow_scale.restype = None
+    L.vmo_flow_concat.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.vmo_flow_concat.restype = None
+    L.vmo_set_commit_order.argtypes = [C.c_int]
+    L.vmo_set_commit_order.restype = None
     L.vmo_set_threads.argtypes = [C.c_int]
     L.vmo_set_threads.restype = None
     L.vmo_get_threads.restype = C.c_int
@@ -142,6 +161,7 @@ _FIELDS = {  # name -> (id, channels, dtype)
     "cross": (6, 1, np.float32), "value": (7, 1, np.float32), "counter": (8, 1, np.float32),
     "tps_axy": (9, 1, np.float32), "tps_b": (10, 2, np.float32),
     "ui_axy": (11, 1, np.float32), "ui_b": (12, 2, np.float32),
+    "temp_ref": (14, 2, np.float32), "temp_mask": (15, 1, np.float32),
 }
 
 
@@ -198,9 +218,19 @@ class Level:
     def upsample_from(self, src):
         lib().vmo_upsample_v(self._p, src._p)
 
-    def coarse_solve(self, w0, h0, params, cons=()):
+    def coarse_solve(self, w0, h0, params, cons=(), depth=1):
         cs, n = make_constraints(cons)
-        return lib().vmo_coarse_solve(self._p, w0, h0, C.byref(params), cs, n)
+        return lib().vmo_coarse_solve_page(self._p, w0, h0, C.byref(params), cs, n, int(depth))
+
+    def set_temporal(self, flag, factor_d=1.0):
+        lib().vmo_level_set_temporal(self._p, int(flag), float(factor_d))
+
+    def initialize_temp(self, src, fa, fb):
+        """initialize_temp(lvl, i, dir), upsample.cu:214-258: this page's temp.ref / temp.mask from
+        the neighbouring page `src` advected by ITS flows (f0, f1 for dir < 0; b0, b1 for dir > 0)"""
+        fa = np.ascontiguousarray(fa, dtype=np.float32)
+        fb = np.ascontiguousarray(fb, dtype=np.float32)
+        lib().vmo_initialize_temp(self._p, src._p, fa.ctypes.data, fb.ctypes.data)
 
     def energy(self, params):
         out = np.zeros(3, dtype=np.float64)
@@ -308,3 +338,185 @@ def luma_pyramid(rgb, nlevels):
         res.append(out[off:off + a * b].reshape(b, a))
         off += a * b
     return res
+
+
+# ---------------------------------------------------------------------------------------------
+# temporal coherence path: host control flow of the reference over the C kernels of
+# oracle/vm_oracle_temporal.c
+
+
+def video_geometry(w, h, d, start_res, max_stage2=14e6):
+    """Level table of Pyramid::build (stage 2), pyramid.cu:223-240, 462-477, as the reference
+    computes it: returns (levels, factor_t) with levels = [(w, h, d), ...] finest first incl. the
+    coarsest (host-solved) level, factor_t[l] = temporal stride level l was built with.
+    float32 logs and truncation, literally (the product side uses integer arithmetic,
+    videomorphing_amd.synth.video_levels; tests compare the two)."""
+    f32 = np.float32
+    fa = max(np.sqrt(f32(w * h * d) / f32(max_stage2)), f32(1))
+    w, h = int(w / fa), int(h / fa)
+    lg = lambda v: np.log(f32(v)) / np.log(f32(2.0))      # pyramid.cu:51-56
+    el_t = int(lg(d) - lg(start_res) + 1)
+    el_y = int(lg(h) - lg(start_res) + 1)
+    el_x = int(lg(w) - lg(start_res) + 1)
+    el_x = el_y = max(el_x, el_y)
+    maxl = max(el_x, el_t)
+    levels, factors, factor_t = [], [], 1
+    for el in range(maxl):
+        levels.append((w, h, d))
+        factors.append(factor_t)
+        if maxl - el <= el_x:
+            w = int(np.ceil(w / 2.0))
+        if maxl - el <= el_y:
+            h = int(np.ceil(h / 2.0))
+        if maxl - el <= el_t:
+            d, factor_t = int(np.ceil((d + 1) / 2.0)), 2
+        else:
+            factor_t = 1
+    return levels, factors
+
+
+def factor_d_table(depth0, depths):
+    """pyramid.cu:470-477 over [placeholder level 0 (depth0)] + levels: factor_d per entry"""
+    ds = [depth0] + list(depths)
+    fd = [1.0] * len(ds)
+    for i in range(len(ds) - 2, -1, -1):
+        fd[i] = fd[i + 1] * 2 if ds[i + 1] != ds[i] else fd[i + 1]
+    return fd
+
+
+def flow_scale(flow, wout, hout):
+    flow = np.ascontiguousarray(flow, dtype=np.float32)
+    h, w = flow.shape[:2]
+    out = np.zeros((hout, wout, 2), dtype=np.float32)
+    lib().vmo_flow_scale(flow.ctypes.data, w, h, wout, hout, out.ctypes.data)
+    return out
+
+
+def flow_concat(f, f_next):
+    f = np.ascontiguousarray(f, dtype=np.float32).copy()
+    f_next = np.ascontiguousarray(f_next, dtype=np.float32)
+    h, w = f.shape[:2]
+    lib().vmo_flow_concat(f.ctypes.data, f_next.ctypes.data, w, h)
+    return f
+
+
+def flow_pyramids(f0, f1, b0, b1, levels, factors):
+    """All four flow families through Pyramid::build's loop.  f0.. : lists (one per frame) of
+    full-resolution (h, w, 2) flows.  Returns per level (all but the coarsest, which holds no
+    flows... the reference uploads flows for el < maxl-1 only) a dict name -> list of pages."""
+    fam = {"f0": [np.asarray(x, np.float32) for x in f0], "f1": [np.asarray(x, np.float32) for x in f1],
+           "b0": [np.asarray(x, np.float32) for x in b0], "b1": [np.asarray(x, np.float32) for x in b1]}
+    out = []
+    prev_d = levels[0][2]
+    for el, (w, h, d) in enumerate(levels[:-1]):
+        factor_t = factors[el]
+        # every frame of the previous level to this level's size (el == 0: same size)
+        for k in fam:
+            fam[k] = [flow_scale(fl, w, h) for fl in fam[k][:prev_d]]
+        if el > 0 and factor_t > 1:
+            for t in range(d):
+                if t * factor_t > prev_d - 1:
+                    continue
+                if t * factor_t + 1 < prev_d:
+                    for k in ("f0", "f1"):
+                        fam[k][t * factor_t] = flow_concat(fam[k][t * factor_t], fam[k][t * factor_t + 1])
+                if t > 0:
+                    for k in ("b0", "b1"):
+                        fam[k][t * factor_t] = flow_concat(fam[k][t * factor_t], fam[k][t * factor_t - 1])
+        if el > 0 and factor_t > 1:
+            for k in fam:
+                fam[k] = [fam[k][min(t * factor_t, prev_d - 1)].copy() for t in range(d)]
+        out.append({k: [a.copy() for a in fam[k][:d]] for k in fam})
+        prev_d = d
+    return out
+
+
+class Video:
+    """A stage-2 pyramid of a video pair in the oracle: per level `d` pages (Level objects) and
+    the four flow fields per page; the host side of Morph (morph.cu:150-168, 264-390,
+    1353-1441) and of upsample() (upsample.cu:260-340) over it."""
+
+    def __init__(self, levels, depth0=None):
+        self.levels = [tuple(int(x) for x in l) for l in levels]
+        self.depth0 = int(depth0 if depth0 is not None else self.levels[0][2])
+        self.w0, self.h0 = self.levels[0][0], self.levels[0][1]
+        self.factor_d = factor_d_table(self.depth0, [l[2] for l in self.levels])   # [0] = placeholder level
+        self.pages = [[Level(w, h) for _ in range(d)] for (w, h, d) in self.levels]
+        self.flows = [None] * len(self.levels)
+        self.iters = {}
+
+    def set_images(self, lvl, page, img0, img1):
+        self.pages[lvl][page].set_images(img0, img1)
+
+    def set_flows(self, lvl, fl):
+        """fl: dict f0/f1/b0/b1 -> list of (h, w, 2) arrays, one per page"""
+        self.flows[lvl] = {k: [np.ascontiguousarray(a, dtype=np.float32) for a in fl[k]] for k in fl}
+
+    def _cons_for(self, lvl, z, cons):
+        """constraints of page z of level lvl (morph.cu:351-358): rows (lx, ly, rx, ry, weight, frame)"""
+        factor = int(self.factor_d[0] / self.factor_d[lvl + 1])
+        conz = min(z * factor, self.depth0 - 1)
+        cons = np.asarray(cons, dtype=np.float32).reshape(-1, 6)
+        return cons[cons[:, 5] == conz][:, :5]
+
+    def coarse_solve(self, P, cons=()):
+        L = len(self.levels) - 1
+        for z, pg in enumerate(self.pages[L]):
+            pg.coarse_solve(self.w0, self.h0, P, self._cons_for(L, z, cons), depth=self.levels[L][2])
+
+    def upsample(self, dst):
+        """upsample(pyr[dst], pyr[dst+1]), upsample.cu:260-340"""
+        src = dst + 1
+        w, h, d = self.levels[dst]
+        ds = self.levels[src][2]
+        factor = 2 if d > ds else 1
+        for pg in self.pages[dst]:
+            pg.field("v")[...] = 0
+        for i in range(ds):
+            self.pages[dst][min(i * factor, d - 1)].upsample_from(self.pages[src][i])
+        if factor > 1:
+            fl = self.flows[dst]
+            for i in range(1, d, factor):
+                if i == d - 1:
+                    continue
+                out = np.zeros((h, w, 2), dtype=np.float32)
+                a = [np.ascontiguousarray(x, dtype=np.float32) for x in (
+                    self.pages[dst][i - 1].field("v"), fl["f0"][i - 1], fl["f1"][i - 1],
+                    self.pages[dst][i + 1].field("v"), fl["b0"][i + 1], fl["b1"][i + 1])]
+                lib().vmo_temporal_fill(w, h, *[x.ctypes.data for x in a], out.ctypes.data)
+                self.pages[dst][i].field("v")[...] = out
+
+    def init_level(self, lvl, P, cons=()):
+        for z, pg in enumerate(self.pages[lvl]):
+            pg.init(P.ssim_clamp)
+            pg.field("temp_ref")[...] = 0          # lvl.temp.ref/mask.fill(0), morph.cu:313-314
+            pg.field("temp_mask")[...] = 0
+            pg.set_temporal(0, self.factor_d[lvl + 1])
+            pg.splat(self.w0, self.h0, self._cons_for(lvl, z, cons))
+
+    def optimize_level(self, lvl, P, max_iter, stats=None):
+        """Morph::optimize_level, morph.cu:1353-1441: the middle page, then the two chains outward"""
+        d = self.levels[lvl][2]
+        pg, fl = self.pages[lvl], self.flows[lvl]
+        its = {}
+        mid = d // 2
+        pg[mid].set_temporal(0, self.factor_d[lvl + 1])
+        its[mid] = pg[mid].optimize(P, max_iter, stats)
+        for i in range(mid + 1, d):
+            pg[i].initialize_temp(pg[i - 1], fl["f0"][i - 1], fl["f1"][i - 1])
+            its[i] = pg[i].optimize(P, max_iter, stats)
+        for i in range(mid - 1, -1, -1):
+            pg[i].initialize_temp(pg[i + 1], fl["b0"][i + 1], fl["b1"][i + 1])
+            its[i] = pg[i].optimize(P, max_iter, stats)
+        self.iters[lvl] = its
+        return its
+
+    def solve(self, P, max_iter, drop=1.0, cons=(), stats=None):
+        """Morph::calculate_halfway_parametrization, morph.cu:150-168"""
+        self.coarse_solve(P, cons)
+        mi = float(max_iter)
+        for el in range(len(self.levels) - 2, -1, -1):
+            self.upsample(el)
+            self.init_level(el, P, cons)
+            self.optimize_level(el, P, mi, stats)
+            mi /= drop

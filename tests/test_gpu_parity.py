@@ -275,7 +275,9 @@ def test_batched_solve_equals_individual_solves(gpu_ctx):
     gpu_ctx.set_math_mode(capi.MATH_EXACT)
     gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
     w, h = 150, 100
-    frames = [synth.make_pair(w, h, frame=k, amp=0.4 + 0.5 * k) for k in range(3)]
+    # pair 0 is an identical image pair (amp 0): no move lowers its energy, it stops after one
+    # sweep per level while the others run on
+    frames = [synth.make_pair(w, h, frame=k, amp=0.45 * k) for k in range(3)]
     prm = morph.Parameters()
     prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 25, 1.0, 32
     single, iters = [], []

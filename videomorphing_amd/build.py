@@ -29,6 +29,8 @@ UNITS = [
     ("vm_poisson.hip", "vm_poisson.o", ["-ffp-contract=off"]),
     ("vm_mg.hip", "vm_mg.o", ["-ffp-contract=fast"]),
     ("vm_pyramid.hip", "vm_pyramid.o", ["-ffp-contract=off"]),
+    ("vm_temporal.hip", "vm_temporal.o", ["-ffp-contract=off"]),
+    ("vm_video.cpp", "vm_video.o", ["-x", "hip"]),
     ("vm_pyramid_api.cpp", "vm_pyramid_api.o", ["-x", "hip"]),
     ("vm_api.cpp", "vm_api.o", ["-x", "hip"]),
     ("vm_host.cpp", "vm_host.o", ["-x", "hip"]),

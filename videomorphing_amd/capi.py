@@ -20,6 +20,7 @@ FIELDS = {  # name -> (id, channels)
     "img0": (0, 1), "img1": (1, 1), "v": (2, 2), "luma": (3, 2), "mean": (4, 2), "var": (5, 2),
     "cross": (6, 1), "value": (7, 1), "counter": (8, 1), "tps_axy": (9, 1), "tps_b": (10, 2),
     "ui_axy": (11, 1), "ui_b": (12, 2), "impmask": (13, 1),
+    "temp_ref": (14, 2), "temp_mask": (15, 1), "f0": (16, 2), "f1": (17, 2), "b0": (18, 2), "b1": (19, 2),
 }
 
 # every symbol include/vmorph.h declares (checked by tests/test_abi.py)
@@ -33,6 +34,10 @@ SYMBOLS = [
     "vm_frame_download_ext", "vm_frame_set_v_from_level", "vm_render_halfway",
     "vm_render_halfway_dev", "vm_poisson_extend", "vm_frame_quadratic_path", "vm_frame_download_qpath",
     "vm_rccl_bcast",
+    "vm_video_create", "vm_video_destroy", "vm_video_levels", "vm_video_level_dims", "vm_video_upload_luma",
+    "vm_video_upload_flows", "vm_video_build_rgb", "vm_video_build_flows", "vm_video_set_v", "vm_video_get_v",
+    "vm_video_get_field", "vm_video_coarse_solve", "vm_video_upsample", "vm_video_init_level",
+    "vm_video_initialize_temp", "vm_video_optimize_level", "vm_video_solve",
 ]
 
 
@@ -46,6 +51,11 @@ class KernParams(C.Structure):
 class Constraint(C.Structure):
     _fields_ = [("lx", C.c_float), ("ly", C.c_float), ("rx", C.c_float), ("ry", C.c_float),
                 ("weight", C.c_float)]
+
+
+class VideoConstraint(C.Structure):
+    _fields_ = [("lx", C.c_float), ("ly", C.c_float), ("rx", C.c_float), ("ry", C.c_float),
+                ("weight", C.c_float), ("frame", C.c_int)]
 
 
 class Progress(C.Structure):
@@ -115,12 +125,28 @@ def load():
         "vm_frame_quadratic_path": [vp, f, i, C.POINTER(i), C.POINTER(f), C.POINTER(f)],
         "vm_frame_download_qpath": [vp, vp],
         "vm_rccl_bcast": [vp, vp, vp, C.c_uint64, i],
+        "vm_video_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i), i, C.POINTER(vp)],
+        "vm_video_levels": [vp],
+        "vm_video_level_dims": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(f)],
+        "vm_video_upload_luma": [vp, i, i, vp, vp, i],
+        "vm_video_upload_flows": [vp, i, i, vp, vp, vp, vp, i],
+        "vm_video_build_rgb": [vp, i, vp, vp, i],
+        "vm_video_build_flows": [vp, vp, vp, vp, vp],
+        "vm_video_set_v": [vp, i, i, vp, i],
+        "vm_video_get_v": [vp, i, i, vp, i],
+        "vm_video_get_field": [vp, i, i, i, vp],
+        "vm_video_coarse_solve": [vp, vp, i],
+        "vm_video_upsample": [vp, i],
+        "vm_video_init_level": [vp, i, vp, i],
+        "vm_video_initialize_temp": [vp, i, i, i],
+        "vm_video_optimize_level": [vp, i, f, vp, i, vp],
+        "vm_video_solve": [vp, f, f, vp, i, vp, i, vp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i
-    for name in ("vm_ctx_destroy", "vm_pyramid_destroy", "vm_frame_destroy"):
+    for name in ("vm_ctx_destroy", "vm_pyramid_destroy", "vm_frame_destroy", "vm_video_destroy"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = None
     _lib = L

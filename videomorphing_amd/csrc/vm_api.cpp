@@ -403,10 +403,14 @@ extern "C" int vm_level_get_v(vm_pyr *p, int lvl, float *v, int pitch)
 extern "C" int vm_level_get_field(vm_pyr *p, int lvl, int field, void *host)
 {
     CHECK_LVL(p, lvl);
-    vm_level &l = p->lv[lvl];
+    return vm_level_read_field(p->ctx, p->lv[lvl], field, host);
+}
+
+int vm_level_read_field(vm_ctx *c, vm_level &l, int field, void *host)
+{
     if (!host) return vm_fail(VM_E_INVALID, "vm_level_get_field: NULL");
     const VmLevelView &V = l.view;
-    hipStream_t s = p->ctx->stream;
+    hipStream_t s = c->stream;
     const void *src = nullptr;
     int elem = 4;
     switch (field) {
@@ -421,6 +425,8 @@ extern "C" int vm_level_get_field(vm_pyr *p, int lvl, int field, void *host)
     case VM_F_TPS_B: src = V.tps_b; elem = 8; break;
     case VM_F_UI_AXY: src = V.ui_axy; break;
     case VM_F_UI_B: src = V.ui_b; elem = 8; break;
+    case VM_F_TEMP_REF: src = l.temp_ref_store; elem = 8; break;
+    case VM_F_TEMP_MASK: src = l.temp_mask_store; break;
     case VM_F_COUNTER: {
         // pure function of position (morph.cu:225): not stored on the device
         float *o = (float *)host;
@@ -452,7 +458,7 @@ extern "C" int vm_level_get_field(vm_pyr *p, int lvl, int field, void *host)
     default:
         return vm_fail(VM_E_INVALID, "vm_level_get_field: unknown field %d", field);
     }
-    if (!src) return vm_fail(VM_E_STATE, "vm_level_get_field: level %d has no such array", lvl);
+    if (!src) return vm_fail(VM_E_STATE, "vm_level_get_field: the level has no such array");
     VM_HIP(hipMemcpy2DAsync(host, (size_t)l.w * elem, src, (size_t)l.rs * elem, (size_t)l.w * elem, l.h, hipMemcpyDeviceToHost, s));
     VM_HIP(hipStreamSynchronize(s));
     return VM_OK;

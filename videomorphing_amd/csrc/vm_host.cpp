@@ -33,7 +33,7 @@ struct Band {
 } // namespace
 
 int vm_host_coarse_solve(int w, int h, int w0, int h0, const vm_kern_params &kp,
-                         const vm_constraint *cons, int ncon, float *v_out)
+                         const vm_constraint *cons, int ncon, float *v_out, int depth)
 {
     const int n = w * h, kd = 2 * w;
     memset(v_out, 0, sizeof(float) * 2 * (size_t)n);
@@ -82,12 +82,14 @@ int vm_host_coarse_solve(int w, int h, int w0, int h0, const vm_kern_params &kp,
             if (y >= 1 && y <= h - 2) { int id[3] = {i - w, i, i + w}; add_op(id, c3, 3, 1.0); }
             if (x <= w - 2 && y <= h - 2) { int id[4] = {i, i + 1, i + w, i + w + 1}; add_op(id, c4, 4, 2.0); }
         }
-    // boundary condition (morph.cu:507-562), one page
-    const double bd = (double)(kp.w_ui * inv_wh);
+    // boundary condition (morph.cu:507-562); BCOND_BORDER sits in a `for (t < depth)` loop
+    // inside the per-page loop there (:536-560): the border diagonal is added depth times
+    double bd = (double)(kp.w_ui * inv_wh);
     if (kp.bcond == VM_BCOND_CORNER) {
         const int id[4] = {0, (h - 1) * w, (h - 1) * w + w - 1, w - 1};
         for (int k = 0; k < 4; ++k) A.add(id[k], id[k], bd);
     } else if (kp.bcond == VM_BCOND_BORDER) {
+        bd *= depth;
         for (int x = 0; x < w; ++x) { A.add(x, x, bd); A.add((h - 1) * w + x, (h - 1) * w + x, bd); }
         for (int y = 1; y < h - 1; ++y) { A.add(y * w, y * w, bd); A.add(y * w + w - 1, y * w + w - 1, bd); }
     }

@@ -79,11 +79,42 @@ struct vm_level {
     void *ws = nullptr;              // SPLIT / STEP workspace, allocated on first use (vm_api.cpp)
     bool has_state = false;
     VmLevelView view{};
+    // pages of a video level: where lvl.temp.ref / lvl.temp.mask of the page live (the view
+    // points at them only while the page is swept with flag == true)
+    float2 *temp_ref_store = nullptr;
+    float *temp_mask_store = nullptr;
 };
 
 struct vm_pyr {
     vm_ctx *ctx = nullptr;
     std::vector<vm_level> lv;
+};
+
+// One page of a video level: the level state of one frame pair plus what couples it to its
+// neighbours in time -- the four flow fields of the page (PyramidLevel::f0/f1/b0/b1,
+// Pyramid.h:85-90, pitched float2 instead of cudaArray) and lvl.temp.ref / lvl.temp.mask.
+struct vm_video_page {
+    vm_level lv;
+    void *tslab = nullptr;                                   // flows + temporal arrays
+    float2 *flow[4] = {nullptr, nullptr, nullptr, nullptr};  // f0, f1, b0, b1
+    float2 *temp_ref = nullptr;
+    float *temp_mask = nullptr;
+};
+
+// The stage-2 pyramid of a video pair (class Pyramid with depth > 1, Pyramid.h:14-48):
+// level l holds depth[l] pages; level 0 finest, the last level holds only v.
+struct vm_video {
+    vm_ctx *ctx = nullptr;
+    int depth0 = 1;                       // frames of the video (the placeholder level's depth)
+    std::vector<int> depth;               // pages per level
+    std::vector<int> factor_t;            // temporal stride the level was built with (pyramid.cu:468)
+    std::vector<float> factor_d;          // per level (pyramid.cu:470-477); factor_d0 for the placeholder
+    float factor_d0 = 1.0f;
+    std::vector<std::vector<vm_video_page>> pages;
+    // scratch of the splat (sized for the finest level): fixed-point accumulators, v_cur, weight
+    long long *acc = nullptr;
+    float2 *vcur = nullptr;
+    float *weight = nullptr;
 };
 
 struct vm_frame {
@@ -104,6 +135,7 @@ int vm_level_alloc(vm_ctx *c, vm_level &l, bool with_images);
 void vm_level_free(vm_level &l);
 int vm_level_upsample(vm_ctx *c, vm_level &dst, const vm_level &src);
 int vm_level_init(vm_ctx *c, vm_level &l, int w0, int h0, const vm_constraint *cons, int n);
+int vm_level_read_field(vm_ctx *c, vm_level &l, int field, void *host);
 int vm_iteration_cap(float max_iter, int *cap);
 int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile const int *run_flag,
                        int fixed_work, vm_progress *out);
@@ -111,6 +143,6 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
 // Morph::cpu_optimize_level (morph.cu:419-590) on the host: v_out is a tight
 // (h, w, 2) array
 int vm_host_coarse_solve(int w, int h, int w0, int h0, const vm_kern_params &kp,
-                         const vm_constraint *cons, int n, float *v_out);
+                         const vm_constraint *cons, int n, float *v_out, int depth = 1);
 
 #endif

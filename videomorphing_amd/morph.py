@@ -485,3 +485,162 @@ def make_extended(rgb, ex):
     can[ex:ex + h, ex:ex + w, :3] = rgb
     can[ex:ex + h, ex:ex + w, 3] = 0
     return can
+
+
+# ---------------------------------------------------------------------------------------------
+# video pairs: class Pyramid with depth > 1 and the temporally coupled Morph
+
+def _vcons_array(cons):
+    """rows (lx, ly, rx, ry, weight, frame) -> VideoConstraint array"""
+    cons = np.asarray(cons if cons is not None else [], dtype=np.float32).reshape(-1, 6)
+    n = len(cons)
+    arr = (capi.VideoConstraint * max(n, 1))()
+    for k in range(n):
+        arr[k] = capi.VideoConstraint(float(cons[k][0]), float(cons[k][1]), float(cons[k][2]), float(cons[k][3]),
+                                      float(cons[k][4]), int(cons[k][5]))
+    return arr, n
+
+
+def video_constraints(P):
+    """Parameters::lp/rp/cnt resolved with the frame of the left point (morph.cu:354-366)"""
+    out = []
+    for row in P.cnt:
+        for c in row:
+            l = P.lp[c.li[0]][c.li[1]]
+            r = P.rp[c.ri[0]][c.ri[1]]
+            out.append((l.p[0], l.p[1], r.p[0], r.p[1], min(l.weight, r.weight), l.p[2]))
+    return np.asarray(out, dtype=np.float32).reshape(-1, 6)
+
+
+class VideoPage(object):
+    """One page of a PyramidLevel of depth > 1 (device-state access)."""
+
+    def __init__(self, vid, lvl, page, w, h):
+        self._vid, self._lvl, self._page = vid, lvl, page
+        self.width, self.height = int(w), int(h)
+
+    def field(self, name):
+        fid, ch = capi.FIELDS[name]
+        if name == "impmask":
+            out = np.zeros(((self.height + 4) // 5 + 2, (self.width + 4) // 5 + 2), dtype=np.uint32)
+        elif ch == 2:
+            out = np.zeros((self.height, self.width, 2), dtype=np.float32)
+        else:
+            out = np.zeros((self.height, self.width), dtype=np.float32)
+        capi.check(self._vid._L.vm_video_get_field(self._vid._h, self._lvl, self._page, fid, out.ctypes.data))
+        return out
+
+    @property
+    def v(self):
+        out = np.zeros((self.height, self.width, 2), dtype=np.float32)
+        capi.check(self._vid._L.vm_video_get_v(self._vid._h, self._lvl, self._page, out.ctypes.data, 0))
+        return out
+
+    @v.setter
+    def v(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        assert arr.shape == (self.height, self.width, 2)
+        capi.check(self._vid._L.vm_video_set_v(self._vid._h, self._lvl, self._page, arr.ctypes.data, 0))
+
+
+class VideoPyramid(object):
+    """class Pyramid (Pyramid.h:14-48) for a video pair: level l holds depth[l] pages and four
+    flow fields per page.  pages[l][t]: l = 0 finest ... last = coarsest (v only)."""
+
+    def __init__(self, ctx):
+        self._ctx, self._L = ctx, capi.load()
+        self._h = None
+        self.levels, self.factor_t, self.pages = [], [], []
+
+    def clear(self):
+        if getattr(self, "_h", None):
+            self._L.vm_video_destroy(self._h)
+            self._h = None
+
+    __del__ = clear
+
+    def build_levels(self, levels, factor_t=None, depth0=None):
+        """levels: [(w, h, d), ...] finest first incl. the coarsest"""
+        self.clear()
+        n = len(levels)
+        ws = (C.c_int * n)(*[int(l[0]) for l in levels])
+        hs = (C.c_int * n)(*[int(l[1]) for l in levels])
+        ds = (C.c_int * n)(*[int(l[2]) for l in levels])
+        ft = (C.c_int * n)(*[int(x) for x in factor_t]) if factor_t is not None else None
+        h = C.c_void_p()
+        capi.check(self._L.vm_video_create(self._ctx._h, n, ws, hs, ds, ft, int(depth0 if depth0 is not None else levels[0][2]), C.byref(h)))
+        self._h = h
+        self.levels = [tuple(int(x) for x in l) for l in levels]
+        self.factor_t = list(factor_t) if factor_t is not None else [1] + [2 if levels[i][2] != levels[i - 1][2] else 1 for i in range(1, n)]
+        self.pages = [[VideoPage(self, l, t, levels[l][0], levels[l][1]) for t in range(levels[l][2])] for l in range(n)]
+
+    def factor_d(self, lvl):
+        f = C.c_float(0)
+        capi.check(self._L.vm_video_level_dims(self._h, lvl, None, None, None, C.byref(f)))
+        return f.value
+
+    def upload_luma(self, lvl, page, img0, img1):
+        img0 = np.ascontiguousarray(img0, dtype=np.float32)
+        img1 = np.ascontiguousarray(img1, dtype=np.float32)
+        capi.check(self._L.vm_video_upload_luma(self._h, lvl, page, img0.ctypes.data, img1.ctypes.data, 0))
+
+    def upload_flows(self, lvl, page, f0, f1, b0, b1):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (f0, f1, b0, b1)]
+        capi.check(self._L.vm_video_upload_flows(self._h, lvl, page, *[x.ctypes.data for x in a], 0))
+
+    def build_flows(self, f0, f1, b0, b1):
+        """flow half of Pyramid::build on the device from the full-resolution flows of every frame"""
+        fam = [[np.ascontiguousarray(x, dtype=np.float32) for x in f] for f in (f0, f1, b0, b1)]
+        n = len(fam[0])
+        ptrs = [(C.c_void_p * n)(*[a.ctypes.data for a in f]) for f in fam]
+        capi.check(self._L.vm_video_build_flows(self._h, *ptrs))
+
+    def build_rgb_frame(self, frame, rgb0, rgb1):
+        rgb0 = np.ascontiguousarray(rgb0, dtype=np.uint8)
+        rgb1 = np.ascontiguousarray(rgb1, dtype=np.uint8)
+        capi.check(self._L.vm_video_build_rgb(self._h, int(frame), rgb0.ctypes.data, rgb1.ctypes.data, 0))
+
+    def build(self, video0, video1, f0, f1, b0, b1, start_res):
+        """Pyramid::build(video0, video1, f0, f1, b0, b1, start_res), pyramid.cu:166-485, for float
+        luma frames: geometry incl. the temporal pyramid (synth.video_levels), box-filtered lumas
+        per page (as Pyramid.build of a pair does), flows through the device builder."""
+        h, w = video0[0].shape
+        d = len(video0)
+        levels, factor_t = synth.video_levels(w, h, d, start_res)
+        self.build_levels(levels, factor_t, d)
+        frames = synth.page_frames(levels, factor_t)
+        pyr = [synth.build_pyramid(video0[t], video1[t], len(levels)) for t in range(d)]
+        for l in range(len(levels) - 1):
+            for t in range(levels[l][2]):
+                self.upload_luma(l, t, *pyr[frames[l][t]][l])
+        self.build_flows(f0, f1, b0, b1)
+
+
+class VideoMorph(object):
+    """class Morph (morph.h:10-31) over a VideoPyramid: the temporally coupled solve."""
+
+    def __init__(self, params, pyramid, run_flag=None, fixed_work=False):
+        self.m_params, self.m_pyramid = params, pyramid
+        self.m_cb = run_flag if run_flag is not None else C.c_int(1)
+        self.fixed_work = bool(fixed_work)
+        self._max_iter = float(params.max_iter)
+        self.progress = {}
+
+    def calculate_halfway_parametrization(self):
+        """morph.cu:150-168 with the page schedule of optimize_level (:1353-1441)"""
+        P, vid = self.m_params, self.m_pyramid
+        vid._ctx.set_params(KernParameters(P))
+        cons, n = _vcons_array(video_constraints(P))
+        flag = C.cast(C.pointer(self.m_cb), C.c_void_p)
+        total = sum(l[2] for l in vid.levels[:-1])
+        prog = (capi.Progress * total)()
+        capi.check(vid._L.vm_video_solve(vid._h, self._max_iter, float(P.max_iter_drop_factor), cons, n, flag,
+                                         int(self.fixed_work), prog))
+        k = 0
+        for l in range(len(vid.levels) - 1):
+            for t in range(vid.levels[l][2]):
+                pr = prog[k]
+                self.progress[(l, t)] = dict(iters=pr.iters, improving=pr.improving, commits=pr.commits,
+                                             candidates=pr.candidates, elapsed_ms=pr.elapsed_ms)
+                k += 1
+        return True

@@ -129,3 +129,85 @@ def make_constraints(w, h, n=8, amp=None):
         lx, ly = np.rint(rx - 2 * dx), np.rint(ry - 2 * dy)
         pts.append((lx, ly, rx, ry, 1.0))
     return np.asarray(pts, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# video pairs with analytic optical flow (the temporal coherence path)
+
+def make_video_pair(w, h, frame, shift0=(0.5, 0.25), shift1=None, seed=SEED, amp=None):
+    """Frame `frame` of two synthetic videos: video 0 translates by shift0 px per frame, video 1
+    by shift1 (default: the same).  Both are exact warps of the analytic noise field, so the
+    optical flow is known in closed form: f0 = shift0, f1 = shift1 everywhere."""
+    shift1 = shift0 if shift1 is None else shift1
+    base = max(w, h) / 8.0
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    d = displacement(w, h, amp)
+    n0 = value_noise(x - shift0[0] * frame, y - shift0[1] * frame, base, seed)
+    x1, y1 = x - shift1[0] * frame, y - shift1[1] * frame          # undo video 1's motion ...
+    dd = displacement_at(x1, y1, w, h, amp)                          # ... then its warp of frame 0
+    n1 = value_noise(x1 - 2 * dd[..., 0], y1 - 2 * dd[..., 1], base, seed)
+    top = 2.0 - 0.5 ** (OCTAVES - 1)
+    lo, hi = 0.25 * top, 0.75 * top
+    f = lambda n: np.clip(16.0 + (n - lo) / (hi - lo) * 224.0, 16.0, 240.0)
+    return f(n0).astype(np.float32), f(n1).astype(np.float32)
+
+
+def displacement_at(x, y, w, h, amp=None):
+    """d(p) at continuous coordinates (same field as displacement())"""
+    amp = 0.01 * w if amp is None else amp
+    dx = amp * np.sin(2 * np.pi * x / w) * np.cos(2 * np.pi * y / h)
+    dy = amp * np.sin(2 * np.pi * y / h)
+    return np.stack([dx, dy], axis=-1)
+
+
+def constant_flows(w, h, depth, shift0=(0.5, 0.25), shift1=None):
+    """(f0, f1, b0, b1): per frame (h, w, 2) forward flows of video 0 / 1 (frame t -> t+1) and
+    backward flows (t -> t-1) of the translating synthetic videos"""
+    shift1 = shift0 if shift1 is None else shift1
+    mk = lambda s: [np.broadcast_to(np.asarray(s, np.float32), (h, w, 2)).copy() for _ in range(depth)]
+    return mk(shift0), mk(shift1), mk((-shift0[0], -shift0[1])), mk((-shift1[0], -shift1[1]))
+
+
+def video_levels(w, h, d, start_res, max_voxels=14e6):
+    """Level table of the stage-2 Pyramid::build (pyramid.cu:223-240, 462-477): returns
+    (levels, factor_t); levels = [(w, h, d), ...] finest first incl. the coarsest (host-solved)
+    level, factor_t[l] = temporal stride level l is built with.  Level counts in integer
+    arithmetic (the reference truncates float32 logarithms: el = int(log2(dim) - log2(start_res)
+    + 1), exposed to 1-ulp hazards at exact powers of two); the 14 Mvoxel decimation in float32
+    as written there."""
+    f32 = np.float32
+    fa = max(np.sqrt(f32(w * h * d) / f32(max_voxels)), f32(1))
+    w, h = int(f32(w) / fa), int(f32(h) / fa)
+
+    def el(dim):      # largest n with start_res * 2^(n-1) <= dim; 0 below start_res
+        n = 0
+        while dim >= start_res:
+            dim //= 2
+            n += 1
+        return n
+    el_t = el(d)
+    el_x = el_y = max(el(w), el(h))
+    maxl = max(el_x, el_t)
+    levels, factors, factor_t = [], [], 1
+    for k in range(maxl):
+        levels.append((w, h, d))
+        factors.append(factor_t)
+        if maxl - k <= el_x:
+            w = (w + 1) // 2
+        if maxl - k <= el_y:
+            h = (h + 1) // 2
+        if maxl - k <= el_t:
+            d, factor_t = (d + 2) // 2, 2            # ceil((d + 1) / 2)
+        else:
+            factor_t = 1
+    return levels, factors
+
+
+def page_frames(levels, factors):
+    """frame of the video each page shows: page t of level l is scaled from page
+    min(t * factor_t, prev_d - 1) of level l-1 (pyramid.cu:363-364)"""
+    out = [list(range(levels[0][2]))]
+    for l in range(1, len(levels)):
+        pd = levels[l - 1][2]
+        out.append([out[l - 1][min(t * factors[l], pd - 1)] for t in range(levels[l][2])])
+    return out
