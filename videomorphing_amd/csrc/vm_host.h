@@ -24,6 +24,10 @@ struct VmDeviceGuard {
     bool switched = false;
     explicit VmDeviceGuard(int dev)
     {
+        // HIP's "last error" is per thread and sticky across libraries: an error another
+        // library left behind (RCCL probing peers, a framework's failed query) must not be
+        // reported by the hipGetLastError() checks that follow this entry point's launches
+        (void)hipGetLastError();
         if (hipGetDevice(&prev) != hipSuccess || prev != dev)
             switched = hipSetDevice(dev) == hipSuccess && prev >= 0;
     }
