@@ -124,6 +124,13 @@ int  vm_set_math_mode(vm_ctx *ctx, int mode);
  * threads/parts: 0 = automatic. */
 enum { VM_SWEEP_AUTO = 0, VM_SWEEP_TILE = 1, VM_SWEEP_SPLIT = 2, VM_SWEEP_STEP = 3 };
 int  vm_set_tuning(vm_ctx *ctx, int sweep_mode, int threads, int parts);
+/* Diagnostic, EXACT arithmetic only: the order in which the commits of one Jacobi phase are
+ * folded into the shared window sums.  The reference leaves it to float atomics
+ * (morph.cu:951-1015); the oracle and this library fix it as row-major over the committing
+ * pixels.  reversed != 0 applies them in the opposite order -- an equally legal trajectory,
+ * used to measure how far two legal runs drift apart (the chaos floor FAST is judged
+ * against, tests/test_gpu_fullsize.py). */
+int  vm_set_commit_order(vm_ctx *ctx, int reversed);
 /* device facts for reports: name (<=255 chars), CU count, HBM bytes */
 int  vm_device_info(vm_ctx *ctx, char *name256, int *cus, uint64_t *hbm_bytes);
 

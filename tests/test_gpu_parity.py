@@ -574,3 +574,46 @@ def test_context_driven_from_fresh_threads(gpu_ctx):
     assert np.array_equal(out["a"], out["main"]) and np.array_equal(out["b"], out["main"])
     assert np.abs(out["main"]).max() > 0
     ctx.close()
+
+
+@pytest.mark.parametrize("sched", [capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP])
+def test_reversed_commit_order_matches_the_oracle_switch(gpu_ctx, oracle, sched):
+    """vm_set_commit_order: the commits of a phase folded in reversed row-major order -- another
+    order the reference's atomics may produce -- equals the oracle run with the same switch bit
+    for bit, and differs from the row-major trajectory (so the switch measures something)"""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    w, h = 138, 84
+    i0, i1 = synth.make_pair(w, h)
+    v0 = (0.8 * synth.displacement(w, h)).astype(np.float32)
+    P = oracle.default_params()
+    kp = capi.KernParams()
+    for f, _ in capi.KernParams._fields_:
+        setattr(kp, f, getattr(P, f))
+    gpu_ctx.set_params(kp)
+    res = {}
+    try:
+        gpu_ctx.set_tuning(sched, 0, 0)
+        for rev in (0, 1):
+            oracle.lib().vmo_set_commit_order(rev)
+            gpu_ctx.set_commit_order(rev)
+            lo = oracle.Level(w, h)
+            lo.set_images(i0, i1)
+            lo.field("v")[...] = v0
+            lo.init(0.0)
+            for _ in range(4):
+                lo.optimize_iter(P)
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build_levels([(w, h), (69, 42)])
+            pyr.upload_luma(1, i0, i1)
+            pyr[1].v = v0
+            capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+            pr = capi.Progress()
+            capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 4.0, None, 1, C.byref(pr)))
+            for f in ("v", "mean", "var", "cross", "tps_b", "value"):
+                assert np.array_equal(lo.field(f).view(np.uint32), pyr[1].field(f).view(np.uint32)), (rev, f)
+            res[rev] = pyr[1].field("mean")
+    finally:
+        oracle.lib().vmo_set_commit_order(0)
+        gpu_ctx.set_commit_order(0)
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+    assert not np.array_equal(res[0], res[1])

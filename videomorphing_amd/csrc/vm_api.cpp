@@ -186,6 +186,13 @@ extern "C" int vm_set_math_mode(vm_ctx *c, int mode)
     return VM_OK;
 }
 
+extern "C" int vm_set_commit_order(vm_ctx *c, int reversed)
+{
+    if (!c) return vm_fail(VM_E_INVALID, "vm_set_commit_order: ctx is NULL");
+    c->commit_reversed = reversed ? 1 : 0;
+    return VM_OK;
+}
+
 extern "C" int vm_set_tuning(vm_ctx *c, int sweep_mode, int threads, int parts)
 {
     if (!c || sweep_mode < VM_SWEEP_AUTO || sweep_mode > VM_SWEEP_STEP || threads < 0 || parts < 0 ||
@@ -557,7 +564,7 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
     if (!c->use_graphs) return nullptr;
     for (auto &g : c->graphs)
         if (g.exact == exact && g.n == n && g.w == w && g.h == h && g.cap == cap && g.fixed_work == fixed_work &&
-            g.threads == threads && g.dense == dense && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
+            g.threads == threads && g.dense == dense && g.rev == c->commit_reversed && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
             memcmp(&g.kp, &c->kp, sizeof(c->kp)) == 0)
             return g.exec;
     if (!c->iter_dev && hipMalloc((void **)&c->iter_dev, sizeof(int)) != hipSuccess) {
@@ -590,7 +597,7 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
         for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
         c->graphs.clear();
     }
-    c->graphs.push_back({exact, n, w, h, cap, fixed_work, threads, dense, c->views, c->flags, c->stats, c->kp, exec});
+    c->graphs.push_back({exact, n, w, h, cap, fixed_work, threads, dense, c->commit_reversed, c->views, c->flags, c->stats, c->kp, exec});
     return exec;
 }
 
@@ -639,7 +646,8 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         if ((l.view.temp_mask != nullptr) != (l0.view.temp_mask != nullptr))
             return vm_fail(VM_E_INVALID, "batch: pages with and without the temporal term cannot share a launch");
     }
-    VmKParams P = {c->kp.w_ui, c->kp.w_tps, c->kp.w_ssim, c->kp.ssim_clamp, c->kp.eps, c->kp.bcond, c->kp.w_temp};
+    VmKParams P = {c->kp.w_ui, c->kp.w_tps, c->kp.w_ssim, c->kp.ssim_clamp, c->kp.eps, c->kp.bcond, c->kp.w_temp,
+                   c->commit_reversed};
     int cap = 1;
     int rc0 = vm_iteration_cap(max_iter, &cap);
     if (rc0 != VM_OK) return rc0;

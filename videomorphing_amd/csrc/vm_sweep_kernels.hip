@@ -931,13 +931,41 @@ __device__ __forceinline__ bool commit_own(LdsT &S, const VmLevelView &L, const 
 // (UpdateSSIM, :1258-1279).
 template <class LdsT>
 __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L, int ox, int oy, int rx, int ry,
-                                            int pi, int pj, float2 &m, float2 &q, float &cr, float2 &tb)
+                                            int pi, int pj, float2 &m, float2 &q, float &cr, float2 &tb, int rev)
 {
     int ylo = max(ry - 2, 0), yhi = min(ry + 2, VM_TILE_H - 1);
     int xlo = max(rx - 2, 0), xhi = min(rx + 2, VM_TILE_W - 1);
     ylo += (ylo & 1) ^ pi;
     xlo += (xlo & 1) ^ pj;
     bool touched = false;
+#if VM_EXACT
+    // diagnostic (vm_set_commit_order): the same records in reversed row-major order -- an
+    // equally legal order of the commits the reference leaves to atomics
+    if (rev) {
+        yhi -= (yhi & 1) ^ pi;
+        xhi -= (xhi & 1) ^ pj;
+        for (int y = yhi; y >= ylo; y -= 2)
+            for (int x = xhi; x >= xlo; x -= 2) {
+                const int rec = (y >> 1) * 32 + (x >> 1);
+                if (S.d_ok[rec] != 1)
+                    continue;
+                touched = true;
+                const float2 dm = S.d_mean[rec], dv = S.d_var[rec], st = S.d_step[rec];
+                m.x += dm.x;
+                m.y += dm.y;
+                q.x += dv.x;
+                q.y += dv.y;
+                cr += S.d_cross[rec];
+                const int By = border_class(oy + y, L.h), Bx = border_class(ox + x, L.w);
+                const float k = S.tps[(By * 5 + Bx) * 25 + (ry - y + 2) * 5 + (rx - x + 2)];
+                tb.x += st.x * k;
+                tb.y += st.y * k;
+            }
+        return touched;
+    }
+#else
+    (void)rev;
+#endif
     for (int y = ylo; y <= yhi; y += 2)
         for (int x = xlo; x <= xhi; x += 2) {
             const int rec = (y >> 1) * 32 + (x >> 1);
@@ -1221,7 +1249,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
                     }
                     float2 m = S.mean[cell], q = S.var[cell], tb = S.tpsb[cell];
                     float cr = S.cross[cell];
-                    if (gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb)) {
+                    if (gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb, P.rev_commit)) {
                         S.mean[cell] = m;
                         S.var[cell] = q;
                         S.cross[cell] = cr;
@@ -1501,7 +1529,7 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
             const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2;
             float2 m = cm[e], q = cq[e], tb = ctb[e];
             float cr = ccr[e];
-            if (!gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb))
+            if (!gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb, P.rev_commit))
                 continue;
             const int gi = cgi[e];
             L.mean[gi] = m;
@@ -1577,8 +1605,11 @@ __device__ __forceinline__ uint32_t cell_hits(const uint32_t (*bits)[4], int bx0
 // cost 72 VGPRs and with them a workgroup per CU.
 __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__restrict__ r_a,
                                           const float4 *__restrict__ r_b, const float *s_tps, uint32_t hits, int qx,
-                                          int qy, float2 &m, float2 &q, float &cr, float2 &tb)
+                                          int qy, float2 &m, float2 &q, float &cr, float2 &tb, int rev)
 {
+#if !VM_EXACT
+    (void)rev;
+#endif
     const bool touched = hits != 0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -1592,8 +1623,15 @@ __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__
                 bidx[k] = -1;
                 continue;
             }
+#if VM_EXACT
+            // rev (vm_set_commit_order): the highest window bit first = reversed row-major order
+            const int b = hits ? (rev ? 31 - __clz(hits) : __ffs(hits) - 1) : -1;
+            if (b >= 0)
+                hits &= ~(1u << b);
+#else
             const int b = hits ? __ffs(hits) - 1 : -1;
             hits &= hits - 1;
+#endif
             bidx[k] = b;
             const int bb = max(b, 0);
             const int dy = (bb * 13) >> 6, dx = bb - dy * 5;
@@ -1733,7 +1771,7 @@ __global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__
             float2 m = cm[e], q = cq[e], tb = ctb[e];
             float cr = ccr[e], val = cval[e];
             const uint32_t hits = in ? cell_hits(S.bits, bx0, by0, qx, qy) : 0u;
-            const bool touched = fold_cell(L, r_a, r_b, S.tps, hits, in ? qx : 0, in ? qy : 0, m, q, cr, tb);
+            const bool touched = fold_cell(L, r_a, r_b, S.tps, hits, in ? qx : 0, in ? qy : 0, m, q, cr, tb, P.rev_commit);
             if (!in)
                 continue;
             if (touched) {
@@ -1842,7 +1880,7 @@ __global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__
         float2 m = s_mean[gi], q = s_var[gi], tb = s_tpsb[gi];
         float cr = s_cross[gi], val = s_value[gi];
         const uint32_t hits = live && okc ? cell_hits(S.bits, bx0, by0, cx, cy) : 0u;
-        if (fold_cell(L, r_a, r_b, S.tps, hits, cx, cy, m, q, cr, tb)) {
+        if (fold_cell(L, r_a, r_b, S.tps, hits, cx, cy, m, q, cr, tb, P.rev_commit)) {
             const float counter = (float)(window_count(cy, L.h) * window_count(cx, L.w));
             val = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
         }

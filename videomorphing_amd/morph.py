@@ -108,6 +108,10 @@ class Context(object):
     def set_tuning(self, sweep_mode=0, threads=0, parts=0):
         capi.check(self._L.vm_set_tuning(self._h, int(sweep_mode), int(threads), int(parts)))
 
+    def set_commit_order(self, reversed_=False):
+        """diagnostic (EXACT): fold a phase's commits in reversed row-major order"""
+        capi.check(self._L.vm_set_commit_order(self._h, int(bool(reversed_))))
+
     def sync(self):
         capi.check(self._L.vm_ctx_sync(self._h))
 
