@@ -75,9 +75,9 @@ def parse_args(argv=None):
     ap.add_argument("--semantics", default="fixed", choices=["fixed", "reference"],
                     help="fixed: every level runs its max_iter sweeps (BASELINE config: 500 iters/level); "
                          "reference: a level stops when no pixel improved (morph.cu:1390)")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="config 1/3: independent pairs solved concurrently per GPU (one HIP stream and one "
-                         "host thread each)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="HIP streams (contexts, one host thread each) per GPU working on different pairs at the same "
+                         "time; 0 = 1 for config 1/3, 2 for config 2")
     ap.add_argument("--batch", type=int, default=1,
                     help="config 1/3: pairs solved together by the same sweep launches; a step is then one batch")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -136,7 +136,12 @@ def main():
         raw = vdist.broadcast_block(raw, coll_dev)
     blk, _cons = vdist.unpack_block(raw)
 
-    nctx = max(1, args.inflight) if config != 2 else 1
+    # config 2: two streams per GPU by default -- measured on MI355X (tools/dev_inflight.sh, 8 / 60 pairs
+    # on one GPU): 1 stream 21.3 / 38.2, 2 streams 25.3 / 47.9, 4 streams 20.2 / 46.2 G pixel*iters/s
+    # (beyond two the host's launch rate, ~3.5 us per eager launch under the runtime's lock, binds)
+    if config == 2 and args.inflight == 0:
+        args.inflight = 2
+    nctx = max(1, args.inflight)
     ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(nctx)]
     for c in ctxs:
         c.set_params(blk.kp)
@@ -162,10 +167,15 @@ def main():
         distinct = mine[:8]                       # 8 distinct frames per rank, reused cyclically
         distinct_frames = len(distinct)
         imgs = frames(distinct)
-        pyrs = [pyramid(ctx, imgs[k % len(imgs)]) for k in range(len(mine))]
-        B = max(1, min(args.max_batch, len(mine)))
-        nb = (len(mine) + B - 1) // B
-        B = (len(mine) + nb - 1) // nb            # even batches: 60 pairs on one GPU = 2 x 30
+        # the rank's pairs in nctx contiguous chunks, one context (HIP stream + host thread) each;
+        # a chunk is solved in even batches of <= max_batch pairs per launch
+        nctx = min(nctx, max(1, len(mine)))
+        chunk_of = [k * nctx // max(len(mine), 1) for k in range(len(mine))]
+        pyrs = [pyramid(ctxs[chunk_of[k]], imgs[k % len(imgs)]) for k in range(len(mine))]
+        per_ctx = (len(mine) + nctx - 1) // nctx
+        B = max(1, min(args.max_batch, per_ctx))
+        nb = (per_ctx + B - 1) // B
+        B = (per_ctx + nb - 1) // nb              # even batches: 60 pairs on one GPU and stream = 2 x 30
         step_sets = [pyrs] * (args.steps + args.warmup)       # every step re-solves the rank's shard
     else:
         B = max(1, args.batch)
@@ -202,6 +212,17 @@ def main():
     def run_step(ps):
         """one step; with several contexts, one host thread per context (a vm_ctx is
         single-threaded by contract)"""
+        if config == 2 and nctx > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            chunks = [[p for p in ps if p._ctx is c] for c in ctxs]
+
+            def work(chunk):
+                res = []
+                for g0 in range(0, len(chunk), B):
+                    res += solve_group(chunk[g0:g0 + B])
+                return res
+            with ThreadPoolExecutor(max_workers=nctx) as ex:           # ctypes calls release the GIL
+                return [r for res in ex.map(work, chunks) for r in res]
         if B > 1 or config == 2:
             out = []
             for g0 in range(0, len(ps), B):

@@ -58,7 +58,7 @@ def test_bench_gpus_2_self_launches_two_ranks():
     n_gpus == 2 in the line.  This box has one GPU, so the two collectives go over gloo and the
     ranks share the device (--backend gloo); with RCCL the same code path runs one rank per GPU."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pairs", "4",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pairs", "4", "--inflight", "1",
                         "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
