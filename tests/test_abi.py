@@ -30,14 +30,16 @@ def test_every_declared_symbol_is_exported(vmlib):
 
 def test_header_is_plain_c_and_struct_layouts_match(tmp_path):
     prog = tmp_path / "sz.c"
-    prog.write_text('#include <stdio.h>\n#include "vmorph.h"\nint main(void){printf("%zu %zu %zu %zu\\n",'
-                    'sizeof(vm_kern_params),sizeof(vm_constraint),sizeof(vm_progress),sizeof(vm_param_block));return 0;}\n')
+    prog.write_text('#include <stdio.h>\n#include "vmorph.h"\nint main(void){printf("%zu %zu %zu %zu ",'
+                    'sizeof(vm_kern_params),sizeof(vm_constraint),sizeof(vm_progress),sizeof(vm_param_block));'
+                    'printf("%zu\\n",sizeof(vm_video_constraint));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            str(prog), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [C.sizeof(capi.KernParams), C.sizeof(capi.Constraint), C.sizeof(capi.Progress),
-                   C.sizeof(capi.ParamBlock)]
+                   C.sizeof(capi.ParamBlock), C.sizeof(capi.VideoConstraint)]
+    assert got == [28, 20, 80, 48, 24]
 
 
 def test_header_cites_the_reference_interfaces():

@@ -58,3 +58,64 @@ def test_facade_matches_python_mirror(solve_pair, gpu_ctx, tmp_path):
     assert t.percentage == pytest.approx(100.0)
     assert np.array_equal(v_cpp.view(np.uint32), pyr._vector[0].view(np.uint32))
     assert np.abs(v_cpp).max() > 0.1
+
+
+@pytest.fixture(scope="module")
+def solve_video(tmp_path_factory, vmlib):
+    exe = str(tmp_path_factory.mktemp("cppv") / "solve_video")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "solve_video.cpp"), "-o", exe,
+                           "-L", libdir, "-lvmorph_hip", "-Wl,-rpath," + libdir, "-lpthread"])
+    return exe
+
+
+def test_video_facade_builds(solve_video):
+    assert os.path.exists(solve_video)
+
+
+@pytest.mark.gpu
+def test_video_facade_matches_python_mirror(solve_video, gpu_ctx, tmp_path):
+    """the C++ VideoPyramid / VideoMorph (device-side image + flow pyramid, coupled solve) and the
+    Python mirror over the same C-ABI produce the same bits"""
+    from videomorphing_amd import morph
+    w, h, d = 96, 64, 4
+    rgbs = [synth.make_rgb_pair(w, h, frame=t) for t in range(d)]
+    f0, f1, b0, b1 = synth.constant_flows(w, h, d)
+    np.concatenate([np.stack([a, b]).ravel() for a, b in rgbs]).astype(np.uint8).tofile(str(tmp_path / "fr.u8"))
+    np.concatenate([np.stack([f0[t], f1[t], b0[t], b1[t]]).ravel() for t in range(d)]).astype(np.float32).tofile(str(tmp_path / "fl.f32"))
+    out = tmp_path / "v.f32"
+    r = subprocess.run([solve_video, str(w), str(h), str(d), str(tmp_path / "fr.u8"), str(tmp_path / "fl.f32"), str(out),
+                        "12", "16", "exact"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    v_cpp = np.fromfile(str(out), np.float32).reshape(d, h, w, 2)
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    levels, ft = synth.video_levels(w, h, d, 16)
+    vid = morph.VideoPyramid(gpu_ctx)
+    vid.build_levels(levels, ft, d)
+    for t in range(d):
+        vid.build_rgb_frame(t, *rgbs[t])
+    vid.build_flows(f0, f1, b0, b1)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 12, 1.0, 16
+    morph.VideoMorph(prm, vid).calculate_halfway_parametrization()
+    for t in range(d):
+        assert np.array_equal(v_cpp[t].view(np.uint32), vid.pages[0][t].v.view(np.uint32)), t
+    assert np.abs(v_cpp).max() > 0.05
+
+
+def test_cpp_level_table_equals_the_python_geometry(tmp_path, vmlib):
+    """VideoPyramid::level_table (C++) and synth.video_levels (Python, itself checked against the
+    float form the reference evaluates) agree on the temporal pyramid's geometry"""
+    src = tmp_path / "lt.cpp"
+    src.write_text('#include <cstdio>\n#include <cstdlib>\n#include "vmorph/video.hpp"\nint main(int c, char **a){'
+                   'auto t = vmorph::VideoPyramid::level_table(atoi(a[1]), atoi(a[2]), atoi(a[3]), atoi(a[4]));'
+                   'for (auto &l : t) printf("%d %d %d %d\\n", l.width, l.height, l.depth, l.factor_t); return 0;}\n')
+    exe = str(tmp_path / "lt")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe,
+                           "-L", libdir, "-lvmorph_hip", "-Wl,-rpath," + libdir])
+    for (w, h, d, sr) in [(80, 64, 16, 8), (80, 64, 32, 8), (1920, 1080, 60, 32), (320, 200, 40, 8), (256, 256, 1, 64), (127, 99, 5, 4)]:
+        got = [tuple(int(x) for x in l.split()) for l in subprocess.check_output([exe, str(w), str(h), str(d), str(sr)]).decode().splitlines()]
+        levels, ft = synth.video_levels(w, h, d, sr)
+        assert got == [l + (f,) for l, f in zip(levels, ft)], (w, h, d, sr)
