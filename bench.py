@@ -43,8 +43,9 @@ FLOP_PER_EVAL = 25 * 45 + 2 * 30  # 25 ssim() of ~45 flop-eq + 2
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_FLOPS = 157e12         # MI355X_MICROARCH.md: f32 vector peak
 SCHED = ("k_optimize<true> (TILE schedule, dense kernel)", "k_optimize<false> (TILE schedule, lean kernel for pruned sweeps)",
-         "k_step (STEP schedule, one launch per phase)")
-SCHED_PMC = ("k_optimize_fast<true>", "k_optimize_fast<false>", "k_step_fast<512>")
+         "k_step (STEP schedule, one launch per phase)",
+         "k_sparse (SPARSE schedule: one launch per batch of iterations of a pruned level)")
+SCHED_PMC = ("k_optimize_fast<true>", "k_optimize_fast<false>", "k_step_fast<512>", "k_sparse_fast<false>")
 
 
 def tile_visits(w, h):
@@ -204,7 +205,7 @@ def main():
             if i > 0:          # elapsed/launches are per batch: count them once
                 for k in range(nlev - 1):
                     one[k].elapsed_ms, one[k].launches = 0.0, 0
-                    for j in range(3):
+                    for j in range(4):
                         one[k].sched_ms[j], one[k].sched_launches[j] = 0.0, 0
             out.append(one)
         return out
@@ -328,20 +329,27 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
     # ---- per kernel: launches, average duration (HIP events around each batch of launches on
     # the context's stream), algorithmic bytes per launch, nominal and real fraction of HBM peak
     per_kernel = []
-    for k in range(3):
+    for k in range(4):
         ms = sum(pr[i].sched_ms[k] for pr in progs for i in R)
         n = sum(pr[i].sched_launches[k] for pr in progs for i in R)
         if n == 0:
             continue
         # one TILE launch = one pass over the level (a quarter of an iteration's visits) of every
-        # pair of the batch; one STEP launch = one phase of one pass (a sixteenth)
+        # pair of the batch; one STEP launch = one phase of one pass (a sixteenth); a SPARSE
+        # launch covers a whole batch of iterations: its nominal bytes are those of the iterations
+        # it executed (sched_iters is not recorded: the level's executed iterations minus what the
+        # other schedules' launches account for)
         share = 16.0 if k == 2 else 4.0
         nbytes = 0.0
         for pr_i, pr in enumerate(progs):
             for i in R:
                 if pr[i].sched_launches[k]:
                     # launches are recorded once per batch (first pair); the batch's other pairs add their visits
-                    nbytes += pr[i].sched_launches[k] * tile_visits(*sizes[i]) / share * ALG_BYTES_PER_VISIT * B
+                    if k == 3:
+                        others = pr[i].sched_launches[0] / 4.0 + pr[i].sched_launches[1] / 4.0 + pr[i].sched_launches[2] / 16.0
+                        nbytes += max(pr[i].iters - others, 0.0) * tile_visits(*sizes[i]) * ALG_BYTES_PER_VISIT * B
+                    else:
+                        nbytes += pr[i].sched_launches[k] * tile_visits(*sizes[i]) / share * ALG_BYTES_PER_VISIT * B
         avg_us = ms * 1e3 / n
         ent = {"kernel": SCHED[k], "launches": n, "avg_us": round(avg_us, 2), "share_of_sweep_time": round(ms / max(kern_ms, 1e-9), 3),
                "alg_bytes_per_launch": round(nbytes / n), "nominal_GBs": round(nbytes / n / (avg_us * 1e-6) / 1e9, 2),

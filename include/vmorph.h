@@ -88,9 +88,10 @@ typedef struct {
     double evaluations;    /* energy evaluations executed (each: 2 bilinear taps
                               + 25 SSIM terms, morph.cu:671-761)                 */
     /* HIP-event time and launch count of the sweep kernels per schedule:
-     * [0] TILE, dense kernel; [1] TILE, lean kernel (pruned sweeps); [2] STEP / SPLIT */
-    float  sched_ms[3];
-    int    sched_launches[3];
+     * [0] TILE, dense kernel; [1] TILE, lean kernel (pruned sweeps); [2] STEP / SPLIT;
+     * [3] SPARSE */
+    float  sched_ms[4];
+    int    sched_launches[4];
 } vm_progress;
 
 /* device-state arrays a test or a UI may read back (vm_level_get_field) */
@@ -119,10 +120,12 @@ int  vm_set_math_mode(vm_ctx *ctx, int mode);
  * per tile-offset pass, one workgroup per tile; VM_SWEEP_SPLIT = two launches per
  * phase (line searches, then the commit), a tile's candidates spread over `parts`
  * workgroups (small levels); VM_SWEEP_STEP = one launch per phase, the commit of a
- * phase folded into the next phase's launch; VM_SWEEP_AUTO picks per batch of
+ * phase folded into the next phase's launch; VM_SWEEP_SPARSE = TILE, but every batch of
+ * iterations of a pruned level (fewer than a tenth of the pixels searched) runs as ONE launch
+ * in which one workgroup per pair walks the active tiles; VM_SWEEP_AUTO picks per batch of
  * iterations.
  * threads/parts: 0 = automatic. */
-enum { VM_SWEEP_AUTO = 0, VM_SWEEP_TILE = 1, VM_SWEEP_SPLIT = 2, VM_SWEEP_STEP = 3 };
+enum { VM_SWEEP_AUTO = 0, VM_SWEEP_TILE = 1, VM_SWEEP_SPLIT = 2, VM_SWEEP_STEP = 3, VM_SWEEP_SPARSE = 4 };
 int  vm_set_tuning(vm_ctx *ctx, int sweep_mode, int threads, int parts);
 /* Diagnostic, EXACT arithmetic only: the order in which the commits of one Jacobi phase are
  * folded into the shared window sums.  The reference leaves it to float atomics

@@ -309,3 +309,41 @@ def test_config2_batch_of_8_pairs_at_1080p_equals_individual_solves(gpu_ctx, mod
     finally:
         gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
         gpu_ctx.set_math_mode(capi.MATH_EXACT)
+
+
+@pytest.mark.parametrize("npairs", [1, 3])
+def test_sparse_schedule_equals_tile_at_1080p(gpu_ctx, npairs):
+    """config[1] geometry, FAST, 60 sweeps per level, fixed work: the SPARSE schedule (pruned levels
+    swept by one workgroup per pair, 1-2 launches per batch of iterations) ends bit-identical to
+    the TILE schedule (4 launches per iteration), alone and as a batch whose pairs advance
+    independently inside the sparse kernel; and it needs fewer launches"""
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    w, h = 1920, 1080
+    frames = [synth.make_pair(w, h, frame=k) for k in range(npairs)]
+    out = {}
+    try:
+        for sched in (capi.SWEEP_TILE, capi.SWEEP_SPARSE):
+            gpu_ctx.set_tuning(sched, 0, 0)
+            batch = []
+            for k in range(npairs):
+                pyr = morph.Pyramid(gpu_ctx)
+                pyr.build(frames[k][0], frames[k][1], 32)
+                batch.append(pyr)
+            if npairs == 1:
+                prm = morph.Parameters()
+                prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 60, 1.0, 32
+                m = morph.Morph(prm, batch[0], fixed_work=True)
+                m.calculate_halfway_parametrization()
+                launches = sum(m.progress[el]["launches"] for el in m.progress)
+            else:
+                prog = morph.solve_batch(batch, 60, 1.0, fixed_work=True)
+                launches = sum(p["launches"] for p in prog[0])
+            out[sched] = ([b[1].v for b in batch], [b[1].field("impmask") for b in batch], launches)
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    for k in range(npairs):
+        assert np.array_equal(out[capi.SWEEP_TILE][0][k].view(np.uint32), out[capi.SWEEP_SPARSE][0][k].view(np.uint32)), k
+        assert np.array_equal(out[capi.SWEEP_TILE][1][k], out[capi.SWEEP_SPARSE][1][k]), k
+    assert out[capi.SWEEP_SPARSE][2] < out[capi.SWEEP_TILE][2], (out[capi.SWEEP_TILE][2], out[capi.SWEEP_SPARSE][2])

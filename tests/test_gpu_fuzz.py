@@ -33,7 +33,7 @@ def test_exact_sweeps_equal_the_oracle_on_random_levels(gpu_ctx, oracle, seed):
         for trial in range(8):
             w, h, kw, cons = _draw(rng, 300, 120)
             iters = int(rng.randint(1, 4))
-            for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP):
+            for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_SPARSE):
                 P = T._params(oracle, **kw)
                 lo, pyr, P = T._make_level(gpu_ctx, oracle, w, h, cons=cons, P=P, seed=trial)
                 for _ in range(iters):
@@ -68,3 +68,54 @@ def test_fast_step_equals_split_on_random_levels(gpu_ctx, oracle, seed):
     finally:
         gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
         gpu_ctx.set_math_mode(capi.MATH_EXACT)
+
+
+def _pruned_level(gpu_ctx, oracle, rng, w, h, kw, cons, trial):
+    """a level in the pruned regime: the usual random level after 80 sweeps of the TILE schedule
+    (most of its pixels have stopped moving; the continuation is what is compared)"""
+    P = T._params(oracle, **kw)
+    lo, pyr, P = T._make_level(gpu_ctx, oracle, w, h, cons=cons, P=P, seed=trial)
+    gpu_ctx.set_tuning(capi.SWEEP_TILE, 0, 0)
+    capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 80.0, None, 1, None))
+    return pyr
+
+
+@pytest.mark.parametrize("mode,seed", [(capi.MATH_FAST, 31), (capi.MATH_FAST, 32), (capi.MATH_EXACT, 33)])
+def test_sparse_schedule_equals_tile_on_random_levels(gpu_ctx, oracle, mode, seed):
+    """SPARSE (one workgroup per pair walks the active tiles of a pruned level, a whole batch of
+    iterations per launch) against TILE (one launch per pass): bit-identical state, iteration
+    counts and activity counters over 10-60 iterations, fixed work and reference stopping rule"""
+    rng = np.random.RandomState(seed)
+    gpu_ctx.set_math_mode(mode)
+    used = 0
+    try:
+        for trial in range(10):
+            w, h, kw, cons = _draw(rng, 420, 200)
+            w, h = max(w, 40), max(h, 40)
+            if trial % 3:      # the reference's weights (the drawn ones often keep every pixel active)
+                kw = dict(bcond=kw["bcond"], eps=kw["eps"], ssim_clamp=kw["ssim_clamp"])
+            iters = float(rng.randint(10, 60))
+            fixed = int(rng.randint(0, 2))
+            st = rng.get_state()
+            res = []
+            for sched in (capi.SWEEP_TILE, capi.SWEEP_SPARSE):
+                rng.set_state(st)
+                pyr = _pruned_level(gpu_ctx, oracle, rng, w, h, kw, cons, trial)
+                gpu_ctx.set_tuning(sched, 0, 0)
+                pr = capi.Progress()
+                capi.check(pyr._L.vm_optimize_level(pyr._h, 0, iters, None, fixed, C.byref(pr)))
+                res.append(([pyr[1].field(n).copy() for n in STATE], (pr.iters, pr.improving, pr.commits, pr.candidates, pr.evaluations),
+                            pr.sched_launches[3], pr.active_tiles))
+            assert res[0][1] == res[1][1], (w, h, kw, iters, fixed, res[0][1], res[1][1])
+            # (the count of "active" tiles is not compared exactly: under TILE a tile's early-out test
+            # reads ring words a neighbouring tile of the same pass may be updating -- bits of pixels
+            # no tile of that pass owns, so the results do not depend on it, only this counter)
+            assert abs(res[0][3] - res[1][3]) <= 0.02 * res[0][3] + 4
+            for n, a, b in zip(STATE, res[0][0], res[1][0]):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, w, h, kw, iters, fixed)
+            assert res[0][2] == 0
+            used += res[1][2] > 0
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    assert used >= 2, used          # the sparse kernel really ran (the 1080p tests exercise it at length)

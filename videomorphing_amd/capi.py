@@ -14,7 +14,7 @@ VM_OK = 0
 VM_E_INVALID, VM_E_DEVICE, VM_E_STATE, VM_E_NUMERIC, VM_E_CANCELLED = -1, -2, -3, -4, -5
 BCOND_NONE, BCOND_CORNER, BCOND_BORDER = 0, 1, 2
 MATH_EXACT, MATH_FAST = 0, 1
-SWEEP_AUTO, SWEEP_TILE, SWEEP_SPLIT, SWEEP_STEP = 0, 1, 2, 3
+SWEEP_AUTO, SWEEP_TILE, SWEEP_SPLIT, SWEEP_STEP, SWEEP_SPARSE = 0, 1, 2, 3, 4
 
 FIELDS = {  # name -> (id, channels)
     "img0": (0, 1), "img1": (1, 1), "v": (2, 2), "luma": (3, 2), "mean": (4, 2), "var": (5, 2),
@@ -62,7 +62,7 @@ class Progress(C.Structure):
     _fields_ = [("iters", C.c_int), ("improving", C.c_int), ("pixel_iters", C.c_double),
                 ("elapsed_ms", C.c_float), ("launches", C.c_int),
                 ("active_tiles", C.c_double), ("candidates", C.c_double), ("commits", C.c_double),
-                ("evaluations", C.c_double), ("sched_ms", C.c_float * 3), ("sched_launches", C.c_int * 3)]
+                ("evaluations", C.c_double), ("sched_ms", C.c_float * 4), ("sched_launches", C.c_int * 4)]
 
 
 class ParamBlock(C.Structure):

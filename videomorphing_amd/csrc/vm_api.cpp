@@ -195,7 +195,7 @@ extern "C" int vm_set_commit_order(vm_ctx *c, int reversed)
 
 extern "C" int vm_set_tuning(vm_ctx *c, int sweep_mode, int threads, int parts)
 {
-    if (!c || sweep_mode < VM_SWEEP_AUTO || sweep_mode > VM_SWEEP_STEP || threads < 0 || parts < 0 ||
+    if (!c || sweep_mode < VM_SWEEP_AUTO || sweep_mode > VM_SWEEP_SPARSE || threads < 0 || parts < 0 ||
         (threads && (threads % 64 || threads < 256 || threads > 1024)) || parts > 64)
         return vm_fail(VM_E_INVALID, "vm_set_tuning: bad argument");
     c->sweep_mode = sweep_mode;
@@ -220,7 +220,8 @@ void vm_level_free(vm_level &l)
 {
     hipFree(l.slab);
     hipFree(l.ws);
-    l.slab = l.ws = nullptr;
+    hipFree(l.sp_ws);
+    l.slab = l.ws = l.sp_ws = nullptr;
     l.has_state = false;
     VmLevelView &V = l.view;
     V.rec_a = V.rec_b = V.rec_a2 = V.rec_b2 = nullptr;
@@ -230,6 +231,7 @@ void vm_level_free(vm_level &l)
     V.impmask2 = nullptr;
     V.temp_ref = nullptr;
     V.temp_mask = nullptr;
+    V.sp_wl = V.sp_cnt = V.sp_stamp = nullptr;
 }
 
 // one slab per level: every array starts on a 256-byte boundary
@@ -285,6 +287,7 @@ int vm_level_alloc(vm_ctx *c, vm_level &l, bool with_images)
     V.temp_ref = nullptr;
     V.temp_mask = nullptr;
     V.factor_d = 1.0f;
+    V.sp_wl = V.sp_cnt = V.sp_stamp = nullptr;
     return VM_OK;
 }
 
@@ -313,6 +316,23 @@ static int level_ensure_ws(vm_ctx *c, vm_level &l)
     V.cross2 = (float *)b; b += al(n * 4);
     V.value2 = (float *)b; b += al(n * 4);
     V.impmask2 = (uint32_t *)b;
+    return VM_OK;
+}
+
+// The workspace of the SPARSE schedule (vm_sweep_kernels.hip): two lists of mask-word indices,
+// their lengths and a stamp per word -- 12 B per 5x5 block, allocated on first use.
+static int level_ensure_sparse(vm_ctx *c, vm_level &l)
+{
+    if (l.sp_ws) return VM_OK;
+    const size_t nw = (size_t)l.imp_rs * l.imp_rows;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t total = al(2 * nw * 4) + al(nw * 4) + 256;
+    VM_HIP(hipMalloc((void **)&l.sp_ws, total));
+    VM_HIP(hipMemsetAsync(l.sp_ws, 0, total, c->stream));
+    char *b = (char *)l.sp_ws;
+    l.view.sp_wl = (uint32_t *)b; b += al(2 * nw * 4);
+    l.view.sp_stamp = (uint32_t *)b; b += al(nw * 4);
+    l.view.sp_cnt = (uint32_t *)b;
     return VM_OK;
 }
 
@@ -671,6 +691,9 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         c->views_cap = n;
     }
     hipStream_t s = c->stream;
+    const int ntiles_lvl = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
+    // SPARSE: one workgroup per pair walks the few active tiles of a pruned level on the device
+    const bool may_sparse = (c->sweep_mode == VM_SWEEP_AUTO || c->sweep_mode == VM_SWEEP_SPARSE) && ntiles_lvl <= 8192;
     {
         // levels that may run the SPLIT / STEP schedules need their workspace before the views
         // are copied to the device
@@ -680,6 +703,13 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
             for (int i = 0; i < n; ++i) {
                 int rc = level_ensure_ws(c, *lv[i]);
                 if (rc != VM_OK) return rc;
+            }
+        if (may_sparse)
+            for (int i = 0; i < n; ++i) {
+                int rc = level_ensure_sparse(c, *lv[i]);
+                if (rc != VM_OK) return rc;
+                // the stamps are epochs of THIS call (iteration * 4 + pass + 1)
+                VM_HIP(hipMemsetAsync(lv[i]->view.sp_stamp, 0, (size_t)l0.imp_rs * l0.imp_rows * 4, s));
             }
         std::vector<VmLevelView> hv(n);
         for (int i = 0; i < n; ++i) hv[i] = lv[i]->view;
@@ -704,8 +734,9 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     // 0.32 (STEP) vs 0.64 ms (TILE) per iteration; 240x135 with 900 line searches per
     // iteration 0.22 vs 0.36; with 90: 0.24 vs 0.23; converged 0.08 vs 0.024.  All schedules
     // work on the same state in HBM, so the choice can change from batch to batch.
-    const bool may_split = c->sweep_mode != VM_SWEEP_TILE && tiles_per_pass * n <= 64;
+    const bool may_split = c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= 64;
     double cand_prev = 1e9; // line searches per iteration in the previous batch (first batch: dense)
+    double tiles_prev = 1e9; // active tile visits per iteration and pair in the previous batch
     if (may_split || c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP) // epochs restart with every call: forget old records
         for (int i = 0; i < n; ++i)
         {
@@ -718,8 +749,8 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     int done = 0, launches = 0;
     bool cancelled = false;
     float ms = 0;
-    float sched_ms[3] = {0, 0, 0}; // [0] TILE dense kernel, [1] TILE lean kernel, [2] STEP / SPLIT
-    int sched_launches[3] = {0, 0, 0};
+    float sched_ms[4] = {0, 0, 0, 0}; // [0] TILE dense kernel, [1] TILE lean kernel, [2] STEP / SPLIT, [3] SPARSE
+    int sched_launches[4] = {0, 0, 0, 0};
     static const bool force_dense = getenv("VM_TILE_DENSE") != nullptr; // dev switch
     // Iterations are enqueued in batches; each sweep kernel of iteration i exits at once (per
     // pair) when iteration i-1 did not improve (device-side flag), so running past convergence
@@ -735,14 +766,29 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         const bool step = split && c->sweep_mode != VM_SWEEP_SPLIT;
         // TILE, FAST arithmetic: the register-light kernel variant once fewer than a tenth of the pixels
         // are searched per iteration (after the first sweep of a level, typically)
-        const int dense = exact || force_dense || cand_prev >= 0.1 * l0.w * l0.h * n;
-        const int sched = split ? 2 : (dense ? 0 : 1);
+        const bool lean_regime = cand_prev < 0.1 * l0.w * l0.h * n;
+        const int dense = exact || force_dense || !lean_regime;
+        // SPARSE replaces the TILE launches of a pruned level once at most three tiles per pass
+        // and pair are still active (measured on MI355X, 1080p: a no-op TILE iteration costs
+        // 4 x 3.4 us, a no-op SPARSE iteration 4 x ~0.3 us; with more active tiles than that the
+        // one workgroup per pair serialises what the TILE grid runs side by side)
+        const bool sparse = may_sparse && !split && lean_regime && !force_dense &&
+                            (c->sweep_mode == VM_SWEEP_SPARSE || tiles_prev <= 12.0);
+        const int sched = split ? 2 : (sparse ? 3 : (dense ? 0 : 1));
         const int launches_before = launches;
         VM_HIP(hipEventRecord(c->ev0, s));
         uint32_t last_epoch = 0;
         int sb = 0; // step index inside this batch: parity = which copy of the sums is read
         int it0 = done;
-        if (!split && nb >= VM_GRAPH_ITERS) {
+        if (sparse) {
+            for (int i = 0; i < n; ++i)
+                VM_HIP(hipMemsetAsync(lv[i]->view.sp_cnt, 0, 8, s));
+            (exact ? vm_launch_optimize_sparse_exact : vm_launch_optimize_sparse_fast)(
+                c->views, n, cap, l0.w, l0.h, P, c->tables, c->flags, c->stats, done, nb, fixed_work, threads, dense, s);
+            launches += 2;
+            it0 = done + nb;
+        }
+        if (!split && !sparse && nb >= VM_GRAPH_ITERS) {
             // TILE batch: whole groups of VM_GRAPH_ITERS iterations are graph replays
             if (hipGraphExec_t ge = sweep_graph(c, exact, n, l0.w, l0.h, cap, fixed_work, threads, dense, P)) {
                 if (exact) vm_launch_next_iter_exact(c->iter_dev, 1, done, s);
@@ -794,12 +840,13 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         sched_ms[sched] += bms;
         sched_launches[sched] += launches - launches_before;
         bool all_stopped = true;
-        double b_cand = 0;
+        double b_cand = 0, b_tiles = 0;
         for (int i = 0; i < n; ++i) {
             const uint32_t *fl = c->flags_host + (size_t)i * cap, *st = c->stats_host + (size_t)i * cap * VM_STAT_WORDS;
             for (int it = done; it < done + nb && !stopped[i]; ++it) {
                 // [0] tile visits (TILE schedule), [3] tile-phases with records (SPLIT schedule)
                 st_tiles[i] += st[VM_STAT_WORDS * it] + 0.25 * st[VM_STAT_WORDS * it + 3];
+                b_tiles += st[VM_STAT_WORDS * it] + 0.25 * st[VM_STAT_WORDS * it + 3];
                 st_cand[i] += st[VM_STAT_WORDS * it + 1];
                 b_cand += st[VM_STAT_WORDS * it + 1];
                 st_commit[i] += st[VM_STAT_WORDS * it + 2];
@@ -810,6 +857,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
             all_stopped = all_stopped && stopped[i];
         }
         cand_prev = b_cand / nb;
+        tiles_prev = b_tiles / nb / n;
         done += nb;
         if (all_stopped) break;
         if (run_flag && !*run_flag) {
@@ -829,7 +877,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         out[i].candidates = st_cand[i];
         out[i].commits = st_commit[i];
         out[i].evaluations = st_eval[i];
-        for (int k = 0; k < 3; ++k) { // of the batch, like elapsed_ms
+        for (int k = 0; k < 4; ++k) { // of the batch, like elapsed_ms
             out[i].sched_ms[k] = sched_ms[k];
             out[i].sched_launches[k] = sched_launches[k];
         }

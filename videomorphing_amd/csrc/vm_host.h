@@ -82,6 +82,7 @@ struct vm_level {
     void *slab = nullptr;
     size_t slab_bytes = 0;
     void *ws = nullptr;              // SPLIT / STEP workspace, allocated on first use (vm_api.cpp)
+    void *sp_ws = nullptr;           // SPARSE workspace (word lists, stamps), allocated on first use
     bool has_state = false;
     VmLevelView view{};
     // pages of a video level: where lvl.temp.ref / lvl.temp.mask of the page live (the view

@@ -49,6 +49,9 @@ struct VmLevelView {
     const float2 *temp_ref;
     const float *temp_mask;
     float factor_d;
+    // SPARSE schedule workspace: two lists of non-zero mask word indices (ping-pong, nwords
+    // entries each), their lengths, and an epoch stamp per word
+    uint32_t *sp_wl, *sp_cnt, *sp_stamp;
 };
 
 struct VmKParams {
@@ -80,6 +83,10 @@ struct VmKParams {
                                      int fixed_work, int threads, const int *iter_dev,        \
                                      int dense, hipStream_t s);                               \
     void vm_launch_next_iter_##SUFFIX(int *iter_dev, int set, int value, hipStream_t s);      \
+    void vm_launch_optimize_sparse_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w, \
+                                            int h, const VmKParams &P, const uint32_t *tables, \
+                                            uint32_t *flags, uint32_t *stats, int it0, int nit, \
+                                            int fixed_work, int threads, int dense, hipStream_t s); \
     void vm_launch_optimize_split_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w, \
                                            int h, const VmKParams &P, const uint32_t *tables, \
                                            int offx, int offy, int pass, uint32_t *flags,     \

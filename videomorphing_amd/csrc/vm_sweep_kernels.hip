@@ -988,43 +988,19 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
 
 // ===========================================================================
 // TILE schedule
+// One tile of one pass (one thread block of kernel_optimize_level, morph.cu:1281-1345): mask
+// test, LoadSSIM, four Jacobi phases, SaveSSIM.  Shared by the TILE kernel (one workgroup per
+// tile, one launch per pass) and the SPARSE kernel (one workgroup per frame pair walking the
+// few active tiles of a pruned level).  Returns false when no mask word near the tile is set
+// (nothing read, nothing written).
 // DENSE = false (FAST only): the variant for pruned sweeps -- every phase runs the lean line
 // search, 16 candidates per round; without the dense path the kernel needs 134 instead of
 // 256 VGPRs (measured: pruned sweeps 5-8 % faster).
 template <bool DENSE>
-__global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENSE ? 1 : 4))) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
-                                                        VmKParams P, const uint32_t *__restrict__ tables,
-                                                        int offx, int offy, uint32_t *__restrict__ flags,
-                                                        uint32_t *__restrict__ stats, int iter_idx, int fixed_work,
-                                                        const int *__restrict__ iter_dev)
+__device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, const VmKParams &P,
+                                           const uint32_t *__restrict__ tables, bool tables_staged, int ox, int oy,
+                                           int tid, int T, bool &improving, uint32_t &st_cand, uint32_t &st_commit)
 {
-    __shared__ TileLds S;
-    // replayed from a hipGraph the launch can only carry the iteration's position inside the
-    // graph: the base comes from a device counter that k_next_iter advances once per replay
-    if (iter_dev)
-        iter_idx += *iter_dev;
-#ifdef VM_PROF
-    unsigned long long tso[16];
-    for (int k = 0; k < 16; ++k) tso[k] = 0;
-    tso[0] = wall_clock64();
-#define VM_TSO(i) tso[i] = wall_clock64()
-#else
-#define VM_TSO(i)
-#endif
-    const int tid = threadIdx.x, T = blockDim.x;
-    // blockIdx.z = frame pair of the batch: same geometry, own state, own flags
-    const VmLevelView L = views[blockIdx.z];
-    flags += (size_t)blockIdx.z * cap;
-    stats += (size_t)blockIdx.z * cap * VM_STAT_WORDS;
-
-    // converged in the previous iteration: nothing left to do (sticky)
-    if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
-        return;
-
-    const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
-    if (ox >= L.w || oy >= L.h)
-        return;
-
     // --- improving-mask words of the tile and its ring of neighbour blocks ---
     const MaskGeom g = mask_geom(L, ox, oy);
     uint32_t mymask = 0;
@@ -1037,14 +1013,14 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
     // candidate in any phase, and re-deriving the SSIM values from unchanged sums
     // reproduces them bit for bit
     if (!__syncthreads_or(mymask != 0))
-        return;
+        return false;
 
-    for (int k = tid; k < 625; k += T)
-        S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
-    for (int k = tid; k < 225; k += T)
-        S.imp[k] = tables[VM_TAB_IMP + k];
-    if (tid == 0)
-        S.n_eval = 0;
+    if (!tables_staged) { // TILE: per launch, after the early out; SPARSE: once per kernel
+        for (int k = tid; k < 625; k += T)
+            S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
+        for (int k = tid; k < 225; k += T)
+            S.imp[k] = tables[VM_TAB_IMP + k];
+    }
 
     // --- LoadSSIM (morph.cu:1214-1234) + the tile's tps.b ---
     // (three cells per thread in flight: one HBM/L2 round trip for a 512-thread workgroup)
@@ -1081,9 +1057,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
     }
     __syncthreads();
 
-    bool improving = false;
-    uint32_t st_cand = 0, st_commit = 0;
-    VM_TSO(1);
+    bool tile_improving = false;
 
     for (int pi = 0; pi < 2; ++pi) {
         for (int pj = 0; pj < 2; ++pj) {
@@ -1099,7 +1073,6 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
                 S.d_ok[tid] = state;
             }
             const int n_act = compact256(cand, tid, S.list, S.wave_cnt);
-            VM_TSO(2 + 3 * (pi * 2 + pj));
 
             if (n_act > 0) {
                 st_cand += n_act;
@@ -1216,7 +1189,6 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
                 }
             }
             __syncthreads();
-            VM_TSO(3 + 3 * (pi * 2 + pj));
 
             // ---- 3. commits ----
             const bool ok = tid < 256 && commit_own(S, L, g, tid, ox, oy, pi, pj);
@@ -1229,7 +1201,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
             }
             const int ncommit = __syncthreads_count(ok);
             if (ncommit) {
-                improving = true;
+                tile_improving = true;
                 st_commit += ncommit;
                 for (int cell = tid; cell < VM_NCELL; cell += T) {
                     const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2; // tile-relative
@@ -1260,12 +1232,11 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
                 }
             }
             __syncthreads();
-            VM_TSO(4 + 3 * (pi * 2 + pj));
         }
     }
 
     // ---- SaveSSIM (morph.cu:1236-1256), tps.b and the owned mask words ----
-    if (improving) {
+    if (tile_improving) {
         for (int c = tid; c < VM_NCELL; c += T) {
             int gx = ox - 2 + c % VM_HALO_W, gy = oy - 2 + c / VM_HALO_W;
             if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h)
@@ -1284,13 +1255,42 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
         if (mx >= 1 && mx <= g.nbx - 2 && my >= 1 && my <= g.nby - 2)
             L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)] = S.mask[my][mx];
     }
-#ifdef VM_PROF
-    VM_TSO(14);
-    if (tid == 0 && st_cand > 0) {
-        tso[15] = st_cand;
-        for (int k = 0; k < 16; ++k) vm_prof_buf[((blockIdx.x + blockIdx.y * gridDim.x) % 512) * 16 + k] = tso[k];
-    }
-#endif
+    improving = improving || tile_improving;
+    return true;
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENSE ? 1 : 4))) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
+                                                        VmKParams P, const uint32_t *__restrict__ tables,
+                                                        int offx, int offy, uint32_t *__restrict__ flags,
+                                                        uint32_t *__restrict__ stats, int iter_idx, int fixed_work,
+                                                        const int *__restrict__ iter_dev)
+{
+    __shared__ TileLds S;
+    // replayed from a hipGraph the launch can only carry the iteration's position inside the
+    // graph: the base comes from a device counter that k_next_iter advances once per replay
+    if (iter_dev)
+        iter_idx += *iter_dev;
+    const int tid = threadIdx.x, T = blockDim.x;
+    // blockIdx.z = frame pair of the batch: same geometry, own state, own flags
+    const VmLevelView L = views[blockIdx.z];
+    flags += (size_t)blockIdx.z * cap;
+    stats += (size_t)blockIdx.z * cap * VM_STAT_WORDS;
+
+    // converged in the previous iteration: nothing left to do (sticky)
+    if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
+        return;
+
+    const int ox = blockIdx.x * VM_PITCH_X + offx, oy = blockIdx.y * VM_PITCH_Y + offy;
+    if (ox >= L.w || oy >= L.h)
+        return;
+    if (tid == 0)
+        S.n_eval = 0; // ordered before its first use by the barriers of tile_sweep
+
+    bool improving = false;
+    uint32_t st_cand = 0, st_commit = 0;
+    if (!tile_sweep<DENSE>(S, L, P, tables, false, ox, oy, tid, T, improving, st_cand, st_commit))
+        return;
     if (tid == 0) {
         if (improving)
             atomicOr(&flags[iter_idx], 1u);
@@ -1299,6 +1299,173 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
         atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 1], st_cand);
         atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 2], st_commit);
         atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 4], S.n_eval);
+    }
+}
+
+// ===========================================================================
+// SPARSE schedule: the pruned regime without kernel boundaries.  After the first sweeps of a
+// level the improving mask leaves a handful of active tiles (none once the level has
+// converged), yet the TILE schedule still pays four launches per iteration -- 3.4 us each over
+// a 1080p level just to find every mask word zero -- and, in a batch, every pass waits for the
+// slowest tile of ALL pairs.  Here ONE workgroup per frame pair walks a whole batch of
+// iterations on the device: it keeps a list of the non-zero mask words, derives from it the
+// tiles of the current pass whose mask window holds one (exactly the TILE kernel's early-out
+// test), sweeps them one after the other with the same tile_sweep, and updates the list from
+// the words those tiles own.  A converged level costs a few barriers per pass; pairs of a batch
+// advance independently.  Tiles of one pass touch disjoint state, so their order is free: the
+// results are bit-identical to the TILE schedule.
+struct SparseLds {
+    uint32_t tilebits[256]; // tiles of the current pass with a set mask word in their window
+    int done[128];          // tiles swept in this pass (for the list update)
+    int ndone;
+    uint32_t nnew;
+};
+
+// does the mask window of the tile at (ox, oy) hold block (bx, by)?  (mask_geom: the words
+// k_optimize / tile_sweep test before doing anything)
+__device__ __forceinline__ bool tile_window_has(const VmLevelView &L, int ox, int oy, int bx, int by)
+{
+    const MaskGeom g = mask_geom(L, ox, oy);
+    return bx >= g.bx0 && bx < g.bx0 + g.nbx && by >= g.by0 && by < g.by0 + g.nby;
+}
+
+// every non-zero mask word of the level into the pair's list 0
+__global__ __launch_bounds__(256) void SUF(k_sparse_scan)(const VmLevelView *__restrict__ views)
+{
+    const VmLevelView L = views[blockIdx.z];
+    const int nwords = L.imp_rs * L.imp_rows;
+    const int wi = blockIdx.x * 256 + threadIdx.x;
+    if (wi < nwords && L.impmask[wi] != 0) {
+        const uint32_t idx = atomicAdd(&L.sp_cnt[0], 1u);
+        L.sp_wl[idx] = (uint32_t)wi;
+    }
+}
+
+template <bool DENSE>
+__global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1))) void SUF(k_sparse)(
+    const VmLevelView *__restrict__ views, int cap, VmKParams P, const uint32_t *__restrict__ tables,
+    uint32_t *__restrict__ flags, uint32_t *__restrict__ stats, int it0, int nit, int fixed_work)
+{
+    __shared__ TileLds S;
+    __shared__ SparseLds Q;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const VmLevelView L = views[blockIdx.z];
+    flags += (size_t)blockIdx.z * cap;
+    stats += (size_t)blockIdx.z * cap * VM_STAT_WORDS;
+    if (!fixed_work && it0 > 0 && flags[it0 - 1] == 0)
+        return; // converged in the previous iteration (sticky)
+    for (int k = tid; k < 625; k += T)
+        S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
+    for (int k = tid; k < 225; k += T)
+        S.imp[k] = tables[VM_TAB_IMP + k];
+    const int gx = (L.w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (L.h + VM_PITCH_Y - 1) / VM_PITCH_Y;
+    const int ntw = (gx * gy + 31) / 32; // <= 256 (the host checks)
+    const int nwords = L.imp_rs * L.imp_rows;
+    uint32_t *const lists[2] = {L.sp_wl, L.sp_wl + nwords};
+    int cur = 0;
+    uint32_t nw = L.sp_cnt[0]; // length of the current list (from k_sparse_scan); then carried in registers
+    __syncthreads();
+    for (int it = it0; it < it0 + nit; ++it) {
+        // no set mask word anywhere: no tile of any pass of any later iteration can be active --
+        // every remaining sweep of this batch is a no-op (its flags and counters stay zero)
+        if (nw == 0)
+            break;
+        bool improving = false;
+        uint32_t st_cand = 0, st_commit = 0, st_tiles = 0;
+        if (tid == 0)
+            S.n_eval = 0;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int offx = (pass & 1) ? VM_TILE_W : 0, offy = (pass & 2) ? VM_TILE_H : 0; // morph.cu:1382-1385
+            const uint32_t *list = lists[cur];
+            uint32_t *nlist = lists[cur ^ 1];
+            // ---- 1. the tiles of this pass whose mask window holds a listed word ----
+            for (int k = tid; k < ntw; k += T)
+                Q.tilebits[k] = 0;
+            if (tid == 0) {
+                Q.ndone = 0;
+                Q.nnew = 0;
+            }
+            __syncthreads();
+            for (uint32_t k = tid; k < nw; k += T) {
+                const int wi = (int)list[k];
+                const int bx = wi % L.imp_rs - 1, by = wi / L.imp_rs - 1;
+                const int ce = (5 * bx - offx) / VM_PITCH_X, re = (5 * by - offy) / VM_PITCH_Y;
+                for (int r = max(re - 1, 0); r <= re + 1 && r < gy; ++r)
+                    for (int c = max(ce - 1, 0); c <= ce + 1 && c < gx; ++c) {
+                        const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
+                        if (ox < L.w && oy < L.h && tile_window_has(L, ox, oy, bx, by))
+                            atomicOr(&Q.tilebits[(r * gx + c) >> 5], 1u << ((r * gx + c) & 31));
+                    }
+            }
+            __syncthreads();
+            // ---- 2. sweep them, one after the other ----
+            for (int wd = 0; wd < ntw; ++wd) {
+                uint32_t bits = Q.tilebits[wd];
+                while (bits) {
+                    const int t = wd * 32 + __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    const int ox = (t % gx) * VM_PITCH_X + offx, oy = (t / gx) * VM_PITCH_Y + offy;
+                    if (tile_sweep<DENSE>(S, L, P, tables, true, ox, oy, tid, T, improving, st_cand, st_commit)) {
+                        ++st_tiles;
+                        if (tid == 0) {
+                            if (Q.ndone < 128)
+                                Q.done[Q.ndone] = t;
+                            ++Q.ndone;
+                        }
+                    }
+                    __syncthreads(); // the tile's state and mask words are out before anything reads them
+                }
+            }
+            // ---- 3. the list for the next pass: old entries that are still set, plus the set
+            // words the swept tiles own (no other word can have changed) ----
+            const uint32_t epoch = (uint32_t)(it * 4 + pass) + 1u;
+            for (uint32_t k = tid; k < nw; k += T) {
+                const uint32_t wi = list[k];
+                if (L.impmask[wi] != 0) {
+                    L.sp_stamp[wi] = epoch;
+                    nlist[atomicAdd(&Q.nnew, 1u)] = wi;
+                }
+            }
+            __syncthreads();
+            const int nd = Q.ndone;
+            if (nd > 128) { // more tiles than the list of swept ones holds: rescan the level
+                for (int wi = tid; wi < nwords; wi += T)
+                    if (L.impmask[wi] != 0 && L.sp_stamp[wi] != epoch) {
+                        L.sp_stamp[wi] = epoch;
+                        nlist[atomicAdd(&Q.nnew, 1u)] = (uint32_t)wi;
+                    }
+            } else {
+                for (int d = 0; d < nd; ++d) {
+                    const int t = Q.done[d];
+                    const int ox = (t % gx) * VM_PITCH_X + offx, oy = (t / gx) * VM_PITCH_Y + offy;
+                    const MaskGeom g = mask_geom(L, ox, oy);
+                    if (tid < g.nbx * g.nby) {
+                        const int mx = tid % g.nbx, my = tid / g.nbx;
+                        if (mx >= 1 && mx <= g.nbx - 2 && my >= 1 && my <= g.nby - 2) { // words the tile owns
+                            const int wi = (g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1);
+                            if (L.impmask[wi] != 0 && L.sp_stamp[wi] != epoch) {
+                                L.sp_stamp[wi] = epoch;
+                                nlist[atomicAdd(&Q.nnew, 1u)] = (uint32_t)wi;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            nw = Q.nnew;
+            cur ^= 1;
+            __syncthreads(); // Q.nnew is reset at the top of the next pass
+        }
+        if (tid == 0) { // one writer per pair and iteration; the host zeroed the arrays
+            flags[it] = improving ? 1u : 0u;
+            stats[it * VM_STAT_WORDS + 0] = st_tiles;
+            stats[it * VM_STAT_WORDS + 1] = st_cand;
+            stats[it * VM_STAT_WORDS + 2] = st_commit;
+            stats[it * VM_STAT_WORDS + 4] = S.n_eval;
+        }
+        if (!fixed_work && !improving)
+            break; // reference semantics: the level stops here (the following flags stay 0)
+        __syncthreads();
     }
 }
 
@@ -1994,6 +2161,25 @@ void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int 
     (void)dense;
     hipLaunchKernelGGL(SUF(k_optimize)<true>, g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats, iter_idx,
                        fixed_work, iter_dev);
+}
+
+// a batch of `nit` iterations of the SPARSE schedule: list scan + one workgroup per pair
+void SUF(vm_launch_optimize_sparse)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
+                                    const uint32_t *tables, uint32_t *flags, uint32_t *stats, int it0, int nit,
+                                    int fixed_work, int threads, int dense, hipStream_t s)
+{
+    const int nwords = ((w + 4) / 5 + 2) * ((h + 4) / 5 + 2);
+    hipLaunchKernelGGL(SUF(k_sparse_scan), dim3((nwords + 255) / 256, 1, nbatch), dim3(256), 0, s, views);
+#if !VM_EXACT
+    if (!dense) {
+        hipLaunchKernelGGL(SUF(k_sparse)<false>, dim3(1, 1, nbatch), dim3(threads), 0, s, views, cap, P, tables, flags,
+                           stats, it0, nit, fixed_work);
+        return;
+    }
+#endif
+    (void)dense;
+    hipLaunchKernelGGL(SUF(k_sparse)<true>, dim3(1, 1, nbatch), dim3(threads), 0, s, views, cap, P, tables, flags, stats,
+                       it0, nit, fixed_work);
 }
 
 // the device iteration counter of graph-replayed sweeps: set it to, or advance it by, `value`

@@ -356,7 +356,7 @@ extern "C" int vm_video_optimize_level(vm_video *v, int lvl, float max_iter, vol
                 if (i > 0) { // time and launches belong to the batch: count them once
                     out[idx[i]].elapsed_ms = 0;
                     out[idx[i]].launches = 0;
-                    for (int q = 0; q < 3; ++q) { out[idx[i]].sched_ms[q] = 0; out[idx[i]].sched_launches[q] = 0; }
+                    for (int q = 0; q < 4; ++q) { out[idx[i]].sched_ms[q] = 0; out[idx[i]].sched_launches[q] = 0; }
                 }
             }
     }
