@@ -221,9 +221,11 @@ def test_full_solve_exact_256(gpu_ctx, oracle):
     assert np.sqrt(((b - d) ** 2).sum(-1).mean()) < np.sqrt((d ** 2).sum(-1).mean())
 
 
-def test_fast_mode_tolerance(gpu_ctx, oracle):
+@pytest.mark.parametrize("sched", [capi.SWEEP_AUTO, capi.SWEEP_SPARSE])
+def test_fast_mode_tolerance(gpu_ctx, oracle, sched):
     """FAST arithmetic (fused multiply-add, v_rcp/v_sqrt, lane fan-out) against the
-    oracle, tolerances stated in pixels of the level:
+    oracle -- under the automatic schedule and under TILE + SPARSE -- tolerances stated in pixels
+    of the level:
       - after 1 sweep: |dv| <= eps (0.01 px, the line-search resolution) on >= 99 % of
         the pixels and <= 0.02 px everywhere;
       - after 61 sweeps: RMS dv <= 0.02 px, >= 99 % of pixels within 0.05 px, none
@@ -232,6 +234,7 @@ def test_fast_mode_tolerance(gpu_ctx, oracle):
     compared mid-descent here, where it still falls by 1 % per sweep.)"""
     w, h = 160, 120
     gpu_ctx.set_math_mode(capi.MATH_FAST)
+    gpu_ctx.set_tuning(sched, 0, 0)
     lo, pyr, P = _make_level(gpu_ctx, oracle, w, h)
     lo.optimize_iter(P)
     capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 1.0, None, 0, None))
@@ -247,6 +250,7 @@ def test_fast_mode_tolerance(gpu_ctx, oracle):
     eo = (1 - lo.field("value")).sum()
     eg = (1 - pyr[1].field("value")).sum()
     assert abs(eo - eg) <= 0.02 * eo, (eo, eg)
+    gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
     gpu_ctx.set_math_mode(capi.MATH_EXACT)
 
 
@@ -302,7 +306,7 @@ def test_batched_solve_equals_individual_solves(gpu_ctx):
     assert len({tuple(i) for i in iters}) > 1, iters
 
 
-@pytest.mark.parametrize("sched", [capi.SWEEP_STEP, capi.SWEEP_TILE])
+@pytest.mark.parametrize("sched", [capi.SWEEP_STEP, capi.SWEEP_TILE, capi.SWEEP_SPARSE])
 def test_fast_batched_solve_equals_individual_solves(gpu_ctx, sched):
     """FAST, a fixed schedule: the batch dimension (grid.z = pair; STEP: per-pair ping-pong copies
     and record sets, TILE: graph replays with the device iteration counter) changes no bit"""

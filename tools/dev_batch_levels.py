@@ -12,7 +12,7 @@ ctx.set_tuning(sched, 0, 0)
 w, h = 1920, 1080
 pyrs = []
 for k in range(nb):
-    i0, i1 = synth.make_pair(w, h, frame=k)
+    i0, i1 = synth.make_pair(w, h, frame=k % 4)
     p = morph.Pyramid(ctx); p.build(i0, i1, 32); pyrs.append(p)
 L = pyrs[0]._L
 nl = pyrs[0].size() - 1
