@@ -90,6 +90,19 @@ static void build_tables(uint32_t *tab)
 // ---------------------------------------------------------------------------
 static void ctx_free(vm_ctx *c);
 
+// Live contexts.  Destroying a pyramid, video or frame after its context is a caller error; a
+// garbage-collected host language can produce that order.  The destroy functions check here and
+// then only release the host-side object (the device memory went with the context's process
+// state): a no-op instead of a use-after-free.
+#include <set>
+static std::mutex g_live_mu;
+static std::set<const vm_ctx *> g_live;
+bool vm_ctx_alive(const vm_ctx *c)
+{
+    std::lock_guard<std::mutex> lock(g_live_mu);
+    return g_live.count(c) != 0;
+}
+
 extern "C" int vm_ctx_create(int device, vm_ctx **out)
 {
     if (!out) return vm_fail(VM_E_INVALID, "vm_ctx_create: out is NULL");
@@ -123,6 +136,10 @@ extern "C" int vm_ctx_create(int device, vm_ctx **out)
         ctx_free(c);
         return vm_fail(VM_E_DEVICE, "vm_ctx_create: %s", hipGetErrorString(e2));
     }
+    {
+        std::lock_guard<std::mutex> lock(g_live_mu);
+        g_live.insert(c);
+    }
     *out = c;
     return VM_OK;
 }
@@ -148,7 +165,11 @@ static void ctx_free(vm_ctx *c)
 
 extern "C" void vm_ctx_destroy(vm_ctx *c)
 {
-    if (!c) return;
+    if (!c || !vm_ctx_alive(c)) return;
+    {
+        std::lock_guard<std::mutex> lock(g_live_mu);
+        g_live.erase(c);
+    }
     VM_ON_DEVICE(c);
     ctx_free(c);
 }
@@ -363,6 +384,10 @@ extern "C" int vm_pyramid_create(vm_ctx *c, int nlevels, const int *w, const int
 extern "C" void vm_pyramid_destroy(vm_pyr *p)
 {
     if (!p) return;
+    if (!vm_ctx_alive(p->ctx)) { // destroyed after its context: nothing of the device is touched
+        delete p;
+        return;
+    }
     VM_ON_DEVICE(p->ctx);
     hipStreamSynchronize(p->ctx->stream);
     for (auto &l : p->lv) vm_level_free(l);

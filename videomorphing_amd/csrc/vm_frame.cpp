@@ -36,6 +36,10 @@ extern "C" int vm_frame_create(vm_ctx *c, int w, int h, int ex, vm_frame **out)
 extern "C" void vm_frame_destroy(vm_frame *f)
 {
     if (!f) return;
+    if (!vm_ctx_alive(f->ctx)) { // destroyed after its context (vm_api.cpp)
+        delete f;
+        return;
+    }
     VM_ON_DEVICE(f->ctx);
     hipStreamSynchronize(f->ctx->stream);
     hipFree(f->ext[0]); hipFree(f->ext[1]);

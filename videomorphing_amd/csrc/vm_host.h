@@ -7,6 +7,8 @@
 #include <vector>
 
 int vm_fail(int code, const char *fmt, ...);
+struct vm_ctx;
+bool vm_ctx_alive(const vm_ctx *c); // vm_api.cpp: is this context still alive?
 
 #define VM_HIP(call)                                                                       \
     do {                                                                                   \

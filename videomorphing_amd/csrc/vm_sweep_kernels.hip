@@ -633,8 +633,10 @@ __device__ __forceinline__ int med3i(int x, int lo, int hi)
 
 // tex2D(linear, clamp) of both images at p -+ (vx, vy) (the arithmetic of tap(), the four
 // products summed in quad order)
-__device__ __forceinline__ void taps32(const VmLevelView &L, const TapLane &t, const PixelCtx &c, float vx, float vy,
-                                       float &lx, float &ly)
+// ... in two halves, so that the texel loads of independent evaluations (the four of the
+// gradient) can be in flight together: the lane's texel and its corner weight,
+__device__ __forceinline__ void taps32_issue(const VmLevelView &L, const TapLane &t, const PixelCtx &c, float vx,
+                                             float vy, float &texel, float &wgt)
 {
     const float xb = fmaf(t.sgn, vx, (float)c.px), yb = fmaf(t.sgn, vy, (float)c.py);
     float fi = floorf(xb), fj = floorf(yb);
@@ -642,13 +644,25 @@ __device__ __forceinline__ void taps32(const VmLevelView &L, const TapLane &t, c
     fi = __builtin_amdgcn_fmed3f(fi, -1.0f, (float)L.w);
     fj = __builtin_amdgcn_fmed3f(fj, -1.0f, (float)L.h);
     const int i = med3i((int)fi + t.cx, 0, L.w - 1), j = med3i((int)fj + t.cy, 0, L.h - 1);
-    const float texel = L.img0[t.imgoff + j * L.rs + i];
-    float r = texel * (fmaf(t.wxs, a, t.wxo) * fmaf(t.wys, b, t.wyo));
+    texel = L.img0[t.imgoff + j * L.rs + i];
+    wgt = fmaf(t.wxs, a, t.wxo) * fmaf(t.wys, b, t.wyo);
+}
+// ... then the quad sums and the exchange between the two images' quads
+__device__ __forceinline__ void taps32_finish(const TapLane &t, float texel, float wgt, float &lx, float &ly)
+{
+    float r = texel * wgt;
     r += dpp_xor1(r);
     r += dpp_xor2(r);
     const float o = dpp_half_mirror(r);
     lx = t.odd ? o : r;
     ly = t.odd ? r : o;
+}
+__device__ __forceinline__ void taps32(const VmLevelView &L, const TapLane &t, const PixelCtx &c, float vx, float vy,
+                                       float &lx, float &ly)
+{
+    float texel, wgt;
+    taps32_issue(L, t, c, vx, vy, texel, wgt);
+    taps32_finish(t, texel, wgt, lx, ly);
 }
 
 // sum over the window of (stored SSIM value - value with the pixel's lumas replaced by
@@ -721,11 +735,21 @@ __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &
     const TapLane tl = tap_lane_make(L, sub);
     float lx, ly;
     float gx = 0, gy = 0;
-#pragma unroll 1
+    // compute_gradient (morph.cu:763-778): the four evaluations do not depend on each other --
+    // their texel loads are issued together (one memory latency instead of four), the rest
+    // follows in the order of the reference
+    float g_tex[4], g_wgt[4];
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float sgn = (k & 1) ? -1.0f : 1.0f;
         const float dx = k < 2 ? sgn * P.eps : 0.0f, dy = k < 2 ? 0.0f : sgn * P.eps;
-        taps32(L, tl, c, c.v.x + dx, c.v.y + dy, lx, ly);
+        taps32_issue(L, tl, c, c.v.x + dx, c.v.y + dy, g_tex[k], g_wgt[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float sgn = (k & 1) ? -1.0f : 1.0f;
+        const float dx = k < 2 ? sgn * P.eps : 0.0f, dy = k < 2 ? 0.0f : sgn * P.eps;
+        taps32_finish(tl, g_tex[k], g_wgt[k], lx, ly);
         const float change = change32<INTERIOR>(P, nb, c, lx, ly);
         const float dd = dx * dx + dy * dy;
         const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
@@ -1827,7 +1851,7 @@ __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__
 }
 
 template <int T>
-__global__ __launch_bounds__(T) void SUF(k_step)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) void SUF(k_step)(const VmLevelView *__restrict__ views, int cap, VmKParams P,
                                                    const uint32_t *__restrict__ tables, int offx, int offy, int pi,
                                                    int pj, int parts, uint32_t epoch, uint32_t pe, int srcbuf,
                                                    int n_fold, uint32_t *__restrict__ flags,

@@ -97,6 +97,10 @@ extern "C" int vm_video_create(vm_ctx *c, int nlevels, const int *w, const int *
 extern "C" void vm_video_destroy(vm_video *v)
 {
     if (!v) return;
+    if (!vm_ctx_alive(v->ctx)) { // destroyed after its context (vm_api.cpp)
+        delete v;
+        return;
+    }
     VM_ON_DEVICE(v->ctx);
     hipStreamSynchronize(v->ctx->stream);
     for (auto &lv : v->pages)

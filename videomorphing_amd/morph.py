@@ -13,6 +13,7 @@ Scope: one frame pair per Pyramid (depth 1, the independent-pair formulation).
 import ctypes as C
 import threading
 import time
+import weakref
 
 import numpy as np
 
@@ -135,7 +136,10 @@ class PyramidLevel(object):
     """struct PyramidLevel, Pyramid.h:52-98 (geometry + device-state access)."""
 
     def __init__(self, pyr, el, w, h):
-        self._pyr, self._el = pyr, el
+        # a weak back-reference: no Pyramid <-> PyramidLevel cycle, so a pyramid is released by
+        # reference counting the moment its last user lets go -- before its Context, which it
+        # keeps alive -- and never by the cycle collector in an arbitrary order
+        self._pyr, self._el = weakref.proxy(pyr), el
         self.width, self.height, self.depth = int(w), int(h), 1
         self.rowstride = (self.width + 31) // 32 * 32         # pyramid.cu:535
         self.pagestride = self.rowstride * self.height
@@ -520,7 +524,7 @@ class VideoPage(object):
     """One page of a PyramidLevel of depth > 1 (device-state access)."""
 
     def __init__(self, vid, lvl, page, w, h):
-        self._vid, self._lvl, self._page = vid, lvl, page
+        self._vid, self._lvl, self._page = weakref.proxy(vid), lvl, page   # no cycle (see PyramidLevel)
         self.width, self.height = int(w), int(h)
 
     def field(self, name):
