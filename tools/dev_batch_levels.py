@@ -8,7 +8,8 @@ nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 sched = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ctx = morph.Context(0, capi.MATH_FAST)
 ctx.set_params(morph.KernParameters(morph.Parameters()))
-ctx.set_tuning(sched, 0, 0)
+parts = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+ctx.set_tuning(sched, 0, parts)
 w, h = 1920, 1080
 pyrs = []
 for k in range(nb):
@@ -22,7 +23,7 @@ for rep in range(2):
     ctx.sync(); t = time.perf_counter()
     capi.check(L.vm_solve_batch(arr, nb, 500.0, 1.0, None, 1, prog))
     ctx.sync(); dt = time.perf_counter() - t
-print("batch %d sched %d: %.1f ms per batch, %.1f ms per pair" % (nb, sched, dt * 1e3, dt * 1e3 / nb))
+print("batch %d sched %d parts %d: %.1f ms per batch, %.1f ms per pair" % (nb, sched, parts, dt * 1e3, dt * 1e3 / nb))
 for el in range(nl - 2, -1, -1):
     pr = prog[el]
     print("  level %4dx%-4d  %8.1f ms  launches %6d  cand/iter/pair %8.0f" % (pyrs[0][el + 1].width, pyrs[0][el + 1].height, pr.elapsed_ms, pr.launches, pr.candidates / pr.iters))

@@ -750,7 +750,10 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     const int tiles_per_pass = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
     // SPLIT / STEP schedules: workgroups per tile (every candidate gets 32 lanes, 16 candidates
     // per 512-thread workgroup)
-    const int parts = c->sweep_parts ? c->sweep_parts : 16;
+    // (16 workgroups of 16 candidates per tile while the chip has room for them; 8 of 32 when a
+    // phase-step of the batch would otherwise need more than two full waves of workgroups --
+    // measured on 8 x 120x68: 232 -> 217 ms per level; 4 x 64 is slower again)
+    const int parts = c->sweep_parts ? c->sweep_parts : (tiles_per_pass * n * 16 >= 1024 ? 8 : 16);
     // Schedule, re-decided per batch of iterations (AUTO).  TILE: 4 launches per iteration, a
     // tile's four phases inside one workgroup -- unbeatable when a pass touches nothing (24 us
     // per converged iteration) or when there are enough tiles to fill the chip.  STEP (SPLIT
