@@ -460,6 +460,37 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
                 "ms_per_batch": round(dt * 1e3, 1)}
             del group
         extras["batched_throughput_fixed_work"] = bt
+    # the temporally coupled path: a 5-frame 1080p video pair with analytic
+    # flows, every frame tied to its solved neighbour (middle page, then both chains, two pages
+    # per launch); the device-side flow pyramid included, lumas uploaded per page
+    try:
+        d = 5
+        levels, ft = synth.video_levels(w, h, d, blk.start_res)
+        vid = morph.VideoPyramid(ctx)
+        vid.build_levels(levels, ft, d)
+        pages = synth.page_frames(levels, ft)
+        vf = [synth.make_video_pair(w, h, t) for t in range(d)]
+        vp = [synth.build_pyramid(a, b2, len(levels)) for a, b2 in vf]
+        for l in range(len(levels) - 1):
+            for t in range(levels[l][2]):
+                vid.upload_luma(l, t, *vp[pages[l][t]][l])
+        ctx.sync(); t1 = time.perf_counter()
+        vid.build_flows(*synth.constant_flows(w, h, d))
+        ctx.sync(); t_flow = time.perf_counter() - t1
+        prm = morph.Parameters()
+        prm.max_iter, prm.max_iter_drop_factor, prm.start_res = int(blk.max_iter), blk.max_iter_drop_factor, blk.start_res
+        vm = morph.VideoMorph(prm, vid, fixed_work=bool(FIXED))
+        vm.calculate_halfway_parametrization()          # warm-up (workspaces)
+        ctx.sync(); t1 = time.perf_counter()
+        vm.calculate_halfway_parametrization()
+        ctx.sync(); dt = time.perf_counter() - t1
+        units = sum(l[0] * l[1] * pr["iters"] for (lv, t), pr in vm.progress.items() for l in [levels[lv]])
+        extras["temporal_video_%d_frames" % d] = {"mpix_iters_per_s": round(units / dt / 1e6, 1), "ms_per_video": round(dt * 1e3, 1),
+                                                  "flow_pyramid_ms": round(t_flow * 1e3, 1),
+                                                  "depth_per_level": [l[2] for l in levels]}
+        del vid
+    except capi.VmError as e:
+        extras["temporal_video_5_frames"] = {"error": str(e)[-160:]}
     # compositor: frames/s of render_halfway with device-resident inputs
     ex = int(0.1 * max(w, h))
     rgb0, rgb1 = synth.make_rgb_pair(w, h)

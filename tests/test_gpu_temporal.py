@@ -253,3 +253,47 @@ def test_device_video_luma_pyramid_pages(gpu_ctx, oracle):
         want1 = oracle.luma_pyramid(rgbs[f][1], l + 1)[l]
         assert np.abs(dev.pages[l][t].field("img0") - want0).max() < 2e-2
         assert np.abs(dev.pages[l][t].field("img1") - want1).max() < 2e-2
+
+
+def test_temporal_video_at_1080p(gpu_ctx):
+    """full size, FAST: a 3-frame 1080p video pair (6 levels) with the synthetic videos' analytic
+    flows (video 1 moves faster than video 0, so the halfway field changes from frame to frame),
+    12 sweeps per level.  Checked through properties: every page of every level was swept; the
+    outer pages carry a temporal reference covering (nearly) the whole frame, and that reference
+    is the middle page's solution moved along the flows; the window sums of a tied page still
+    equal their definition after all its commits; the coupled pages stay closer to their
+    neighbour than pages solved without the term"""
+    import test_gpu_fullsize as F
+    w, h, d = 1920, 1080, 3
+    s0, s1 = (0.5, 0.25), (1.5, -0.25)
+    frames = [synth.make_video_pair(w, h, t, s0, s1) for t in range(d)]
+    f0, f1, b0, b1 = synth.constant_flows(w, h, d, s0, s1)
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    res = {}
+    try:
+        for wt in (10.0, 0.0):
+            prm = morph.Parameters()
+            prm.max_iter, prm.max_iter_drop_factor, prm.start_res, prm.w_temp = 12, 1.0, 32, wt
+            vid = morph.VideoPyramid(gpu_ctx)
+            vid.build(frames and [f[0] for f in frames], [f[1] for f in frames], f0, f1, b0, b1, 32)
+            assert [l[2] for l in vid.levels] == [3] * 6
+            vm = morph.VideoMorph(prm, vid)
+            vm.calculate_halfway_parametrization()
+            assert all(vm.progress[(l, t)]["iters"] >= 1 for l in range(5) for t in range(3))
+            res[wt] = [vid.pages[0][t].v for t in range(d)]
+            if wt > 0:
+                mask, ref = vid.pages[0][2].field("temp_mask"), vid.pages[0][2].field("temp_ref")
+                assert (mask > 0).mean() > 0.99
+                # page 2's reference = page 1's v advected by the mean flow (1, 0) and changed by
+                # (f1 - f0) / 2 = (0.5, -0.25): compare away from the border
+                v1 = res[wt][1]
+                want = v1[8:-8, 7:-9] + np.float32([0.5, -0.25])
+                assert np.abs(ref[8:-8, 8:-8] - want).max() < 1e-3
+                F._window_sum_invariants(vid.pages[0][2], frames[2][0], frames[2][1])
+            del vid
+    finally:
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    # the true field changes by (0.5, -0.25) per frame; with the term the pages follow their
+    # advected neighbour more closely than when every frame is solved on its own
+    dev = lambda r: np.abs((r[2][8:-8, 8:-8] - np.float32([0.5, -0.25])) - r[1][8:-8, 7:-9]).mean()
+    assert dev(res[10.0]) < dev(res[0.0]), (dev(res[10.0]), dev(res[0.0]))
