@@ -301,6 +301,67 @@ int  vm_frame_quadratic_path(vm_frame *f, float tol, int max_it,
 /* the frame's quadratic path (Pyramid::_qpath, Pyramid.h:42), tight (h, w, 2) floats */
 int  vm_frame_download_qpath(vm_frame *f, float *u_xy);
 
+/* ---- synchronisation stage ("(later)" row) ------------------ */
+/* Before the morph the reference's app aligns the two videos in time: the user
+ * ties points of video 0 to points of video 1 -- possibly on DIFFERENT frames --
+ * and CSyncThread (Algorithm/SyncThread.h:7-39, SyncThread.cpp) solves for a smooth
+ * field (x, y, frame displacement) per voxel of a decimated (x, y, t) pyramid:
+ * per level three conjugate-gradient solves of one thin-plate + constraint system
+ * (optimize_level, SyncThread.cpp:290-480), level to level by Kernel_upsample
+ * (upsample.cu:343-375).  render_resample_image (render.cu:99-246) then re-times
+ * both videos with the field and the forward optical flows.  vm_sync is
+ * CSyncThread's state plus the four layered arrays Pyramid::build(video0, video1,
+ * f0, f1, start_res) keeps for that renderer (pyramid.cu:57-141). */
+typedef struct vm_sync vm_sync;
+/* a Connect between Conp lp[li] and rp[ri] (parameters.h:16-26): full-resolution
+ * pixel and frame on either side, integers as in the reference */
+typedef struct {
+    int lx, ly, lz, rx, ry, rz;
+} vm_sync_constraint;
+typedef struct {
+    int    iters;          /* passes of the CG loop: floor(max_iter) + 1 (`k <= _max_iter`)  */
+    int    launches;
+    double voxel_iters;    /* iters * W * H * D  (_current_iter += N, SyncThread.cpp:463)   */
+    float  elapsed_ms;     /* HIP-event time of the level                                   */
+    float  resid[3];       /* r . r of the x, y, z systems when the loop ended              */
+} vm_sync_progress;
+/* level geometry of Pyramid::build(video0, video1, f0, f1, start_res), pyramid.cu:143-163:
+ * entry 0 is the full-resolution placeholder, entries 1.. are solved (finest first);
+ * writes at most `cap` entries, *n_out = the number of levels */
+int  vm_sync_level_table(int w, int h, int d, int start_res, int *lw, int *lh, int *ld, int cap, int *n_out);
+/* nlevels entries (placeholder included), uses the context's w_ui / w_tps (vm_set_params) */
+int  vm_sync_create(vm_ctx *ctx, int nlevels, const int *w, const int *h, const int *d, vm_sync **out);
+void vm_sync_destroy(vm_sync *s);
+int  vm_sync_set_constraints(vm_sync *s, const vm_sync_constraint *c, int n);
+/* CSyncThread::load_identity / upsample_level (SyncThread.cpp:86-128): allocate level lvl's
+ * field, zero or upsampled from lvl + 1 (which is released, as there) */
+int  vm_sync_load_identity(vm_sync *s, int lvl);
+int  vm_sync_upsample_level(vm_sync *s, int lvl);
+/* CSyncThread::optimize_level(el): the loop runs while k <= max_iter and *run_flag (polled every
+ * 64 iterations; NULL = never cancelled) */
+int  vm_sync_optimize_level(vm_sync *s, int lvl, float max_iter, volatile const int *run_flag,
+                            vm_sync_progress *out);
+/* CSyncThread::run (SyncThread.cpp:58-84): all levels, coarsest first, max_iter * 10 halved per
+ * level; out (optional) has nlevels - 1 entries, [lvl - 1] for level lvl */
+int  vm_sync_solve(vm_sync *s, float max_iter, volatile const int *run_flag, vm_sync_progress *out);
+/* d_x[lvl], d_y[lvl], d_z[lvl]: tight (d, h, w) float arrays (any may be NULL) */
+int  vm_sync_get_field(vm_sync *s, int lvl, float *x, float *y, float *z);
+int  vm_sync_set_field(vm_sync *s, int lvl, const float *x, const float *y, const float *z);
+/* CSyncThread::update_result (SyncThread.cpp:482-521) for one frame: Pyramid::_vector[frame],
+ * (h0, w0) float4 = (X ratio_x, Y ratio_y, Z, 0) resized to full resolution; vec4 may be NULL
+ * (the frame's field is then only refreshed on the device, where vm_sync_render reads it) */
+int  vm_sync_result(vm_sync *s, int lvl, int frame, float *vec4);
+/* the layered arrays of Pyramid::build (pyramid.cu:93-141): frame `frame` of video `side`
+ * (RGBA8, alpha ignored) and of its forward flow (float2) */
+int  vm_sync_upload_frame(vm_sync *s, int side, int frame, const uint8_t *rgba, int pitch_bytes);
+int  vm_sync_upload_flow(vm_sync *s, int side, int frame, const float *flow_xy, int pitch_floats);
+/* render_resample_image(out, ..., fa, frame, ...) (render.cu:203-246; caller RenderWidget::
+ * RenderStage1, UI/RenderWidget.cpp:205-227) with the field vm_sync_result last produced for
+ * this frame (produced from level 1 if none was); rgb_out: h0 rows of pitch_bytes, RGB8 */
+int  vm_sync_render(vm_sync *s, float fa, int frame, uint8_t *rgb_out, int pitch_bytes);
+/* the same, result left on the device (timing without the download) */
+int  vm_sync_render_dev(vm_sync *s, float fa, int frame, float *elapsed_ms);
+
 /* ---- multi-GPU ----------------------------------------------------------- */
 /* The shared parameter block every rank needs (KernParameters + iteration
  * control + constraints), flattened so that any transport -- the RCCL

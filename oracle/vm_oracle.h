@@ -208,4 +208,24 @@ int  vmo_get_threads(void);
 int vmo_quadratic_path(const float *v, int cols, int rows, double tol, int max_it, float *u_out,
                        float *jopt_out, double *rel_res);
 
+
+/* ---- synchronisation stage (vm_oracle_sync.c; SURVEY 8(f) "(later)" row) ------------------- */
+int   vmo_sync_levels(int w, int h, int d, int start_res, int *lw, int *lh, int *ld, int cap); /* pyramid.cu:143-163 */
+void  vmo_sync_row(int x, int y, int z, int w, int h, int d, float w_tps, float ui, float *data125); /* SyncThread.cpp:190-262 */
+extern const int vmo_sync_taps[25][3];
+int   vmo_sync_state(int p, int n);
+void  vmo_sync_table(int w, int h, int d, float w_tps, float *tab125x25);
+void  vmo_sync_ui(int w, int h, int d, int w0, int h0, const int *cons6, int n, float w_ui,
+                  float *diag, float *bx, float *by, float *bz);                              /* SyncThread.cpp:155-187 */
+void  vmo_sync_diag(int w, int h, int d, float w_tps, const float *ui, float *diag);
+float vmo_sync_dot(const float *a, const float *b, int w, int h, int d);
+void  vmo_sync_apply(int w, int h, int d, float w_tps, const float *ui, const float *p, float *out);
+int   vmo_sync_solve_level(int w, int h, int d, int w0, int h0, const int *cons6, int ncons,
+                           float w_ui, float w_tps, float max_iter, float *x, float *y, float *z,
+                           float *resid3);                                                     /* SyncThread.cpp:290-480 */
+void  vmo_sync_upsample(float *dst, int dw, int dh, const float *src, int sw, int sh, float ratio); /* upsample.cu:343-375 */
+void  vmo_sync_result(const float *X, const float *Y, const float *Z, int w, int h, int w0, int h0, float *out4); /* SyncThread.cpp:482-521 */
+void  vmo_render_resample(uint8_t *out, int w, int h, int d, float fa, int frame, const float *vec,
+                          const uint8_t *video0, const uint8_t *video1, const float *forw0, const float *forw1); /* render.cu:99-246 */
+
 #endif

@@ -137,6 +137,30 @@ def lib():
     L.vmo_set_threads.argtypes = [C.c_int]
     L.vmo_set_threads.restype = None
     L.vmo_get_threads.restype = C.c_int
+    L.vmo_sync_levels.argtypes = [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_int]
+    L.vmo_sync_levels.restype = C.c_int
+    L.vmo_sync_row.argtypes = [C.c_int] * 6 + [C.c_float, C.c_float, C.c_void_p]
+    L.vmo_sync_row.restype = None
+    L.vmo_sync_state.argtypes = [C.c_int, C.c_int]
+    L.vmo_sync_state.restype = C.c_int
+    L.vmo_sync_table.argtypes = [C.c_int] * 3 + [C.c_float, C.c_void_p]
+    L.vmo_sync_table.restype = None
+    L.vmo_sync_ui.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
+    L.vmo_sync_ui.restype = None
+    L.vmo_sync_diag.argtypes = [C.c_int] * 3 + [C.c_float, C.c_void_p, C.c_void_p]
+    L.vmo_sync_diag.restype = None
+    L.vmo_sync_dot.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 3
+    L.vmo_sync_dot.restype = C.c_float
+    L.vmo_sync_apply.argtypes = [C.c_int] * 3 + [C.c_float] + [C.c_void_p] * 3
+    L.vmo_sync_apply.restype = None
+    L.vmo_sync_solve_level.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4
+    L.vmo_sync_solve_level.restype = C.c_int
+    L.vmo_sync_upsample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    L.vmo_sync_upsample.restype = None
+    L.vmo_sync_result.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+    L.vmo_sync_result.restype = None
+    L.vmo_render_resample.argtypes = [C.c_void_p] + [C.c_int] * 3 + [C.c_float, C.c_int] + [C.c_void_p] * 5
+    L.vmo_render_resample.restype = None
     L.vmo_set_threads(default_threads())
     _lib = L
     return L
@@ -520,3 +544,111 @@ class Video:
             self.init_level(el, P, cons)
             self.optimize_level(el, P, mi, stats)
             mi /= drop
+
+
+# ---- synchronisation stage (oracle/vm_oracle_sync.c) -------------------------------------------
+
+def sync_levels(w, h, d, start_res):
+    """[(w, h, d)] of Pyramid::build(video0, video1, f0, f1, start_res), level 0 first"""
+    lw, lh, ld = (np.zeros(64, np.int32) for _ in range(3))
+    n = lib().vmo_sync_levels(w, h, d, start_res, lw.ctypes.data, lh.ctypes.data, ld.ctypes.data, 64)
+    return [(int(lw[i]), int(lh[i]), int(ld[i])) for i in range(n)]
+
+
+def sync_row(x, y, z, w, h, d, w_tps, ui=0.0):
+    out = np.zeros((5, 5, 5), np.float32)
+    lib().vmo_sync_row(x, y, z, w, h, d, w_tps, ui, out.ctypes.data)
+    return out
+
+
+def sync_cons(cons):
+    """[(lx, ly, lz, rx, ry, rz)] integer full-resolution positions / frames -> int32 array"""
+    return np.ascontiguousarray(np.asarray(cons, np.int32).reshape(-1, 6))
+
+
+def sync_ui(w, h, d, w0, h0, cons, w_ui):
+    c = sync_cons(cons)
+    out = [np.zeros((d, h, w), np.float32) for _ in range(4)]
+    lib().vmo_sync_ui(w, h, d, w0, h0, c.ctypes.data, len(c), w_ui, *[o.ctypes.data for o in out])
+    return out
+
+
+def sync_diag(ui, w_tps):
+    d, h, w = ui.shape
+    out = np.zeros_like(ui)
+    lib().vmo_sync_diag(w, h, d, w_tps, np.ascontiguousarray(ui).ctypes.data, out.ctypes.data)
+    return out
+
+
+def sync_dot(a, b):
+    d, h, w = a.shape
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return float(lib().vmo_sync_dot(a.ctypes.data, b.ctypes.data, w, h, d))
+
+
+def sync_apply(ui, w_tps, p):
+    d, h, w = p.shape
+    out = np.zeros_like(p, dtype=np.float32)
+    ui = np.ascontiguousarray(ui, np.float32); p = np.ascontiguousarray(p, np.float32)
+    lib().vmo_sync_apply(w, h, d, w_tps, ui.ctypes.data, p.ctypes.data, out.ctypes.data)
+    return out
+
+
+def sync_solve_level(x, y, z, w0, h0, cons, w_ui, w_tps, max_iter):
+    """in place on x, y, z (d, h, w float32); returns (loop iterations, residual norms^2)"""
+    d, h, w = x.shape
+    c = sync_cons(cons)
+    res = np.zeros(3, np.float32)
+    k = lib().vmo_sync_solve_level(w, h, d, w0, h0, c.ctypes.data, len(c), w_ui, w_tps, max_iter,
+                                   x.ctypes.data, y.ctypes.data, z.ctypes.data, res.ctypes.data)
+    return k, res
+
+
+def sync_upsample(src, dw, dh, ratio):
+    sh, sw = src.shape
+    src = np.ascontiguousarray(src, np.float32)
+    out = np.zeros((dh, dw), np.float32)
+    lib().vmo_sync_upsample(out.ctypes.data, dw, dh, src.ctypes.data, sw, sh, ratio)
+    return out
+
+
+def sync_solve(levels, cons, w_ui, w_tps, max_iter):
+    """CSyncThread::run, SyncThread.cpp:58-84: coarsest level from zero, then upsample + solve,
+    max_iter * 10 halved per level.  levels as sync_levels() gives them.  Returns (X, Y, Z) of
+    level 1."""
+    w0, h0, _ = levels[0]
+    mi = np.float32(max_iter * 10)
+    prev = None
+    for el in range(len(levels) - 1, 0, -1):
+        w, h, d = levels[el]
+        cur = [np.zeros((d, h, w), np.float32) for _ in range(3)]
+        if prev is not None:
+            pw, ph = levels[el + 1][0], levels[el + 1][1]
+            ratios = (np.float32(w) / np.float32(pw), np.float32(h) / np.float32(ph), np.float32(1.0))
+            for c in range(3):
+                for i in range(d):
+                    cur[c][i] = sync_upsample(prev[c][i], w, h, float(ratios[c]))
+        sync_solve_level(cur[0], cur[1], cur[2], w0, h0, cons, w_ui, w_tps, float(mi))
+        prev = cur
+        mi = np.float32(mi / np.float32(2))
+    return prev
+
+
+def sync_result(X, Y, Z, w0, h0):
+    """one frame: (h, w) x 3 -> (h0, w0, 4)"""
+    h, w = X.shape
+    out = np.zeros((h0, w0, 4), np.float32)
+    a = [np.ascontiguousarray(t, np.float32) for t in (X, Y, Z)]
+    lib().vmo_sync_result(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, w, h, w0, h0, out.ctypes.data)
+    return out
+
+
+def render_resample(vec, video0, video1, forw0, forw1, fa, frame):
+    """vec (h, w, 4) f32; video* (d, h, w, 4) u8; forw* (d, h, w, 2) f32 -> (h, w, 3) u8"""
+    d, h, w = video0.shape[:3]
+    out = np.zeros((h, w, 3), np.uint8)
+    a = [np.ascontiguousarray(vec, np.float32), np.ascontiguousarray(video0, np.uint8),
+         np.ascontiguousarray(video1, np.uint8), np.ascontiguousarray(forw0, np.float32),
+         np.ascontiguousarray(forw1, np.float32)]
+    lib().vmo_render_resample(out.ctypes.data, w, h, d, fa, frame, *[t.ctypes.data for t in a])
+    return out

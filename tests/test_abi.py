@@ -32,21 +32,23 @@ def test_header_is_plain_c_and_struct_layouts_match(tmp_path):
     prog = tmp_path / "sz.c"
     prog.write_text('#include <stdio.h>\n#include "vmorph.h"\nint main(void){printf("%zu %zu %zu %zu ",'
                     'sizeof(vm_kern_params),sizeof(vm_constraint),sizeof(vm_progress),sizeof(vm_param_block));'
-                    'printf("%zu\\n",sizeof(vm_video_constraint));return 0;}\n')
+                    'printf("%zu %zu %zu\\n",sizeof(vm_video_constraint),sizeof(vm_sync_constraint),sizeof(vm_sync_progress));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            str(prog), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [C.sizeof(capi.KernParams), C.sizeof(capi.Constraint), C.sizeof(capi.Progress),
-                   C.sizeof(capi.ParamBlock), C.sizeof(capi.VideoConstraint)]
-    assert got == [28, 20, 88, 48, 24]
+                   C.sizeof(capi.ParamBlock), C.sizeof(capi.VideoConstraint), C.sizeof(capi.SyncConstraint),
+                   C.sizeof(capi.SyncProgress)]
+    assert got == [28, 20, 88, 48, 24, 24, 32]
 
 
 def test_header_cites_the_reference_interfaces():
     src = open(HEADER).read()
     for cite in ("morph.cu:150-168", "morph.cu:1353-1391", "morph.cu:264-390", "morph.cu:419-590",
                  "upsample.cu:260-286", "render.cu:62-96", "PoissonExt.cpp:49-362",
-                 "MatchingThread.cpp:22-100", "parameters.h:54-72", "pyramid.cu:525-543"):
+                 "MatchingThread.cpp:22-100", "parameters.h:54-72", "pyramid.cu:525-543",
+                 "SyncThread.cpp:290-480", "render.cu:99-246", "upsample.cu:343-375", "pyramid.cu:143-163"):
         assert cite in src, cite
 
 
@@ -72,6 +74,9 @@ def test_null_handles_are_rejected_not_dereferenced(vmlib):
     assert vmlib.vm_render_halfway(None, 0.5, 0.5, 1, None, 0) == capi.VM_E_INVALID
     assert vmlib.vm_poisson_extend(None, 1, 1e-5, 10, None, None, None) == capi.VM_E_INVALID
     assert vmlib.vm_pyramid_levels(None) == 0
+    assert vmlib.vm_sync_solve(None, 10.0, None, None) == capi.VM_E_INVALID
+    assert vmlib.vm_sync_render(None, 0.5, 0, None, 0) == capi.VM_E_INVALID
+    vmlib.vm_sync_destroy(None)
     vmlib.vm_pyramid_destroy(None)
     vmlib.vm_frame_destroy(None)
     vmlib.vm_ctx_destroy(None)

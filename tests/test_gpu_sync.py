@@ -1,0 +1,261 @@
+"""Synchronisation stage (CSyncThread + render_resample_image) through the C-ABI against the
+oracle: level geometry, the CG solve per level (bit-identical: both sides evaluate every sum in
+one fixed order), level transfer, result delivery and the time-warping renderer."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from videomorphing_amd import capi, morph
+
+
+def test_level_table_equals_the_oracle(vmlib):
+    for (w, h, d, sr) in [(1920, 1080, 60, 16), (256, 128, 10, 32), (64, 64, 4, 64), (640, 360, 30, 16), (3840, 2160, 24, 16),
+                          (127, 99, 5, 4), (100, 100, 1000, 8)]:
+        assert morph.sync_level_table(w, h, d, sr) == oracle.sync_levels(w, h, d, sr), (w, h, d, sr)
+    n = C.c_int(0)
+    a = (C.c_int * 4)()
+    assert vmlib.vm_sync_level_table(0, 10, 10, 8, a, a, a, 4, C.byref(n)) == capi.VM_E_INVALID
+
+
+def _cons(w0, h0, d, n=6, seed=0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        lx, ly = int(rng.integers(2, w0 - 2)), int(rng.integers(2, h0 - 2))
+        lz = int(rng.integers(0, d))
+        out.append((lx, ly, lz, int(np.clip(lx + rng.integers(-6, 7), 0, w0 - 1)), int(np.clip(ly + rng.integers(-6, 7), 0, h0 - 1)),
+                    int(np.clip(lz + rng.integers(-2, 3), 0, d - 1))))
+    return out
+
+
+def _params(w_ui=100.0, w_tps=0.001, max_iter=20):
+    P = morph.Parameters()
+    P.w_ui, P.w_tps, P.max_iter, P.max_iter_drop_factor = w_ui, w_tps, max_iter, 2.0
+    return P
+
+
+def _set_cons(P, cons):
+    P.lp, P.rp, P.cnt = [], [], []
+    for k, c in enumerate(cons):
+        P.lp.append([morph.Conp(c[0], c[1], c[2])])
+        P.rp.append([morph.Conp(c[3], c[4], c[5])])
+        P.cnt.append([morph.Connect((k, 0), (k, 0))])
+
+
+def _level_solve(ctx, levels, lvl, cons, P, max_iter, init=None):
+    pyr = morph.SyncPyramid(ctx)
+    pyr.build_levels(levels)
+    _set_cons(P, cons)
+    th = morph.SyncThread(P, pyr)
+    th._max_iter = float(max_iter)
+    if init is None:
+        th.load_identity(lvl)
+    else:
+        pyr.set_field(lvl, *init)
+    pr = th.optimize_level(lvl)
+    return pyr.field(lvl), pr, pyr
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,iters", [((70, 37, 11), 0), ((70, 37, 11), 60), ((33, 9, 8), 25), ((40, 20, 3), 25),
+                                        ((5, 4, 1), 10), ((64, 16, 16), 40)])
+def test_level_solve_is_bit_identical_to_the_oracle(gpu_ctx, dims, iters):
+    w, h, d = dims
+    w0, h0 = 2 * w, 2 * h
+    cons = _cons(w0, h0, d, seed=w + iters)
+    P = _params()
+    got, pr, _ = _level_solve(gpu_ctx, [(w0, h0, d), (w, h, d)], 1, cons, P, iters)
+    want = [np.zeros((d, h, w), np.float32) for _ in range(3)]
+    k, res = oracle.sync_solve_level(want[0], want[1], want[2], w0, h0, cons, P.w_ui, P.w_tps, float(iters))
+    assert pr.iters == k == iters + 1
+    for c in range(3):
+        assert np.array_equal(_bits(got[c]), _bits(want[c])), (c, np.abs(got[c] - want[c]).max())
+    assert np.array_equal(_bits(np.array(pr.resid[:], np.float32)), _bits(res))
+    assert np.abs(want[0]).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_level_solve_keeps_the_inherited_field_and_inactive_components(gpu_ctx):
+    """the reference starts CG from r = b whatever the field holds (the level ADDS A^-1 b); a
+    component whose right-hand side is zero is never touched"""
+    w, h, d = 48, 30, 9
+    w0, h0 = 96, 60
+    cons = [(c[0], c[1], c[2], c[3], c[4], c[2]) for c in _cons(w0, h0, d, seed=5)]  # same frames: b_z = 0
+    P = _params()
+    rng = np.random.default_rng(7)
+    init = [rng.standard_normal((d, h, w)).astype(np.float32) for _ in range(3)]
+    got, pr, _ = _level_solve(gpu_ctx, [(w0, h0, d), (w, h, d)], 1, cons, P, 30, init=init)
+    want = [a.copy() for a in init]
+    _, res = oracle.sync_solve_level(want[0], want[1], want[2], w0, h0, cons, P.w_ui, P.w_tps, 30.0)
+    for c in range(3):
+        assert np.array_equal(_bits(got[c]), _bits(want[c])), c
+    assert np.array_equal(_bits(got[2]), _bits(init[2])) and res[2] == 0.0 and pr.resid[2] == 0.0
+    # no constraints at all: nothing moves
+    got, pr, _ = _level_solve(gpu_ctx, [(w0, h0, d), (w, h, d)], 1, [], P, 10, init=init)
+    for c in range(3):
+        assert np.array_equal(_bits(got[c]), _bits(init[c]))
+
+
+@pytest.mark.gpu
+def test_whole_solve_is_bit_identical_and_repeatable(gpu_ctx):
+    w0, h0, d = 160, 96, 7
+    levels = morph.sync_level_table(w0, h0, d, 8)
+    assert len(levels) >= 4
+    cons = _cons(w0, h0, d, n=9, seed=3)
+    P = _params(max_iter=6)  # 60 iterations at the coarsest level, halved per level
+    _set_cons(P, cons)
+    fields = []
+    for rep in range(2):
+        pyr = morph.SyncPyramid(gpu_ctx)
+        pyr.build_levels(levels)
+        th = morph.SyncThread(P, pyr)
+        th.start()
+        th.wait()
+        assert th.percentage > 0 and th._current_l == 0
+        fields.append(pyr.field(1))
+        if rep == 0:
+            vec = [v.copy() for v in pyr._vector]
+            iters = {el: th.progress[el]["iters"] for el in th.progress}
+    want = oracle.sync_solve(levels, cons, P.w_ui, P.w_tps, P.max_iter)
+    mi = np.float32(P.max_iter * 10)
+    for el in range(len(levels) - 1, 0, -1):
+        assert iters[el] == int(np.floor(mi)) + 1
+        mi = np.float32(mi / np.float32(2))
+    for c in range(3):
+        assert np.array_equal(_bits(fields[0][c]), _bits(want[c])), c
+        assert np.array_equal(_bits(fields[0][c]), _bits(fields[1][c]))
+    # result delivery of every frame (update_result)
+    for z in range(d):
+        assert np.array_equal(_bits(vec[z]), _bits(oracle.sync_result(want[0][z], want[1][z], want[2][z], w0, h0))), z
+    assert max(np.abs(v[..., :3]).max() for v in vec) > 0.05
+
+
+@pytest.mark.gpu
+def test_solve_through_the_c_entry_point_and_cancellation(gpu_ctx, vmlib):
+    w0, h0, d = 96, 64, 5
+    levels = morph.sync_level_table(w0, h0, d, 8)
+    cons = _cons(w0, h0, d, n=5, seed=11)
+    P = _params(max_iter=4)
+    gpu_ctx.set_params(morph.KernParameters(P))
+    pyr = morph.SyncPyramid(gpu_ctx)
+    pyr.build_levels(levels)
+    arr = (capi.SyncConstraint * len(cons))(*[capi.SyncConstraint(*c) for c in cons])
+    capi.check(vmlib.vm_sync_set_constraints(pyr._h, arr, len(cons)))
+    prog = (capi.SyncProgress * (len(levels) - 1))()
+    capi.check(vmlib.vm_sync_solve(pyr._h, float(P.max_iter), None, prog))
+    want = oracle.sync_solve(levels, cons, P.w_ui, P.w_tps, P.max_iter)
+    got = pyr.field(1)
+    for c in range(3):
+        assert np.array_equal(_bits(got[c]), _bits(want[c]))
+    assert prog[len(levels) - 2].iters == 41 and prog[0].voxel_iters == prog[0].iters * levels[1][0] * levels[1][1] * d
+    # a cleared run flag stops before the first pass
+    flag = C.c_int(0)
+    pyr2 = morph.SyncPyramid(gpu_ctx)
+    pyr2.build_levels(levels)
+    capi.check(vmlib.vm_sync_set_constraints(pyr2._h, arr, len(cons)))
+    capi.check(vmlib.vm_sync_solve(pyr2._h, float(P.max_iter), C.cast(C.pointer(flag), C.c_void_p), prog))
+    assert prog[len(levels) - 2].iters == 0
+    # call order and argument errors
+    assert vmlib.vm_sync_optimize_level(pyr2._h, 1, 5.0, None, None) == capi.VM_E_STATE
+    assert vmlib.vm_sync_optimize_level(pyr2._h, 0, 5.0, None, None) == capi.VM_E_INVALID
+    assert vmlib.vm_sync_optimize_level(pyr2._h, len(levels) - 1, float("nan"), None, None) == capi.VM_E_INVALID
+    assert vmlib.vm_sync_upsample_level(pyr2._h, 1) == capi.VM_E_STATE
+    assert vmlib.vm_sync_render(pyr2._h, 0.5, 0, (C.c_uint8 * (w0 * h0 * 3))(), w0 * 3) == capi.VM_E_STATE
+
+
+@pytest.mark.gpu
+def test_upsample_level_matches_the_oracle(gpu_ctx, vmlib):
+    levels = [(90, 70, 4), (45, 35, 4), (23, 18, 4)]
+    pyr = morph.SyncPyramid(gpu_ctx)
+    pyr.build_levels(levels)
+    rng = np.random.default_rng(13)
+    src = [rng.standard_normal((4, 18, 23)).astype(np.float32) for _ in range(3)]
+    pyr.set_field(2, *src)
+    capi.check(vmlib.vm_sync_upsample_level(pyr._h, 1))
+    got = pyr.field(1)
+    ratios = (float(np.float32(45) / np.float32(23)), float(np.float32(35) / np.float32(18)), 1.0)
+    for c in range(3):
+        for z in range(4):
+            assert np.array_equal(_bits(got[c][z]), _bits(oracle.sync_upsample(src[c][z], 45, 35, ratios[c]))), (c, z)
+    assert vmlib.vm_sync_get_field(pyr._h, 2, None, None, None) == capi.VM_E_STATE  # released, as in the reference
+
+
+def _smooth(shape, seed, amp):
+    rng = np.random.default_rng(seed)
+    coarse = rng.standard_normal((shape[0] // 8 + 2, shape[1] // 8 + 2)).astype(np.float32)
+    yy = np.linspace(0, coarse.shape[0] - 1.001, shape[0])
+    xx = np.linspace(0, coarse.shape[1] - 1.001, shape[1])
+    y0, x0 = yy.astype(int), xx.astype(int)
+    fy, fx = (yy - y0)[:, None], (xx - x0)[None, :]
+    a = coarse[y0][:, x0] * (1 - fy) * (1 - fx) + coarse[y0][:, x0 + 1] * (1 - fy) * fx
+    a = a + coarse[y0 + 1][:, x0] * fy * (1 - fx) + coarse[y0 + 1][:, x0 + 1] * fy * fx
+    return (amp * a).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fa", [0.0, 1.0, 0.5, 0.3])
+def test_render_resample_is_bit_identical(gpu_ctx, fa):
+    w0, h0, d = 80, 48, 6
+    w, h = 40, 24
+    rng = np.random.default_rng(17)
+    video = [rng.integers(0, 256, (d, h0, w0, 4), dtype=np.uint8) for _ in range(2)]
+    flows = [np.stack([np.stack([_smooth((h0, w0), 100 * s + 2 * t, 2.0), _smooth((h0, w0), 100 * s + 2 * t + 1, 2.0)], -1)
+                       for t in range(d)]) for s in range(2)]
+    field = [np.stack([_smooth((h, w), 50 + 10 * c + t, a) for t in range(d)]) for c, a in enumerate((1.5, 1.5, 1.2))]
+    pyr = morph.SyncPyramid(gpu_ctx)
+    pyr.build_levels([(w0, h0, d), (w, h, d), (20, 12, d)])
+    for s in range(2):
+        for t in range(d):
+            pyr.upload_frame(s, t, video[s][t])
+            pyr.upload_flow(s, t, flows[s][t])
+    pyr.set_field(1, *field)
+    for frame in (0, 2, d - 1):
+        vec = oracle.sync_result(field[0][frame], field[1][frame], field[2][frame], w0, h0)
+        assert np.array_equal(_bits(pyr.result(1, frame)), _bits(vec))
+        want = oracle.render_resample(vec, video[0], video[1], flows[0], flows[1], fa, frame)
+        got = pyr.render_resample(fa, frame)
+        assert np.array_equal(got, want), (frame, np.abs(got.astype(int) - want.astype(int)).max())
+    # both branches of the time lookup were exercised: clamped ends and in-between frames
+    assert np.abs(field[2]).max() > 1.0
+
+
+@pytest.mark.gpu
+def test_render_before_the_solve_uses_a_zero_field(gpu_ctx):
+    w0, h0, d = 32, 16, 3
+    rng = np.random.default_rng(19)
+    video = [rng.integers(0, 256, (d, h0, w0, 3), dtype=np.uint8) for _ in range(2)]
+    flows = [np.zeros((d, h0, w0, 2), np.float32) for _ in range(2)]
+    pyr = morph.SyncPyramid(gpu_ctx)
+    pyr.build(video[0], video[1], flows[0], flows[1], 8)
+    assert np.array_equal(pyr.render_resample(0.0, 1), video[0][1])
+    assert np.array_equal(pyr.render_resample(1.0, 2), video[1][2])
+
+
+@pytest.mark.gpu
+def test_level_solve_at_the_1080p_x_60_level_size(gpu_ctx):
+    """the finest sync level of a 1080p x 60-frame pair (344 x 193 x 60, 4 M voxels): a few
+    iterations against the oracle bit for bit, then properties of a longer run"""
+    w0, h0, d = 1920, 1080, 60
+    levels = morph.sync_level_table(w0, h0, d, 16)
+    w, h, _ = levels[1]
+    cons = _cons(w0, h0, d, n=24, seed=23)
+    P = _params(w_ui=100.0, w_tps=0.001)
+    got, pr, _ = _level_solve(gpu_ctx, levels, 1, cons, P, 3)
+    want = [np.zeros((d, h, w), np.float32) for _ in range(3)]
+    _, res = oracle.sync_solve_level(want[0], want[1], want[2], w0, h0, cons, P.w_ui, P.w_tps, 3.0)
+    for c in range(3):
+        assert np.array_equal(_bits(got[c]), _bits(want[c])), c
+    assert np.array_equal(_bits(np.array(pr.resid[:], np.float32)), _bits(res))
+    # 300 iterations: repeatable bit for bit, residuals fall
+    a, pra, _ = _level_solve(gpu_ctx, levels, 1, cons, P, 299)
+    b, prb, _ = _level_solve(gpu_ctx, levels, 1, cons, P, 299)
+    for c in range(3):
+        assert np.array_equal(_bits(a[c]), _bits(b[c]))
+        assert pra.resid[c] < 0.5 * pr.resid[c]
+    assert pra.iters == 300 and pra.launches == 601

@@ -34,6 +34,8 @@ UNITS = [
     ("vm_mg.hip", "vm_mg.o", ["-ffp-contract=fast"]),
     ("vm_pyramid.hip", "vm_pyramid.o", ["-ffp-contract=off"]),
     ("vm_temporal.hip", "vm_temporal.o", ["-ffp-contract=off"]),
+    ("vm_sync.hip", "vm_sync_kernels.o", ["-ffp-contract=off"]),
+    ("vm_sync.cpp", "vm_sync.o", ["-x", "hip"]),
     ("vm_video.cpp", "vm_video.o", ["-x", "hip"]),
     ("vm_pyramid_api.cpp", "vm_pyramid_api.o", ["-x", "hip"]),
     ("vm_api.cpp", "vm_api.o", ["-x", "hip"]),

@@ -38,6 +38,9 @@ SYMBOLS = [
     "vm_video_upload_flows", "vm_video_build_rgb", "vm_video_build_flows", "vm_video_set_v", "vm_video_get_v",
     "vm_video_get_field", "vm_video_coarse_solve", "vm_video_upsample", "vm_video_init_level",
     "vm_video_initialize_temp", "vm_video_optimize_level", "vm_video_solve",
+    "vm_sync_level_table", "vm_sync_create", "vm_sync_destroy", "vm_sync_set_constraints", "vm_sync_load_identity",
+    "vm_sync_upsample_level", "vm_sync_optimize_level", "vm_sync_solve", "vm_sync_get_field", "vm_sync_set_field",
+    "vm_sync_result", "vm_sync_upload_frame", "vm_sync_upload_flow", "vm_sync_render", "vm_sync_render_dev",
 ]
 
 
@@ -63,6 +66,16 @@ class Progress(C.Structure):
                 ("elapsed_ms", C.c_float), ("launches", C.c_int),
                 ("active_tiles", C.c_double), ("candidates", C.c_double), ("commits", C.c_double),
                 ("evaluations", C.c_double), ("sched_ms", C.c_float * 4), ("sched_launches", C.c_int * 4)]
+
+
+class SyncConstraint(C.Structure):
+    """a Connect between lp[li] and rp[ri]: full-resolution pixel + frame on either side"""
+    _fields_ = [("lx", C.c_int), ("ly", C.c_int), ("lz", C.c_int), ("rx", C.c_int), ("ry", C.c_int), ("rz", C.c_int)]
+
+
+class SyncProgress(C.Structure):
+    _fields_ = [("iters", C.c_int), ("launches", C.c_int), ("voxel_iters", C.c_double),
+                ("elapsed_ms", C.c_float), ("resid", C.c_float * 3)]
 
 
 class ParamBlock(C.Structure):
@@ -142,12 +155,26 @@ def load():
         "vm_video_initialize_temp": [vp, i, i, i],
         "vm_video_optimize_level": [vp, i, f, vp, i, vp],
         "vm_video_solve": [vp, f, f, vp, i, vp, i, vp],
+        "vm_sync_level_table": [i, i, i, i, vp, vp, vp, i, C.POINTER(i)],
+        "vm_sync_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(vp)],
+        "vm_sync_set_constraints": [vp, vp, i],
+        "vm_sync_load_identity": [vp, i],
+        "vm_sync_upsample_level": [vp, i],
+        "vm_sync_optimize_level": [vp, i, f, vp, C.POINTER(SyncProgress)],
+        "vm_sync_solve": [vp, f, vp, vp],
+        "vm_sync_get_field": [vp, i, vp, vp, vp],
+        "vm_sync_set_field": [vp, i, vp, vp, vp],
+        "vm_sync_result": [vp, i, i, vp],
+        "vm_sync_upload_frame": [vp, i, i, vp, i],
+        "vm_sync_upload_flow": [vp, i, i, vp, i],
+        "vm_sync_render": [vp, f, i, vp, i],
+        "vm_sync_render_dev": [vp, f, i, C.POINTER(f)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i
-    for name in ("vm_ctx_destroy", "vm_pyramid_destroy", "vm_frame_destroy", "vm_video_destroy"):
+    for name in ("vm_ctx_destroy", "vm_pyramid_destroy", "vm_frame_destroy", "vm_video_destroy", "vm_sync_destroy"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = None
     _lib = L

@@ -652,3 +652,202 @@ class VideoMorph(object):
                                              candidates=pr.candidates, elapsed_ms=pr.elapsed_ms)
                 k += 1
         return True
+
+
+# ---- synchronisation stage: CSyncThread (SyncThread.h:7-39) + the stage-1 renderer ------------
+
+def sync_constraints(P):
+    """Resolve lp / rp / cnt the way CSyncThread::genMatrix walks them (SyncThread.cpp:155-165):
+    every Connect ties (x, y, frame) of video 0 to (x, y, frame) of video 1."""
+    out = []
+    for row in P.cnt:
+        for c in row:
+            l, r = P.lp[c.li[0]][c.li[1]], P.rp[c.ri[0]][c.ri[1]]
+            out.append((int(l.p[0]), int(l.p[1]), int(l.p[2]), int(r.p[0]), int(r.p[1]), int(r.p[2])))
+    return out
+
+
+def sync_level_table(w, h, d, start_res):
+    """[(w, h, d)] of Pyramid::build(video0, video1, f0, f1, start_res): entry 0 = full resolution"""
+    L = capi.load()
+    lw, lh, ld = ((C.c_int * 64)() for _ in range(3))
+    n = C.c_int(0)
+    capi.check(L.vm_sync_level_table(int(w), int(h), int(d), int(start_res), lw, lh, ld, 64, C.byref(n)))
+    return [(lw[i], lh[i], ld[i]) for i in range(n.value)]
+
+
+class SyncPyramid(object):
+    """What class Pyramid holds after build(video0, video1, f0, f1, start_res) (pyramid.cu:57-165):
+    the level table, the four layered arrays the stage-1 renderer samples, and _vector."""
+
+    def __init__(self, ctx):
+        self._ctx, self._L = ctx, capi.load()
+        self._h = None
+        self.levels = []
+        self._vector = []
+
+    def clear(self):
+        if getattr(self, "_h", None):
+            self._L.vm_sync_destroy(self._h)
+            self._h = None
+
+    __del__ = clear
+
+    def size(self):
+        return len(self.levels)
+
+    def build_levels(self, levels):
+        self.clear()
+        n = len(levels)
+        ws = (C.c_int * n)(*[int(l[0]) for l in levels])
+        hs = (C.c_int * n)(*[int(l[1]) for l in levels])
+        ds = (C.c_int * n)(*[int(l[2]) for l in levels])
+        h = C.c_void_p()
+        capi.check(self._L.vm_sync_create(self._ctx._h, n, ws, hs, ds, C.byref(h)))
+        self._h = h
+        self.levels = [tuple(int(x) for x in l) for l in levels]
+        w0, h0, d0 = self.levels[0]
+        self._vector = [np.zeros((h0, w0, 4), np.float32) for _ in range(d0)]
+
+    def build(self, video0, video1, f0, f1, start_res):
+        """video*: (d, h, w, 3 or 4) u8; f*: (d, h, w, 2) float32 forward flows"""
+        d, h, w = video0.shape[:3]
+        self.build_levels(sync_level_table(w, h, d, start_res))
+        for side, (vid, fl) in enumerate(((video0, f0), (video1, f1))):
+            for t in range(d):
+                self.upload_frame(side, t, vid[t])
+                self.upload_flow(side, t, fl[t])
+
+    def upload_frame(self, side, frame, rgb):
+        rgb = np.asarray(rgb, np.uint8)
+        if rgb.shape[-1] == 3:
+            rgb = np.concatenate([rgb, np.zeros(rgb.shape[:2] + (1,), np.uint8)], axis=-1)
+        rgb = np.ascontiguousarray(rgb)
+        capi.check(self._L.vm_sync_upload_frame(self._h, side, frame, rgb.ctypes.data, rgb.shape[1] * 4))
+
+    def upload_flow(self, side, frame, flow):
+        flow = np.ascontiguousarray(flow, np.float32)
+        capi.check(self._L.vm_sync_upload_flow(self._h, side, frame, flow.ctypes.data, flow.shape[1] * 2))
+
+    def field(self, lvl):
+        """(X, Y, Z) of level lvl, each (d, h, w) float32"""
+        w, h, d = self.levels[lvl]
+        out = [np.zeros((d, h, w), np.float32) for _ in range(3)]
+        capi.check(self._L.vm_sync_get_field(self._h, lvl, *[o.ctypes.data for o in out]))
+        return out
+
+    def set_field(self, lvl, X, Y, Z):
+        a = [np.ascontiguousarray(t, np.float32) for t in (X, Y, Z)]
+        capi.check(self._L.vm_sync_set_field(self._h, lvl, *[t.ctypes.data for t in a]))
+
+    def result(self, lvl, frame):
+        w0, h0, _ = self.levels[0]
+        out = np.zeros((h0, w0, 4), np.float32)
+        capi.check(self._L.vm_sync_result(self._h, lvl, frame, out.ctypes.data))
+        return out
+
+    def render_resample(self, fa, frame):
+        """RenderWidget::RenderStage1 (UI/RenderWidget.cpp:205-227) -> (h, w, 3) u8"""
+        w0, h0, _ = self.levels[0]
+        out = np.zeros((h0, w0, 3), np.uint8)
+        capi.check(self._L.vm_sync_render(self._h, float(fa), int(frame), out.ctypes.data, w0 * 3))
+        return out
+
+    def render_resample_dev(self, fa, frame):
+        ms = C.c_float(0)
+        capi.check(self._L.vm_sync_render_dev(self._h, float(fa), int(frame), C.byref(ms)))
+        return ms.value
+
+
+class SyncThread(object):
+    """class CSyncThread (SyncThread.h:7-39) on threading.Thread: runflag, percentage, run_time,
+    run(), update_result()."""
+
+    def __init__(self, parameters, pyramids):
+        self._parameters, self._pyramids = parameters, pyramids
+        self._flag = C.c_int(1)
+        self.percentage = 0.0
+        self.run_time = 0.0
+        self._total_l = pyramids.size() - 1
+        self._current_l = self._total_l
+        self._max_iter = float(parameters.max_iter * 10)
+        self._current_iter = 0.0
+        self._total_iter = 0.0
+        it = parameters.max_iter * 10
+        for el in range(self._total_l, 0, -1):  # SyncThread.cpp:15-22 (integer division by the drop factor)
+            w, h, d = pyramids.levels[el]
+            self._total_iter += float(it) * w * h * d
+            it = int(it / parameters.max_iter_drop_factor)
+        self.progress = {}
+        self._thread = None
+        self.error = None
+
+    @property
+    def runflag(self):
+        return bool(self._flag.value)
+
+    @runflag.setter
+    def runflag(self, v):
+        self._flag.value = 1 if v else 0
+
+    def load_identity(self, el):
+        capi.check(self._pyramids._L.vm_sync_load_identity(self._pyramids._h, el))
+
+    def upsample_level(self, el, pel=None):
+        capi.check(self._pyramids._L.vm_sync_upsample_level(self._pyramids._h, el))
+
+    def optimize_level(self, el):
+        pyr = self._pyramids
+        pyr._ctx.set_params(KernParameters(self._parameters))
+        cons = sync_constraints(self._parameters)
+        arr = (capi.SyncConstraint * max(len(cons), 1))()
+        for i, c in enumerate(cons):
+            arr[i] = capi.SyncConstraint(*c)
+        capi.check(pyr._L.vm_sync_set_constraints(pyr._h, arr, len(cons)))
+        pr = capi.SyncProgress()
+        flag = C.cast(C.pointer(self._flag), C.c_void_p)
+        capi.check(pyr._L.vm_sync_optimize_level(pyr._h, el, self._max_iter, flag, C.byref(pr)))
+        self.progress[el] = dict(iters=pr.iters, launches=pr.launches, voxel_iters=pr.voxel_iters,
+                                 elapsed_ms=pr.elapsed_ms, resid=tuple(pr.resid))
+        self._current_iter += pr.voxel_iters
+        return pr
+
+    def run(self):
+        """SyncThread.cpp:58-84"""
+        t0 = time.time()
+        try:
+            self._current_l = self._total_l
+            while self._current_l > 0:
+                el = self._current_l
+                if el == self._total_l:
+                    self.load_identity(el)
+                else:
+                    self.upsample_level(el, el + 1)
+                self.optimize_level(el)
+                self._max_iter = float(np.float32(self._max_iter) / np.float32(2))
+                if not self.runflag:
+                    break
+                self._current_l -= 1
+        except Exception as e:
+            self.error = e
+        self.run_time = time.time() - t0
+        if self.error is None:
+            self.update_result()
+
+    def start(self):
+        self._thread = threading.Thread(target=self.run)
+        self._thread.start()
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+        if self.error is not None:
+            raise self.error
+
+    def update_result(self):
+        """SyncThread.cpp:482-521: _vector[z] = (X ratio_x, Y ratio_y, Z, 0) resized to full size"""
+        pyr = self._pyramids
+        el = max(self._current_l, 1)
+        for z in range(pyr.levels[el][2]):
+            pyr._vector[z] = pyr.result(el, z)
+        self.percentage = (self._current_iter / self._total_iter * 100.0) if self._total_iter else 100.0
