@@ -15,13 +15,14 @@
  * PARITY UNPINNED: the reference holds no test or golden vector for this stage, and its
  * arithmetic lives in cuBLAS / cuSPARSE (CUDA 6.5) and cv::resize (OpenCV 3.0), none of which is
  * here.  What the libraries leave unspecified is FIXED here (and mirrored by the HIP path):
- *   - csrmv accumulates a row in CSR order (z, then y, then x ascending), float, no FMA;
+ *   - csrmv accumulates a row in CSR order (z, then y, then x ascending) by fused multiply-adds
+ *     in float (a GPU library's a * x + y is one FMA);
  *   - sdot multiplies in float and accumulates in double in a blocked order: bricks of
  *     32 x 8 x 8 voxels; inside a brick each (x, y) column of 8 voxels sequentially, the 64 columns
  *     of two brick rows by a butterfly (strides 32, 16, ... 1), the four row pairs in sequence; brick
  *     partials in groups t, t + 256, ... sequentially, then the same butterfly over 256 groups.
  *     Rounded to float once at the end (the reference keeps the scalars in float);
- *   - sscal/saxpy are evaluated as the BLAS definitions read (alpha * x + y: one multiply, one add).
+ *   - saxpy is one fused multiply-add per element (alpha * x + y), sscal one multiply.
  * Replicated quirks: the CG starts from the UPSAMPLED solution but with r = b, not b - A x
  * (SyncThread.cpp:372-375 with :95-117), so a level adds A^-1 b to what it inherited; the
  * constraint's frame midpoint is compared with z unscaled; the loop runs floor(max_iter) + 1
@@ -291,15 +292,17 @@ void vmo_sync_apply(int w, int h, int d, float w_tps, const float *ui, const flo
                     const int *o = vmo_sync_taps[t];
                     float c = data[((o[0] + 2) * 5 + (o[1] + 2)) * 5 + (o[2] + 2)];
                     if (c != 0.0f) /* only stored entries take part, :264-275 */
-                        sum += c * p[((size_t)(z + o[0]) * h + (y + o[1])) * w + (x + o[2])];
+                        sum = fmaf(c, p[((size_t)(z + o[0]) * h + (y + o[1])) * w + (x + o[2])], sum);
                 }
                 out[((size_t)z * h + y) * w + x] = sum;
             }
 }
 
-/* fast form of the same: rows from the per-class table + the stored diagonal (identical bits:
- * the off-diagonal entries depend on the class only, the diagonal is the stored one) */
-static void sync_apply_fast(const sync_sys *S, const float *p, float *out)
+/* fast form of the same: rows from the per-state table + the stored diagonal (identical bits:
+ * the off-diagonal entries depend on the state triple only, the diagonal is the stored one).
+ * fmaf is exact either way; where the CPU has FMA instructions the body is also compiled for
+ * them (a libm call per tap is ~10x slower) and picked at run time. */
+static inline __attribute__((always_inline)) void apply_body(const sync_sys *S, const float *p, float *out)
 {
     const int w = S->w, h = S->h, d = S->d;
 #pragma omp parallel for schedule(static)
@@ -313,11 +316,38 @@ static void sync_apply_fast(const sync_sys *S, const float *p, float *out)
                     float c = t == 12 ? S->diag[i] : row[t];
                     if (c != 0.0f) {
                         const int *o = vmo_sync_taps[t];
-                        sum += c * p[((size_t)(z + o[0]) * h + (y + o[1])) * w + (x + o[2])];
+                        sum = __builtin_fmaf(c, p[((size_t)(z + o[0]) * h + (y + o[1])) * w + (x + o[2])], sum);
                     }
                 }
                 out[i] = sum;
             }
+}
+
+static inline __attribute__((always_inline)) void update_body(size_t N, float alpha, const float *p, const float *om, float *sol, float *r)
+{
+    const float nalpha = -alpha;
+    for (size_t i = 0; i < N; ++i) {
+        sol[i] = __builtin_fmaf(alpha, p[i], sol[i]);   /* cublasSaxpy(alpha, p, x) */
+        r[i] = __builtin_fmaf(nalpha, om[i], r[i]);     /* cublasSaxpy(-alpha, omega, r) */
+    }
+}
+
+#if defined(__x86_64__)
+__attribute__((target("fma"))) static void apply_hw(const sync_sys *S, const float *p, float *out) { apply_body(S, p, out); }
+__attribute__((target("fma"))) static void update_hw(size_t N, float alpha, const float *p, const float *om, float *sol, float *r) { update_body(N, alpha, p, om, sol, r); }
+static int have_fma(void) { return __builtin_cpu_supports("fma"); }
+#else
+#define apply_hw apply_sw
+#define update_hw update_sw
+static int have_fma(void) { return 0; }
+#endif
+static void apply_sw(const sync_sys *S, const float *p, float *out) { apply_body(S, p, out); }
+static void update_sw(size_t N, float alpha, const float *p, const float *om, float *sol, float *r) { update_body(N, alpha, p, om, sol, r); }
+
+static void sync_apply_fast(const sync_sys *S, const float *p, float *out)
+{
+    if (have_fma()) apply_hw(S, p, out);
+    else apply_sw(S, p, out);
 }
 
 /* CSyncThread::optimize_level, SyncThread.cpp:290-480.  x, y, z: the level's solution, in/out
@@ -351,19 +381,15 @@ int vmo_sync_solve_level(int w, int h, int d, int w0, int h0, const int *cons6, 
             else {
                 float beta = r1[c] / r0[c];
                 for (size_t i = 0; i < N; ++i) {
-                    float t = beta * p[c][i];
-                    p[c][i] = 1.0f * r[c][i] + t;
+                    float t = beta * p[c][i];           /* cublasSscal */
+                    p[c][i] = fmaf(1.0f, r[c][i], t);   /* cublasSaxpy(1, r, p) */
                 }
             }
             sync_apply_fast(&S, p[c], om);
             float dot = vmo_sync_dot(p[c], om, w, h, d);
-            float alpha = r1[c] / dot, nalpha = -alpha;
-            for (size_t i = 0; i < N; ++i) {
-                float t = alpha * p[c][i];
-                sol[c][i] = t + sol[c][i];
-                float u = nalpha * om[i];
-                r[c][i] = u + r[c][i];
-            }
+            float alpha = r1[c] / dot;
+            if (have_fma()) update_hw(N, alpha, p[c], om, sol[c], r[c]);
+            else update_sw(N, alpha, p[c], om, sol[c], r[c]);
             r0[c] = r1[c];
             r1[c] = vmo_sync_dot(r[c], r[c], w, h, d);
         }

@@ -83,13 +83,12 @@ extern "C" int vm_sync_create(vm_ctx *ctx, int nlevels, const int *w, const int 
     return VM_OK;
 }
 
+// the three components of a level live in ONE allocation (x at the base): large allocations get
+// large page fragments, which the plane-strided accesses of the CG kernels need
 static void free_field(vm_sync *s, int lvl)
 {
-    for (int c = 0; c < 3; ++c)
-        if (s->f[lvl][c]) {
-            (void)hipFree(s->f[lvl][c]);
-            s->f[lvl][c] = nullptr;
-        }
+    if (s->f[lvl][0]) (void)hipFree(s->f[lvl][0]);
+    s->f[lvl] = {nullptr, nullptr, nullptr};
 }
 
 extern "C" void vm_sync_destroy(vm_sync *s)
@@ -126,11 +125,13 @@ extern "C" int vm_sync_set_constraints(vm_sync *s, const vm_sync_constraint *c, 
 static int alloc_field(vm_sync *s, int lvl)
 {
     const size_t N = (size_t)s->w[lvl] * s->h[lvl] * s->d[lvl];
-    for (int c = 0; c < 3; ++c)
-        if (!s->f[lvl][c]) {
-            VM_HIP(hipMalloc((void **)&s->f[lvl][c], N * sizeof(float)));
-            VM_HIP(hipMemsetAsync(s->f[lvl][c], 0, N * sizeof(float), s->ctx->stream));
-        }
+    if (!s->f[lvl][0]) {
+        const size_t bytes = (3 * N * sizeof(float) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        float *base = nullptr;
+        VM_HIP(hipMalloc((void **)&base, bytes));
+        VM_HIP(hipMemsetAsync(base, 0, 3 * N * sizeof(float), s->ctx->stream));
+        s->f[lvl] = {base, base + N, base + 2 * N};
+    }
     return VM_OK;
 }
 
@@ -268,7 +269,8 @@ extern "C" int vm_sync_optimize_level(vm_sync *s, int lvl, float max_iter, volat
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     const size_t o_r = take(3 * N * sizeof(float)), o_p = take(6 * N * sizeof(float)), o_om = take(3 * N * sizeof(float));
     const size_t o_diag = take(N * sizeof(float)), o_tab = take(125 * 25 * sizeof(float));
-    const size_t o_part = take((size_t)3 * g.nb * sizeof(double)), o_sc = take(VM_SYNC_SC_WORDS * sizeof(float) + 64);
+    const size_t o_part = take((size_t)3 * g.nb * sizeof(double)), o_sc = take(VM_SYNC_SC_WORDS * sizeof(float));
+    const size_t tk_bytes = (size_t)VM_SYNC_TICKET_WORDS(8 * g.per_xcd) * sizeof(unsigned), o_tk = take(tk_bytes);
     const size_t o_idx = take((size_t)std::max(ne, 1) * sizeof(int)), o_val = take((size_t)std::max(ne, 1) * 4 * sizeof(float));
     if (off > s->ws_bytes) {
         VM_HIP(hipStreamSynchronize(c->stream));
@@ -291,14 +293,15 @@ extern "C" int vm_sync_optimize_level(vm_sync *s, int lvl, float max_iter, volat
     S.tab = (float *)(base + o_tab);
     S.part = (double *)(base + o_part);
     S.sc = (float *)(base + o_sc);
-    S.ticket = (unsigned *)(base + o_sc + VM_SYNC_SC_WORDS * sizeof(float));
+    S.ticket = (unsigned *)(base + o_tk);
     int *d_idx = (int *)(base + o_idx);
     float *d_val = (float *)(base + o_val);
 
     VM_HIP(hipEventRecord(c->ev0, c->stream));
     VM_HIP(hipMemsetAsync(base + o_r, 0, 3 * N * sizeof(float), c->stream));
     VM_HIP(hipMemsetAsync(S.diag, 0, N * sizeof(float), c->stream));
-    VM_HIP(hipMemsetAsync(S.sc, 0, VM_SYNC_SC_WORDS * sizeof(float) + 64, c->stream));
+    VM_HIP(hipMemsetAsync(S.sc, 0, VM_SYNC_SC_WORDS * sizeof(float), c->stream));
+    VM_HIP(hipMemsetAsync(S.ticket, 0, tk_bytes, c->stream));
     std::vector<float> tab(125 * 25, 0.0f);
     for (int sz = 0; sz < 5; ++sz)
         for (int sy = 0; sy < 5; ++sy)

@@ -10,6 +10,7 @@
 #define VM_SB_Y 8
 #define VM_SB_Z 8
 #define VM_SYNC_SC_WORDS 16 // r0[3], r1[2][3], dot[3]
+#define VM_SYNC_TICKET_WORDS(blocks) (3 * (1 + ((blocks) + 31) / 32) * 32)
 
 struct VmSyncGrid {
     int w, h, d;
@@ -27,7 +28,7 @@ struct VmSyncSys {
     const float *tab;  // [5][5][5][25] off-diagonal entries per border-state triple
     double *part;      // [3][nb] brick partial sums
     float *sc;         // VM_SYNC_SC_WORDS scalars
-    unsigned *ticket;  // arrival counter of the running launch
+    unsigned *ticket;  // arrival counters: per component 1 + ceil(workgroups / 32), each on its own line
 };
 
 void vm_sync_launch_diag(const VmSyncGrid &g, float *diag, float w_tps, hipStream_t s);

@@ -54,22 +54,35 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     return t;
 }
 
-// One lane publishes the workgroup's partials write-through, drains them, and takes a ticket; the
+// One lane publishes the workgroup's partial write-through, drains it, and takes a ticket; the
 // workgroup whose ticket is the last one may read every partial (with sc1 loads, after the
 // barrier the ticket-taking wave joins).  MI355X_MICROARCH.md, "inter-workgroup visibility".
-__device__ __forceinline__ bool publish_and_arrive(const VmSyncSys &S, int nb, int lin, bool has, const double part3[3],
-                                                   const bool act[3], int *s_last)
+// Tickets are two-level -- 32 workgroups share a counter (each on a line of its own), the last of
+// a group arrives at the component's top counter -- because agent-scope atomics on ONE line
+// serialise at ~45 ns each (measured: 6600 arrivals on one line held a 60 us kernel for 350 us).
+#define VM_TK_GROUP 32
+#define VM_TK_STRIDE 32 // words between counters: one 128-B line each
+__device__ __forceinline__ bool publish_and_arrive(const VmSyncSys &S, int c, int nb, int lin, bool has, double part, int *s_last)
 {
     if (threadIdx.x == 0) {
         if (has)
-            for (int c = 0; c < 3; ++c)
-                if (act[c])
-                    __hip_atomic_store((unsigned long long *)&S.part[(size_t)c * nb + lin],
-                                       (unsigned long long)__double_as_longlong(part3[c]), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((unsigned long long *)&S.part[(size_t)c * nb + lin], (unsigned long long)__double_as_longlong(part),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned tk = __hip_atomic_fetch_add(S.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_last = tk == gridDim.x - 1;
+        const int ngr = (gridDim.x + VM_TK_GROUP - 1) / VM_TK_GROUP, grp = blockIdx.x / VM_TK_GROUP;
+        const unsigned gsize = min((unsigned)VM_TK_GROUP, gridDim.x - grp * VM_TK_GROUP);
+        unsigned *tk = S.ticket + (size_t)c * (ngr + 1) * VM_TK_STRIDE;
+        int last = 0;
+        if (__hip_atomic_fetch_add(tk + (size_t)(1 + grp) * VM_TK_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+            __hip_atomic_store(tk + (size_t)(1 + grp) * VM_TK_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ngr == 1) // one group: its last arrival is the last of the launch
+                last = 1;
+            else if (__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ngr - 1) {
+                __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        *s_last = last;
     }
     __syncthreads();
     return *s_last != 0;
@@ -91,128 +104,149 @@ __device__ __forceinline__ double total_of(const double *part, int nb, double *r
 #define TILE_Y (VM_SB_Y + 4)
 #define TILE_Z (VM_SB_Z + 4)
 #define TILE_P (TILE_X * TILE_Y)
+#define TILE_N (TILE_Z * TILE_P)
+#define TILE_LOADS ((TILE_N + 255) / 256)
 
-// iteration k (1-based): p <- r (k == 1) or r + beta p; omega = A p; dot = p . omega
-template <bool FIRST>
+#define TILE_ROW_LOADS ((TILE_P + 255) / 256) // in-plane slots per thread: 432 = 256 + 176
+
+// iteration k (1-based), component blockIdx.y: p <- r (k == 1) or r + beta p; omega = A p;
+// dot = p . omega
+// TABLDS: the coefficient table is staged in LDS (launch-bound small levels: no round trip when
+// the border state changes along z) or read through L1 (large levels: 12.5 KB less LDS keeps 7
+// workgroups per CU, which is what hides the latency there).
+template <bool FIRST, bool TABLDS>
 __global__ __launch_bounds__(256) void k_sync_A(VmSyncSys S, VmSyncGrid g, int k)
 {
-    __shared__ float tile[TILE_Z * TILE_P];
+    __shared__ float tile[TILE_N];
+    __shared__ float tab_s[TABLDS ? 125 * 25 : 1];
     __shared__ double red[4];
     __shared__ int s_last;
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+    const int c = blockIdx.y;
     const int lin = brick_of_block(g);
     const bool has = lin < g.nb;
     const int cur = (k + 1) & 1; // r1 as iteration k - 1 left it
     const float tol = 1e-12f;
-    float r1c[3], r0[3];
-    bool act[3];
-    for (int c = 0; c < 3; ++c) {
-        r1c[c] = S.sc[3 + cur * 3 + c];
-        r0[c] = S.sc[c];
-        act[c] = r1c[c] > tol * tol;
-    }
-    double part3[3] = {0, 0, 0};
+    const float r1c = S.sc[3 + cur * 3 + c], r0 = S.sc[c];
+    if (!(r1c > tol * tol)) return; // this component is finished (SyncThread.cpp:382)
+    double part = 0;
     if (has) {
         const int bz = lin / (g.nbx * g.nby), rem = lin - bz * (g.nbx * g.nby), by = rem / g.nbx, bx = rem - by * g.nbx;
         const int x0 = bx * VM_SB_X, y0 = by * VM_SB_Y, z0 = bz * VM_SB_Z;
         const int x = x0 + tx, y = y0 + ty;
         const bool mine = x < g.w && y < g.h;
         const int sx = sync_state(mine ? x : 0, g.w), sy = sync_state(mine ? y : 0, g.h);
-        const size_t plane = (size_t)g.w * g.h;
-        const size_t col = (size_t)y * g.w + x;
+        const int plane = g.w * g.h;
+        const int col = y * g.w + x;
+        const float *__restrict__ rc = S.r[c];
+        const float *__restrict__ po = S.p[(k + 1) & 1][c];
+        float *__restrict__ pn = S.p[k & 1][c];
+        float *__restrict__ om = S.om[c];
+        const float beta = FIRST ? 0.0f : r1c / r0;
+        // Stage p over the brick + halo.  A thread owns the same <= 2 in-plane slots on every
+        // plane (their offsets are worked out once), and every load of the workgroup -- the tile,
+        // the diagonal, the coefficient table -- is issued before the first use.
+        int off_xy[TILE_ROW_LOADS];
+        bool ok_xy[TILE_ROW_LOADS];
+#pragma unroll
+        for (int j = 0; j < TILE_ROW_LOADS; ++j) {
+            const int i = t + 256 * j, ly = i / TILE_X, lx = i - ly * TILE_X;
+            const int gx = x0 + lx - 2, gy = y0 + ly - 2;
+            ok_xy[j] = i < TILE_P && gx >= 0 && gx < g.w && gy >= 0 && gy < g.h;
+            off_xy[j] = gy * g.w + gx;
+        }
+        float rv[TILE_Z][TILE_ROW_LOADS], pv[TILE_Z][TILE_ROW_LOADS];
+#pragma unroll
+        for (int lz = 0; lz < TILE_Z; ++lz) {
+            const int gz = z0 + lz - 2;
+            const bool zin = gz >= 0 && gz < g.d;
+#pragma unroll
+            for (int j = 0; j < TILE_ROW_LOADS; ++j) {
+                const bool in = zin && ok_xy[j];
+                const size_t gi = in ? (size_t)gz * plane + off_xy[j] : 0;
+                rv[lz][j] = in ? rc[gi] : 0.0f;
+                pv[lz][j] = (!FIRST && in) ? po[gi] : 0.0f;
+            }
+        }
         float dg[VM_SB_Z];
 #pragma unroll
         for (int zz = 0; zz < VM_SB_Z; ++zz) dg[zz] = (mine && z0 + zz < g.d) ? S.diag[(size_t)(z0 + zz) * plane + col] : 0.0f;
-        for (int c = 0; c < 3; ++c) {
-            if (!act[c]) continue;
-            const float *__restrict__ rc = S.r[c];
-            const float *__restrict__ po = S.p[(k + 1) & 1][c];
-            float *__restrict__ pn = S.p[k & 1][c];
-            float *__restrict__ om = S.om[c];
-            const float beta = FIRST ? 0.0f : r1c[c] / r0[c];
-            for (int i = t; i < TILE_Z * TILE_P; i += 256) {
-                const int lz = i / TILE_P, r2 = i - lz * TILE_P, ly = r2 / TILE_X, lx = r2 - ly * TILE_X;
-                const int gx = x0 + lx - 2, gy = y0 + ly - 2, gz = z0 + lz - 2;
-                float v = 0.0f;
-                if (gx >= 0 && gx < g.w && gy >= 0 && gy < g.h && gz >= 0 && gz < g.d) {
-                    const size_t gi = (size_t)gz * plane + (size_t)gy * g.w + gx;
-                    const float rr = rc[gi];
-                    if (FIRST)
-                        v = rr;
-                    else {
-                        const float tb = beta * po[gi]; // cublasSscal, then cublasSaxpy(1, r, p)
-                        v = 1.0f * rr + tb;
-                    }
+        if (TABLDS)
+            for (int i = t; i < 125 * 25; i += 256) tab_s[i] = S.tab[i];
+#pragma unroll
+        for (int lz = 0; lz < TILE_Z; ++lz)
+#pragma unroll
+            for (int j = 0; j < TILE_ROW_LOADS; ++j) {
+                float v = rv[lz][j];
+                if (!FIRST) {
+                    const float tb = beta * pv[lz][j];  // cublasSscal
+                    v = fmaf(1.0f, rv[lz][j], tb);      // cublasSaxpy(1, r, p)
                 }
-                tile[i] = v;
+                if (t + 256 * j < TILE_P) tile[lz * TILE_P + t + 256 * j] = v;
             }
-            __syncthreads();
-            double acc = 0;
-            if (mine) {
-                int szp = -1;
-                float cf[25];
+        __syncthreads();
+        double acc = 0;
+        if (mine) {
+            int szp = -1;
+            float cf[25];
 #pragma unroll
-                for (int zz = 0; zz < VM_SB_Z; ++zz) {
-                    const int z = z0 + zz;
-                    if (z < g.d) {
-                        const int sz = sync_state(z, g.d);
-                        if (sz != szp) {
-                            const float *row = S.tab + ((sz * 5 + sy) * 5 + sx) * 25;
+            for (int zz = 0; zz < VM_SB_Z; ++zz) {
+                const int z = z0 + zz;
+                if (z < g.d) {
+                    const int sz = sync_state(z, g.d);
+                    if (sz != szp) {
+                        const float *row = (TABLDS ? (const float *)tab_s : S.tab) + ((sz * 5 + sy) * 5 + sx) * 25;
 #pragma unroll
-                            for (int q = 0; q < 25; ++q) cf[q] = row[q];
-                            szp = sz;
-                        }
-                        const float *T = tile + ((zz + 2) * TILE_Y + (ty + 2)) * TILE_X + (tx + 2);
-                        // the row in CSR order: z, then y, then x ascending
-                        float sum = 0.0f;
-                        sum += cf[0] * T[-2 * TILE_P];
-                        sum += cf[1] * T[-TILE_P - TILE_X];
-                        sum += cf[2] * T[-TILE_P - 1];
-                        sum += cf[3] * T[-TILE_P];
-                        sum += cf[4] * T[-TILE_P + 1];
-                        sum += cf[5] * T[-TILE_P + TILE_X];
-                        sum += cf[6] * T[-2 * TILE_X];
-                        sum += cf[7] * T[-TILE_X - 1];
-                        sum += cf[8] * T[-TILE_X];
-                        sum += cf[9] * T[-TILE_X + 1];
-                        sum += cf[10] * T[-2];
-                        sum += cf[11] * T[-1];
-                        sum += dg[zz] * T[0];
-                        sum += cf[13] * T[1];
-                        sum += cf[14] * T[2];
-                        sum += cf[15] * T[TILE_X - 1];
-                        sum += cf[16] * T[TILE_X];
-                        sum += cf[17] * T[TILE_X + 1];
-                        sum += cf[18] * T[2 * TILE_X];
-                        sum += cf[19] * T[TILE_P - TILE_X];
-                        sum += cf[20] * T[TILE_P - 1];
-                        sum += cf[21] * T[TILE_P];
-                        sum += cf[22] * T[TILE_P + 1];
-                        sum += cf[23] * T[TILE_P + TILE_X];
-                        sum += cf[24] * T[2 * TILE_P];
-                        const size_t gi = (size_t)z * plane + col;
-                        const float pv = T[0];
-                        om[gi] = sum;
-                        pn[gi] = pv;
-                        const float pr = pv * sum;
-                        acc += (double)pr;
+                        for (int q = 0; q < 25; ++q) cf[q] = row[q];
+                        szp = sz;
                     }
+                    const float *T = tile + ((zz + 2) * TILE_Y + (ty + 2)) * TILE_X + (tx + 2);
+                    // the row in CSR order (z, then y, then x ascending), one FMA per entry
+                    float sum = 0.0f;
+                    sum = fmaf(cf[0], T[-2 * TILE_P], sum);
+                    sum = fmaf(cf[1], T[-TILE_P - TILE_X], sum);
+                    sum = fmaf(cf[2], T[-TILE_P - 1], sum);
+                    sum = fmaf(cf[3], T[-TILE_P], sum);
+                    sum = fmaf(cf[4], T[-TILE_P + 1], sum);
+                    sum = fmaf(cf[5], T[-TILE_P + TILE_X], sum);
+                    sum = fmaf(cf[6], T[-2 * TILE_X], sum);
+                    sum = fmaf(cf[7], T[-TILE_X - 1], sum);
+                    sum = fmaf(cf[8], T[-TILE_X], sum);
+                    sum = fmaf(cf[9], T[-TILE_X + 1], sum);
+                    sum = fmaf(cf[10], T[-2], sum);
+                    sum = fmaf(cf[11], T[-1], sum);
+                    sum = fmaf(dg[zz], T[0], sum);
+                    sum = fmaf(cf[13], T[1], sum);
+                    sum = fmaf(cf[14], T[2], sum);
+                    sum = fmaf(cf[15], T[TILE_X - 1], sum);
+                    sum = fmaf(cf[16], T[TILE_X], sum);
+                    sum = fmaf(cf[17], T[TILE_X + 1], sum);
+                    sum = fmaf(cf[18], T[2 * TILE_X], sum);
+                    sum = fmaf(cf[19], T[TILE_P - TILE_X], sum);
+                    sum = fmaf(cf[20], T[TILE_P - 1], sum);
+                    sum = fmaf(cf[21], T[TILE_P], sum);
+                    sum = fmaf(cf[22], T[TILE_P + 1], sum);
+                    sum = fmaf(cf[23], T[TILE_P + TILE_X], sum);
+                    sum = fmaf(cf[24], T[2 * TILE_P], sum);
+                    const size_t gi = (size_t)z * plane + col;
+                    const float pc = T[0];
+                    om[gi] = sum;
+                    pn[gi] = pc;
+                    const float pr = pc * sum;
+                    acc += (double)pr;
                 }
             }
-            part3[c] = block_sum(acc, red); // its barriers also fence the tile for the next component
         }
+        part = block_sum(acc, red);
     }
-    if (publish_and_arrive(S, g.nb, lin, has, part3, act, &s_last)) {
-        for (int c = 0; c < 3; ++c)
-            if (act[c]) {
-                const double tot = total_of(S.part + (size_t)c * g.nb, g.nb, red);
-                if (t == 0) S.sc[9 + c] = (float)tot;
-            }
-        if (t == 0) *S.ticket = 0;
+    if (publish_and_arrive(S, c, g.nb, lin, has, part, &s_last)) {
+        const double tot = total_of(S.part + (size_t)c * g.nb, g.nb, red);
+        if (t == 0) S.sc[9 + c] = (float)tot;
     }
 }
 
-// x += alpha p, r -= alpha omega, r1 = r . r  (INIT: only r1 = r . r before the first iteration)
+// component blockIdx.y: x += alpha p, r -= alpha omega, r1 = r . r  (INIT: only r1 = r . r before
+// the first iteration)
 template <bool INIT>
 __global__ __launch_bounds__(256) void k_sync_B(VmSyncSys S, VmSyncGrid g, int k)
 {
@@ -223,77 +257,65 @@ __global__ __launch_bounds__(256) void k_sync_B(VmSyncSys S, VmSyncGrid g, int k
     const bool has = lin < g.nb;
     const int cur = (k + 1) & 1, nxt = k & 1;
     const float tol = 1e-12f;
-    float r1c[3], alpha[3];
-    bool act[3];
-    for (int c = 0; c < 3; ++c) {
-        r1c[c] = INIT ? 0.0f : S.sc[3 + cur * 3 + c];
-        act[c] = INIT ? true : r1c[c] > tol * tol;
-        alpha[c] = INIT ? 0.0f : r1c[c] / S.sc[9 + c];
+    const int c = blockIdx.y;
+    const float r1c = INIT ? 0.0f : S.sc[3 + cur * 3 + c];
+    if (!INIT && !(r1c > tol * tol)) {
+        if (blockIdx.x == 0 && t == 0) S.sc[3 + nxt * 3 + c] = r1c; // carried over unchanged
+        return;
     }
-    double part3[3] = {0, 0, 0};
+    const float al = INIT ? 0.0f : r1c / S.sc[9 + c], nal = -al;
+    double part = 0;
     if (has) {
         const int bz = lin / (g.nbx * g.nby), rem = lin - bz * (g.nbx * g.nby), by = rem / g.nbx, bx = rem - by * g.nbx;
         const int x = bx * VM_SB_X + tx, y = by * VM_SB_Y + ty, z0 = bz * VM_SB_Z;
         const bool mine = x < g.w && y < g.h;
         const size_t plane = (size_t)g.w * g.h;
         const size_t col = (size_t)y * g.w + x;
-        for (int c = 0; c < 3; ++c) {
-            if (!act[c]) continue;
-            float *__restrict__ xc = S.x[c];
-            float *__restrict__ rc = S.r[c];
-            const float *__restrict__ pn = S.p[k & 1][c];
-            const float *__restrict__ om = S.om[c];
-            const float al = alpha[c], nal = -al;
-            double acc = 0;
-            if (mine) {
-                float rv[VM_SB_Z];
-                if (INIT) {
+        float *__restrict__ xc = S.x[c];
+        float *__restrict__ rc = S.r[c];
+        const float *__restrict__ pn = S.p[k & 1][c];
+        const float *__restrict__ om = S.om[c];
+        double acc = 0;
+        if (mine) {
+            float rv[VM_SB_Z];
+            if (INIT) {
 #pragma unroll
-                    for (int zz = 0; zz < VM_SB_Z; ++zz) rv[zz] = z0 + zz < g.d ? rc[(size_t)(z0 + zz) * plane + col] : 0.0f;
-                } else {
-                    float pv[VM_SB_Z], ov[VM_SB_Z], xv[VM_SB_Z];
+                for (int zz = 0; zz < VM_SB_Z; ++zz) rv[zz] = z0 + zz < g.d ? rc[(size_t)(z0 + zz) * plane + col] : 0.0f;
+            } else {
+                float pv[VM_SB_Z], ov[VM_SB_Z], xv[VM_SB_Z];
 #pragma unroll
-                    for (int zz = 0; zz < VM_SB_Z; ++zz) {
-                        const bool in = z0 + zz < g.d;
-                        const size_t gi = (size_t)(z0 + zz) * plane + col;
-                        pv[zz] = in ? pn[gi] : 0.0f;
-                        ov[zz] = in ? om[gi] : 0.0f;
-                        xv[zz] = in ? xc[gi] : 0.0f;
-                        rv[zz] = in ? rc[gi] : 0.0f;
-                    }
-#pragma unroll
-                    for (int zz = 0; zz < VM_SB_Z; ++zz)
-                        if (z0 + zz < g.d) {
-                            const size_t gi = (size_t)(z0 + zz) * plane + col;
-                            const float tp = al * pv[zz]; // cublasSaxpy(alpha, p, x)
-                            xc[gi] = tp + xv[zz];
-                            const float tu = nal * ov[zz]; // cublasSaxpy(-alpha, omega, r)
-                            rv[zz] = tu + rv[zz];
-                            rc[gi] = rv[zz];
-                        }
+                for (int zz = 0; zz < VM_SB_Z; ++zz) {
+                    const bool in = z0 + zz < g.d;
+                    const size_t gi = in ? (size_t)(z0 + zz) * plane + col : col;
+                    pv[zz] = in ? pn[gi] : 0.0f;
+                    ov[zz] = in ? om[gi] : 0.0f;
+                    xv[zz] = in ? xc[gi] : 0.0f;
+                    rv[zz] = in ? rc[gi] : 0.0f;
                 }
 #pragma unroll
                 for (int zz = 0; zz < VM_SB_Z; ++zz)
                     if (z0 + zz < g.d) {
-                        const float pr = rv[zz] * rv[zz];
-                        acc += (double)pr;
+                        const size_t gi = (size_t)(z0 + zz) * plane + col;
+                        xc[gi] = fmaf(al, pv[zz], xv[zz]);  // cublasSaxpy(alpha, p, x)
+                        rv[zz] = fmaf(nal, ov[zz], rv[zz]); // cublasSaxpy(-alpha, omega, r)
+                        rc[gi] = rv[zz];
                     }
             }
-            part3[c] = block_sum(acc, red);
-        }
-    }
-    if (publish_and_arrive(S, g.nb, lin, has, part3, act, &s_last)) {
-        for (int c = 0; c < 3; ++c) {
-            if (act[c]) {
-                const double tot = total_of(S.part + (size_t)c * g.nb, g.nb, red);
-                if (t == 0) {
-                    if (!INIT) S.sc[c] = r1c[c]; // r0 = r1
-                    S.sc[3 + nxt * 3 + c] = (float)tot;
+#pragma unroll
+            for (int zz = 0; zz < VM_SB_Z; ++zz)
+                if (z0 + zz < g.d) {
+                    const float pr = rv[zz] * rv[zz];
+                    acc += (double)pr;
                 }
-            } else if (t == 0)
-                S.sc[3 + nxt * 3 + c] = r1c[c];
         }
-        if (t == 0) *S.ticket = 0;
+        part = block_sum(acc, red);
+    }
+    if (publish_and_arrive(S, c, g.nb, lin, has, part, &s_last)) {
+        const double tot = total_of(S.part + (size_t)c * g.nb, g.nb, red);
+        if (t == 0) {
+            if (!INIT) S.sc[c] = r1c; // r0 = r1
+            S.sc[3 + nxt * 3 + c] = (float)tot;
+        }
     }
 }
 
@@ -536,16 +558,25 @@ void vm_sync_launch_scatter(float *dst, const int *idx, const float *val, int n,
 
 void vm_sync_launch_rr(const VmSyncGrid &g, const VmSyncSys &S, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sync_B<true>, dim3(8 * g.per_xcd), dim3(256), 0, s, S, g, 0);
+    hipLaunchKernelGGL(k_sync_B<true>, dim3(8 * g.per_xcd, 3), dim3(256), 0, s, S, g, 0);
 }
 
 void vm_sync_launch_iteration(const VmSyncGrid &g, const VmSyncSys &S, int k, hipStream_t s)
 {
-    if (k == 1)
-        hipLaunchKernelGGL(k_sync_A<true>, dim3(8 * g.per_xcd), dim3(256), 0, s, S, g, k);
-    else
-        hipLaunchKernelGGL(k_sync_A<false>, dim3(8 * g.per_xcd), dim3(256), 0, s, S, g, k);
-    hipLaunchKernelGGL(k_sync_B<false>, dim3(8 * g.per_xcd), dim3(256), 0, s, S, g, k);
+    const bool small = g.nb * 3 <= 1024;
+    const dim3 grid(8 * g.per_xcd, 3);
+    if (k == 1) {
+        if (small)
+            hipLaunchKernelGGL((k_sync_A<true, true>), grid, dim3(256), 0, s, S, g, k);
+        else
+            hipLaunchKernelGGL((k_sync_A<true, false>), grid, dim3(256), 0, s, S, g, k);
+    } else {
+        if (small)
+            hipLaunchKernelGGL((k_sync_A<false, true>), grid, dim3(256), 0, s, S, g, k);
+        else
+            hipLaunchKernelGGL((k_sync_A<false, false>), grid, dim3(256), 0, s, S, g, k);
+    }
+    hipLaunchKernelGGL(k_sync_B<false>, dim3(8 * g.per_xcd, 3), dim3(256), 0, s, S, g, k);
 }
 
 void vm_sync_launch_upsample(float *dst, int dw, int dh, const float *src, int sw, int sh, float ratio, int pages,
