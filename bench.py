@@ -491,6 +491,14 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         del vid
     except capi.VmError as e:
         extras["temporal_video_5_frames"] = {"error": str(e)[-160:]}
+    # the synchronisation stage that precedes the morph in the reference's app (CSyncThread +
+    # render_resample_image, SURVEY 8(f) "(later)"): a 1080p x 60-frame pair, 24 constraints across
+    # frames, the reference's iteration schedule (max_iter * 10 at the coarsest level, halved per
+    # level).  HBM-bound: 124 algorithmic bytes per voxel and CG iteration.
+    try:
+        extras["sync_stage_1080p_x60"] = sync_stage_extra(ctx, w, h, 60, blk)
+    except capi.VmError as e:
+        extras["sync_stage_1080p_x60"] = {"error": str(e)[-160:]}
     # compositor: frames/s of render_halfway with device-resident inputs
     ex = int(0.1 * max(w, h))
     rgb0, rgb1 = synth.make_rgb_pair(w, h)
@@ -542,6 +550,53 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         del group
     fr.close()
     return extras
+
+
+def sync_stage_extra(ctx, w, h, d, blk):
+    prm = morph.Parameters()
+    prm.w_ui, prm.w_tps, prm.max_iter = 100.0, 0.001, int(blk.max_iter)
+    rng = np.random.default_rng(23)
+    for k in range(24):
+        lx, ly, lz = int(rng.integers(2, w - 2)), int(rng.integers(2, h - 2)), int(rng.integers(0, d))
+        prm.lp.append([morph.Conp(lx, ly, lz)])
+        prm.rp.append([morph.Conp(int(np.clip(lx + rng.integers(-40, 41), 0, w - 1)), int(np.clip(ly + rng.integers(-40, 41), 0, h - 1)),
+                                  int(np.clip(lz + rng.integers(-3, 4), 0, d - 1)))])
+        prm.cnt.append([morph.Connect((k, 0), (k, 0))])
+    levels = morph.sync_level_table(w, h, d, max(blk.start_res // 2, 1))   # UI/MdiEditor.cpp:1837
+    pyr = morph.SyncPyramid(ctx)
+    pyr.build_levels(levels)
+    for rep in range(2):                                 # the first pass allocates the workspaces
+        th = morph.SyncThread(prm, pyr)
+        ctx.sync(); t1 = time.perf_counter()
+        th.run()
+        ctx.sync(); dt = time.perf_counter() - t1
+    solve_ms = sum(pr["elapsed_ms"] for pr in th.progress.values())
+    units = sum(pr["voxel_iters"] for pr in th.progress.values())
+    fin = th.progress[1]
+    n1 = levels[1][0] * levels[1][1] * levels[1][2]
+    us = fin["elapsed_ms"] * 1e3 / max(fin["iters"], 1)
+    gbs = n1 * 124.0 / (us * 1e-6) / 1e9
+    out = {"levels": [list(l) for l in levels[1:]], "cg_iterations": [th.progress[el]["iters"] for el in sorted(th.progress)],
+           "solve_ms": round(solve_ms, 1), "wall_ms_with_result_delivery": round(dt * 1e3, 1),
+           "mvoxel_iters_per_s": round(units / solve_ms / 1e3, 1),
+           "finest_level": {"voxels": n1, "us_per_iteration": round(us, 1), "algorithmic_bytes_per_voxel_iter": 124,
+                            "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 3)}}
+    # stage-1 renderer on 8 of the frames (render_resample_image): both videos re-timed
+    frame = np.zeros((h, w, 4), np.uint8)
+    frame[..., 0] = (np.arange(w) % 256)[None, :]
+    frame[..., 1] = (np.arange(h) % 256)[:, None]
+    flow = np.zeros((h, w, 2), np.float32)
+    flow[..., 0] = 1.5
+    for side in range(2):
+        for t in range(d):
+            pyr.upload_frame(side, t, frame)
+            pyr.upload_flow(side, t, flow)
+    ms = []
+    for f in range(8):
+        ms.append(pyr.render_resample_dev(0.0, f) + pyr.render_resample_dev(1.0, f))   # MdiEditor::NextStage: both sides per frame
+    out["resample_ms_per_frame_both_videos"] = round(float(np.median(ms[1:])), 3)
+    pyr.clear()
+    return out
 
 
 def effective_cpus():

@@ -119,3 +119,55 @@ def test_cpp_level_table_equals_the_python_geometry(tmp_path, vmlib):
         got = [tuple(int(x) for x in l.split()) for l in subprocess.check_output([exe, str(w), str(h), str(d), str(sr)]).decode().splitlines()]
         levels, ft = synth.video_levels(w, h, d, sr)
         assert got == [l + (f,) for l, f in zip(levels, ft)], (w, h, d, sr)
+
+
+@pytest.fixture(scope="module")
+def solve_sync(tmp_path_factory, vmlib):
+    exe = str(tmp_path_factory.mktemp("cpps") / "solve_sync")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "solve_sync.cpp"), "-o", exe,
+                           "-L", libdir, "-lvmorph_hip", "-Wl,-rpath," + libdir, "-lpthread"])
+    return exe
+
+
+def test_sync_facade_builds(solve_sync):
+    assert os.path.exists(solve_sync)
+
+
+@pytest.mark.gpu
+def test_sync_facade_matches_python_mirror(solve_sync, gpu_ctx, tmp_path):
+    """the C++ SyncPyramid / SyncThread (CSyncThread::run, update_result, the stage-1 renderer) and
+    the Python mirror over the same C-ABI produce the same bits"""
+    from videomorphing_amd import morph
+    w, h, d = 96, 64, 5
+    rng = np.random.default_rng(31)
+    video = [rng.integers(0, 256, (d, h, w, 4), dtype=np.uint8) for _ in range(2)]
+    flows = [rng.standard_normal((d, h, w, 2)).astype(np.float32) for _ in range(2)]
+    cons = [(20, 20, 1, 26, 24, 2), (70, 40, 3, 64, 44, 1), (48, 12, 0, 50, 10, 0), (30, 50, 4, 34, 52, 2)]
+    np.stack([np.stack([video[0][t], video[1][t]]) for t in range(d)]).tofile(str(tmp_path / "fr.u8"))
+    np.stack([np.stack([flows[0][t], flows[1][t]]) for t in range(d)]).tofile(str(tmp_path / "fl.f32"))
+    np.asarray(cons, np.int32).tofile(str(tmp_path / "c.i32"))
+    r = subprocess.run([solve_sync, str(w), str(h), str(d), str(tmp_path / "fr.u8"), str(tmp_path / "fl.f32"), str(tmp_path / "c.i32"),
+                        str(len(cons)), str(tmp_path / "field.f32"), str(tmp_path / "out.u8"), "6", "16"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    P = morph.Parameters()
+    P.w_ui, P.w_tps, P.max_iter, P.start_res = 100.0, 0.001, 6, 16
+    for k, c in enumerate(cons):
+        P.lp.append([morph.Conp(c[0], c[1], c[2])])
+        P.rp.append([morph.Conp(c[3], c[4], c[5])])
+        P.cnt.append([morph.Connect((k, 0), (k, 0))])
+    pyr = morph.SyncPyramid(gpu_ctx)
+    pyr.build(video[0], video[1], flows[0], flows[1], 16)
+    th = morph.SyncThread(P, pyr)
+    th.run()
+    X, Y, Z = pyr.field(1)
+    lw, lh, ld = pyr.levels[1]
+    got = np.fromfile(str(tmp_path / "field.f32"), np.float32).reshape(3, ld, lh, lw)
+    for c, want in enumerate((X, Y, Z)):
+        assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), c
+    frames = np.fromfile(str(tmp_path / "out.u8"), np.uint8).reshape(d, 2, h, w, 3)
+    for t in range(d):
+        for side in range(2):
+            assert np.array_equal(frames[t, side], pyr.render_resample(float(side), t)), (t, side)
+    assert np.abs(X).max() > 0.01 and np.abs(Z).max() > 0.001

@@ -8,6 +8,7 @@ from videomorphing_amd import capi, morph
 max_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 render = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+only = int(sys.argv[4]) if len(sys.argv) > 4 else 0     # > 0: solve just this level, from zero (profiling)
 w0, h0 = 1920, 1080
 ctx = morph.Context(0, capi.MATH_FAST)
 P = morph.Parameters()
@@ -26,7 +27,12 @@ pyr.build_levels(levels)
 for rep in range(2):
     th = morph.SyncThread(P, pyr)
     ctx.sync(); t = time.perf_counter()
-    th.run()
+    if only:
+        th._max_iter = float(max_iter)
+        th.load_identity(only)
+        th.optimize_level(only)
+    else:
+        th.run()
     ctx.sync(); dt = time.perf_counter() - t
 print("sync solve: %.1f ms wall (incl. result delivery of %d frames)" % (dt * 1e3, d))
 tot = 0

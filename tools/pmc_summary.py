@@ -1,7 +1,7 @@
 """Summarise rocprofv3 output for profiles/: per-kernel averages of a --kernel-trace --stats run and
 the HBM traffic of the sweep kernels from two --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-  python tools/pmc_summary.py <fetch_dir> <write_dir> <out_csv> <out_json> "<command profiled>"
+  python tools/pmc_summary.py <fetch_dir> <write_dir> <out_csv> <out_json> "<command profiled>" [kernel,substrings]
 """
 import csv, glob, json, os, sys
 
@@ -23,7 +23,10 @@ def counters(d, name):
 
 
 def main():
+    global SWEEP
     fd, wd, out_csv, out_json, cmd = sys.argv[1:6]
+    if len(sys.argv) > 6:
+        SWEEP = tuple(sys.argv[6].split(","))
     F, W = counters(fd, "FETCH_SIZE"), counters(wd, "WRITE_SIZE")
     rows = []
     tot_l = tot_f = tot_w = 0
@@ -47,7 +50,7 @@ def main():
         per_kernel[name] = (2 * f + w) * 1024
     json.dump({
         "per_kernel": per_kernel,
-        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `%s`; all sweep kernels (%s), %d launches" % (cmd, ", ".join(SWEEP), tot_l),
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `%s`; kernels summed below (%s), %d launches" % (cmd, ", ".join(SWEEP), tot_l),
         "fetch_size_kb_per_launch_raw": fk, "write_size_kb_per_launch_raw": wk,
         "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
         "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section; calibrated there for 16 B/lane streams; these kernels read 4-16 B/lane, so the read side is an upper estimate); WRITE_SIZE as reported",

@@ -269,7 +269,7 @@ extern "C" int vm_sync_optimize_level(vm_sync *s, int lvl, float max_iter, volat
     auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
     const size_t o_r = take(3 * N * sizeof(float)), o_p = take(6 * N * sizeof(float)), o_om = take(3 * N * sizeof(float));
     const size_t o_diag = take(N * sizeof(float)), o_tab = take(125 * 25 * sizeof(float));
-    const size_t o_part = take((size_t)3 * g.nb * sizeof(double)), o_sc = take(VM_SYNC_SC_WORDS * sizeof(float));
+    const size_t o_part = take((size_t)9 * g.nb * sizeof(double)), o_sc = take(VM_SYNC_SC_WORDS * sizeof(float));
     const size_t tk_bytes = (size_t)VM_SYNC_TICKET_WORDS(8 * g.per_xcd) * sizeof(unsigned), o_tk = take(tk_bytes);
     const size_t o_idx = take((size_t)std::max(ne, 1) * sizeof(int)), o_val = take((size_t)std::max(ne, 1) * 4 * sizeof(float));
     if (off > s->ws_bytes) {
@@ -343,6 +343,7 @@ extern "C" int vm_sync_optimize_level(vm_sync *s, int lvl, float max_iter, volat
             VM_HIP(hipStreamSynchronize(c->stream)); // bounds the queue, so a cancel takes effect soon
         }
     }
+    vm_sync_launch_finish(g, S, k, c->stream);
     VM_HIP(hipGetLastError());
     VM_HIP(hipEventRecord(c->ev1, c->stream));
     float sc[VM_SYNC_SC_WORDS];

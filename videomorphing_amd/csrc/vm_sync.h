@@ -26,7 +26,7 @@ struct VmSyncSys {
     float *om[3];      // A p
     float *diag;       // the diagonal of A: UI term first, then the stencil's increments in order
     const float *tab;  // [5][5][5][25] off-diagonal entries per border-state triple
-    double *part;      // [3][nb] brick partial sums
+    double *part;      // [9][nb] brick partial sums: p.omega [3], r.r [2 parities][3]
     float *sc;         // VM_SYNC_SC_WORDS scalars
     unsigned *ticket;  // arrival counters: per component 1 + ceil(workgroups / 32), each on its own line
 };
@@ -35,6 +35,7 @@ void vm_sync_launch_diag(const VmSyncGrid &g, float *diag, float w_tps, hipStrea
 void vm_sync_launch_scatter(float *dst, const int *idx, const float *val, int n, hipStream_t s);
 void vm_sync_launch_rr(const VmSyncGrid &g, const VmSyncSys &S, hipStream_t s);
 void vm_sync_launch_iteration(const VmSyncGrid &g, const VmSyncSys &S, int k, hipStream_t s);
+void vm_sync_launch_finish(const VmSyncGrid &g, const VmSyncSys &S, int k, hipStream_t s);
 void vm_sync_launch_upsample(float *dst, int dw, int dh, const float *src, int sw, int sh, float ratio, int pages,
                              hipStream_t s);
 void vm_sync_launch_result(const float *X, const float *Y, const float *Z, int w, int h, int w0, int h0, float4 *out,

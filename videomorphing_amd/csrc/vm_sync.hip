@@ -109,12 +109,28 @@ __device__ __forceinline__ double total_of(const double *part, int nb, double *r
 
 #define TILE_ROW_LOADS ((TILE_P + 255) / 256) // in-plane slots per thread: 432 = 256 + 176
 
-// iteration k (1-based), component blockIdx.y: p <- r (k == 1) or r + beta p; omega = A p;
-// dot = p . omega
+// brick partials of p . omega (kernel A) and of r . r (kernel B, ping-pong by iteration parity)
+__device__ __forceinline__ double *part_a(const VmSyncSys &S, int nb, int c) { return S.part + (size_t)c * nb; }
+__device__ __forceinline__ double *part_b(const VmSyncSys &S, int nb, int par, int c) { return S.part + (size_t)(3 + par * 3 + c) * nb; }
+
+// the same fold as total_of on partials a PREVIOUS launch stored (plain loads)
+__device__ __forceinline__ double total_plain(const double *part, int nb, double *red)
+{
+    double s = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+    return block_sum(s, red);
+}
+
+// Iteration k (1-based), component blockIdx.y: p <- r (k == 1) or r + beta p; omega = A p;
+// dot = p . omega.
 // TABLDS: the coefficient table is staged in LDS (launch-bound small levels: no round trip when
 // the border state changes along z) or read through L1 (large levels: 12.5 KB less LDS keeps 7
 // workgroups per CU, which is what hides the latency there).
-template <bool FIRST, bool TABLDS>
+// SELF (levels of <= 512 bricks): no tickets -- every workgroup folds the partials the PREVIOUS
+// launch left (same fixed order, so every workgroup gets the same bits) while its tile loads are
+// in flight, and ends by storing its own partial; the launch boundary publishes it.  Saves the
+// ~4 us store-drain + atomic + re-read tail per launch that a launch-bound level cannot hide.
+template <bool FIRST, bool TABLDS, bool SELF>
 __global__ __launch_bounds__(256) void k_sync_A(VmSyncSys S, VmSyncGrid g, int k)
 {
     __shared__ float tile[TILE_N];
@@ -123,56 +139,68 @@ __global__ __launch_bounds__(256) void k_sync_A(VmSyncSys S, VmSyncGrid g, int k
     __shared__ int s_last;
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
     const int c = blockIdx.y;
-    const int lin = brick_of_block(g);
-    const bool has = lin < g.nb;
+    const int q = brick_of_block(g);
+    const bool has = q < g.nb;
+    if (SELF && !has) return;
     const int cur = (k + 1) & 1; // r1 as iteration k - 1 left it
     const float tol = 1e-12f;
-    const float r1c = S.sc[3 + cur * 3 + c], r0 = S.sc[c];
-    if (!(r1c > tol * tol)) return; // this component is finished (SyncThread.cpp:382)
-    double part = 0;
-    if (has) {
-        const int bz = lin / (g.nbx * g.nby), rem = lin - bz * (g.nbx * g.nby), by = rem / g.nbx, bx = rem - by * g.nbx;
-        const int x0 = bx * VM_SB_X, y0 = by * VM_SB_Y, z0 = bz * VM_SB_Z;
-        const int x = x0 + tx, y = y0 + ty;
-        const bool mine = x < g.w && y < g.h;
-        const int sx = sync_state(mine ? x : 0, g.w), sy = sync_state(mine ? y : 0, g.h);
-        const int plane = g.w * g.h;
-        const int col = y * g.w + x;
-        const float *__restrict__ rc = S.r[c];
-        const float *__restrict__ po = S.p[(k + 1) & 1][c];
-        float *__restrict__ pn = S.p[k & 1][c];
-        float *__restrict__ om = S.om[c];
-        const float beta = FIRST ? 0.0f : r1c / r0;
-        // Stage p over the brick + halo.  A thread owns the same <= 2 in-plane slots on every
-        // plane (their offsets are worked out once), and every load of the workgroup -- the tile,
-        // the diagonal, the coefficient table -- is issued before the first use.
-        int off_xy[TILE_ROW_LOADS];
-        bool ok_xy[TILE_ROW_LOADS];
+    // dispatch order is y-slab major (an XCD's run of bricks spans all of z: the z halo, a third of
+    // the tile, is then shared inside ONE L2); the partial's slot keeps the z-major brick order
+    const int qc = has ? q : 0;
+    const int by = qc / (g.nbx * g.nbz), rem = qc - by * (g.nbx * g.nbz), bz = rem / g.nbx, bx = rem - bz * g.nbx;
+    const int lin = has ? (bz * g.nby + by) * g.nbx + bx : g.nb;
+    const int x0 = bx * VM_SB_X, y0 = by * VM_SB_Y, z0 = bz * VM_SB_Z;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool mine = has && x < g.w && y < g.h;
+    const int sx = sync_state(mine ? x : 0, g.w), sy = sync_state(mine ? y : 0, g.h);
+    const int plane = g.w * g.h;
+    const int col = y * g.w + x;
+    const float *__restrict__ rc = S.r[c];
+    const float *__restrict__ po = S.p[(k + 1) & 1][c];
+    float *__restrict__ pn = S.p[k & 1][c];
+    float *__restrict__ om = S.om[c];
+    // Stage p over the brick + halo.  A thread owns the same <= 2 in-plane slots on every plane
+    // (their offsets are worked out once), and every load of the workgroup -- the tile, the
+    // diagonal, the coefficient table, in SELF mode the partials -- is issued before the first use.
+    int off_xy[TILE_ROW_LOADS];
+    bool ok_xy[TILE_ROW_LOADS];
+#pragma unroll
+    for (int j = 0; j < TILE_ROW_LOADS; ++j) {
+        const int i = t + 256 * j, ly = i / TILE_X, lx = i - ly * TILE_X;
+        const int gx = x0 + lx - 2, gy = y0 + ly - 2;
+        ok_xy[j] = has && i < TILE_P && gx >= 0 && gx < g.w && gy >= 0 && gy < g.h;
+        off_xy[j] = gy * g.w + gx;
+    }
+    float rv[TILE_Z][TILE_ROW_LOADS], pv[TILE_Z][TILE_ROW_LOADS];
+#pragma unroll
+    for (int lz = 0; lz < TILE_Z; ++lz) {
+        const int gz = z0 + lz - 2;
+        const bool zin = gz >= 0 && gz < g.d;
 #pragma unroll
         for (int j = 0; j < TILE_ROW_LOADS; ++j) {
-            const int i = t + 256 * j, ly = i / TILE_X, lx = i - ly * TILE_X;
-            const int gx = x0 + lx - 2, gy = y0 + ly - 2;
-            ok_xy[j] = i < TILE_P && gx >= 0 && gx < g.w && gy >= 0 && gy < g.h;
-            off_xy[j] = gy * g.w + gx;
+            const bool in = zin && ok_xy[j];
+            const size_t gi = in ? (size_t)gz * plane + off_xy[j] : 0;
+            rv[lz][j] = in ? rc[gi] : 0.0f;
+            pv[lz][j] = (!FIRST && in) ? po[gi] : 0.0f;
         }
-        float rv[TILE_Z][TILE_ROW_LOADS], pv[TILE_Z][TILE_ROW_LOADS];
+    }
+    float dg[VM_SB_Z];
 #pragma unroll
-        for (int lz = 0; lz < TILE_Z; ++lz) {
-            const int gz = z0 + lz - 2;
-            const bool zin = gz >= 0 && gz < g.d;
-#pragma unroll
-            for (int j = 0; j < TILE_ROW_LOADS; ++j) {
-                const bool in = zin && ok_xy[j];
-                const size_t gi = in ? (size_t)gz * plane + off_xy[j] : 0;
-                rv[lz][j] = in ? rc[gi] : 0.0f;
-                pv[lz][j] = (!FIRST && in) ? po[gi] : 0.0f;
-            }
-        }
-        float dg[VM_SB_Z];
-#pragma unroll
-        for (int zz = 0; zz < VM_SB_Z; ++zz) dg[zz] = (mine && z0 + zz < g.d) ? S.diag[(size_t)(z0 + zz) * plane + col] : 0.0f;
-        if (TABLDS)
-            for (int i = t; i < 125 * 25; i += 256) tab_s[i] = S.tab[i];
+    for (int zz = 0; zz < VM_SB_Z; ++zz) dg[zz] = (mine && z0 + zz < g.d) ? S.diag[(size_t)(z0 + zz) * plane + col] : 0.0f;
+    if (TABLDS)
+        for (int i = t; i < 125 * 25; i += 256) tab_s[i] = S.tab[i];
+    float r1c, r0;
+    if (SELF) {
+        r1c = (float)total_plain(part_b(S, g.nb, cur, c), g.nb, red);
+        r0 = FIRST ? 0.0f : (float)total_plain(part_b(S, g.nb, k & 1, c), g.nb, red);
+    } else {
+        r1c = S.sc[3 + cur * 3 + c];
+        r0 = S.sc[c];
+    }
+    if (!(r1c > tol * tol)) return; // this component is finished (SyncThread.cpp:382)
+    const float beta = FIRST ? 0.0f : r1c / r0;
+    double part = 0;
+    if (has) {
 #pragma unroll
         for (int lz = 0; lz < TILE_Z; ++lz)
 #pragma unroll
@@ -239,59 +267,73 @@ __global__ __launch_bounds__(256) void k_sync_A(VmSyncSys S, VmSyncGrid g, int k
         }
         part = block_sum(acc, red);
     }
-    if (publish_and_arrive(S, c, g.nb, lin, has, part, &s_last)) {
-        const double tot = total_of(S.part + (size_t)c * g.nb, g.nb, red);
+    if (SELF) {
+        if (t == 0) part_a(S, g.nb, c)[lin] = part;
+    } else if (publish_and_arrive(S, c, g.nb, lin, has, part, &s_last)) {
+        const double tot = total_of(part_a(S, g.nb, c), g.nb, red);
         if (t == 0) S.sc[9 + c] = (float)tot;
     }
 }
 
 // component blockIdx.y: x += alpha p, r -= alpha omega, r1 = r . r  (INIT: only r1 = r . r before
-// the first iteration)
-template <bool INIT>
+// the first iteration).  SELF as in k_sync_A; the r . r partials ping-pong by iteration parity so
+// that the next k_sync_A can fold both r1 (this launch's) and r0 (the previous one's).
+template <bool INIT, bool SELF>
 __global__ __launch_bounds__(256) void k_sync_B(VmSyncSys S, VmSyncGrid g, int k)
 {
     __shared__ double red[4];
     __shared__ int s_last;
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
-    const int lin = brick_of_block(g);
-    const bool has = lin < g.nb;
+    const int q = brick_of_block(g);
+    const bool has = q < g.nb;
+    if (SELF && !has) return;
     const int cur = (k + 1) & 1, nxt = k & 1;
     const float tol = 1e-12f;
     const int c = blockIdx.y;
-    const float r1c = INIT ? 0.0f : S.sc[3 + cur * 3 + c];
-    if (!INIT && !(r1c > tol * tol)) {
-        if (blockIdx.x == 0 && t == 0) S.sc[3 + nxt * 3 + c] = r1c; // carried over unchanged
-        return;
+    const int qc = has ? q : 0; // same brick order as k_sync_A
+    const int by = qc / (g.nbx * g.nbz), rem = qc - by * (g.nbx * g.nbz), bz = rem / g.nbx, bx = rem - bz * g.nbx;
+    const int lin = has ? (bz * g.nby + by) * g.nbx + bx : g.nb;
+    const int x = bx * VM_SB_X + tx, y = by * VM_SB_Y + ty, z0 = bz * VM_SB_Z;
+    const bool mine = has && x < g.w && y < g.h;
+    const size_t plane = (size_t)g.w * g.h;
+    const size_t col = (size_t)y * g.w + x;
+    float *__restrict__ xc = S.x[c];
+    float *__restrict__ rc = S.r[c];
+    const float *__restrict__ pn = S.p[k & 1][c];
+    const float *__restrict__ om = S.om[c];
+    float pv[VM_SB_Z], ov[VM_SB_Z], xv[VM_SB_Z], rv[VM_SB_Z];
+#pragma unroll
+    for (int zz = 0; zz < VM_SB_Z; ++zz) {
+        const bool in = mine && z0 + zz < g.d;
+        const size_t gi = in ? (size_t)(z0 + zz) * plane + col : 0;
+        pv[zz] = (!INIT && in) ? pn[gi] : 0.0f;
+        ov[zz] = (!INIT && in) ? om[gi] : 0.0f;
+        xv[zz] = (!INIT && in) ? xc[gi] : 0.0f;
+        rv[zz] = in ? rc[gi] : 0.0f;
     }
-    const float al = INIT ? 0.0f : r1c / S.sc[9 + c], nal = -al;
+    float r1c = 0.0f, dot = 0.0f;
+    if (!INIT) {
+        if (SELF) {
+            r1c = (float)total_plain(part_b(S, g.nb, cur, c), g.nb, red);
+            dot = (float)total_plain(part_a(S, g.nb, c), g.nb, red);
+        } else {
+            r1c = S.sc[3 + cur * 3 + c];
+            dot = S.sc[9 + c];
+        }
+        if (!(r1c > tol * tol)) { // finished: r1 is carried over unchanged
+            if (SELF) {
+                if (t == 0) part_b(S, g.nb, nxt, c)[lin] = part_b(S, g.nb, cur, c)[lin];
+            } else if (blockIdx.x == 0 && t == 0)
+                S.sc[3 + nxt * 3 + c] = r1c;
+            return;
+        }
+    }
+    const float al = INIT ? 0.0f : r1c / dot, nal = -al;
     double part = 0;
     if (has) {
-        const int bz = lin / (g.nbx * g.nby), rem = lin - bz * (g.nbx * g.nby), by = rem / g.nbx, bx = rem - by * g.nbx;
-        const int x = bx * VM_SB_X + tx, y = by * VM_SB_Y + ty, z0 = bz * VM_SB_Z;
-        const bool mine = x < g.w && y < g.h;
-        const size_t plane = (size_t)g.w * g.h;
-        const size_t col = (size_t)y * g.w + x;
-        float *__restrict__ xc = S.x[c];
-        float *__restrict__ rc = S.r[c];
-        const float *__restrict__ pn = S.p[k & 1][c];
-        const float *__restrict__ om = S.om[c];
         double acc = 0;
         if (mine) {
-            float rv[VM_SB_Z];
-            if (INIT) {
-#pragma unroll
-                for (int zz = 0; zz < VM_SB_Z; ++zz) rv[zz] = z0 + zz < g.d ? rc[(size_t)(z0 + zz) * plane + col] : 0.0f;
-            } else {
-                float pv[VM_SB_Z], ov[VM_SB_Z], xv[VM_SB_Z];
-#pragma unroll
-                for (int zz = 0; zz < VM_SB_Z; ++zz) {
-                    const bool in = z0 + zz < g.d;
-                    const size_t gi = in ? (size_t)(z0 + zz) * plane + col : col;
-                    pv[zz] = in ? pn[gi] : 0.0f;
-                    ov[zz] = in ? om[gi] : 0.0f;
-                    xv[zz] = in ? xc[gi] : 0.0f;
-                    rv[zz] = in ? rc[gi] : 0.0f;
-                }
+            if (!INIT) {
 #pragma unroll
                 for (int zz = 0; zz < VM_SB_Z; ++zz)
                     if (z0 + zz < g.d) {
@@ -310,13 +352,24 @@ __global__ __launch_bounds__(256) void k_sync_B(VmSyncSys S, VmSyncGrid g, int k
         }
         part = block_sum(acc, red);
     }
-    if (publish_and_arrive(S, c, g.nb, lin, has, part, &s_last)) {
-        const double tot = total_of(S.part + (size_t)c * g.nb, g.nb, red);
+    if (SELF) {
+        if (t == 0) part_b(S, g.nb, nxt, c)[lin] = part;
+    } else if (publish_and_arrive(S, c, g.nb, lin, has, part, &s_last)) {
+        const double tot = total_of(part_a(S, g.nb, c), g.nb, red);
         if (t == 0) {
             if (!INIT) S.sc[c] = r1c; // r0 = r1
             S.sc[3 + nxt * 3 + c] = (float)tot;
         }
     }
+}
+
+// SELF mode: r1 of the last iteration into the scalar block (for the host's read-back)
+__global__ __launch_bounds__(256) void k_sync_total(VmSyncSys S, int nb, int par)
+{
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const double tot = total_plain(part_b(S, nb, par, c), nb, red);
+    if (threadIdx.x == 0) S.sc[3 + par * 3 + c] = (float)tot;
 }
 
 // the diagonal: diag[] arrives holding the UI term; the stencil's increments follow in
@@ -556,27 +609,47 @@ void vm_sync_launch_scatter(float *dst, const int *idx, const float *val, int n,
     if (n > 0) hipLaunchKernelGGL(k_sync_scatter, dim3((n + 255) / 256), dim3(256), 0, s, dst, idx, val, n);
 }
 
+bool vm_sync_self_mode(const VmSyncGrid &g) { return g.nb <= 512; }
+
 void vm_sync_launch_rr(const VmSyncGrid &g, const VmSyncSys &S, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_sync_B<true>, dim3(8 * g.per_xcd, 3), dim3(256), 0, s, S, g, 0);
+    const dim3 grid(8 * g.per_xcd, 3);
+    if (vm_sync_self_mode(g))
+        hipLaunchKernelGGL((k_sync_B<true, true>), grid, dim3(256), 0, s, S, g, 0);
+    else
+        hipLaunchKernelGGL((k_sync_B<true, false>), grid, dim3(256), 0, s, S, g, 0);
 }
 
 void vm_sync_launch_iteration(const VmSyncGrid &g, const VmSyncSys &S, int k, hipStream_t s)
 {
-    const bool small = g.nb * 3 <= 1024;
     const dim3 grid(8 * g.per_xcd, 3);
-    if (k == 1) {
-        if (small)
-            hipLaunchKernelGGL((k_sync_A<true, true>), grid, dim3(256), 0, s, S, g, k);
+    if (vm_sync_self_mode(g)) {
+        if (k == 1)
+            hipLaunchKernelGGL((k_sync_A<true, true, true>), grid, dim3(256), 0, s, S, g, k);
         else
-            hipLaunchKernelGGL((k_sync_A<true, false>), grid, dim3(256), 0, s, S, g, k);
+            hipLaunchKernelGGL((k_sync_A<false, true, true>), grid, dim3(256), 0, s, S, g, k);
+        hipLaunchKernelGGL((k_sync_B<false, true>), grid, dim3(256), 0, s, S, g, k);
     } else {
-        if (small)
-            hipLaunchKernelGGL((k_sync_A<false, true>), grid, dim3(256), 0, s, S, g, k);
-        else
-            hipLaunchKernelGGL((k_sync_A<false, false>), grid, dim3(256), 0, s, S, g, k);
+        const bool small = g.nb * 3 <= 1024;
+        if (k == 1) {
+            if (small)
+                hipLaunchKernelGGL((k_sync_A<true, true, false>), grid, dim3(256), 0, s, S, g, k);
+            else
+                hipLaunchKernelGGL((k_sync_A<true, false, false>), grid, dim3(256), 0, s, S, g, k);
+        } else {
+            if (small)
+                hipLaunchKernelGGL((k_sync_A<false, true, false>), grid, dim3(256), 0, s, S, g, k);
+            else
+                hipLaunchKernelGGL((k_sync_A<false, false, false>), grid, dim3(256), 0, s, S, g, k);
+        }
+        hipLaunchKernelGGL((k_sync_B<false, false>), grid, dim3(256), 0, s, S, g, k);
     }
-    hipLaunchKernelGGL(k_sync_B<false>, dim3(8 * g.per_xcd, 3), dim3(256), 0, s, S, g, k);
+}
+
+// after the loop: make r1 of iteration k readable in the scalar block (SELF mode keeps it as partials)
+void vm_sync_launch_finish(const VmSyncGrid &g, const VmSyncSys &S, int k, hipStream_t s)
+{
+    if (vm_sync_self_mode(g)) hipLaunchKernelGGL(k_sync_total, dim3(3), dim3(256), 0, s, S, g.nb, k & 1);
 }
 
 void vm_sync_launch_upsample(float *dst, int dw, int dh, const float *src, int sw, int sh, float ratio, int pages,
