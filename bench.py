@@ -496,7 +496,7 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
     # frames, the reference's iteration schedule (max_iter * 10 at the coarsest level, halved per
     # level).  HBM-bound: 124 algorithmic bytes per voxel and CG iteration.
     try:
-        extras["sync_stage_1080p_x60"] = sync_stage_extra(ctx, w, h, 60, blk)
+        extras["sync_stage_1080p_x60"] = sync_stage_extra(np, morph, ctx, w, h, 60, blk)
     except capi.VmError as e:
         extras["sync_stage_1080p_x60"] = {"error": str(e)[-160:]}
     # compositor: frames/s of render_halfway with device-resident inputs
@@ -552,7 +552,7 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
     return extras
 
 
-def sync_stage_extra(ctx, w, h, d, blk):
+def sync_stage_extra(np, morph, ctx, w, h, d, blk):
     prm = morph.Parameters()
     prm.w_ui, prm.w_tps, prm.max_iter = 100.0, 0.001, int(blk.max_iter)
     rng = np.random.default_rng(23)
