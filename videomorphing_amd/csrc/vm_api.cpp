@@ -152,6 +152,7 @@ static void ctx_free(vm_ctx *c)
     hipHostFree(c->flags_host);
     hipFree(c->stats);
     hipHostFree(c->stats_host);
+    hipFree(c->step_slots);
     hipFree(c->cons_dev);
     hipFree(c->views);
     hipFree(c->iter_dev);
@@ -807,6 +808,20 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         VM_HIP(hipEventRecord(c->ev0, s));
         uint32_t last_epoch = 0;
         int sb = 0; // step index inside this batch: parity = which copy of the sums is read
+        int slot_iter = -1; // iteration whose counts the previous STEP launch left in its slots
+        if (step) {
+            // per-workgroup count slots of the last two launches (k_step folds them one launch late)
+            const int gxs = (l0.w + VM_PITCH_X - 1) / VM_PITCH_X, gys = (l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y;
+            const size_t need = (size_t)gxs * gys * parts * n * 4;
+            if (c->step_slots_words < need) {
+                VM_HIP(hipStreamSynchronize(s));
+                hipFree(c->step_slots);
+                c->step_slots = nullptr;
+                c->step_slots_words = 0;
+                VM_HIP(hipMalloc((void **)&c->step_slots, 2 * need * sizeof(uint32_t)));
+                c->step_slots_words = need;
+            }
+        }
         int it0 = done;
         if (sparse) {
             for (int i = 0; i < n; ++i)
@@ -834,7 +849,10 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
                         const uint32_t epoch = 1u + (uint32_t)((it * 4 + k) * 4 + ph);
                         (exact ? vm_launch_optimize_step_exact : vm_launch_optimize_step_fast)(
                             c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], ph >> 1, ph & 1, epoch,
-                            sb == 0 ? 0u : epoch - 1u, sb & 1, 1, c->flags, c->stats, it, fixed_work, threads, parts, s);
+                            sb == 0 ? 0u : epoch - 1u, sb & 1, 1, c->flags, c->stats, it, fixed_work, threads, parts,
+                            c->step_slots + (size_t)(sb & 1) * c->step_slots_words,
+                            c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, sb == 0 ? -1 : slot_iter, s);
+                        slot_iter = it;
                         last_epoch = epoch;
                     }
                     launches += 4;
@@ -851,7 +869,8 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         if (step) { // fold the last phase's records in place: copy 0 is complete again
             (exact ? vm_launch_optimize_step_exact : vm_launch_optimize_step_fast)(
                 c->views, n, cap, l0.w, l0.h, P, c->tables, 0, 0, 0, 0, 0u, last_epoch, 2, 0, c->flags, c->stats,
-                done + nb - 1, fixed_work, threads, parts, s);
+                done + nb - 1, fixed_work, threads, parts, c->step_slots + (size_t)(sb & 1) * c->step_slots_words,
+                c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, sb == 0 ? -1 : slot_iter, s);
             ++launches;
         }
         VM_HIP(hipEventRecord(c->ev1, s));

@@ -57,6 +57,8 @@ struct vm_ctx {
     uint32_t *flags_host = nullptr;  // pinned mirror
     uint32_t *stats = nullptr;       // per-iteration activity counters, 4 words each (device)
     uint32_t *stats_host = nullptr;  // pinned mirror
+    uint32_t *step_slots = nullptr;  // STEP schedule: per-workgroup activity counts of the last two launches
+    size_t step_slots_words = 0;     // capacity of ONE of the two halves, in words
     int sweep_threads = 0;           // 0 = automatic
     int sweep_mode = 0;              // VM_SWEEP_AUTO / TILE / SPLIT
     int sweep_parts = 0;             // workgroups per tile in the SPLIT schedule, 0 = automatic

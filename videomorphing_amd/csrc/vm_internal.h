@@ -98,7 +98,8 @@ struct VmKParams {
                                           uint32_t prev_epoch, int src, int decide,           \
                                           uint32_t *flags, uint32_t *stats, int iter_idx,     \
                                           int fixed_work, int threads, int parts,             \
-                                          hipStream_t s);                                     \
+                                          uint32_t *slots_cur, const uint32_t *slots_prev,    \
+                                          int prev_iter_idx, hipStream_t s);                  \
     void vm_launch_upsample_##SUFFIX(float2 *dst, int dw, int dh, int drs, const float2 *src, \
                                      int sw, int sh, int srs, hipStream_t s);                 \
     void vm_launch_splat_##SUFFIX(const VmLevelView &L, int w0, int h0,                       \

@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
         return;
     if (tid == 0) {
         if (improving)
-            atomicOr(&flags[iter_idx], 1u);
+            flags[iter_idx] = 1u; // every writer stores the same 1: no atomic needed (see k_step)
         // per-iteration activity counters: active tiles, line searches, commits
         atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 0], 1u);
         atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 1], st_cand);
@@ -1739,7 +1739,7 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
     }
     if (tid == 0) {
         if (ncommit)
-            atomicOr(&flags[iter_idx], 1u);
+            flags[iter_idx] = 1u; // every writer stores the same 1: no atomic needed (see k_step)
         atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 3], 1u); // tile-phases with records
         atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 1], (uint32_t)n_rec);
         atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 2], (uint32_t)ncommit);
@@ -1855,7 +1855,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
                                                    const uint32_t *__restrict__ tables, int offx, int offy, int pi,
                                                    int pj, int parts, uint32_t epoch, uint32_t pe, int srcbuf,
                                                    int n_fold, uint32_t *__restrict__ flags,
-                                                   uint32_t *__restrict__ stats, int iter_idx, int fixed_work)
+                                                   uint32_t *__restrict__ stats, int iter_idx, int fixed_work,
+                                                   uint32_t *__restrict__ slots_cur, const uint32_t *__restrict__ slots_prev,
+                                                   int prev_iter_idx, int nslot)
 {
     __shared__ StepLds S;
     const int tid = threadIdx.x;
@@ -1978,19 +1980,57 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
             d_tpsb[gi] = tb;
             d_value[gi] = val;
         }
+        // Activity counters: a decide workgroup leaves its counts in a slot (a plain store); the
+        // first fold workgroup of the NEXT launch adds them up.  Five agent-scope atomics per
+        // workgroup on one line were 0.8 us of every launch (they drain at memory, and the launch
+        // cannot end before they have).
+        if (blockIdx.x == 0 && prev_iter_idx >= 0) {
+            __syncthreads();
+            if (tid < 4)
+                S.wave_cnt[tid] = 0;
+            __syncthreads();
+            uint32_t acc[4] = {0, 0, 0, 0};
+            const uint4 *sl = (const uint4 *)slots_prev + (size_t)blockIdx.z * nslot;
+            for (int k = tid; k < nslot; k += T) {
+                const uint4 q = sl[k];
+                acc[0] += q.x;
+                acc[1] += q.y;
+                acc[2] += q.z;
+                acc[3] += q.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (acc[k])
+                    atomicAdd((uint32_t *)&S.wave_cnt[k], acc[k]);
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t *st = stats + (size_t)prev_iter_idx * VM_STAT_WORDS;
+                st[1] += (uint32_t)S.wave_cnt[0]; // line searches
+                st[2] += (uint32_t)S.wave_cnt[1]; // commits
+                st[4] += (uint32_t)S.wave_cnt[2]; // energy evaluations
+                st[3] += (uint32_t)S.wave_cnt[3]; // tile-phases with records
+            }
+        }
         return;
     }
 
     // ------------------------------------------------------------- DECIDE
     // converged in the previous iteration: nothing can be a candidate (sticky); the folds go on
-    if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0)
-        return;
     const int bid = (int)blockIdx.x - n_fold;
+    uint4 *my_slot = (uint4 *)slots_cur + (size_t)blockIdx.z * nslot + bid; // read by the next launch: always written
+    if (!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0) {
+        if (tid == 0)
+            *my_slot = make_uint4(0, 0, 0, 0);
+        return;
+    }
     const int part = bid % parts, tile = bid / parts;
     const int gxn = (L.w + VM_PITCH_X - 1) / VM_PITCH_X;
     const int ox = (tile % gxn) * VM_PITCH_X + offx, oy = (tile / gxn) * VM_PITCH_Y + offy;
-    if (ox >= L.w || oy >= L.h)
+    if (ox >= L.w || oy >= L.h) {
+        if (tid == 0)
+            *my_slot = make_uint4(0, 0, 0, 0);
         return;
+    }
     const MaskGeom g = mask_geom(L, ox, oy);
     const int bx0 = ox - 4, by0 = oy - 4; // staged window: 72 x 24
     constexpr int NTD = (VM_STEP_BW * VM_STEP_BH + T - 1) / T;
@@ -2041,8 +2081,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
     }
     const int n_hit = compact256(hit, tid, S.list, S.wave_cnt);
     const int n_mine = (n_hit - part + parts - 1) / parts;
-    if (n_mine <= 0)
+    if (n_mine <= 0) {
+        if (tid == 0)
+            *my_slot = make_uint4(0, 0, 0, 0);
         return;
+    }
     const int slots = T / 32;
     const int sub = tid & 31, grp = tid >> 5;
     uint32_t my_commits = 0;
@@ -2138,15 +2181,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
     __syncthreads();
     if (tid == 0) {
         const uint32_t nc = S.n_commit;
+        // the next iteration's first launch reads this flag, so it cannot wait for the slot fold;
+        // every writer stores the same 1 into a word that was cleared before the batch: a plain
+        // store does (L2 write-back is byte-masked), no atomic has to drain at memory
         if (nc)
-            atomicOr(&flags[iter_idx], 1u);
-        if (part == 0)
-            atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 3], 1u); // tile-phases with records
-        atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 1], (uint32_t)n_mine);
-        if (nc)
-            atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 2], nc);
-        if (S.n_eval)
-            atomicAdd(&stats[iter_idx * VM_STAT_WORDS + 4], S.n_eval);
+            flags[iter_idx] = 1u;
+        *my_slot = make_uint4((uint32_t)n_mine, nc, S.n_eval, part == 0 ? 1u : 0u);
     }
 }
 
@@ -2234,15 +2274,19 @@ void SUF(vm_launch_optimize_split)(const VmLevelView *views, int nbatch, int cap
 void SUF(vm_launch_optimize_step)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
                                   const uint32_t *tables, int offx, int offy, int pi, int pj, uint32_t epoch,
                                   uint32_t prev_epoch, int src, int decide, uint32_t *flags, uint32_t *stats,
-                                  int iter_idx, int fixed_work, int threads, int parts, hipStream_t s)
+                                  int iter_idx, int fixed_work, int threads, int parts, uint32_t *slots_cur,
+                                  const uint32_t *slots_prev, int prev_iter_idx, hipStream_t s)
 {
     const int gx = (w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (h + VM_PITCH_Y - 1) / VM_PITCH_Y;
     const int n_fold = ((w + 63) / 64) * ((h + 15) / 16);
-    const dim3 grid(n_fold + (decide ? gx * gy * parts : 0), 1, nbatch);
+    const int nslot = gx * gy * parts;
+    const dim3 grid(n_fold + (decide ? nslot : 0), 1, nbatch);
     if (threads <= 256)
         hipLaunchKernelGGL(SUF(k_step)<256>, grid, dim3(256), 0, s, views, cap, P, tables, offx, offy, pi, pj, parts,
-                           epoch, prev_epoch, src, n_fold, flags, stats, iter_idx, fixed_work);
+                           epoch, prev_epoch, src, n_fold, flags, stats, iter_idx, fixed_work, slots_cur, slots_prev,
+                           prev_iter_idx, nslot);
     else
         hipLaunchKernelGGL(SUF(k_step)<512>, grid, dim3(512), 0, s, views, cap, P, tables, offx, offy, pi, pj, parts,
-                           epoch, prev_epoch, src, n_fold, flags, stats, iter_idx, fixed_work);
+                           epoch, prev_epoch, src, n_fold, flags, stats, iter_idx, fixed_work, slots_cur, slots_prev,
+                           prev_iter_idx, nslot);
 }
