@@ -1254,9 +1254,12 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 // ---- 2. line searches on the pre-phase state, L lanes per candidate ----
 #if !VM_EXACT
                 if (!DENSE || n_act * 32 <= T) {
-                    // sparse phase: the lean 32-lane line search
-                    for (int base = 0; base < n_act; base += T / 32) {
-                    const int li = base + (tid >> 5), sub = tid & 31;
+                    // sparse phase: the lean 32-lane line search; with <= T / 64 candidates a whole
+                    // wave each, two points of the search per round (decide64)
+                    const bool wide = n_act * 64 <= T;
+                    for (int base = 0; base < n_act; base += wide ? T / 64 : T / 32) {
+                    const int li = base + (wide ? tid >> 6 : tid >> 5), sub = tid & 31;
+                    const bool writer = wide ? (tid & 63) == 0 : sub == 0;
                     const int slot = S.list[min(li, n_act - 1)];
                     const int tx = slot & 31, ty = slot >> 5;
                     const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
@@ -1275,14 +1278,16 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                         uint32_t n_eval = 0;
                         if (wave_interior) {
                             nb1_load<true>(nb, L, src, c, sub);
-                            ok = decide32<true>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
+                            ok = wide ? decide64<true>(L, P, nb, c, sub, (tid & 32) != 0, step, luma, n_eval)
+                                      : decide32<true>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
                         } else {
                             nb1_load<false>(nb, L, src, c, sub);
-                            ok = decide32<false>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
+                            ok = wide ? decide64<false>(L, P, nb, c, sub, (tid & 32) != 0, step, luma, n_eval)
+                                      : decide32<false>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
                         }
-                        if (sub == 0)
+                        if (writer)
                             atomicAdd(&S.n_eval, n_eval);
-                        if (ok && sub == 0) {
+                        if (ok && writer) {
                             // commit_pixel_motion (morph.cu:990-1026), the pixel's own part, at once:
                             // nothing else of this phase reads its v, luma or ui.b (state 3)
                             const float2 ol = c.old_luma;
