@@ -9,7 +9,8 @@ sched = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ctx = morph.Context(0, capi.MATH_FAST)
 ctx.set_params(morph.KernParameters(morph.Parameters()))
 parts = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-ctx.set_tuning(sched, 0, parts)
+threads = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+ctx.set_tuning(sched, threads, parts)
 w, h = 1920, 1080
 pyrs = []
 for k in range(nb):
