@@ -178,6 +178,39 @@ def test_step_schedule_is_bit_identical_to_split_on_a_long_run(gpu_ctx):
     assert np.abs(_box5(luma[..., 0] * luma[..., 1]) - cross).max() < 4.0 * 25
 
 
+def test_wave_wide_line_search_is_bit_identical_to_the_32_lane_one(gpu_ctx):
+    """FAST, STEP schedule, 120x68 and 240x135 levels, 150 fixed-work iterations: with 32 workgroups
+    per tile a workgroup holds <= 8 candidates and every candidate gets a whole wave (decide64: two
+    line-search points per round, the next golden-section step speculated); with 2 workgroups per
+    tile the same candidates go through the 32-lane search.  Same bits, same counters -- the
+    speculation may only ever change the time."""
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    try:
+        for (w, h, cw, ch) in [(120, 68, 60, 34), (240, 135, 120, 68)]:
+            i0, i1 = synth.make_pair(w, h)
+            v0 = (0.9 * synth.displacement(w, h) + 0.05 * np.random.RandomState(3).randn(h, w, 2)).astype(np.float32)
+            out = []
+            for parts in (32, 2):
+                gpu_ctx.set_tuning(capi.SWEEP_STEP, 0, parts)
+                pyr = morph.Pyramid(gpu_ctx)
+                pyr.build_levels([(w, h), (cw, ch)])
+                pyr.upload_luma(1, i0, i1)
+                pyr[1].v = v0
+                capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+                pr = capi.Progress()
+                capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 150.0, None, 1, C.byref(pr)))
+                lv = pyr[1]
+                out.append(([lv.field(n).copy() for n in ("v", "luma", "mean", "var", "cross", "value", "tps_b", "impmask")],
+                            (pr.commits, pr.candidates, pr.evaluations)))
+            assert out[0][1] == out[1][1] and out[0][1][0] > 5000, out[0][1]
+            for a, b in zip(out[0][0], out[1][0]):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (w, h)
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+
+
 def _oracle_energy(i0, i1, v):
     """E = w_ssim E_ssim / (W H) + w_tps E_tps of a finest-level field (vmo_energy on the host)"""
     import oracle as O
