@@ -754,11 +754,11 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     // (16 workgroups of 16 candidates per tile while the chip has room for them; 8 of 32 when a
     // phase-step of the batch would otherwise need more than two full waves of workgroups --
     // measured on 8 x 120x68: 232 -> 217 ms per level; 4 x 64 is slower again)
-    // 32 on the smallest levels (FAST): with <= 8 candidates per workgroup k_step gives every
+    // 32 on the smallest levels: with <= 8 candidates per workgroup k_step gives every
     // candidate a whole wave and its line search takes two steps per round (decide64) --
     // 120x68: 107 -> 98.5 ms per 500 iterations; 240x135 (28 tiles) is better off at 16.
     const int parts = c->sweep_parts ? c->sweep_parts
-                                     : (tiles_per_pass * n * 16 >= 1024 ? 8 : (!exact && tiles_per_pass * n <= 12 ? 32 : 16));
+                                     : (tiles_per_pass * n * 16 >= 1024 ? 8 : (tiles_per_pass * n <= 12 ? 32 : 16));
     // Schedule, re-decided per batch of iterations (AUTO).  TILE: 4 launches per iteration, a
     // tile's four phases inside one workgroup -- unbeatable when a pass touches nothing (24 us
     // per converged iteration) or when there are enough tiles to fill the chip.  STEP (SPLIT

@@ -364,6 +364,14 @@ __device__ __forceinline__ bool pixel_locked(const VmLevelView &L, int bcond, in
     return false;
 }
 
+// both halves' values of a wave-uniform-per-half float: lo = lanes 0-31's, hi = lanes 32-63's
+__device__ __forceinline__ void halves(float v, float &lo, float &hi)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
 // optimize_pixel (morph.cu:1030-1083) after the mask test: gradient, fold-over bound,
 // golden-section search.  All L lanes of the pixel's group run it in lockstep and
 // agree bit for bit.  Returns true and the accepted step when the energy drops.
@@ -442,6 +450,98 @@ __device__ __forceinline__ bool decide_with(const VmLevelView &L, const VmKParam
     }
 #undef ENERGY
     VM_TS(7);
+    const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
+    if (!(fmin < 0))
+        return false;
+    step = make_float2(gx * tmin, gy * tmin);
+    return true;
+}
+
+// decide_with for a 32-lane energy and a whole wave per pixel: the two halves of the wave evaluate
+// two points of the line search at once -- +eps / -eps of a gradient axis, the two initial points
+// of the golden section, then per round the point the search needs now and the one it needs next
+// if the coming comparison repeats the last (the next point's position depends on that one bit
+// only).  Every evaluation that is USED is the one decide_with makes at that step, with the same
+// arguments: bit-identical results; n_eval counts the search's evaluations.  (The FAST lean path
+// has its own copy, decide64, which also carries the lumas along.)
+template <class Energy>
+__device__ __forceinline__ bool decide_with64(const VmLevelView &L, const VmKParams &P, const PixelCtx &c,
+                                              const Energy &energy, bool hi, float2 &step, uint32_t &n_eval)
+{
+    float gx = 0, gy = 0;
+    {
+        const float sgn = hi ? -1.0f : 1.0f;
+#pragma unroll 1
+        for (int r = 0; r < 2; ++r) {
+            const float e = energy(r == 0 ? sgn * P.eps : 0.0f, r == 0 ? 0.0f : sgn * P.eps) * sgn;
+            float e_lo, e_hi;
+            halves(e, e_lo, e_hi);
+            if (r == 0) {
+                gx += e_lo; // (0 + E+) + (-E-), as decide_with
+                gx += e_hi;
+            } else {
+                gy += e_lo;
+                gy += e_hi;
+            }
+        }
+        n_eval += 4;
+    }
+    gx = -gx;
+    gy = -gy;
+    const float ng = fsqrt(gx * gx + gy * gy);
+    if (ng == 0)
+        return false;
+    gx = fdiv(gx, ng);
+    gy = fdiv(gy, ng);
+    float t_min = 10;
+    fover_ring(L, c.px, c.py, -1.0f, -c.v.x, -c.v.y, -gx, -gy, t_min);
+    fover_ring(L, c.px, c.py, 1.0f, c.v.x, c.v.y, gx, gy, t_min);
+    float cc = fmaxf(t_min - P.eps, 0.0f);
+    const float R = 0.618033989f, C = 1.0f - R;
+    float a = 0;
+    float b = a * R + cc * C, x = b * R + cc * C;
+    float fb, fx;
+    {
+        const float t = hi ? x : b;
+        halves(energy(gx * t, gy * t), fb, fx);
+        n_eval += 2;
+    }
+#pragma unroll 1
+    for (;;) {
+        if (!(cc - a > P.eps))
+            break;
+        const bool lt = fx < fb;
+        // this step (decide_with: lt -> a = b, b = x, x = b R + cc C;  else cc = x, x = b R + a C, swap b, x)
+        const float a1 = lt ? b : a, cc1 = lt ? cc : x;
+        const float xn = lt ? x * R + cc * C : b * R + a * C;
+        const float b1 = lt ? x : xn, x1 = lt ? xn : b;
+        // the next one under the guess that the comparison repeats
+        const bool G = lt;
+        const float xn2 = G ? x1 * R + cc1 * C : b1 * R + a1 * C;
+        const float t = hi ? xn2 : xn;
+        float f1, f2;
+        halves(energy(gx * t, gy * t), f1, f2);
+        ++n_eval;
+        {
+            const float nfb = lt ? fx : f1, nfx = lt ? f1 : fb;
+            a = a1;
+            cc = cc1;
+            b = b1;
+            x = x1;
+            fb = nfb;
+            fx = nfx;
+        }
+        if (cc - a > P.eps && (fx < fb) == G) {
+            const float ob = b, ofb = fb;
+            a = G ? b : a;
+            cc = G ? cc : x;
+            b = G ? x : xn2;
+            x = G ? xn2 : ob;
+            fb = G ? fx : f2;
+            fx = G ? f2 : ofb;
+            ++n_eval;
+        }
+    }
     const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
     if (!(fmin < 0))
         return false;
@@ -828,14 +928,6 @@ __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &
     step = make_float2(gx * tmin, gy * tmin);
     luma = fx < fb ? lq : lb;
     return true;
-}
-
-// both halves' values of a wave-uniform-per-half float: lo = lanes 0-31's, hi = lanes 32-63's
-__device__ __forceinline__ void halves(float v, float &lo, float &hi)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    lo = __uint_as_float(r[0]);
-    hi = __uint_as_float(r[1]);
 }
 
 // decide32 with a whole wave per pixel: the line search is a chain of dependent energy
@@ -2243,11 +2335,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
         return;
     }
     // few candidates (the launch-bound small levels): a whole wave per pixel, decide64
-#if VM_EXACT
-    const bool wide = false;
-#else
     const bool wide = n_mine * 64 <= T;
-#endif
     const int slots = wide ? T / 64 : T / 32;
     const int sub = tid & 31, grp = wide ? tid >> 6 : tid >> 5;
     const bool writer = wide ? (tid & 63) == 0 : sub == 0;
@@ -2295,8 +2383,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
             nb.cr = cr;
             nb.val = val;
             nb.counter = okc ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
-            ok = decide_with(
-                L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step, n_eval VM_TS_PASS);
+            if (wide)
+                ok = decide_with64(
+                    L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, (tid & 32) != 0, step, n_eval);
+            else
+                ok = decide_with(
+                    L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step, n_eval VM_TS_PASS);
             if (ok) { // the lumas commit_pixel_motion samples (morph.cu:997-1003)
                 const float nvx = c.v.x + step.x, nvy = c.v.y + step.y;
                 luma.x = tap(L.img0, L.w, L.h, L.rs, px - nvx + 0.5f, py - nvy + 0.5f);
