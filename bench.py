@@ -474,8 +474,10 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         for l in range(len(levels) - 1):
             for t in range(levels[l][2]):
                 vid.upload_luma(l, t, *vp[pages[l][t]][l])
+        flows = synth.constant_flows(w, h, d)
+        vid.build_flows(*flows)                         # warm-up (scratch planes are allocated on first use)
         ctx.sync(); t1 = time.perf_counter()
-        vid.build_flows(*synth.constant_flows(w, h, d))
+        vid.build_flows(*flows)
         ctx.sync(); t_flow = time.perf_counter() - t1
         prm = morph.Parameters()
         prm.max_iter, prm.max_iter_drop_factor, prm.start_res = int(blk.max_iter), blk.max_iter_drop_factor, blk.start_res
