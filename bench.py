@@ -426,6 +426,8 @@ def workload_name(config, w, h, nlev, blk, B, args, world, pairs_this_rank):
 def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, B, solve, solve_group):
     """context numbers beside the headline (rank 0, one GPU): the other stopping rule, the other
     arithmetic, batched throughput, compositor stages"""
+    saved_kp = capi.KernParams()      # extras that bring their own Parameters put these back
+    capi.check(L.vm_get_params(ctx._h, C.byref(saved_kp)))
     extras = {}
     R = range(nlev - 1)
     ctx.sync(); t1 = time.perf_counter(); pr = solve(p, fixed=1 - FIXED); ctx.sync(); dt = time.perf_counter() - t1
@@ -493,6 +495,8 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         del vid
     except capi.VmError as e:
         extras["temporal_video_5_frames"] = {"error": str(e)[-160:]}
+    finally:
+        ctx.set_params(saved_kp)
     # the synchronisation stage that precedes the morph in the reference's app (CSyncThread +
     # render_resample_image, SURVEY 8(f) "(later)"): a 1080p x 60-frame pair, 24 constraints across
     # frames, the reference's iteration schedule (max_iter * 10 at the coarsest level, halved per
@@ -501,6 +505,8 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         extras["sync_stage_1080p_x60"] = sync_stage_extra(np, morph, ctx, w, h, 60, blk)
     except capi.VmError as e:
         extras["sync_stage_1080p_x60"] = {"error": str(e)[-160:]}
+    finally:
+        ctx.set_params(saved_kp)        # the sync stage runs with its own w_ui / w_tps
     # compositor: frames/s of render_halfway with device-resident inputs
     ex = int(0.1 * max(w, h))
     rgb0, rgb1 = synth.make_rgb_pair(w, h)
