@@ -263,7 +263,7 @@ typedef struct {
 /* the diagonal of A: the UI term, then the stencil's increments in genMatrix's order */
 void vmo_sync_diag(int w, int h, int d, float w_tps, const float *ui, float *diag)
 {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(vmo_get_threads()) schedule(static)
     for (int z = 0; z < d; ++z)
         for (int y = 0; y < h; ++y)
             for (int x = 0; x < w; ++x) {
@@ -305,7 +305,7 @@ void vmo_sync_apply(int w, int h, int d, float w_tps, const float *ui, const flo
 static inline __attribute__((always_inline)) void apply_body(const sync_sys *S, const float *p, float *out)
 {
     const int w = S->w, h = S->h, d = S->d;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(vmo_get_threads()) schedule(static)
     for (int z = 0; z < d; ++z)
         for (int y = 0; y < h; ++y)
             for (int x = 0; x < w; ++x) {
@@ -524,7 +524,7 @@ static void resample_side(int w, int h, int d, int frame, float sign, const floa
 {
     const size_t page = (size_t)w * h;
     const float alpha = 0.5f;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for num_threads(vmo_get_threads()) schedule(static)
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
             float q[3] = {(float)x, (float)y, (float)frame}, p[3], v[4], t[4];

@@ -259,3 +259,36 @@ def test_level_solve_at_the_1080p_x_60_level_size(gpu_ctx):
         assert np.array_equal(_bits(a[c]), _bits(b[c]))
         assert pra.resid[c] < 0.5 * pr.resid[c]
     assert pra.iters == 300 and pra.launches == 601
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_level_solve_fuzz(gpu_ctx, seed):
+    """random geometry (incl. levels thinner than a brick or a stencil), constraint sets (duplicates,
+    image corners, first / last frames), weights and iteration counts: bit-identical every time"""
+    rng = np.random.default_rng(1000 + seed)
+    w, h, d = int(rng.integers(1, 90)), int(rng.integers(1, 40)), int(rng.integers(1, 20))
+    if seed == 0:
+        w, h, d = 1, 1, 1
+    if seed == 1:
+        w, h, d = 2, 3, 2
+    w0, h0 = w * int(rng.integers(1, 4)), h * int(rng.integers(1, 4))
+    n = int(rng.integers(1, 12))
+    cons = []
+    for _ in range(n):
+        lx, ly, lz = int(rng.integers(0, w0)), int(rng.integers(0, h0)), int(rng.integers(0, d))
+        cons.append((lx, ly, lz, int(np.clip(lx + rng.integers(-5, 6), 0, w0 - 1)), int(np.clip(ly + rng.integers(-5, 6), 0, h0 - 1)),
+                     int(np.clip(lz + rng.integers(-2, 3), 0, d - 1))))
+    cons += cons[:2]  # duplicates accumulate in order
+    cons.append((0, 0, 0, w0 - 1, h0 - 1, d - 1))
+    iters = int(rng.integers(0, 40))
+    P = _params(w_ui=float(rng.choice([1.0, 100.0, 1e5])), w_tps=float(rng.choice([0.001, 0.05, 1.0])))
+    init = [rng.standard_normal((d, h, w)).astype(np.float32) for _ in range(3)] if seed % 2 else None
+    got, pr, _ = _level_solve(gpu_ctx, [(w0, h0, d), (w, h, d)], 1, cons, P, iters, init=init)
+    want = [a.copy() for a in init] if init is not None else [np.zeros((d, h, w), np.float32) for _ in range(3)]
+    k, res = oracle.sync_solve_level(want[0], want[1], want[2], w0, h0, cons, P.w_ui, P.w_tps, float(iters))
+    assert pr.iters == k
+    for c in range(3):
+        assert np.array_equal(_bits(got[c]), _bits(want[c])), (seed, (w, h, d), c, np.abs(got[c] - want[c]).max())
+    a, b = np.array(pr.resid[:], np.float32), res
+    assert np.array_equal(_bits(a), _bits(b)) or (np.isnan(a) == np.isnan(b)).all()
