@@ -630,6 +630,16 @@ __device__ __forceinline__ bool decide_x32(const VmLevelView &L, const VmKParams
     return decide_with(
         L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step, n_eval VM_TS_PASS);
 }
+// ... with a whole wave per pixel (both halves hold the same neighbour sums)
+template <class Src>
+__device__ __forceinline__ bool decide_x64(const VmLevelView &L, const VmKParams &P, const Src &src,
+                                           const PixelCtx &c, int sub, bool hi, float2 &step, uint32_t &n_eval)
+{
+    NbX nb;
+    nbx_load(nb, L, src, c, sub);
+    return decide_with64(
+        L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, hi, step, n_eval);
+}
 #endif
 
 #if !VM_EXACT
@@ -1397,9 +1407,12 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 } else
 #else
                 if (n_act * 32 <= 4 * T) {
-                    // up to four rounds of T / 32 candidates on 32 lanes each (decide_x32)
-                    for (int base = 0; base < n_act; base += T / 32) {
-                        const int li = base + (tid >> 5), sub = tid & 31;
+                    // up to four rounds of T / 32 candidates on 32 lanes each (decide_x32); up to
+                    // T / 64 candidates get a whole wave each (decide_x64)
+                    const bool wide = n_act * 64 <= T;
+                    for (int base = 0; base < n_act; base += wide ? T / 64 : T / 32) {
+                        const int li = base + (wide ? tid >> 6 : tid >> 5), sub = tid & 31;
+                        const bool writer = wide ? (tid & 63) == 0 : sub == 0;
                         const int slot = S.list[min(li, n_act - 1)];
                         const int tx = slot & 31, ty = slot >> 5;
                         const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
@@ -1413,10 +1426,11 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                             unsigned long long ts[16];
 #endif
                             uint32_t n_eval = 0;
-                            const bool ok = decide_x32(L, P, src, c, sub, step, n_eval VM_TS_PASS);
-                            if (sub == 0)
+                            const bool ok = wide ? decide_x64(L, P, src, c, sub, (tid & 32) != 0, step, n_eval)
+                                                 : decide_x32(L, P, src, c, sub, step, n_eval VM_TS_PASS);
+                            if (writer)
                                 atomicAdd(&S.n_eval, n_eval);
-                            if (ok && sub == 0) {
+                            if (ok && writer) {
                                 S.d_step[slot] = step;
                                 S.d_ok[slot] = 1;
                             }
