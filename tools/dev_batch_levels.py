@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from videomorphing_amd import capi, morph, synth
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 sched = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-ctx = morph.Context(0, capi.MATH_FAST)
+ctx = morph.Context(0, capi.MATH_EXACT if os.environ.get("VM_DEV_EXACT") else capi.MATH_FAST)
 ctx.set_params(morph.KernParameters(morph.Parameters()))
 parts = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 threads = int(sys.argv[4]) if len(sys.argv) > 4 else 0
