@@ -192,6 +192,45 @@ def test_video_solve_exact(gpu_ctx, oracle):
     assert prog[2].iters >= 1 and prog[2].elapsed_ms > 0
 
 
+def test_video_solve_level_pipeline_exact(gpu_ctx, oracle):
+    """levels that hold the same frames are pipelined by vm_video_solve (page p of level l starts as
+    soon as page p of level l + 1 and its chain neighbour on level l are done, on parallel lanes):
+    bit-identical to the oracle's level-by-level walk and to the driver with the pipeline off"""
+    import os
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    P = _kp(gpu_ctx, oracle, w_temp=10.0)
+    levels = [(96, 64, 5), (48, 32, 5), (24, 16, 5), (12, 8, 5)]
+    vid, dev = _make(oracle, gpu_ctx, levels, seed=33)
+    cons = np.float32([[30, 20, 33, 21, 1.0, 0], [60, 40, 58, 41, 1.0, 2], [20, 50, 22, 48, 0.8, 4]])
+    carr, n = morph._vcons_array(cons)
+    L = dev._L
+    capi.check(L.vm_video_coarse_solve(dev._h, carr, n))
+    coarse = [dev.pages[3][t].v.copy() for t in range(5)]
+    # the oracle, level by level, from the device's coarse solution
+    for t in range(5):
+        vid.pages[3][t].field("v")[...] = coarse[t]
+    for el in (2, 1, 0):
+        vid.upsample(el)
+        vid.init_level(el, P, cons)
+        vid.optimize_level(el, P, 8.0)
+    results = {}
+    for mode in ("pipeline", "sequential"):
+        if mode == "sequential":
+            os.environ["VM_NO_VIDEO_PIPELINE"] = "1"
+        try:
+            prog = (capi.Progress * 15)()
+            capi.check(L.vm_video_solve(dev._h, 8.0, 1.0, carr, n, None, 0, prog))
+        finally:
+            os.environ.pop("VM_NO_VIDEO_PIPELINE", None)
+        results[mode] = ([[dev.pages[el][t].v.copy() for t in range(5)] for el in range(3)], [prog[k].iters for k in range(15)])
+    for el in range(3):
+        for t in range(5):
+            assert np.array_equal(_bits(results["pipeline"][0][el][t]), _bits(vid.pages[el][t].field("v"))), (el, t)
+            assert np.array_equal(_bits(results["pipeline"][0][el][t]), _bits(results["sequential"][0][el][t])), (el, t)
+    assert results["pipeline"][1] == results["sequential"][1] and min(results["pipeline"][1]) >= 1
+    assert max(np.abs(v).max() for v in results["pipeline"][0][0]) > 0.2
+
+
 def test_video_solve_fast_tolerance(gpu_ctx, oracle):
     """FAST arithmetic over a coupled video solve: the tolerance of the frame-pair path
     (tests/test_gpu_parity.py: RMS <= 0.05 px, >= 99 % of pixels within 0.25 px) per page"""

@@ -113,6 +113,14 @@ struct vm_video_page {
 
 // The stage-2 pyramid of a video pair (class Pyramid with depth > 1, Pyramid.h:14-48):
 // level l holds depth[l] pages; level 0 finest, the last level holds only v.
+// A lane of the level pipeline of vm_video_solve: its own stream and sweep scratch (a context of
+// its own on the same device) and its own splat accumulators, so that independent (level, chain
+// step) tasks can run side by side (vm_video.cpp).
+struct vm_video_lane {
+    vm_ctx *c = nullptr;
+    long long *acc = nullptr;
+};
+
 struct vm_video {
     vm_ctx *ctx = nullptr;
     int depth0 = 1;                       // frames of the video (the placeholder level's depth)
@@ -125,6 +133,7 @@ struct vm_video {
     long long *acc = nullptr;
     float2 *vcur = nullptr;
     float *weight = nullptr;
+    std::vector<vm_video_lane> lanes;     // created by the first pipelined solve
 };
 
 struct vm_frame {

@@ -14,6 +14,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <string>
+#include <thread>
 #include <vector>
 
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -109,6 +112,10 @@ extern "C" void vm_video_destroy(vm_video *v)
             hipFree(pg.tslab);
         }
     hipFree(v->acc); hipFree(v->vcur); hipFree(v->weight);
+    for (vm_video_lane &ln : v->lanes) {
+        hipFree(ln.acc);
+        if (ln.c) vm_ctx_destroy(ln.c);
+    }
     delete v;
 }
 
@@ -367,6 +374,116 @@ extern "C" int vm_video_optimize_level(vm_video *v, int lvl, float max_iter, vol
     return VM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Level pipeline.  The reference finishes a level (middle page, then the chain outward) before it
+// touches the next finer one.  But page p of level l needs only (i) page p of level l + 1 -- its
+// own coarser solution, when both levels hold the same frames -- and (ii) its chain neighbour on
+// level l.  So the tasks T(l, k) = "pages mid +- k of level l" form a grid whose anti-diagonals are
+// independent: while the chain of the coarsest level is still walking outward (its 8000 dependent
+// launch-bound steps per page are what a video solve waits for), the pages it has finished are
+// already being solved on the finer levels, on other streams.  Same arithmetic per page, hence the
+// same bits; about (levels + chain - 1) task slots instead of levels x chain.
+
+static int ensure_lanes(vm_video *v, int n)
+{
+    vm_ctx *p = v->ctx;
+    const vm_level &l0 = v->pages[0][0].lv;
+    const size_t np = (size_t)l0.rs * l0.h;
+    while ((int)v->lanes.size() < n) {
+        vm_video_lane ln;
+        int rc = vm_ctx_create(p->device, &ln.c);
+        if (rc != VM_OK) return rc;
+        if (hipMalloc((void **)&ln.acc, np * 3 * sizeof(long long)) != hipSuccess) {
+            vm_ctx_destroy(ln.c);
+            return vm_fail(VM_E_DEVICE, "vm_video_solve: out of device memory (pipeline lane)");
+        }
+        // Lane 0 always runs the coarsest level in flight -- the chain of launch-bound steps the
+        // whole solve waits for -- so its stream gets the highest priority: a finer level's
+        // chip-filling dense kernel on another lane must not sit in front of those launches.
+        {
+            int least = 0, greatest = 0;
+            hipStream_t ps = nullptr;
+            const int j = (int)v->lanes.size();
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
+                hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, std::min(greatest + j, least)) == hipSuccess) {
+                (void)hipStreamDestroy(ln.c->stream);
+                ln.c->stream = ps;
+            }
+        }
+        v->lanes.push_back(ln);
+    }
+    for (vm_video_lane &ln : v->lanes) { // the solver settings of the video's context, as they are now
+        ln.c->kp = p->kp;
+        ln.c->math_mode = p->math_mode;
+        ln.c->sweep_threads = p->sweep_threads;
+        ln.c->sweep_mode = p->sweep_mode;
+        ln.c->sweep_parts = p->sweep_parts;
+        ln.c->commit_reversed = p->commit_reversed;
+    }
+    return VM_OK;
+}
+
+// T(el, k): upsample + initialize_level of the task's pages, initialize_temp against their chain
+// neighbours (k > 0), the sweeps.  Runs on the lane's stream; everything is complete on return.
+static int video_task(vm_video *v, vm_video_lane &ln, int el, int k, float max_iter, const vm_video_constraint *cons,
+                      int n, volatile const int *run_flag, int fixed_work, vm_progress *out)
+{
+    vm_ctx *c = ln.c;
+    VM_ON_DEVICE(c);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    hipStream_t s = c->stream;
+    const int d = v->depth[el], mid = d / 2;
+    const int w0 = v->pages[0][0].lv.w, h0 = v->pages[0][0].lv.h;
+    int idx[2], dir[2], m = 0;
+    if (k == 0) {
+        idx[m] = mid; dir[m++] = 0;
+    } else {
+        if (mid + k < d) { idx[m] = mid + k; dir[m++] = -1; }
+        if (mid - k >= 0) { idx[m] = mid - k; dir[m++] = +1; }
+    }
+    if (m == 0) return VM_OK;
+    vm_level *pair[2];
+    int rc;
+    for (int i = 0; i < m; ++i) {
+        vm_video_page &pg = v->pages[el][idx[i]];
+        vm_level &l = pg.lv;
+        const size_t np = (size_t)l.rs * l.h;
+        VM_HIP(hipMemsetAsync(l.view.v, 0, np * 8, s)); // upsample(): dest.v.fill(0)
+        if ((rc = vm_level_upsample(c, l, v->pages[el + 1][idx[i]].lv)) != VM_OK) return rc;
+        std::vector<vm_constraint> pc = page_constraints(v, el, idx[i], cons, n);
+        if ((rc = vm_level_init(c, l, w0, h0, pc.data(), (int)pc.size())) != VM_OK) return rc;
+        VM_HIP(hipMemsetAsync(pg.temp_ref, 0, np * 8, s));
+        VM_HIP(hipMemsetAsync(pg.temp_mask, 0, np * 4, s));
+        l.view.temp_ref = nullptr;
+        l.view.temp_mask = nullptr;
+        l.view.factor_d = v->factor_d[el];
+        if (dir[i] != 0) { // initialize_temp(lvl, page, dir), upsample.cu:214-258
+            const vm_video_page &src = v->pages[el][idx[i] + dir[i]];
+            VM_HIP(hipMemsetAsync(ln.acc, 0, np * 3 * sizeof(long long), s));
+            vm_temp_launch_splat(src.lv.w, src.lv.h, src.lv.rs, src.lv.view.v, dir[i] < 0 ? src.flow[0] : src.flow[2],
+                                 dir[i] < 0 ? src.flow[1] : src.flow[3], src.lv.view.value, ln.acc, s);
+            vm_temp_launch_finish(l.w, l.h, l.rs, ln.acc, pg.temp_ref, pg.temp_mask, 1, s);
+            VM_HIP(hipGetLastError());
+            l.view.temp_ref = pg.temp_ref;
+            l.view.temp_mask = pg.temp_mask;
+        }
+        pair[i] = &l;
+    }
+    vm_progress pr[2] = {};
+    if ((rc = vm_optimize_levels(c, pair, m, max_iter, run_flag, fixed_work, pr)) != VM_OK) return rc;
+    VM_HIP(hipStreamSynchronize(s));
+    if (out)
+        for (int i = 0; i < m; ++i) {
+            out[idx[i]] = pr[i];
+            if (i > 0) { // time and launches belong to the batch: count them once
+                out[idx[i]].elapsed_ms = 0;
+                out[idx[i]].launches = 0;
+                for (int q = 0; q < 4; ++q) { out[idx[i]].sched_ms[q] = 0; out[idx[i]].sched_launches[q] = 0; }
+            }
+        }
+    return VM_OK;
+}
+
 // Morph::calculate_halfway_parametrization, morph.cu:150-168.  per_page (may be NULL):
 // sum over the levels with images of depth[l] entries, level-major (finest first), page-minor.
 extern "C" int vm_video_solve(vm_video *v, float max_iter, float drop, const vm_video_constraint *cons, int n,
@@ -381,13 +498,44 @@ extern "C" int vm_video_solve(vm_video *v, float max_iter, float drop, const vm_
     if (rc != VM_OK) return rc;
     std::vector<size_t> off(L, 0);
     for (int l = 1; l < L; ++l) off[l] = off[l - 1] + v->depth[l - 1];
+    // the finest levels that hold the same frames as the level above them can be pipelined:
+    // E = the coarsest of them (levels E..0); -1 = none
+    int E = -1;
+    if (!getenv("VM_NO_VIDEO_PIPELINE") && v->depth[0] > 1)
+        while (E + 1 <= L - 2 && v->depth[E + 1] == v->depth[E + 2]) ++E;
+    if (E < 1) E = -1; // a single level has nothing to overlap with
     float mi = max_iter;
+    std::vector<float> mi_of(L, max_iter);
     for (int el = L - 2; el >= 0; --el) {
+        mi_of[el] = mi;
+        mi /= drop;
+    }
+    for (int el = L - 2; el > E; --el) { // level by level, as the reference walks them
         if (run_flag && !*run_flag) return vm_fail(VM_E_CANCELLED, "vm_video_solve: cancelled by run_flag");
         if ((rc = vm_video_upsample(v, el)) != VM_OK) return rc;
         if ((rc = vm_video_init_level(v, el, cons, n)) != VM_OK) return rc;
-        if ((rc = vm_video_optimize_level(v, el, mi, run_flag, fixed_work, per_page ? per_page + off[el] : nullptr)) != VM_OK) return rc;
-        mi /= drop;
+        if ((rc = vm_video_optimize_level(v, el, mi_of[el], run_flag, fixed_work, per_page ? per_page + off[el] : nullptr)) != VM_OK) return rc;
+    }
+    if (E < 0) return VM_OK;
+    VM_HIP(hipStreamSynchronize(v->ctx->stream));
+    const int A = E + 1, d = v->depth[0], mid = d / 2, K = std::max(mid, d - 1 - mid);
+    if ((rc = ensure_lanes(v, std::min(A, K + 1))) != VM_OK) return rc;
+    for (int sdiag = 0; sdiag <= (A - 1) + K; ++sdiag) {
+        if (run_flag && !*run_flag) return vm_fail(VM_E_CANCELLED, "vm_video_solve: cancelled by run_flag");
+        struct Job { int el, k, rc; std::string err; };
+        std::vector<Job> jobs;
+        for (int a = std::max(0, sdiag - K); a <= std::min(A - 1, sdiag); ++a) jobs.push_back({E - a, sdiag - a, VM_OK, {}});
+        std::vector<std::thread> th;
+        for (size_t j = 0; j < jobs.size(); ++j)
+            th.emplace_back([&, j] {
+                Job &jb = jobs[j];
+                jb.rc = video_task(v, v->lanes[j], jb.el, jb.k, mi_of[jb.el], cons, n, run_flag, fixed_work,
+                                   per_page ? per_page + off[jb.el] : nullptr);
+                if (jb.rc != VM_OK) jb.err = vm_last_error();
+            });
+        for (std::thread &t : th) t.join();
+        for (const Job &jb : jobs)
+            if (jb.rc != VM_OK) return vm_fail(jb.rc, "%s", jb.err.c_str());
     }
     return VM_OK;
 }
