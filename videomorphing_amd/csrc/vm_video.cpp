@@ -100,6 +100,16 @@ extern "C" int vm_video_create(vm_ctx *c, int nlevels, const int *w, const int *
 extern "C" void vm_video_destroy(vm_video *v)
 {
     if (!v) return;
+    for (vm_video_lane &ln : v->lanes) // the pipeline's lanes are contexts of their own
+        if (ln.c && vm_ctx_alive(ln.c)) {
+            {
+                VM_ON_DEVICE(ln.c);
+                hipStreamSynchronize(ln.c->stream);
+                hipFree(ln.acc);
+            }
+            vm_ctx_destroy(ln.c);
+        }
+    v->lanes.clear();
     if (!vm_ctx_alive(v->ctx)) { // destroyed after its context (vm_api.cpp)
         delete v;
         return;
@@ -112,10 +122,6 @@ extern "C" void vm_video_destroy(vm_video *v)
             hipFree(pg.tslab);
         }
     hipFree(v->acc); hipFree(v->vcur); hipFree(v->weight);
-    for (vm_video_lane &ln : v->lanes) {
-        hipFree(ln.acc);
-        if (ln.c) vm_ctx_destroy(ln.c);
-    }
     delete v;
 }
 
