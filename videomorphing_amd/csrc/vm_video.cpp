@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -526,22 +528,64 @@ extern "C" int vm_video_solve(vm_video *v, float max_iter, float drop, const vm_
     VM_HIP(hipStreamSynchronize(v->ctx->stream));
     const int A = E + 1, d = v->depth[0], mid = d / 2, K = std::max(mid, d - 1 - mid);
     if ((rc = ensure_lanes(v, std::min(A, K + 1))) != VM_OK) return rc;
-    for (int sdiag = 0; sdiag <= (A - 1) + K; ++sdiag) {
-        if (run_flag && !*run_flag) return vm_fail(VM_E_CANCELLED, "vm_video_solve: cancelled by run_flag");
-        struct Job { int el, k, rc; std::string err; };
-        std::vector<Job> jobs;
-        for (int a = std::max(0, sdiag - K); a <= std::min(A - 1, sdiag); ++a) jobs.push_back({E - a, sdiag - a, VM_OK, {}});
-        std::vector<std::thread> th;
-        for (size_t j = 0; j < jobs.size(); ++j)
-            th.emplace_back([&, j] {
-                Job &jb = jobs[j];
-                jb.rc = video_task(v, v->lanes[j], jb.el, jb.k, mi_of[jb.el], cons, n, run_flag, fixed_work,
-                                   per_page ? per_page + off[jb.el] : nullptr);
-                if (jb.rc != VM_OK) jb.err = vm_last_error();
-            });
-        for (std::thread &t : th) t.join();
-        for (const Job &jb : jobs)
-            if (jb.rc != VM_OK) return vm_fail(jb.rc, "%s", jb.err.c_str());
-    }
+    // Dataflow over the task grid: T(a, k) (a = 0: the coarsest pipelined level, k = chain step) is
+    // ready once T(a - 1, k) and T(a, k - 1) are done.  One worker per lane; lane 0 (highest stream
+    // priority) is reserved for the coarsest level's chain, the critical path; the others take the
+    // ready task of the coarsest level first.
+    struct Task { int deps; bool done; };
+    std::vector<Task> tasks((size_t)A * (K + 1));
+    auto T = [&](int a_, int k_) -> Task & { return tasks[(size_t)a_ * (K + 1) + k_]; };
+    for (int a_ = 0; a_ < A; ++a_)
+        for (int k_ = 0; k_ <= K; ++k_) T(a_, k_) = {(a_ > 0) + (k_ > 0), false};
+    std::mutex mu;
+    std::condition_variable cv;
+    int remaining = A * (K + 1), failed_rc = VM_OK;
+    std::string failed_msg;
+    const int nl = std::min(A, K + 1);
+    auto worker = [&](int lane) {
+        for (;;) {
+            int ta = -1, tk = -1;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    if (remaining == 0 || failed_rc != VM_OK) return;
+                    // lane 0: only the coarsest level; other lanes: everything else (all of it when there is one lane)
+                    for (int a_ = (lane == 0 || nl == 1) ? 0 : 1; a_ < ((lane == 0 && nl > 1) ? 1 : A) && ta < 0; ++a_)
+                        for (int k_ = 0; k_ <= K; ++k_)
+                            if (!T(a_, k_).done && T(a_, k_).deps == 0) { ta = a_; tk = k_; break; }
+                    if (ta >= 0) break;
+                    // nothing ready for this lane: is anything left that it could ever take?
+                    bool mine_left = false;
+                    for (int a_ = (lane == 0 || nl == 1) ? 0 : 1; a_ < ((lane == 0 && nl > 1) ? 1 : A); ++a_)
+                        for (int k_ = 0; k_ <= K; ++k_) mine_left = mine_left || !T(a_, k_).done;
+                    if (!mine_left) return;
+                    cv.wait(lk);
+                }
+                T(ta, tk).deps = -1; // taken
+            }
+            const int el = E - ta;
+            int trc = VM_OK;
+            std::string msg;
+            if (run_flag && !*run_flag)
+                trc = VM_E_CANCELLED, msg = "vm_video_solve: cancelled by run_flag";
+            else {
+                trc = video_task(v, v->lanes[lane], el, tk, mi_of[el], cons, n, run_flag, fixed_work, per_page ? per_page + off[el] : nullptr);
+                if (trc != VM_OK) msg = vm_last_error();
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                T(ta, tk).done = true;
+                --remaining;
+                if (trc != VM_OK && failed_rc == VM_OK) { failed_rc = trc; failed_msg = msg; }
+                if (ta + 1 < A) --T(ta + 1, tk).deps;
+                if (tk + 1 <= K) --T(ta, tk + 1).deps;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> th;
+    for (int lane = 0; lane < nl; ++lane) th.emplace_back(worker, lane);
+    for (std::thread &t : th) t.join();
+    if (failed_rc != VM_OK) return vm_fail(failed_rc, "%s", failed_msg.c_str());
     return VM_OK;
 }
