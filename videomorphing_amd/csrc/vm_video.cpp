@@ -543,21 +543,21 @@ extern "C" int vm_video_solve(vm_video *v, float max_iter, float drop, const vm_
     std::string failed_msg;
     const int nl = std::min(A, K + 1);
     auto worker = [&](int lane) {
+        // lane 0 takes only the coarsest level, the other lanes everything else (one lane: all of it)
+        const int a_lo = (lane == 0 || nl == 1) ? 0 : 1, a_hi = (lane == 0 && nl > 1) ? 1 : A;
         for (;;) {
             int ta = -1, tk = -1;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
                     if (remaining == 0 || failed_rc != VM_OK) return;
-                    // lane 0: only the coarsest level; other lanes: everything else (all of it when there is one lane)
-                    for (int a_ = (lane == 0 || nl == 1) ? 0 : 1; a_ < ((lane == 0 && nl > 1) ? 1 : A) && ta < 0; ++a_)
-                        for (int k_ = 0; k_ <= K; ++k_)
-                            if (!T(a_, k_).done && T(a_, k_).deps == 0) { ta = a_; tk = k_; break; }
+                    bool mine_left = false; // anything this lane could still take, now or later?
+                    for (int a_ = a_lo; a_ < a_hi && ta < 0; ++a_)
+                        for (int k_ = 0; k_ <= K && ta < 0; ++k_) {
+                            mine_left = mine_left || !T(a_, k_).done;
+                            if (!T(a_, k_).done && T(a_, k_).deps == 0) { ta = a_; tk = k_; }
+                        }
                     if (ta >= 0) break;
-                    // nothing ready for this lane: is anything left that it could ever take?
-                    bool mine_left = false;
-                    for (int a_ = (lane == 0 || nl == 1) ? 0 : 1; a_ < ((lane == 0 && nl > 1) ? 1 : A); ++a_)
-                        for (int k_ = 0; k_ <= K; ++k_) mine_left = mine_left || !T(a_, k_).done;
                     if (!mine_left) return;
                     cv.wait(lk);
                 }
