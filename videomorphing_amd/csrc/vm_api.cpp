@@ -5,6 +5,12 @@
 #include "vm_internal.h"
 #include "vm_host.h"
 
+#ifndef VM_STEP_MAX_TILES
+#define VM_STEP_MAX_TILES 64 // AUTO: levels of a batch with at most this many tiles per pass may run STEP
+#endif
+#ifndef VM_STEP_BIG_PARTS
+#define VM_STEP_BIG_PARTS 8
+#endif
 #ifndef VM_SPARSE_TILES
 #define VM_SPARSE_TILES 12 // SPARSE takes a pruned level over once <= this many tiles per iteration were active
 #endif
@@ -729,7 +735,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         // are copied to the device
         const int tiles0 = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
         if (c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP ||
-            (c->sweep_mode == VM_SWEEP_AUTO && tiles0 * n <= 64))
+            (c->sweep_mode == VM_SWEEP_AUTO && tiles0 * n <= VM_STEP_MAX_TILES))
             for (int i = 0; i < n; ++i) {
                 int rc = level_ensure_ws(c, *lv[i]);
                 if (rc != VM_OK) return rc;
@@ -762,7 +768,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     // candidate a whole wave and its line search takes two steps per round (decide64) --
     // 120x68: 107 -> 98.5 ms per 500 iterations; 240x135 (28 tiles) is better off at 16.
     const int parts = c->sweep_parts ? c->sweep_parts
-                                     : (tiles_per_pass * n * 16 >= 1024 ? 8 : (tiles_per_pass * n <= 12 ? 32 : 16));
+                                     : (tiles_per_pass * n * 16 >= 1024 ? (tiles_per_pass * n > 64 ? VM_STEP_BIG_PARTS : 8) : (tiles_per_pass * n <= 12 ? 32 : 16));
     // Schedule, re-decided per batch of iterations (AUTO).  TILE: 4 launches per iteration, a
     // tile's four phases inside one workgroup -- unbeatable when a pass touches nothing (24 us
     // per converged iteration) or when there are enough tiles to fill the chip.  STEP (SPLIT
@@ -771,7 +777,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     // 0.32 (STEP) vs 0.64 ms (TILE) per iteration; 240x135 with 900 line searches per
     // iteration 0.22 vs 0.36; with 90: 0.24 vs 0.23; converged 0.08 vs 0.024.  All schedules
     // work on the same state in HBM, so the choice can change from batch to batch.
-    const bool may_split = c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= 64;
+    const bool may_split = c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= VM_STEP_MAX_TILES;
     double cand_prev = 1e9; // line searches per iteration in the previous batch (first batch: dense)
     double tiles_prev = 1e9; // active tile visits per iteration and pair in the previous batch
     if (may_split || c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP) // epochs restart with every call: forget old records
