@@ -44,8 +44,12 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_FLOPS = 157e12         # MI355X_MICROARCH.md: f32 vector peak
 SCHED = ("k_optimize<true> (TILE schedule, dense kernel)", "k_optimize<false> (TILE schedule, lean kernel for pruned sweeps)",
          "k_step (STEP schedule, one launch per phase)",
-         "k_sparse (SPARSE schedule: one launch per batch of iterations of a pruned level)")
-SCHED_PMC = ("k_optimize_fast<true>", "k_optimize_fast<false>", "k_step_fast<512>", "k_sparse_fast<false>")
+         "k_sparse (SPARSE schedule: one launch per batch of iterations of a pruned level)",
+         "k_pass (PASS schedule: one launch per pass, the four phases of a tile behind tile-local barriers)")
+SCHED_PMC = ("k_optimize_fast<true>", "k_optimize_fast<false>", "k_step_fast<512>", "k_sparse_fast<false>", "k_pass_fast")
+NSCHED = 5
+# launches per iteration of each schedule (a SPARSE launch covers a batch of iterations)
+SCHED_LAUNCHES_PER_ITER = (4.0, 4.0, 16.0, None, 4.0)
 
 
 def tile_visits(w, h):
@@ -205,7 +209,7 @@ def main():
             if i > 0:          # elapsed/launches are per batch: count them once
                 for k in range(nlev - 1):
                     one[k].elapsed_ms, one[k].launches = 0.0, 0
-                    for j in range(4):
+                    for j in range(NSCHED):
                         one[k].sched_ms[j], one[k].sched_launches[j] = 0.0, 0
             out.append(one)
         return out
@@ -275,10 +279,13 @@ def main():
 
     R = range(nlev - 1)
     pix_iters = sum(pr[i].pixel_iters for pr in progs for i in R)
+    # ... of which executed: iterations up to and including a level's first without an accepted
+    # move (what the reference's loop runs); the rest of a fixed-work level are skipped no-ops
+    pix_live = sum(float(pr[i].iters_live) * sizes[i][0] * sizes[i][1] for pr in progs for i in R)
     if world > 1:
-        el_max, pix_total = vdist.reduce_report(el, pix_iters, coll_dev)
+        el_max, pix_total, pix_live_total = vdist.reduce_report(el, pix_iters, coll_dev, pix_live)
     else:
-        el_max, pix_total = el, pix_iters
+        el_max, pix_total, pix_live_total = el, pix_iters, pix_live
 
     extras = {}
     if rank == 0 and not args.no_extras and config != 2:
@@ -286,11 +293,11 @@ def main():
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(np, capi, L, blk, pyrs[0], nlev)
+        cpu = cpu_baseline(np, capi, L, blk, pyrs[0], nlev, ctx)
 
     if rank == 0:
         out = report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, progs, step_ms, el_max, pix_total,
-                     cpu, distinct_frames, len(pyrs) if config == 2 else None)
+                     cpu, distinct_frames, len(pyrs) if config == 2 else None, pix_live_total)
         out.update(extras)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -298,8 +305,24 @@ def main():
         dist.destroy_process_group()
 
 
+def load_pmc(config, pairs_per_launch):
+    """HBM bytes per launch of the sweep kernels from the committed PMC profile of THIS workload
+    shape (config, pairs per launch); counters need rocprofv3, so they are never of this run.
+    No matching entry: no PMC figures (a figure taken at another batch size would be wrong)."""
+    tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        tj = json.load(open(tp))
+    except Exception:
+        return {}, None
+    for e in tj.get("entries", []):
+        if e.get("config") == config and e.get("pairs_per_launch") == pairs_per_launch:
+            return e.get("per_kernel", {}) or {}, "profiles/traffic_latest.json[config %d, %d pair(s) per launch]: %s" % (
+                config, pairs_per_launch, e.get("source", "")[:200])
+    return {}, None
+
+
 def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, progs, step_ms, el_max, pix_total, cpu,
-           distinct_frames, pairs_this_rank):
+           distinct_frames, pairs_this_rank, pix_live_total):
     R = range(nlev - 1)
     nsolve = max(len(progs), 1)
     kern_ms = sum(pr[i].elapsed_ms for pr in progs for i in R)
@@ -314,42 +337,31 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
     evals = sum(pr[i].evaluations for pr in progs for i in R)
     alg_executed = active_tiles * 64 * 16 * ALG_BYTES_PER_VISIT
     achieved = alg_nominal / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    # ---- HBM traffic per launch from the PMC passes of the committed profile (not of this run:
-    # counters need rocprofv3)
-    traffic, traffic_src, pmc_k = None, None, {}
-    for name in ("traffic_latest.json",):
-        tp = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/%s (%s)" % (name, tj.get("source", "")[:160])
-                pmc_k = tj.get("per_kernel", {}) or {}
-            except Exception:
-                traffic = None
+    # ---- HBM traffic per launch from the PMC passes of the committed profile of this workload
+    # shape (not of this run: counters need rocprofv3)
+    pmc_k, traffic_src = load_pmc(config, B)
     # ---- per kernel: launches, average duration (HIP events around each batch of launches on
     # the context's stream), algorithmic bytes per launch, nominal and real fraction of HBM peak
     per_kernel = []
-    for k in range(4):
+    for k in range(NSCHED):
         ms = sum(pr[i].sched_ms[k] for pr in progs for i in R)
         n = sum(pr[i].sched_launches[k] for pr in progs for i in R)
         if n == 0:
             continue
-        # one TILE launch = one pass over the level (a quarter of an iteration's visits) of every
-        # pair of the batch; one STEP launch = one phase of one pass (a sixteenth); a SPARSE
+        # one TILE or PASS launch = one pass over the level (a quarter of an iteration's visits) of
+        # every pair of the batch; one STEP launch = one phase of one pass (a sixteenth); a SPARSE
         # launch covers a whole batch of iterations: its nominal bytes are those of the iterations
-        # it executed (sched_iters is not recorded: the level's executed iterations minus what the
-        # other schedules' launches account for)
-        share = 16.0 if k == 2 else 4.0
+        # it executed (the level's executed iterations minus what the other schedules account for)
         nbytes = 0.0
         for pr_i, pr in enumerate(progs):
             for i in R:
                 if pr[i].sched_launches[k]:
                     # launches are recorded once per batch (first pair); the batch's other pairs add their visits
                     if k == 3:
-                        others = pr[i].sched_launches[0] / 4.0 + pr[i].sched_launches[1] / 4.0 + pr[i].sched_launches[2] / 16.0
-                        nbytes += max(pr[i].iters - others, 0.0) * tile_visits(*sizes[i]) * ALG_BYTES_PER_VISIT * B
+                        others = sum(pr[i].sched_launches[j] / SCHED_LAUNCHES_PER_ITER[j] for j in range(NSCHED) if j != 3)
+                        nbytes += max(pr[i].iters_live - others, 0.0) * tile_visits(*sizes[i]) * ALG_BYTES_PER_VISIT * B
                     else:
-                        nbytes += pr[i].sched_launches[k] * tile_visits(*sizes[i]) / share * ALG_BYTES_PER_VISIT * B
+                        nbytes += pr[i].sched_launches[k] * tile_visits(*sizes[i]) / SCHED_LAUNCHES_PER_ITER[k] * ALG_BYTES_PER_VISIT * B
         avg_us = ms * 1e3 / n
         ent = {"kernel": SCHED[k], "launches": n, "avg_us": round(avg_us, 2), "share_of_sweep_time": round(ms / max(kern_ms, 1e-9), 3),
                "alg_bytes_per_launch": round(nbytes / n), "nominal_GBs": round(nbytes / n / (avg_us * 1e-6) / 1e9, 2),
@@ -362,7 +374,10 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
             ent["traffic_over_algorithmic"] = round(pb / max(nbytes / n, 1.0), 2)
         per_kernel.append(ent)
     avg_launch_us = kern_ms * 1e3 / max(launches, 1)
-    hbm_real_frac = (traffic / (avg_launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and launches) else None
+    # the kernel the job spends most of its sweep time in: the roofline line is ITS
+    dom = max(per_kernel, key=lambda e: e["share_of_sweep_time"]) if per_kernel else None
+    pmc_total = sum(e.get("pmc_bytes_per_launch", 0) * e["launches"] for e in per_kernel)
+    hbm_real_frac = (pmc_total / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (pmc_total and kern_ms > 0) else None
     steps = args.steps
     out = {
         "metric": "Mpixel*iters/s (halfway optimizer, 1080p pair, 6-level pyramid, 500 iters/level)" if config != 3 else
@@ -376,20 +391,35 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
         "data": "synthetic" if config != 2 else "synthetic (%d distinct frames per rank, reused cyclically over its pairs)" % distinct_frames,
         "config": {"workload": workload_name(config, w, h, nlev, blk, B, args, world, pairs_this_rank),
                    "math_mode": "fast" if blk.math_mode == capi.MATH_FAST else "exact",
-                   "semantics": "fixed work: every sweep of every level is launched" if FIXED
+                   "semantics": ("fixed iteration count per level: value credits max_iter sweeps of every level (the BASELINE "
+                                 "config, '500 iters/level'); sweeps past a level's convergence are provable no-ops that the device "
+                                 "skips -- value_executed counts only the sweeps up to convergence") if FIXED
                                 else "reference: a level stops when no pixel improved",
                    "iters_per_level_fine_to_coarse": [progs[0][i].iters for i in R],
+                   "iters_executed_per_level_fine_to_coarse": [progs[0][i].iters_live for i in R],
                    "pairs_in_flight_per_gpu": nctx, "pairs_per_launch": B,
                    "parallelism": "independent frame pairs, %d rank(s), 1 RCCL broadcast + 1 all-gather of the report" % world},
-        "roofline": {"bound": "hbm", "kernel": "sweep kernels (k_optimize | k_step); per_kernel splits them",
-                     # SURVEY 8(d)'s figure: NOMINAL algorithmic bytes (every pixel-visit of every executed
-                     # iteration, whether or not the improving mask skipped its tile) / HIP-event time
-                     "achieved": round(achieved, 2), "achieved_is": "nominal algorithmic rate (SURVEY 8(d)), not DRAM throughput",
+        # what actually ran: sweeps up to and including each level's first without an accepted move
+        "executed_pixel_iters": round(pix_live_total),
+        "value_executed": round(pix_live_total / el_max / 1e6, 2),
+        "roofline": {"bound": "hbm",
+                     # the dominant sweep kernel (largest share of sweep time): ALGORITHMIC bytes of one
+                     # launch (100 B per pixel-visit x the visits one launch covers) / its
+                     # average duration (HIP events on the context's stream)
+                     "kernel": dom["kernel"] if dom else None,
+                     "achieved": dom["nominal_GBs"] if dom else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "frac": dom["nominal_frac"] if dom else None,
+                     "traffic": dom.get("pmc_bytes_per_launch") if dom else None,
+                     "traffic_source": traffic_src,
+                     "launch_us": dom["avg_us"] if dom else None,
+                     "alg_bytes_per_launch": dom["alg_bytes_per_launch"] if dom else None,
+                     "share_of_sweep_time": dom["share_of_sweep_time"] if dom else None,
+                     # SURVEY 8(d)'s aggregate over all sweep kernels: NOMINAL algorithmic bytes of every
+                     # credited iteration (skipped no-op sweeps included) / HIP-event time -- not DRAM throughput
+                     "achieved_nominal": round(achieved, 2), "frac_nominal": round(achieved / HBM_PEAK_GBS, 5),
                      "achieved_executed": round(alg_executed / (kern_ms * 1e-3) / 1e9, 2) if kern_ms > 0 else None,
                      "frac_executed": round(alg_executed / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kern_ms > 0 else None,
-                     "traffic": traffic, "traffic_source": traffic_src,
                      "hbm_real_frac": round(hbm_real_frac, 5) if hbm_real_frac is not None else None,
                      "avg_launch_us": round(avg_launch_us, 2), "launches": launches,
                      "alg_bytes_per_pixel_visit": ALG_BYTES_PER_VISIT,
@@ -625,13 +655,15 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(np, capi, L, blk, gp, nlev):
+def cpu_baseline(np, capi, L, blk, gp, nlev, ctx):
     """The CPU restatement (oracle, OpenMP over tiles) timed on this host on a bounded sample
     of the same workload, and the GPU timed on the IDENTICAL sample beside it: every level of
     the solve just timed (coarsest first, incl. the 120x68 one), each started -- like the
     solver does -- from the upsampled solution of the next coarser level and swept with
     reference semantics (stop when no pixel improved) for at most max_iter iterations or 8 s
-    of CPU time; the GPU then runs exactly the iterations the CPU ran, from the same start."""
+    of CPU time; the GPU then runs exactly the iterations the CPU ran, from the same start --
+    once in the quoted arithmetic (timed: gpu_same_sample) and once in EXACT arithmetic, whose
+    halfway field is compared with the oracle's bit for bit (parity_same_sample)."""
     import oracle as O
     threads = effective_cpus()
     O.lib().vmo_set_threads(threads)
@@ -640,7 +672,9 @@ def cpu_baseline(np, capi, L, blk, gp, nlev):
         if hasattr(blk.kp, f):
             setattr(P, f, getattr(blk.kp, f))
     stats = np.zeros(4)
-    units, spent, gpu_ms, parts = 0.0, 0.0, 0.0, []
+    units, spent, gpu_ms, exact_ms, parts = 0.0, 0.0, 0.0, 0.0, []
+    identical, max_dv, words_diff = True, 0.0, 0
+    mode0 = blk.math_mode
     for el in range(nlev - 1, 0, -1):       # el = python-side level index, nlev = coarsest (host-solved)
         if spent > 20.0:
             break
@@ -662,20 +696,40 @@ def cpu_baseline(np, capi, L, blk, gp, nlev):
         units += float(w) * h * iters
         parts.append("%dx%d:%d" % (w, h, iters))
         # the GPU on the same sample: same start, reference semantics, the CPU's iteration count
-        capi.check(L.vm_upsample_v(gp._h, el - 1, el))
-        capi.check(L.vm_init_level(gp._h, el - 1, gp[1].width, gp[1].height, None, 0))
-        pr = capi.Progress()
-        t1 = time.perf_counter()
-        capi.check(L.vm_optimize_level(gp._h, el - 1, float(iters), None, 0, C.byref(pr)))
-        gpu_ms += (time.perf_counter() - t1) * 1e3
-    return {"value": round(units / spent / 1e6, 3), "unit": "Mpixel*iters/s",
+        for mode in (mode0, capi.MATH_EXACT):      # EXACT last: the next finer level starts from the oracle's own field
+            ctx.set_math_mode(mode)
+            capi.check(L.vm_upsample_v(gp._h, el - 1, el))
+            capi.check(L.vm_init_level(gp._h, el - 1, gp[1].width, gp[1].height, None, 0))
+            pr = capi.Progress()
+            t1 = time.perf_counter()
+            capi.check(L.vm_optimize_level(gp._h, el - 1, float(iters), None, 0, C.byref(pr)))
+            dt = (time.perf_counter() - t1) * 1e3
+            if mode == mode0:
+                gpu_ms += dt
+            if mode == capi.MATH_EXACT:
+                exact_ms += dt
+                a, b = tgt.field("v"), gp[el].v
+                nd = int((a.view(np.uint32) != b.view(np.uint32)).sum())
+                words_diff += nd
+                identical = identical and nd == 0 and pr.iters == iters
+                max_dv = max(max_dv, float(np.abs(a - b).max()))
+    ctx.set_math_mode(mode0)
+    cpu_rate = units / spent / 1e6
+    gpu_rate = units / (gpu_ms * 1e-3) / 1e6
+    return {"value": round(cpu_rate, 3), "unit": "Mpixel*iters/s",
             "cores": threads, "kind": "port",
             "sample": "reference-semantics sweeps of levels [%s] (coarse to fine, each from the upsampled coarser solution) of the "
                       "first timed pair (oracle, OpenMP over tiles, %d threads), %.1f s; %.0f energy evaluations" % (
                           ", ".join(parts), threads, spent, stats[3]),
-            "gpu_same_sample": {"value": round(units / (gpu_ms * 1e-3) / 1e6, 2), "unit": "Mpixel*iters/s", "ms": round(gpu_ms, 2),
+            "note": "executed sweeps only: compare with gpu_same_sample (the identical sample), never with the fixed-work `value`",
+            "gpu_same_sample": {"value": round(gpu_rate, 2), "unit": "Mpixel*iters/s", "ms": round(gpu_ms, 2),
+                                "ratio_to_cpu": round(gpu_rate / max(cpu_rate, 1e-9), 1),
                                 "note": "the HIP path on the identical sample: same levels, same starts, same iteration counts "
-                                        "(wall time incl. launches and flag read-backs)"}}
+                                        "(wall time incl. launches and flag read-backs)"},
+            "parity_same_sample": {"bit_identical": bool(identical), "max_abs_dv": max_dv, "words_differing": words_diff,
+                                   "exact_ms": round(exact_ms, 2),
+                                   "note": "EXACT arithmetic on the identical sample vs the oracle: halfway field of every level, "
+                                           "bit for bit, and the iteration counts"}}
 
 
 if __name__ == "__main__":

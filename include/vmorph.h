@@ -89,9 +89,14 @@ typedef struct {
                               + 25 SSIM terms, morph.cu:671-761)                 */
     /* HIP-event time and launch count of the sweep kernels per schedule:
      * [0] TILE, dense kernel; [1] TILE, lean kernel (pruned sweeps); [2] STEP / SPLIT;
-     * [3] SPARSE */
-    float  sched_ms[4];
-    int    sched_launches[4];
+     * [3] SPARSE; [4] PASS */
+    float  sched_ms[5];
+    int    sched_launches[5];
+    /* iterations up to and including the first that accepted no move: what the reference's
+     * stopping rule (morph.cu:1390) executes.  A fixed-work run reports iters = max_iter; the
+     * iters - iters_live sweeps past convergence are provable no-ops (every mask bit is clear)
+     * and are skipped on the device. */
+    int    iters_live;
 } vm_progress;
 
 /* device-state arrays a test or a UI may read back (vm_level_get_field) */

@@ -79,7 +79,12 @@ class MatchingThread {
 public:
     MatchingThread(Parameters &parameters, Pyramid &pyramids)
         : runflag(1), _pyramids(pyramids), _parameters(parameters), gpu_morph(parameters, pyramids, runflag) {}
-    ~MatchingThread() { wait(); }
+    // joins the worker; an exception it stored is dropped here (a destructor must not throw:
+    // call wait() first to see it)
+    ~MatchingThread()
+    {
+        if (thread_.joinable()) thread_.join();
+    }
 
     // MatchingThread.cpp:138-150
     void run()

@@ -106,7 +106,11 @@ public:
                 iter_num = (int)(iter_num / parameters.max_iter_drop_factor);
             }
     }
-    ~SyncThread() { wait(); }
+    // joins the worker; a stored exception is dropped (a destructor must not throw: wait() shows it)
+    ~SyncThread()
+    {
+        if (thread_.joinable()) thread_.join();
+    }
 
     void load_identity(int el) { check(vm_sync_load_identity(_pyramids.handle(), el)); }
     void upsample_level(int el, int /*pel*/) { check(vm_sync_upsample_level(_pyramids.handle(), el)); }

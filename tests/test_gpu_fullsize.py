@@ -1,6 +1,14 @@
-"""BASELINE.json's full sizes (config[1] 1080p, config[3] 4K) on the GPU, checked
-through size-independent properties of the solver state -- the oracle cannot run
-these sizes in seconds:
+"""BASELINE.json's full sizes (config[1] 1080p, config[3] 4K) on the GPU.
+
+Against the oracle itself, bit for bit (EXACT arithmetic; the oracle needs ~10-20 s of the
+box's host cores for each):
+  * config[1] as stated -- one 1920x1080 pair, 6 levels, max_iter 500 per level, the
+    reference's stopping rule: the whole coarse-to-fine vm_solve equals oracle.solve incl. the
+    per-level iteration counts (test_full_solve_exact_1080p);
+  * one dense sweep of the 3840x2160 level of config[3] (test_dense_sweep_exact_4k), and the
+    TILE and SPLIT schedules walking the same trajectory there (test_schedules_agree_exactly_at_4k).
+And through size-independent properties of the solver state, where the run is too long for the
+oracle (FAST arithmetic, hundreds of sweeps, batches):
   * window-sum invariants: after any number of sweeps, mean/var/cross of every pixel
     equal the 5x5 (border-clipped) box sums of the stored warped lumas, and tps_b
     equals the thin-plate stencil applied to the final v (both are maintained
@@ -8,9 +16,11 @@ these sizes in seconds:
   * the stored SSIM value is the SSIM of the stored sums;
   * stored lumas are the images sampled at p -/+ v;
   * a level that reports improving == 0 is a fixed point: another sweep changes nothing;
-  * the two sweep schedules (TILE / SPLIT) walk the same trajectory in EXACT mode.
+  * the sweep schedules walk the same trajectory (EXACT: TILE / SPLIT; FAST: SPLIT / STEP / PASS,
+    TILE / SPARSE).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -18,6 +28,111 @@ import pytest
 from videomorphing_amd import capi, morph, synth
 
 pytestmark = pytest.mark.gpu
+
+
+def _all_cpus():
+    """host threads for the oracle: what this process may really use (cgroup quota respected)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(q) // int(per)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+_STATE = ("v", "luma", "mean", "var", "cross", "value", "tps_b", "ui_b", "impmask")
+
+
+def _assert_level_equals_oracle(lo, lv, what):
+    for f in _STATE:
+        a, b = lo.field(f), lv.field(f)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "%s: %s differs (%d of %d words)" % (
+            what, f, int((a.view(np.uint32) != b.view(np.uint32)).sum()), a.size)
+
+
+def test_full_solve_exact_1080p(gpu_ctx, oracle):
+    """config[1] ITSELF against the oracle: one 1920x1080 frame pair, 6-level pyramid
+    (start_res 32), max_iter 500 per level, drop 1, the reference's stopping rule
+    (morph.cu:150-168, 1353-1391) -- the EXACT vm_solve is bit-identical to oracle.solve on all
+    host cores: per-level iteration counts, the final halfway field and every state array of
+    the finest level."""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    w, h = 1920, 1080
+    i0, i1 = synth.make_pair(w, h)
+    pyr_imgs = synth.build_pyramid(i0, i1, 6)
+    P = oracle.default_params()
+    per = []
+    lo = oracle.solve(pyr_imgs, P, 500, 1.0, threads=_all_cpus(), per_level=per)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 500, 1.0, 32
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build(i0, i1, 32)
+    assert pyr.size() == 7 and (pyr[5].width, pyr[5].height) == (120, 68)
+    gpu_ctx.set_params(morph.KernParameters(prm))
+    L = pyr._L
+    prog = (capi.Progress * 5)()
+    capi.check(L.vm_solve(pyr._h, 500.0, 1.0, None, 0, None, 0, prog))       # without clear_level: the state stays readable
+    assert [prog[el].iters for el in (4, 3, 2, 1, 0)] == [p[1] for p in per], ([prog[el].iters for el in (4, 3, 2, 1, 0)], per)
+    assert per[0][1] == 500                    # the 120x68 level uses all of its 500 iterations
+    _assert_level_equals_oracle(lo, pyr[1], "1080p solve")
+    assert np.abs(pyr[1].v).max() > 5.0        # ~19 px of displacement were found
+
+
+def test_dense_sweep_exact_4k(gpu_ctx, oracle):
+    """config[3]'s finest level: one dense sweep (every pixel searched: 23 M line searches) of a
+    3840x2160 level from a rough start, EXACT, bit-identical to the oracle in every state array"""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    w, h = 3840, 2160
+    i0, i1 = synth.make_pair(w, h)
+    v0 = (0.9 * synth.displacement(w, h) + 0.05 * np.random.RandomState(4).randn(h, w, 2)).astype(np.float32)
+    oracle.lib().vmo_set_threads(_all_cpus())
+    P = oracle.default_params()
+    lo = oracle.Level(w, h)
+    lo.set_images(i0, i1)
+    lo.field("v")[...] = v0
+    lo.init(0.0)
+    st = np.zeros(4)
+    lo.optimize_iter(P, st)
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build_levels([(w, h), (1920, 1080)])
+    pyr.upload_luma(1, i0, i1)
+    pyr[1].v = v0
+    capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+    pr = capi.Progress()
+    capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 1.0, None, 0, C.byref(pr)))
+    assert pr.commits == st[2] > 1e6 and pr.candidates == st[1], (pr.commits, pr.candidates, st)
+    _assert_level_equals_oracle(lo, pyr[1], "4K sweep")
+
+
+def test_schedules_agree_exactly_at_4k(gpu_ctx):
+    """EXACT arithmetic, two sweeps of the 3840x2160 level from the same start: the TILE and the
+    SPLIT schedule produce identical bits (schedule independence at config[3]'s size)"""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    w, h = 3840, 2160
+    i0, i1 = synth.make_pair(w, h)
+    v0 = (0.9 * synth.displacement(w, h) + 0.05 * np.random.RandomState(4).randn(h, w, 2)).astype(np.float32)
+    out = []
+    try:
+        for mode in (capi.SWEEP_TILE, capi.SWEEP_SPLIT):
+            gpu_ctx.set_tuning(mode, 0, 2)
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build_levels([(w, h), (1920, 1080)])
+            pyr.upload_luma(1, i0, i1)
+            pyr[1].v = v0
+            capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+            pr = capi.Progress()
+            capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 2.0, None, 1, C.byref(pr)))
+            out.append(([pyr[1].field(f) for f in _STATE], pr.commits))
+            del pyr
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+    assert out[0][1] == out[1][1] > 1e6
+    for f, a, b in zip(_STATE, out[0][0], out[1][0]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f
 
 
 def _box5(a):

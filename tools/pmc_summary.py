@@ -2,10 +2,13 @@
 the HBM traffic of the sweep kernels from two --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
   python tools/pmc_summary.py <fetch_dir> <write_dir> <out_csv> <out_json> "<command profiled>" [kernel,substrings]
+  python tools/pmc_summary.py --merge <traffic.json> <entry.json> <config> <pairs_per_launch>
+      (profiles/traffic_latest.json holds one entry per workload shape: bench.py only quotes PMC
+      bytes taken at the same config and pairs per launch)
 """
 import csv, glob, json, os, sys
 
-SWEEP = ("k_optimize", "k_step", "k_decide", "k_commit")
+SWEEP = ("k_optimize", "k_step", "k_decide", "k_commit", "k_pass", "k_sparse")
 
 
 def counters(d, name):
@@ -22,8 +25,22 @@ def counters(d, name):
     return out
 
 
+def merge():
+    path, entry, config, pairs = sys.argv[2], json.load(open(sys.argv[3])), int(sys.argv[4]), int(sys.argv[5])
+    try:
+        cur = json.load(open(path))
+    except Exception:
+        cur = {}
+    ents = [e for e in cur.get("entries", []) if not (e.get("config") == config and e.get("pairs_per_launch") == pairs)]
+    ents.append({"config": config, "pairs_per_launch": pairs, "per_kernel": entry["per_kernel"], "source": entry["source"]})
+    ents.sort(key=lambda e: (e["config"], e["pairs_per_launch"]))
+    json.dump({"entries": ents, "correction": entry["correction"]}, open(path, "w"), indent=1)
+
+
 def main():
     global SWEEP
+    if sys.argv[1] == "--merge":
+        return merge()
     fd, wd, out_csv, out_json, cmd = sys.argv[1:6]
     if len(sys.argv) > 6:
         SWEEP = tuple(sys.argv[6].split(","))

@@ -65,7 +65,8 @@ class Progress(C.Structure):
     _fields_ = [("iters", C.c_int), ("improving", C.c_int), ("pixel_iters", C.c_double),
                 ("elapsed_ms", C.c_float), ("launches", C.c_int),
                 ("active_tiles", C.c_double), ("candidates", C.c_double), ("commits", C.c_double),
-                ("evaluations", C.c_double), ("sched_ms", C.c_float * 4), ("sched_launches", C.c_int * 4)]
+                ("evaluations", C.c_double), ("sched_ms", C.c_float * 5), ("sched_launches", C.c_int * 5),
+                ("iters_live", C.c_int)]
 
 
 class SyncConstraint(C.Structure):

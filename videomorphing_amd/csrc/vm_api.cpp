@@ -102,8 +102,10 @@ static void ctx_free(vm_ctx *c);
 
 // Live contexts.  Destroying a pyramid, video or frame after its context is a caller error; a
 // garbage-collected host language can produce that order.  The destroy functions check here and
-// then only release the host-side object (the device memory went with the context's process
-// state): a no-op instead of a use-after-free.
+// then free the object's device buffers without the context (every object remembers its device;
+// hipFree needs neither the stream nor the context, after a device-wide synchronise nothing can
+// still be using them): no use-after-free and no leak.  Every other entry point refuses an object
+// whose context is gone.
 #include <set>
 static std::mutex g_live_mu;
 static std::set<const vm_ctx *> g_live;
@@ -181,7 +183,7 @@ extern "C" void vm_ctx_destroy(vm_ctx *c)
         std::lock_guard<std::mutex> lock(g_live_mu);
         g_live.erase(c);
     }
-    VM_ON_DEVICE(c);
+    VM_ON_DEVICE_VOID(c);
     ctx_free(c);
 }
 
@@ -378,6 +380,7 @@ extern "C" int vm_pyramid_create(vm_ctx *c, int nlevels, const int *w, const int
     VM_ON_DEVICE(c);
     vm_pyr *p = new vm_pyr();
     p->ctx = c;
+    p->device = c->device;
     p->lv.resize(nlevels);
     for (int i = 0; i < nlevels; ++i) {
         vm_level &l = p->lv[i];
@@ -395,11 +398,17 @@ extern "C" int vm_pyramid_create(vm_ctx *c, int nlevels, const int *w, const int
 extern "C" void vm_pyramid_destroy(vm_pyr *p)
 {
     if (!p) return;
-    if (!vm_ctx_alive(p->ctx)) { // destroyed after its context: nothing of the device is touched
+    if (!vm_ctx_alive(p->ctx)) { // destroyed after its context: the buffers are freed without it
+        VmDeviceGuard g(p->device);
+        if (g.ok) {
+            hipDeviceSynchronize();
+            for (auto &l : p->lv) vm_level_free(l);
+            (void)hipGetLastError();
+        }
         delete p;
         return;
     }
-    VM_ON_DEVICE(p->ctx);
+    VM_ON_DEVICE_VOID(p->ctx);
     hipStreamSynchronize(p->ctx->stream);
     for (auto &l : p->lv) vm_level_free(l);
     delete p;
@@ -411,6 +420,7 @@ extern "C" int vm_pyramid_levels(vm_pyr *p) { return p ? (int)p->lv.size() : 0; 
     if (!(p)) return vm_fail(VM_E_INVALID, "%s: pyramid is NULL", __func__);     \
     if ((lvl) < 0 || (lvl) >= (int)(p)->lv.size())                               \
         return vm_fail(VM_E_INVALID, "%s: level %d out of range", __func__, (lvl)); \
+    if (!vm_ctx_alive((p)->ctx)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__); \
     VM_ON_DEVICE((p)->ctx);
 
 extern "C" int vm_level_dims(vm_pyr *p, int lvl, int *w, int *h, int *rs)
@@ -787,13 +797,13 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
             VM_HIP(hipMemsetAsync(lv[i]->view.rec_tag2, 0, (size_t)l0.rs * l0.h * 4, s));
         }
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
-    std::vector<int> executed(n, cap), improving(n, 1), stopped(n, 0);
+    std::vector<int> executed(n, cap), improving(n, 1), stopped(n, 0), live(n, -1);
     std::vector<double> st_tiles(n, 0.0), st_cand(n, 0.0), st_commit(n, 0.0), st_eval(n, 0.0);
     int done = 0, launches = 0;
     bool cancelled = false;
     float ms = 0;
-    float sched_ms[4] = {0, 0, 0, 0}; // [0] TILE dense kernel, [1] TILE lean kernel, [2] STEP / SPLIT, [3] SPARSE
-    int sched_launches[4] = {0, 0, 0, 0};
+    float sched_ms[5] = {0, 0, 0, 0, 0}; // [0] TILE dense kernel, [1] TILE lean kernel, [2] STEP / SPLIT, [3] SPARSE, [4] PASS
+    int sched_launches[5] = {0, 0, 0, 0, 0};
     static const bool force_dense = getenv("VM_TILE_DENSE") != nullptr; // dev switch
     // Iterations are enqueued in batches; each sweep kernel of iteration i exits at once (per
     // pair) when iteration i-1 did not improve (device-side flag), so running past convergence
@@ -913,6 +923,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
                 st_commit[i] += st[VM_STAT_WORDS * it + 2];
                 st_eval[i] += st[VM_STAT_WORDS * it + 4];
                 improving[i] = fl[it] != 0;
+                if (!improving[i] && live[i] < 0) live[i] = it + 1; // the reference's loop ends here (morph.cu:1390)
                 if (!improving[i] && !fixed_work) { executed[i] = it + 1; stopped[i] = 1; }
             }
             all_stopped = all_stopped && stopped[i];
@@ -930,6 +941,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     }
     for (int i = 0; i < n && out; ++i) {
         out[i].iters = executed[i];
+        out[i].iters_live = live[i] < 0 ? executed[i] : std::min(live[i], executed[i]);
         out[i].improving = improving[i];
         out[i].pixel_iters = (double)executed[i] * l0.w * l0.h;
         out[i].elapsed_ms = ms;       // of the batch the pair was solved in
@@ -938,7 +950,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         out[i].candidates = st_cand[i];
         out[i].commits = st_commit[i];
         out[i].evaluations = st_eval[i];
-        for (int k = 0; k < 4; ++k) { // of the batch, like elapsed_ms
+        for (int k = 0; k < 5; ++k) { // of the batch, like elapsed_ms
             out[i].sched_ms[k] = sched_ms[k];
             out[i].sched_launches[k] = sched_launches[k];
         }

@@ -13,6 +13,7 @@ extern "C" int vm_frame_create(vm_ctx *c, int w, int h, int ex, vm_frame **out)
     VM_ON_DEVICE(c);
     vm_frame *f = new vm_frame();
     f->ctx = c;
+    f->device = c->device;
     f->w = w; f->h = h; f->ex = ex;
     f->cw = w + 2 * ex; f->ch = h + 2 * ex;
     f->rs = (w + 31) / 32 * 32; // UI/RenderWidget.cpp:235
@@ -36,15 +37,16 @@ extern "C" int vm_frame_create(vm_ctx *c, int w, int h, int ex, vm_frame **out)
 extern "C" void vm_frame_destroy(vm_frame *f)
 {
     if (!f) return;
-    if (!vm_ctx_alive(f->ctx)) { // destroyed after its context (vm_api.cpp)
-        delete f;
-        return;
+    const bool alive = vm_ctx_alive(f->ctx); // destroyed after its context: freed without it (vm_api.cpp)
+    VmDeviceGuard g(f->device);
+    if (g.ok) {
+        if (alive) hipStreamSynchronize(f->ctx->stream);
+        else hipDeviceSynchronize();
+        hipFree(f->ext[0]); hipFree(f->ext[1]);
+        hipFree(f->crop[0]); hipFree(f->crop[1]);
+        hipFree(f->v); hipFree(f->u); hipFree(f->out); hipFree(f->pws);
+        (void)hipGetLastError();
     }
-    VM_ON_DEVICE(f->ctx);
-    hipStreamSynchronize(f->ctx->stream);
-    hipFree(f->ext[0]); hipFree(f->ext[1]);
-    hipFree(f->crop[0]); hipFree(f->crop[1]);
-    hipFree(f->v); hipFree(f->u); hipFree(f->out); hipFree(f->pws);
     delete f;
 }
 
@@ -52,6 +54,7 @@ extern "C" int vm_frame_upload(vm_frame *f, const uint8_t *e0, const uint8_t *e1
                                const float *q)
 {
     if (!f) return vm_fail(VM_E_INVALID, "vm_frame_upload: frame is NULL");
+    if (!vm_ctx_alive(f->ctx)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__);
     VM_ON_DEVICE(f->ctx);
     hipStream_t s = f->ctx->stream;
     size_t nc = (size_t)f->cw * f->ch * 4;
@@ -73,6 +76,7 @@ extern "C" int vm_frame_download_ext(vm_frame *f, int side, uint8_t *ext)
 {
     if (!f || !ext || (side != 1 && side != 2))
         return vm_fail(VM_E_INVALID, "vm_frame_download_ext: bad argument");
+    if (!vm_ctx_alive(f->ctx)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__);
     VM_ON_DEVICE(f->ctx);
     hipStream_t s = f->ctx->stream;
     VM_HIP(hipMemcpyAsync(ext, f->ext[side - 1], (size_t)f->cw * f->ch * 4, hipMemcpyDeviceToHost, s));
@@ -85,6 +89,7 @@ extern "C" int vm_frame_set_v_from_level(vm_frame *f, vm_pyr *p, int lvl)
     if (!f || !p || lvl < 0 || lvl >= (int)p->lv.size())
         return vm_fail(VM_E_INVALID, "vm_frame_set_v_from_level: bad argument");
     if (p->ctx != f->ctx) return vm_fail(VM_E_INVALID, "frame and pyramid belong to different contexts");
+    if (!vm_ctx_alive(f->ctx)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__);
     VM_ON_DEVICE(f->ctx);
     vm_level &l = p->lv[lvl];
     vm_launch_upscale(f->v, f->w, f->h, f->rs, l.view.v, l.w, l.h, l.rs, f->ctx->stream);
@@ -144,6 +149,7 @@ extern "C" int vm_render_halfway(vm_frame *f, float color_fa, float geo_fa, int 
     if (rc != VM_OK) return rc;
     if (pitch == 0) pitch = f->w * 3;
     if (pitch < f->w * 3) return vm_fail(VM_E_INVALID, "vm_render_halfway: pitch < 3*w");
+    if (!vm_ctx_alive(f->ctx)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__);
     VM_ON_DEVICE(f->ctx);
     hipStream_t s = f->ctx->stream;
     VM_HIP(hipMemcpy2DAsync(rgb, pitch, f->out, (size_t)f->w * 3, (size_t)f->w * 3, f->h, hipMemcpyDeviceToHost, s));

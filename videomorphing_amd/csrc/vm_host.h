@@ -24,14 +24,18 @@ bool vm_ctx_alive(const vm_ctx *c); // vm_api.cpp: is this context still alive?
 struct VmDeviceGuard {
     int prev = -1;
     bool switched = false;
+    bool ok = true; // false: the device could not be made current -- nothing may be launched
     explicit VmDeviceGuard(int dev)
     {
         // HIP's "last error" is per thread and sticky across libraries: an error another
         // library left behind (RCCL probing peers, a framework's failed query) must not be
         // reported by the hipGetLastError() checks that follow this entry point's launches
         (void)hipGetLastError();
-        if (hipGetDevice(&prev) != hipSuccess || prev != dev)
-            switched = hipSetDevice(dev) == hipSuccess && prev >= 0;
+        if (hipGetDevice(&prev) != hipSuccess || prev != dev) {
+            ok = hipSetDevice(dev) == hipSuccess;
+            switched = ok && prev >= 0;
+            (void)hipGetLastError();
+        }
     }
     ~VmDeviceGuard()
     {
@@ -43,7 +47,14 @@ struct VmDeviceGuard {
 };
 #define VM_CAT2(a, b) a##b
 #define VM_CAT(a, b) VM_CAT2(a, b)
-#define VM_ON_DEVICE(ctx) VmDeviceGuard VM_CAT(vm_device_guard_, __LINE__)((ctx)->device)
+// In functions that return a status: a device that cannot be made current is an error, not a
+// launch on whatever device the calling thread happened to have.
+#define VM_ON_DEVICE(ctx)                                                                          \
+    VmDeviceGuard VM_CAT(vm_device_guard_, __LINE__)((ctx)->device);                                \
+    if (!VM_CAT(vm_device_guard_, __LINE__).ok)                                                    \
+        return vm_fail(VM_E_DEVICE, "%s: device %d cannot be made current", __func__, (ctx)->device)
+// ... and in destructors / void functions (best effort)
+#define VM_ON_DEVICE_VOID(ctx) VmDeviceGuard VM_CAT(vm_device_guard_, __LINE__)((ctx)->device)
 
 struct vm_ctx {
     std::recursive_mutex mu;         // a context is single-threaded by contract; this makes misuse safe
@@ -97,6 +108,7 @@ struct vm_level {
 
 struct vm_pyr {
     vm_ctx *ctx = nullptr;
+    int device = 0;                  // of ctx: the buffers can be freed after the context is gone
     std::vector<vm_level> lv;
 };
 
@@ -123,6 +135,7 @@ struct vm_video_lane {
 
 struct vm_video {
     vm_ctx *ctx = nullptr;
+    int device = 0;
     int depth0 = 1;                       // frames of the video (the placeholder level's depth)
     std::vector<int> depth;               // pages per level
     std::vector<int> factor_t;            // temporal stride the level was built with (pyramid.cu:468)
@@ -138,6 +151,7 @@ struct vm_video {
 
 struct vm_frame {
     vm_ctx *ctx = nullptr;
+    int device = 0;
     int w = 0, h = 0, ex = 0, cw = 0, ch = 0, rs = 0;
     uchar4 *ext[2] = {nullptr, nullptr};  // (w+2ex) x (h+2ex) RGBA8 canvases
     uchar4 *crop[2] = {nullptr, nullptr}; // w x h originals (CPoissonExt::_image1/_image2, PoissonExt.cpp:26-27)

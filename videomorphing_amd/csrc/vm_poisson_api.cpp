@@ -374,6 +374,7 @@ extern "C" int vm_frame_quadratic_path(vm_frame *f, float tol, int max_it, int *
 extern "C" int vm_frame_download_qpath(vm_frame *f, float *u_xy)
 {
     if (!f || !u_xy) return vm_fail(VM_E_INVALID, "vm_frame_download_qpath: bad argument");
+    if (!vm_ctx_alive(f->ctx)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__);
     VM_ON_DEVICE(f->ctx);
     hipStream_t s = f->ctx->stream;
     VM_HIP(hipMemcpy2DAsync(u_xy, (size_t)f->w * 8, f->u, (size_t)f->rs * 8, (size_t)f->w * 8, f->h, hipMemcpyDeviceToHost, s));

@@ -96,7 +96,7 @@ extern "C" void vm_sync_destroy(vm_sync *s)
     if (!s) return;
     if (s->ctx && vm_ctx_alive(s->ctx)) {
         std::lock_guard<std::recursive_mutex> lock(s->ctx->mu);
-        VM_ON_DEVICE(s->ctx);
+        VM_ON_DEVICE_VOID(s->ctx);
         (void)hipStreamSynchronize(s->ctx->stream);
         for (size_t l = 0; l < s->f.size(); ++l) free_field(s, (int)l);
         if (s->ws) (void)hipFree(s->ws);

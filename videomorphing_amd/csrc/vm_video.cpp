@@ -29,6 +29,7 @@ static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
         return vm_fail(VM_E_INVALID, "%s: level %d out of range", __func__, (lvl));                    \
     if ((page) < 0 || (page) >= (v)->depth[(lvl)])                                                     \
         return vm_fail(VM_E_INVALID, "%s: page %d out of range (level %d has %d)", __func__, (page), (lvl), (v)->depth[(lvl)]); \
+    if (!vm_ctx_alive((v)->ctx)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__); \
     VM_ON_DEVICE((v)->ctx);
 
 extern "C" int vm_video_create(vm_ctx *c, int nlevels, const int *w, const int *h, const int *d,
@@ -43,9 +44,20 @@ extern "C" int vm_video_create(vm_ctx *c, int nlevels, const int *w, const int *
             return vm_fail(VM_E_INVALID, "vm_video_create: depth of level %d is %d (must be >= 1 and not grow towards coarse levels)", i, d[i]);
     }
     if (depth0 < d[0]) return vm_fail(VM_E_INVALID, "vm_video_create: depth0 %d < depth of the finest level %d", depth0, d[0]);
+    // a level built with temporal stride 2 takes its page t from page min(2 t, d_prev - 1) of the
+    // finer level (pyramid.cu:406-442; the reference's own depths are ceil((d_prev + 1) / 2),
+    // pyramid.cu:237): two pages must never name the same source -- the flow pyramid scales the
+    // pages it carries over in place
+    for (int i = 1; i < nlevels; ++i) {
+        const int ft = factor_t ? (factor_t[i] > 1 ? 2 : 1) : (d[i] != d[i - 1] ? 2 : 1);
+        if (ft == 2 && (d[i] - 2) * 2 >= d[i - 1] - 1)
+            return vm_fail(VM_E_INVALID, "vm_video_create: level %d (temporal stride 2, %d pages) would take two pages from the same page of level %d (%d pages)",
+                           i, d[i], i - 1, d[i - 1]);
+    }
     VM_ON_DEVICE(c);
     vm_video *v = new vm_video();
     v->ctx = c;
+    v->device = c->device;
     v->depth0 = depth0;
     v->depth.assign(d, d + nlevels);
     // temporal stride each level was built with (pyramid.cu:468): given, or 2 where the depth shrank
@@ -105,25 +117,26 @@ extern "C" void vm_video_destroy(vm_video *v)
     for (vm_video_lane &ln : v->lanes) // the pipeline's lanes are contexts of their own
         if (ln.c && vm_ctx_alive(ln.c)) {
             {
-                VM_ON_DEVICE(ln.c);
+                VM_ON_DEVICE_VOID(ln.c);
                 hipStreamSynchronize(ln.c->stream);
                 hipFree(ln.acc);
             }
             vm_ctx_destroy(ln.c);
         }
     v->lanes.clear();
-    if (!vm_ctx_alive(v->ctx)) { // destroyed after its context (vm_api.cpp)
-        delete v;
-        return;
+    const bool alive = vm_ctx_alive(v->ctx); // destroyed after its context: freed without it (vm_api.cpp)
+    VmDeviceGuard g(v->device);
+    if (g.ok) {
+        if (alive) hipStreamSynchronize(v->ctx->stream);
+        else hipDeviceSynchronize();
+        for (auto &lv : v->pages)
+            for (auto &pg : lv) {
+                vm_level_free(pg.lv);
+                hipFree(pg.tslab);
+            }
+        hipFree(v->acc); hipFree(v->vcur); hipFree(v->weight);
+        (void)hipGetLastError();
     }
-    VM_ON_DEVICE(v->ctx);
-    hipStreamSynchronize(v->ctx->stream);
-    for (auto &lv : v->pages)
-        for (auto &pg : lv) {
-            vm_level_free(pg.lv);
-            hipFree(pg.tslab);
-        }
-    hipFree(v->acc); hipFree(v->vcur); hipFree(v->weight);
     delete v;
 }
 
@@ -375,7 +388,7 @@ extern "C" int vm_video_optimize_level(vm_video *v, int lvl, float max_iter, vol
                 if (i > 0) { // time and launches belong to the batch: count them once
                     out[idx[i]].elapsed_ms = 0;
                     out[idx[i]].launches = 0;
-                    for (int q = 0; q < 4; ++q) { out[idx[i]].sched_ms[q] = 0; out[idx[i]].sched_launches[q] = 0; }
+                    for (int q = 0; q < 5; ++q) { out[idx[i]].sched_ms[q] = 0; out[idx[i]].sched_launches[q] = 0; }
                 }
             }
     }
@@ -486,7 +499,7 @@ static int video_task(vm_video *v, vm_video_lane &ln, int el, int k, float max_i
             if (i > 0) { // time and launches belong to the batch: count them once
                 out[idx[i]].elapsed_ms = 0;
                 out[idx[i]].launches = 0;
-                for (int q = 0; q < 4; ++q) { out[idx[i]].sched_ms[q] = 0; out[idx[i]].sched_launches[q] = 0; }
+                for (int q = 0; q < 5; ++q) { out[idx[i]].sched_ms[q] = 0; out[idx[i]].sched_launches[q] = 0; }
             }
         }
     return VM_OK;

@@ -64,13 +64,14 @@ def broadcast_block(raw, device):
     return t.cpu().numpy()
 
 
-def reduce_report(elapsed, units, device):
-    """(max over ranks of elapsed, sum over ranks of units): one all-gather of two scalars
-    per rank."""
+def reduce_report(elapsed, units, device, *more):
+    """(max over ranks of elapsed, sum over ranks of units[, sums of `more`]): one all-gather of
+    a few scalars per rank."""
     import torch
     import torch.distributed as dist
-    mine = torch.tensor([elapsed, units], dtype=torch.float64, device=device)
+    mine = torch.tensor([elapsed, units] + [float(x) for x in more], dtype=torch.float64, device=device)
     every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(every, mine)
     vals = torch.stack(every).cpu().numpy()
-    return float(vals[:, 0].max()), float(vals[:, 1].sum())
+    out = (float(vals[:, 0].max()), float(vals[:, 1].sum()))
+    return out + tuple(float(vals[:, 2 + k].sum()) for k in range(len(more)))

@@ -139,7 +139,7 @@ class PyramidLevel(object):
         # a weak back-reference: no Pyramid <-> PyramidLevel cycle, so a pyramid is released by
         # reference counting the moment its last user lets go -- before its Context, which it
         # keeps alive -- and never by the cycle collector in an arbitrary order
-        self._pyr, self._el = weakref.proxy(pyr), el
+        self._pyr_ref, self._el = weakref.ref(pyr), el
         self.width, self.height, self.depth = int(w), int(h), 1
         self.rowstride = (self.width + 31) // 32 * 32         # pyramid.cu:535
         self.pagestride = self.rowstride * self.height
@@ -147,6 +147,16 @@ class PyramidLevel(object):
         self.impmask_rowstride = (self.width + 4) // 5 + 2
         self.impmask_pagestride = self.impmask_rowstride * ((self.height + 4) // 5 + 2)
         self.factor_d = 1.0
+
+    @property
+    def _pyr(self):
+        # lifetime rule: a level is a view into its Pyramid and does not keep
+        # it alive -- hold the Pyramid for as long as its levels are used
+        p = self._pyr_ref()
+        if p is None:
+            raise capi.VmError(capi.VM_E_STATE, "this PyramidLevel outlived its Pyramid: keep a reference to the "
+                                                "Pyramid while its levels are in use")
+        return p
 
     def _lvl(self):
         if self._el < 1:
@@ -524,8 +534,16 @@ class VideoPage(object):
     """One page of a PyramidLevel of depth > 1 (device-state access)."""
 
     def __init__(self, vid, lvl, page, w, h):
-        self._vid, self._lvl, self._page = weakref.proxy(vid), lvl, page   # no cycle (see PyramidLevel)
+        self._vid_ref, self._lvl, self._page = weakref.ref(vid), lvl, page   # no cycle (see PyramidLevel)
         self.width, self.height = int(w), int(h)
+
+    @property
+    def _vid(self):
+        v = self._vid_ref()
+        if v is None:
+            raise capi.VmError(capi.VM_E_STATE, "this VideoPage outlived its VideoPyramid: keep a reference to the "
+                                                "VideoPyramid while its pages are in use")
+        return v
 
     def field(self, name):
         fid, ch = capi.FIELDS[name]
