@@ -11,6 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def total_credit(d):
+    return d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * d["steps"] * 1.01
+
+
 def test_bench_json_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--no-extras"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -29,15 +33,24 @@ def test_bench_json_line():
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
-    # the honest split: what the figure is, where the traffic number comes from, per-kernel entries
-    for k in ("achieved_is", "achieved_executed", "frac_executed", "traffic_source", "hbm_real_frac", "valu_frac",
-              "active_pixel_ratio", "per_kernel"):
+    # the line is the DOMINANT sweep kernel's (named, with its share of the sweep time); the
+    # nominal aggregate, the executed-work figure and the PMC traffic sit beside it
+    for k in ("kernel", "launch_us", "alg_bytes_per_launch", "share_of_sweep_time", "frac_nominal", "achieved_executed",
+              "frac_executed", "traffic_source", "hbm_real_frac", "valu_frac", "active_pixel_ratio", "per_kernel"):
         assert k in rf, k
-    assert rf["frac_executed"] <= rf["frac"] and 0 < rf["valu_frac"] < 1 and 0 < rf["active_pixel_ratio"] <= 1
+    assert rf["frac_executed"] <= rf["frac_nominal"] and 0 < rf["valu_frac"] < 1 and 0 < rf["active_pixel_ratio"] <= 1
     assert len(rf["per_kernel"]) >= 2
     for e in rf["per_kernel"]:
         for k in ("kernel", "launches", "avg_us", "alg_bytes_per_launch", "nominal_frac"):
             assert k in e, k
+    dom = max(rf["per_kernel"], key=lambda e: e["share_of_sweep_time"])
+    assert rf["kernel"] == dom["kernel"] and rf["frac"] == dom["nominal_frac"] and rf["launch_us"] == dom["avg_us"]
+    assert abs(rf["achieved"] - rf["alg_bytes_per_launch"] / (rf["launch_us"] * 1e-6) / 1e9) < 0.02 * rf["achieved"] + 0.01
+    # what ran vs what is credited: fixed work credits 500 sweeps per level, executed counts the
+    # sweeps up to each level's convergence
+    assert "skips" in d["config"]["semantics"]
+    assert 0 < d["executed_pixel_iters"] <= total_credit(d) and 0 < d["value_executed"] <= d["value"]
+    assert d["config"]["iters_executed_per_level_fine_to_coarse"][-1] <= 500
     assert abs(sum(e["share_of_sweep_time"] for e in rf["per_kernel"]) - 1.0) < 0.02
     assert abs(sum(e["launches"] for e in rf["per_kernel"]) - rf["launches"]) <= 0
     cb = d["cpu_baseline"]
@@ -45,6 +58,8 @@ def test_bench_json_line():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert cb["gpu_same_sample"]["value"] > cb["value"]        # like for like: same levels, starts, iteration counts
+    # ... and the EXACT arithmetic on that sample is the oracle's result bit for bit
+    assert cb["parity_same_sample"]["bit_identical"] is True and cb["parity_same_sample"]["max_abs_dv"] == 0.0
     # value = pixel-iterations of one fixed-work 1080p solve / time of the step
     sizes = [(1920, 1080), (960, 540), (480, 270), (240, 135), (120, 68)]
     total = 500 * sum(w * h for w, h in sizes)

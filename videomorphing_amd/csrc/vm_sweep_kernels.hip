@@ -327,10 +327,27 @@ __device__ __forceinline__ void fover_isec(float cx, float cy, float gx, float g
     }
 }
 
+// Where the halfway vectors of a pixel's 8 ring neighbours come from (ring position k =
+// offsets (-1,-1) (0,-1) (1,-1) (1,0) (1,1) (0,1) (-1,1) (-1,0)): global memory, or -- in the
+// PASS schedule, whose phases hand data over inside a launch -- lanes 0..7 of the pixel's
+// 32-lane group, which fetched them with L1-bypassing loads after the tile barrier.
+struct RingGlobal {
+    const float2 *v;
+    __device__ __forceinline__ float2 operator()(int, int gi) const { return v[gi]; }
+};
+struct RingLanes {
+    float2 mine; // lane k < 8 of the group: v of ring neighbour k (anything where it is outside the image)
+    __device__ __forceinline__ float2 operator()(int k, int) const
+    {
+        return make_float2(__shfl(mine.x, k, 32), __shfl(mine.y, k, 32));
+    }
+};
+
 // fover_calc_isec_min (morph.cu:833-870) with fover_calc_vtx (:782-792, note the
 // `p - off` of the original) for one sign
-__device__ __forceinline__ void fover_ring(const VmLevelView &L, int px, int py, float sgn, float vx, float vy,
-                                           float gx, float gy, float &t_min)
+template <class Ring>
+__device__ __forceinline__ void fover_ring(const VmLevelView &L, const Ring &ring, int px, int py, float sgn, float vx,
+                                           float vy, float gx, float gy, float &t_min)
 {
     const int rx[8] = {-1, 0, 1, 1, 1, 0, -1, -1};
     const int ry[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
@@ -339,8 +356,9 @@ __device__ __forceinline__ void fover_ring(const VmLevelView &L, int px, int py,
     for (int k = 0; k < 8; ++k) {
         float ux = vx, uy = vy;
         int qx = px + rx[k], qy = py + ry[k];
-        if (qx >= 0 && qx < L.w && qy >= 0 && qy < L.h) {
-            float2 nv = L.v[qy * L.rs + qx];
+        const bool in = qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
+        const float2 nv = ring(k, in ? qy * L.rs + qx : py * L.rs + px);
+        if (in) {
             ux = sgn * nv.x;
             uy = sgn * nv.y;
         }
@@ -375,9 +393,9 @@ __device__ __forceinline__ void halves(float v, float &lo, float &hi)
 // optimize_pixel (morph.cu:1030-1083) after the mask test: gradient, fold-over bound,
 // golden-section search.  All L lanes of the pixel's group run it in lockstep and
 // agree bit for bit.  Returns true and the accepted step when the energy drops.
-template <class Energy>
+template <class Energy, class Ring>
 __device__ __forceinline__ bool decide_with(const VmLevelView &L, const VmKParams &P, const PixelCtx &c,
-                                            const Energy &energy, float2 &step, uint32_t &n_eval VM_TS_ARG)
+                                            const Energy &energy, const Ring &ring, float2 &step, uint32_t &n_eval VM_TS_ARG)
 {
     VM_TS(4);
 #define ENERGY(DX, DY) (++n_eval, energy((DX), (DY)))
@@ -404,8 +422,8 @@ __device__ __forceinline__ bool decide_with(const VmLevelView &L, const VmKParam
     gy = fdiv(gy, ng);
     // prevent_foldover, morph.cu:872-883
     float t_min = 10;
-    fover_ring(L, c.px, c.py, -1.0f, -c.v.x, -c.v.y, -gx, -gy, t_min);
-    fover_ring(L, c.px, c.py, 1.0f, c.v.x, c.v.y, gx, gy, t_min);
+    fover_ring(L, ring, c.px, c.py, -1.0f, -c.v.x, -c.v.y, -gx, -gy, t_min);
+    fover_ring(L, ring, c.px, c.py, 1.0f, c.v.x, c.v.y, gx, gy, t_min);
     float cc = fmaxf(t_min - P.eps, 0.0f);
     VM_TS(6);
     // golden_section_search, morph.cu:885-947: step 0 and 1 evaluate the two initial
@@ -464,9 +482,10 @@ __device__ __forceinline__ bool decide_with(const VmLevelView &L, const VmKParam
 // only).  Every evaluation that is USED is the one decide_with makes at that step, with the same
 // arguments: bit-identical results; n_eval counts the search's evaluations.  (The FAST lean path
 // has its own copy, decide64, which also carries the lumas along.)
-template <class Energy>
+template <class Energy, class Ring>
 __device__ __forceinline__ bool decide_with64(const VmLevelView &L, const VmKParams &P, const PixelCtx &c,
-                                              const Energy &energy, bool hi, float2 &step, uint32_t &n_eval)
+                                              const Energy &energy, const Ring &ring, bool hi, float2 &step,
+                                              uint32_t &n_eval)
 {
     float gx = 0, gy = 0;
     {
@@ -494,8 +513,8 @@ __device__ __forceinline__ bool decide_with64(const VmLevelView &L, const VmKPar
     gx = fdiv(gx, ng);
     gy = fdiv(gy, ng);
     float t_min = 10;
-    fover_ring(L, c.px, c.py, -1.0f, -c.v.x, -c.v.y, -gx, -gy, t_min);
-    fover_ring(L, c.px, c.py, 1.0f, c.v.x, c.v.y, gx, gy, t_min);
+    fover_ring(L, ring, c.px, c.py, -1.0f, -c.v.x, -c.v.y, -gx, -gy, t_min);
+    fover_ring(L, ring, c.px, c.py, 1.0f, c.v.x, c.v.y, gx, gy, t_min);
     float cc = fmaxf(t_min - P.eps, 0.0f);
     const float R = 0.618033989f, C = 1.0f - R;
     float a = 0;
@@ -558,7 +577,7 @@ __device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P,
     nb_load<INTERIOR>(nb, L, src, c, sub, Lf);
     return decide_with(
         L, P, c, [&](float dx, float dy) { return energy_change<INTERIOR>(L, P, src, nb, c, dx, dy, Lf); },
-        step, n_eval VM_TS_PASS);
+        RingGlobal{L.v}, step, n_eval VM_TS_PASS);
 }
 
 #if VM_EXACT
@@ -628,7 +647,8 @@ __device__ __forceinline__ bool decide_x32(const VmLevelView &L, const VmKParams
     NbX nb;
     nbx_load(nb, L, src, c, sub);
     return decide_with(
-        L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step, n_eval VM_TS_PASS);
+        L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, RingGlobal{L.v}, step,
+        n_eval VM_TS_PASS);
 }
 // ... with a whole wave per pixel (both halves hold the same neighbour sums)
 template <class Src>
@@ -638,7 +658,8 @@ __device__ __forceinline__ bool decide_x64(const VmLevelView &L, const VmKParams
     NbX nb;
     nbx_load(nb, L, src, c, sub);
     return decide_with64(
-        L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, hi, step, n_eval);
+        L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, RingGlobal{L.v}, hi, step,
+        n_eval);
 }
 #endif
 
@@ -803,7 +824,9 @@ __device__ __forceinline__ float change32(const VmKParams &P, const Nb1 &nb, con
 // prevent_foldover (morph.cu:872-883): lane s < 16 tests segment s & 7 of ring s >> 3
 // (ring 0: sign -1 on (-v, -g); ring 1: sign +1 on (v, g)); the bound is the minimum of
 // the 16 crossings (the reference's running minimum up to the rounding of `td < t_min d`)
-__device__ __forceinline__ float fover32(const VmLevelView &L, const PixelCtx &c, float gx, float gy, int sub)
+template <class Ring>
+__device__ __forceinline__ float fover32(const VmLevelView &L, const Ring &ring, const PixelCtx &c, float gx, float gy,
+                                         int sub)
 {
     const int k = sub & 7, k1 = (k + 1) & 7;
     const float sgn = (sub & 8) ? 1.0f : -1.0f;
@@ -816,8 +839,9 @@ __device__ __forceinline__ float fover32(const VmLevelView &L, const PixelCtx &c
         const int rx = ((0x06A4 >> (2 * kk)) & 3) - 1, ry = ((0x6A40 >> (2 * kk)) & 3) - 1;
         const int qx = c.px + rx, qy = c.py + ry;
         float ux = vx, uy = vy;
-        if (qx >= 0 && qx < L.w && qy >= 0 && qy < L.h) {
-            const float2 nv = L.v[qy * L.rs + qx];
+        const bool in = qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
+        const float2 nv = ring(kk, in ? qy * L.rs + qx : c.idx);
+        if (in) {
             ux = sgn * nv.x;
             uy = sgn * nv.y;
         }
@@ -833,8 +857,8 @@ __device__ __forceinline__ float fover32(const VmLevelView &L, const PixelCtx &c
 // the accepted point (what commit_pixel_motion would sample again).  The gradient uses the
 // energy as energy_change (morph.cu:730-761) writes it; along the search line d = g t the
 // quadratic terms collapse to t (Q2 t + Q1).
-template <bool INTERIOR>
-__device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &P, const Nb1 &nb,
+template <bool INTERIOR, class Ring>
+__device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &P, const Nb1 &nb, const Ring &ring,
                                          const PixelCtx &c, int sub, float2 &step, float2 &luma,
                                          uint32_t &n_eval VM_TS_ARG)
 {
@@ -881,7 +905,7 @@ __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &
         return false;
     gx = fdiv(gx, ng);
     gy = fdiv(gy, ng);
-    float cc = fmaxf(fover32(L, c, gx, gy, sub) - P.eps, 0.0f);
+    float cc = fmaxf(fover32(L, ring, c, gx, gy, sub) - P.eps, 0.0f);
     VM_TS(6);
     // E(t) = WS change(t) + t (Q2 t + Q1)
     const float gg = gx * gx + gy * gy;
@@ -951,8 +975,8 @@ __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &
 // Every evaluation that is USED is the one decide32 makes at that step (same point, same
 // arithmetic, same lanes' roles), so the result is bit-identical to decide32's; n_eval counts
 // the search's evaluations, not the speculative ones.
-template <bool INTERIOR>
-__device__ __forceinline__ bool decide64(const VmLevelView &L, const VmKParams &P, const Nb1 &nb,
+template <bool INTERIOR, class Ring>
+__device__ __forceinline__ bool decide64(const VmLevelView &L, const VmKParams &P, const Nb1 &nb, const Ring &ring,
                                          const PixelCtx &c, int sub, bool hi, float2 &step, float2 &luma,
                                          uint32_t &n_eval)
 {
@@ -1001,7 +1025,7 @@ __device__ __forceinline__ bool decide64(const VmLevelView &L, const VmKParams &
         return false;
     gx = fdiv(gx, ng);
     gy = fdiv(gy, ng);
-    float cc = fmaxf(fover32(L, c, gx, gy, sub) - P.eps, 0.0f);
+    float cc = fmaxf(fover32(L, ring, c, gx, gy, sub) - P.eps, 0.0f);
     const float gg = gx * gx + gy * gy;
     const float WS = P.w_ssim * L.inv_wh, WU = P.w_ui * L.inv_wh;
     const float Q2 = (WU * c.ui_axy + P.w_tps * c.tps_axy) * gg;
@@ -1380,12 +1404,12 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                         uint32_t n_eval = 0;
                         if (wave_interior) {
                             nb1_load<true>(nb, L, src, c, sub);
-                            ok = wide ? decide64<true>(L, P, nb, c, sub, (tid & 32) != 0, step, luma, n_eval)
-                                      : decide32<true>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
+                            ok = wide ? decide64<true>(L, P, nb, RingGlobal{L.v}, c, sub, (tid & 32) != 0, step, luma, n_eval)
+                                      : decide32<true>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
                         } else {
                             nb1_load<false>(nb, L, src, c, sub);
-                            ok = wide ? decide64<false>(L, P, nb, c, sub, (tid & 32) != 0, step, luma, n_eval)
-                                      : decide32<false>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
+                            ok = wide ? decide64<false>(L, P, nb, RingGlobal{L.v}, c, sub, (tid & 32) != 0, step, luma, n_eval)
+                                      : decide32<false>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
                         }
                         if (writer)
                             atomicAdd(&S.n_eval, n_eval);
@@ -1853,10 +1877,10 @@ __global__ __launch_bounds__(VM_SWEEP_T) void SUF(k_decide)(const VmLevelView *_
                 bool ok;
                 if (wave_interior) {
                     nb1_load<true>(nb, L, src, c, sub);
-                    ok = decide32<true>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
+                    ok = decide32<true>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
                 } else {
                     nb1_load<false>(nb, L, src, c, sub);
-                    ok = decide32<false>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
+                    ok = decide32<false>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
                 }
 #endif
                 if (ok)
@@ -2056,6 +2080,20 @@ __device__ __forceinline__ uint32_t cell_hits(const uint32_t (*bits)[4], int bx0
 // are fetched in two batches of 5 and 4 -- all loads of a batch are issued before the first is
 // used, and a batch is skipped when no lane of the wave has a record left; one batch of 9 would
 // cost 72 VGPRs and with them a workgroup per CU.
+// COH: the records were written by other workgroups of THIS launch (PASS schedule): L1-bypassing loads.
+template <bool COH>
+__device__ __forceinline__ float4 rec_load(const float4 *p)
+{
+    if (!COH)
+        return *p;
+    const unsigned long long *u = (const unsigned long long *)p;
+    const unsigned long long a = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b),
+                       __uint_as_float((uint32_t)(b >> 32)));
+}
+
+template <bool COH = false>
 __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__restrict__ r_a,
                                           const float4 *__restrict__ r_b, const float *s_tps, uint32_t hits, int qx,
                                           int qy, float2 &m, float2 &q, float &cr, float2 &tb, int rev)
@@ -2089,8 +2127,8 @@ __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__
             const int bb = max(b, 0);
             const int dy = (bb * 13) >> 6, dx = bb - dy * 5;
             const int rsafe = b >= 0 ? (qy + dy - 2) * L.rs + (qx + dx - 2) : qy * L.rs + qx;
-            ra[k] = r_a[rsafe];
-            rb[k] = r_b[rsafe];
+            ra[k] = rec_load<COH>(r_a + rsafe);
+            rb[k] = rec_load<COH>(r_b + rsafe);
         }
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -2399,10 +2437,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
             nb.counter = okc ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
             if (wide)
                 ok = decide_with64(
-                    L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, (tid & 32) != 0, step, n_eval);
+                    L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, RingGlobal{L.v},
+                    (tid & 32) != 0, step, n_eval);
             else
                 ok = decide_with(
-                    L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, step, n_eval VM_TS_PASS);
+                    L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, RingGlobal{L.v}, step,
+                    n_eval VM_TS_PASS);
             if (ok) { // the lumas commit_pixel_motion samples (morph.cu:997-1003)
                 const float nvx = c.v.x + step.x, nvy = c.v.y + step.y;
                 luma.x = tap(L.img0, L.w, L.h, L.rs, px - nvx + 0.5f, py - nvy + 0.5f);
@@ -2414,17 +2454,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
                 const bool hi = (tid & 32) != 0;
                 if (wave_interior) {
                     nb1_make<true>(nb, L, okc, qx, qy, m, q, cr, val);
-                    ok = decide64<true>(L, P, nb, c, sub, hi, step, luma, n_eval);
+                    ok = decide64<true>(L, P, nb, RingGlobal{L.v}, c, sub, hi, step, luma, n_eval);
                 } else {
                     nb1_make<false>(nb, L, okc, qx, qy, m, q, cr, val);
-                    ok = decide64<false>(L, P, nb, c, sub, hi, step, luma, n_eval);
+                    ok = decide64<false>(L, P, nb, RingGlobal{L.v}, c, sub, hi, step, luma, n_eval);
                 }
             } else if (wave_interior) {
                 nb1_make<true>(nb, L, okc, qx, qy, m, q, cr, val);
-                ok = decide32<true>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
+                ok = decide32<true>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
             } else {
                 nb1_make<false>(nb, L, okc, qx, qy, m, q, cr, val);
-                ok = decide32<false>(L, P, nb, c, sub, step, luma, n_eval VM_TS_PASS);
+                ok = decide32<false>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
             }
 #endif
             if (ok)
@@ -2466,6 +2506,485 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
             flags[iter_idx] = 1u;
         *my_slot = make_uint4((uint32_t)n_mine, nc, S.n_eval, part == 0 ? 1u : 0u);
     }
+}
+
+
+// ===========================================================================
+// PASS schedule: ONE launch per pass for the small levels a single frame pair is bound by
+// (120x68 of a 1080p pyramid: 8 tiles per pass, every pixel active for all 500 iterations,
+// 8000 dependent phases).  STEP pays a kernel boundary per phase: launch gap, three cold
+// dependent round trips at entry, the level re-staged into eight cold L2s.  Here the four
+// Jacobi phases of a tile stay inside one launch behind a TILE-LOCAL barrier:
+//  - a tile is worked by a GROUP of 32 workgroups of 8 waves: one wave per phase pixel
+//    (slot = part * 8 + wave), no candidate list, no workgroup-wide staging -- every wave
+//    tests its own pixel's mask bits, folds the last phase's records into the window cell
+//    each lane owns and runs the wave-wide line search (decide64 / decide_with64);
+//  - workgroup ids b, b + 8, b + 16, ... belong to one group: under the observed round-robin
+//    dispatch they share an XCD, so a tile's state stays in ONE L2 (speed only -- every
+//    hand-off below is valid wherever the workgroups land);
+//  - between phases the group meets at a counter of its own (32 arrivals, one agent-scope
+//    add per workgroup behind every wave's vmcnt(0) and the workgroup barrier; one lane polls
+//    with L1-bypassing loads, bounded: a timeout raises an error word instead of hanging);
+//    everything handed from phase to phase -- records, tags, v, the folded window sums, mask
+//    words -- is stored write-through and loaded L1-bypassing (relaxed agent-scope atomics =
+//    sc1), the acquire-free form of MI355X_MICROARCH.md "Valid forms";
+//  - the fold of phase s-1's records into the sums (tile + halo, 1360 cells) is shared out
+//    over the group (43 cells per workgroup, done by the first wave to finish its line
+//    search) and ping-pongs between the canonical arrays and the second copy:
+//        phase 0 reads C | 1: C + rec(0), folds C -> T | 2: T + rec(1), T -> C |
+//        3: C + rec(2), C -> T | after the last barrier: T + rec(3) -> C
+//    so a pass leaves the canonical state complete and the next pass (other tile geometry)
+//    starts from it like any other schedule.
+// Same arithmetic, same fold order (fold_cell), same records as STEP: bit-identical to it.
+struct PassLds {
+    float tps[625];
+    uint32_t imp[225];
+    uint32_t ticket[4];       // first wave to finish phase s takes the fold share of that phase
+    uint32_t n_cand, n_commit, n_eval;
+    uint32_t go;
+};
+
+__device__ __forceinline__ uint32_t ldc(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ldc(const float *p) { return __uint_as_float(ldc((const uint32_t *)p)); }
+__device__ __forceinline__ float2 ldc(const float2 *p)
+{
+    const unsigned long long u = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((uint32_t)u), __uint_as_float((uint32_t)(u >> 32)));
+}
+__device__ __forceinline__ void stc(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stc(float *p, float v) { stc((uint32_t *)p, __float_as_uint(v)); }
+__device__ __forceinline__ void stc(float2 *p, float2 v)
+{
+    const unsigned long long u = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+    __hip_atomic_store((unsigned long long *)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stc(float4 *p, float4 v)
+{
+    stc((float2 *)p, make_float2(v.x, v.y));
+    stc((float2 *)p + 1, make_float2(v.z, v.w));
+}
+
+// bits of mask word (bx, by) whose pixels lie inside [x0, x1] x [y0, y1]
+__device__ __forceinline__ uint32_t block_bits_in(int bx, int by, int x0, int x1, int y0, int y1)
+{
+    uint32_t cols = 0, m = 0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+        if (5 * bx + r >= x0 && 5 * bx + r <= x1)
+            cols |= 1u << r;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+        if (5 * by + r >= y0 && 5 * by + r <= y1)
+            m |= cols << (5 * r);
+    return m;
+}
+
+#define VM_PASS_PARTS 32
+#define VM_PASS_CELLS ((VM_NCELL + VM_PASS_PARTS - 1) / VM_PASS_PARTS)
+
+// one wave adds the per-workgroup count slots of a finished PASS launch into the counters of
+// iteration `it`, pair by pair (slot k belongs to group (k >> 8) * 8 + (k & 7))
+__device__ __forceinline__ void pass_sum_slots(uint32_t *stats0, const uint32_t *slots, int it, int nslot, int ntiles,
+                                               int ngroups, int cap, int lane)
+{
+    const uint4 *sl = (const uint4 *)slots;
+    const int npairs = ngroups / ntiles;
+    for (int p = 0; p < npairs; ++p) {
+        uint32_t acc[4] = {0, 0, 0, 0};
+        for (int k = lane; k < nslot; k += 64) {
+            const int grp = (k >> 8) * 8 + (k & 7);
+            if (grp >= ngroups || grp / ntiles != p)
+                continue;
+            const uint4 q = sl[k];
+            acc[0] += q.x;
+            acc[1] += q.y;
+            acc[2] += q.z;
+            acc[3] += q.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            for (int o = 32; o > 0; o >>= 1)
+                acc[k] += __shfl_xor(acc[k], o);
+        if (lane == 0) {
+            uint32_t *st = stats0 + ((size_t)p * cap + it) * VM_STAT_WORDS;
+            st[1] += acc[0]; // line searches
+            st[2] += acc[1]; // commits
+            st[4] += acc[2]; // energy evaluations
+            st[0] += acc[3]; // tile visits
+        }
+    }
+}
+#define VM_PASS_TIMEOUT_TICKS 200000000ull // 2 s of the 100 MHz wall clock
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4))) void SUF(k_pass)(
+    const VmLevelView *__restrict__ views, int cap, VmKParams P, const uint32_t *__restrict__ tables, int offx, int offy,
+    uint32_t epoch0, int ngroups, int ntiles, uint32_t *__restrict__ bar, uint32_t *__restrict__ flags,
+    uint32_t *__restrict__ stats, int iter_idx, int fixed_work, uint32_t *__restrict__ slots_cur,
+    const uint32_t *__restrict__ slots_prev, int prev_iter_idx, int nslot_prev, uint32_t *__restrict__ err,
+    uint32_t *__restrict__ dbg)
+{
+    __shared__ PassLds S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & 31;
+    const bool hi = (tid & 32) != 0;
+    // workgroup -> (group, part): ids b, b + 8, ... of a 256-block chunk form one group
+    const int b = (int)blockIdx.x, within = b & 255;
+    const int grp = (b >> 8) * 8 + (within & 7), part = within >> 3;
+    uint4 *my_slot = (uint4 *)slots_cur + b; // read by the next launch: always written
+    if (grp >= ngroups) {
+        if (tid == 0)
+            *my_slot = make_uint4(0, 0, 0, 0);
+        return;
+    }
+    const int pair = grp / ntiles, tile = grp - pair * ntiles;
+    const VmLevelView L = views[pair];
+    flags += (size_t)pair * cap;
+    uint32_t *const stats0 = stats;
+    for (int k = tid; k < 625; k += 512)
+        S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
+    for (int k = tid; k < 225; k += 512)
+        S.imp[k] = tables[VM_TAB_IMP + k];
+    if (tid < 4)
+        S.ticket[tid] = 0;
+    if (tid == 0) {
+        S.n_cand = S.n_commit = S.n_eval = 0;
+        S.go = 1;
+    }
+    if (dbg && tid == 0) // diagnostic: which XCD the workgroup runs on (HW_REG_XCC_ID, bits 3:0)
+        dbg[b] = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;
+    const int gxn = (L.w + VM_PITCH_X - 1) / VM_PITCH_X;
+    const int ox = (tile % gxn) * VM_PITCH_X + offx, oy = (tile / gxn) * VM_PITCH_Y + offy;
+    const MaskGeom g = mask_geom(L, ox, oy);
+    // Group-wide early outs.  Every workgroup of the group must take the same decision from data
+    // no workgroup of this launch can have changed yet: the flag of the previous iteration, and
+    // the mask bits of the pixels within +-2 of the tile (pixels of this tile or of the gaps: no
+    // other tile of the pass owns them).  No set bit there = no candidate in phase 0, hence no
+    // commit, hence none in the later phases.
+    bool live = ox < L.w && oy < L.h && !(!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0);
+    {
+        uint32_t mine = 0;
+        if (live && tid < g.nbx * g.nby) {
+            const int mx = tid % g.nbx, my = tid / g.nbx;
+            mine = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)] &
+                   block_bits_in(g.bx0 + mx, g.by0 + my, max(ox - 2, 0), min(ox + VM_TILE_W + 1, L.w - 1), max(oy - 2, 0),
+                                 min(oy + VM_TILE_H + 1, L.h - 1));
+        }
+        if (!__syncthreads_or(mine != 0))
+            live = false;
+    }
+    // the activity counts of the previous launch, added up by one wave of workgroup 0 (a plain
+    // read-modify-write by one thread: nothing else touches that iteration's counters now)
+    if (b == 0 && wave == 7 && prev_iter_idx >= 0)
+        pass_sum_slots(stats0, slots_prev, prev_iter_idx, nslot_prev, ntiles, ngroups, cap, lane);
+    if (!live) {
+        if (tid == 0)
+            *my_slot = make_uint4(0, 0, 0, 0);
+        return;
+    }
+
+    // this wave's pixel slot of the tile: (tx, ty), pixel (ox + 2 tx + pj, oy + 2 ty + pi) in phase (pi, pj)
+    const int slot = part * 8 + wave, tx = slot & 31, ty = slot >> 5;
+    // my share of the fold: cells of the tile + halo
+    const int cell = part * VM_PASS_CELLS + lane;
+    const int frx = cell % VM_HALO_W - 2, fry = cell / VM_HALO_W - 2;
+    const int fqx = ox + frx, fqy = oy + fry;
+    const bool fcell = lane < VM_PASS_CELLS && cell < VM_NCELL && fqx >= 0 && fqx < L.w && fqy >= 0 && fqy < L.h;
+    // ... and of the mask words the tile owns (blocks holding one of its pixels): word part, part + 32, ...
+    const int own_bx0 = ox / 5, own_by0 = oy / 5;
+    const int own_nx = min(ox + VM_TILE_W - 1, L.w - 1) / 5 - own_bx0 + 1, own_ny = min(oy + VM_TILE_H - 1, L.h - 1) / 5 - own_by0 + 1;
+    const int tx1 = min(ox + VM_TILE_W, L.w), ty1 = min(oy + VM_TILE_H, L.h); // tile pixels: [ox, tx1) x [oy, ty1)
+
+    // fold of phase `fph`'s records (epoch epoch0 + fph) into the group's share of cells and mask
+    // words: src copy -> dst copy.  One wave.
+    auto fold_share = [&](int fph, bool src_t, bool dst_t) {
+        const uint32_t pe = epoch0 + (uint32_t)fph, want = (pe << 2) | 1u;
+        const int fpi = fph >> 1, fpj = fph & 1;
+        const uint32_t *r_tag = (pe & 1u) ? L.rec_tag2 : L.rec_tag;
+        const float4 *r_a = (pe & 1u) ? L.rec_a2 : L.rec_a, *r_b = (pe & 1u) ? L.rec_b2 : L.rec_b;
+        const float2 *s_mean = src_t ? L.mean2 : L.mean, *s_var = src_t ? L.var2 : L.var, *s_tpsb = src_t ? L.tps_b2 : L.tps_b;
+        const float *s_cross = src_t ? L.cross2 : L.cross, *s_value = src_t ? L.value2 : L.value;
+        float2 *d_mean = dst_t ? L.mean2 : L.mean, *d_var = dst_t ? L.var2 : L.var, *d_tpsb = dst_t ? L.tps_b2 : L.tps_b;
+        float *d_cross = dst_t ? L.cross2 : L.cross, *d_value = dst_t ? L.value2 : L.value;
+        const uint32_t *s_imp = src_t ? L.impmask2 : L.impmask;
+        uint32_t *d_imp = dst_t ? L.impmask2 : L.impmask;
+        {
+            const int gi = fcell ? fqy * L.rs + fqx : 0;
+            float2 m = make_float2(0, 0), q = m, tb = m;
+            float cr = 0, val = 0;
+            uint32_t hits = 0;
+            if (fcell) {
+                m = ldc(s_mean + gi);
+                q = ldc(s_var + gi);
+                tb = ldc(s_tpsb + gi);
+                cr = ldc(s_cross + gi);
+                val = ldc(s_value + gi);
+                // records of that phase within +-2 of the cell: the (at most 3 x 3) pixels of its
+                // parity class in the window, inside the tile
+                const int ax = (fpj - (fqx - 2 - ox)) & 1, ay = (fpi - (fqy - 2 - oy)) & 1;
+                uint32_t tg[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int dx = ax + 2 * (k % 3), dy = ay + 2 * (k / 3);
+                    const int x = fqx + dx - 2, y = fqy + dy - 2;
+                    const bool ok = dx <= 4 && dy <= 4 && x >= ox && x < tx1 && y >= oy && y < ty1;
+                    tg[k] = ldc(r_tag + (ok ? y * L.rs + x : gi));
+                    if (!ok)
+                        tg[k] = 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (tg[k] == want)
+                        hits |= 1u << ((ay + 2 * (k / 3)) * 5 + ax + 2 * (k % 3));
+            }
+            const bool touched = fold_cell<true>(L, r_a, r_b, S.tps, hits, fcell ? fqx : 0, fcell ? fqy : 0, m, q, cr, tb, P.rev_commit);
+            if (fcell) {
+                if (touched) {
+                    const float counter = (float)(window_count(fqy, L.h) * window_count(fqx, L.w));
+                    val = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
+                }
+                stc(d_mean + gi, m);
+                stc(d_var + gi, q);
+                stc(d_cross + gi, cr);
+                stc(d_tpsb + gi, tb);
+                stc(d_value + gi, val);
+            }
+        }
+        for (int wk = part; wk < own_nx * own_ny; wk += VM_PASS_PARTS) {
+            const int bx = own_bx0 + wk % own_nx, by = own_by0 + wk / own_nx;
+            const int wi = (by + 1) * L.imp_rs + (bx + 1);
+            const int x = 5 * bx + sub % 5, y = 5 * by + sub / 5;
+            uint32_t t = 0;
+            if (lane < 25 && x >= ox && x < tx1 && y >= oy && y < ty1)
+                t = ldc(r_tag + y * L.rs + x);
+            const uint32_t setb = (uint32_t)__ballot(lane < 25 && t == want);
+            const uint32_t clrb = (uint32_t)__ballot(lane < 25 && t == ((pe << 2) | 2u));
+            if (lane == 0)
+                stc(d_imp + wi, (ldc(s_imp + wi) | setb) & ~clrb);
+        }
+    };
+
+    uint32_t my_cand = 0, my_commit = 0, my_eval = 0; // of this wave, over the four phases
+    bool timed_out = false;
+    for (int ph = 0; ph < 4; ++ph) {
+        const int pi = ph >> 1, pj = ph & 1;
+        const bool src_t = ph == 2; // which copy holds the sums before the last phase's records
+        const uint32_t epoch = epoch0 + (uint32_t)ph, pe = epoch - 1u, want = (pe << 2) | 1u;
+        const uint32_t *r_tag = (pe & 1u) ? L.rec_tag2 : L.rec_tag;
+        const float4 *r_a = (pe & 1u) ? L.rec_a2 : L.rec_a, *r_b = (pe & 1u) ? L.rec_b2 : L.rec_b;
+        uint32_t *w_tag = (epoch & 1u) ? L.rec_tag2 : L.rec_tag;
+        float4 *w_a = (epoch & 1u) ? L.rec_a2 : L.rec_a, *w_b = (epoch & 1u) ? L.rec_b2 : L.rec_b;
+        const float2 *s_mean = src_t ? L.mean2 : L.mean, *s_var = src_t ? L.var2 : L.var, *s_tpsb = src_t ? L.tps_b2 : L.tps_b;
+        const float *s_cross = src_t ? L.cross2 : L.cross, *s_value = src_t ? L.value2 : L.value;
+        const uint32_t *s_imp = src_t ? L.impmask2 : L.impmask;
+        const int ppi = (ph - 1) >> 1, ppj = (ph - 1) & 1; // parity class of the last phase's pixels (ph > 0)
+
+        const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
+        const bool in_img = px < L.w && py < L.h;
+        const int spx = in_img ? px : ox, spy = in_img ? py : oy; // a safe pixel for the speculative loads
+        // ---- everything the phase needs from memory that does not depend on another load: one round trip
+        // (a) mask words of the 2 x 2 blocks the pixel's window reaches + the last phase's tags in them
+        const int oxb = spx % 5, oyb = spy % 5, pbx = spx / 5, pby = spy / 5;
+        const int begi = oyb >= 2 ? 1 : 0, begj = oxb >= 2 ? 1 : 0;
+        uint32_t mword[2], mtag[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { // lanes 0-31: block column begj - 1, lanes 32-63: begj; round r: block row begi - 1 + r
+            const int bx = pbx + begj - 1 + (hi ? 1 : 0), by = pby + begi - 1 + r;
+            const bool owned = bx >= own_bx0 && bx < own_bx0 + own_nx && by >= own_by0 && by < own_by0 + own_ny;
+            // words the tile does not own hold bits of gap pixels only as far as this pixel is
+            // concerned: always the canonical array (their owner may rewrite them, never those bits)
+            mword[r] = ldc((owned ? s_imp : L.impmask) + (by + 1) * L.imp_rs + (bx + 1));
+            const int x = 5 * bx + sub % 5, y = 5 * by + sub / 5;
+            mtag[r] = 0;
+            if (ph > 0 && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1)
+                mtag[r] = ldc(r_tag + y * L.rs + x);
+        }
+        // (b) commits of the last phase within +-4 of the pixel (the records its window cells fold)
+        const int sx0 = -4 + ((ppj ^ pj) & 1), sy0 = -4 + ((ppi ^ pi) & 1);
+        uint32_t ctag = 0;
+        if (ph > 0 && sub < 25) {
+            const int dx = sx0 + 2 * (sub % 5), dy = sy0 + 2 * (sub / 5);
+            const int x = spx + dx, y = spy + dy;
+            if (dx <= 4 && dy <= 4 && x >= ox && x < tx1 && y >= oy && y < ty1)
+                ctag = ldc(r_tag + y * L.rs + x);
+        }
+        // (c) the pixel's own state, (d) the window cell of this lane, (e) the ring neighbours' v
+        PixelCtx c;
+        c.px = spx;
+        c.py = spy;
+        c.idx = spy * L.rs + spx;
+        c.v = ldc(L.v + c.idx);
+        c.old_luma = ldc(L.luma + c.idx);
+        c.ui_b = ldc(L.ui_b + c.idx);
+        c.ui_axy = L.ui_axy[c.idx];
+        c.tps_axy = S.tps[(border_class(spy, L.h) * 5 + border_class(spx, L.w)) * 25 + 12] / 2;
+        c.tref = make_float2(0, 0);
+        c.tmask = 0.0f;
+        if (L.temp_mask) { // uniform in the launch
+            c.tref = L.temp_ref[c.idx];
+            c.tmask = L.temp_mask[c.idx];
+        }
+        const int wi_ = (sub * 13) >> 6, wj_ = sub - wi_ * 5; // lane sub < 25 owns neighbour (sub % 5 - 2, sub / 5 - 2)
+        const int qx = spx + wj_ - 2, qy = spy + wi_ - 2;
+        const bool okc = sub < 25 && qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
+        const int cx = okc ? qx : spx, cy = okc ? qy : spy, gi = cy * L.rs + cx;
+        float2 m = ldc(s_mean + gi), q = ldc(s_var + gi), tb = ldc(s_tpsb + gi);
+        float cr = ldc(s_cross + gi), val = ldc(s_value + gi);
+        RingLanes ring;
+        {
+            const int k = sub & 7;
+            const int rx = ((0x06A4 >> (2 * k)) & 3) - 1, ry = ((0x6A40 >> (2 * k)) & 3) - 1;
+            const int nx = spx + rx, ny = spy + ry;
+            const bool in = nx >= 0 && nx < L.w && ny >= 0 && ny < L.h;
+            ring.mine = ldc(L.v + (in ? ny * L.rs + nx : c.idx));
+        }
+
+        // ---- mask test (get_improve_mask_idx, morph.cu:621-646) on the words + the last phase's tags
+        bool hit = false;
+        {
+            const uint32_t *ib = S.imp + (oyb * 5 + oxb) * 9;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned long long sb = __ballot(mtag[r] == want), cb = __ballot(mtag[r] == ((pe << 2) | 2u));
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t w0 = (uint32_t)__shfl(mword[r], h * 32);
+                    const uint32_t word = (w0 | ((uint32_t)(sb >> (32 * h)) & 0x1FFFFFFu)) & ~((uint32_t)(cb >> (32 * h)) & 0x1FFFFFFu);
+                    if (word & ib[(begi + r) * 3 + begj + h])
+                        hit = true;
+                }
+            }
+            hit = hit && in_img;
+        }
+        uint32_t state = 0;
+        float2 step = make_float2(0, 0), luma = make_float2(0, 0);
+        uint32_t n_eval = 0;
+        if (hit) { // wave-uniform
+            state = 2;
+            ++my_cand;
+            if (!pixel_locked(L, P.bcond, px, py)) {
+                // which window bits of this lane's cell hold a commit of the last phase
+                uint32_t hits = 0;
+                if (ph > 0) {
+                    uint32_t cset = (uint32_t)__ballot(sub < 25 && ctag == want && !hi);
+                    while (cset) { // wave-uniform
+                        const int bk = __ffs(cset) - 1;
+                        cset &= cset - 1;
+                        const int ex = sx0 + 2 * (bk % 5) - (wj_ - 2), ey = sy0 + 2 * (bk / 5) - (wi_ - 2);
+                        if (okc && ex >= -2 && ex <= 2 && ey >= -2 && ey <= 2)
+                            hits |= 1u << ((ey + 2) * 5 + (ex + 2));
+                    }
+                }
+                if (fold_cell<true>(L, r_a, r_b, S.tps, hits, cx, cy, m, q, cr, tb, P.rev_commit)) {
+                    const float counter = (float)(window_count(cy, L.h) * window_count(cx, L.w));
+                    val = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
+                }
+                // tps.b of the pixel itself is the folded value of its own cell (lane 12)
+                c.tps_b.x = __shfl(tb.x, 12, 32);
+                c.tps_b.y = __shfl(tb.y, 12, 32);
+                bool ok;
+#if VM_EXACT
+                NbX nb;
+                nb.ok = okc;
+                nb.m = m;
+                nb.q = q;
+                nb.cr = cr;
+                nb.val = val;
+                nb.counter = okc ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
+                ok = decide_with64(
+                    L, P, c, [&](float dx, float dy) { return energy_x32(L, P, nb, c, dx, dy); }, ring, hi, step, n_eval);
+                if (ok) { // the lumas commit_pixel_motion samples (morph.cu:997-1003)
+                    const float nvx = c.v.x + step.x, nvy = c.v.y + step.y;
+                    luma.x = tap(L.img0, L.w, L.h, L.rs, px - nvx + 0.5f, py - nvy + 0.5f);
+                    luma.y = tap(L.img1, L.w, L.h, L.rs, px + nvx + 0.5f, py + nvy + 0.5f);
+                }
+#else
+                Nb1 nb;
+                if (is_interior(L, px, py)) { // wave-uniform: one pixel per wave
+                    nb1_make<true>(nb, L, okc, qx, qy, m, q, cr, val);
+                    ok = decide64<true>(L, P, nb, ring, c, sub, hi, step, luma, n_eval);
+                } else {
+                    nb1_make<false>(nb, L, okc, qx, qy, m, q, cr, val);
+                    ok = decide64<false>(L, P, nb, ring, c, sub, hi, step, luma, n_eval);
+                }
+#endif
+                if (ok)
+                    state = 1;
+            }
+            my_eval += n_eval;
+            if (lane == 0) {
+                if (state == 1) {
+                    const float2 ol = c.old_luma;
+                    stc(w_a + c.idx, make_float4(luma.x - ol.x, luma.y - ol.y, luma.x * luma.x - ol.x * ol.x,
+                                                 luma.y * luma.y - ol.y * ol.y));
+                    stc(w_b + c.idx, make_float4(luma.x * luma.y - ol.x * ol.y, step.x, step.y, 0.0f));
+                    stc(L.luma + c.idx, luma);
+                    stc(L.ui_b + c.idx, make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy));
+                    stc(L.v + c.idx, make_float2(c.v.x + step.x, c.v.y + step.y));
+                }
+                stc(w_tag + c.idx, (epoch << 2) | state);
+            }
+            if (state == 1)
+                ++my_commit;
+        }
+        // ---- the group's fold of the LAST phase's records, by the first wave that gets here
+        if (ph > 0) {
+            uint32_t t = 0;
+            if (lane == 0)
+                t = atomicAdd(&S.ticket[ph], 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t == 0)
+                fold_share(ph - 1, src_t, !src_t);
+        }
+        // ---- tile barrier: every store of this workgroup has left (vmcnt(0) per wave, then the
+        // workgroup barrier), one agent-scope arrival, one lane polls with L1-bypassing loads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(bar + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t target = (uint32_t)VM_PASS_PARTS * (uint32_t)(ph + 1);
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(bar + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > VM_PASS_TIMEOUT_TICKS) { // never hang the device: report and go on
+                    S.go = 0;
+                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (S.go == 0) {
+            timed_out = true;
+            break;
+        }
+    }
+    // ---- the last phase's records: second copy + rec(3) -> canonical arrays (wave 0)
+    if (!timed_out && wave == 0)
+        fold_share(3, true, false);
+    // ---- counts of the workgroup (plain stores; the next launch adds the slots up)
+    if (lane == 0) {
+        atomicAdd(&S.n_cand, my_cand);
+        atomicAdd(&S.n_commit, my_commit);
+        atomicAdd(&S.n_eval, my_eval);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (S.n_commit)
+            flags[iter_idx] = 1u; // every writer stores the same 1 (see k_step)
+        *my_slot = make_uint4(S.n_cand, S.n_commit, S.n_eval, part == 0 ? 1u : 0u);
+    }
+}
+
+// closes a batch of PASS launches: the counts the last launch left in its slots
+__global__ __launch_bounds__(64) void SUF(k_pass_tail)(uint32_t *__restrict__ stats, const uint32_t *__restrict__ slots_prev,
+                                                        int prev_iter_idx, int nslot_prev, int ntiles, int ngroups, int cap)
+{
+    pass_sum_slots(stats, slots_prev, prev_iter_idx, nslot_prev, ntiles, ngroups, cap, (int)threadIdx.x);
 }
 
 __global__ void SUF(k_next_iter)(int *iter_dev, int set, int value)
@@ -2567,4 +3086,24 @@ void SUF(vm_launch_optimize_step)(const VmLevelView *views, int nbatch, int cap,
         hipLaunchKernelGGL(SUF(k_step)<512>, grid, dim3(512), 0, s, views, cap, P, tables, offx, offy, pi, pj, parts,
                            epoch, prev_epoch, src, n_fold, flags, stats, iter_idx, fixed_work, slots_cur, slots_prev,
                            prev_iter_idx, nslot);
+}
+
+// one pass of the PASS schedule: four phases of every tile behind tile-local barriers.  `bar`:
+// ngroups zeroed counters of this launch.  decide == 0: only the closing slot fold of a batch.
+void SUF(vm_launch_optimize_pass)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
+                                  const uint32_t *tables, int offx, int offy, uint32_t epoch0, uint32_t *bar,
+                                  uint32_t *flags, uint32_t *stats, int iter_idx, int fixed_work, uint32_t *slots_cur,
+                                  const uint32_t *slots_prev, int prev_iter_idx, uint32_t *err, uint32_t *dbg,
+                                  int decide, hipStream_t s)
+{
+    const int gx = (w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (h + VM_PITCH_Y - 1) / VM_PITCH_Y;
+    const int ntiles = gx * gy, ngroups = ntiles * nbatch;
+    const int nblocks = (ngroups + 7) / 8 * 256;
+    if (!decide) {
+        hipLaunchKernelGGL(SUF(k_pass_tail), dim3(1), dim3(64), 0, s, stats, slots_prev, prev_iter_idx, nblocks, ntiles, ngroups, cap);
+        return;
+    }
+    hipLaunchKernelGGL(SUF(k_pass), dim3(nblocks), dim3(512), 0, s, views, cap, P, tables, offx, offy, epoch0, ngroups,
+                       ntiles, bar, flags, stats, iter_idx, fixed_work, slots_cur, slots_prev, prev_iter_idx, nblocks, err,
+                       dbg);
 }
