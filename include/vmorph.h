@@ -127,10 +127,12 @@ int  vm_set_math_mode(vm_ctx *ctx, int mode);
  * workgroups (small levels); VM_SWEEP_STEP = one launch per phase, the commit of a
  * phase folded into the next phase's launch; VM_SWEEP_SPARSE = TILE, but every batch of
  * iterations of a pruned level (fewer than a tenth of the pixels searched) runs as ONE launch
- * in which one workgroup per pair walks the active tiles; VM_SWEEP_AUTO picks per batch of
- * iterations.
+ * in which one workgroup per pair walks the active tiles; VM_SWEEP_PASS = one launch per
+ * pass for small levels: a tile's four phases stay inside the launch, its 32 workgroups (one
+ * wave per phase pixel) meet at a tile-local barrier between phases; VM_SWEEP_AUTO picks per
+ * batch of iterations.
  * threads/parts: 0 = automatic. */
-enum { VM_SWEEP_AUTO = 0, VM_SWEEP_TILE = 1, VM_SWEEP_SPLIT = 2, VM_SWEEP_STEP = 3, VM_SWEEP_SPARSE = 4 };
+enum { VM_SWEEP_AUTO = 0, VM_SWEEP_TILE = 1, VM_SWEEP_SPLIT = 2, VM_SWEEP_STEP = 3, VM_SWEEP_SPARSE = 4, VM_SWEEP_PASS = 5 };
 int  vm_set_tuning(vm_ctx *ctx, int sweep_mode, int threads, int parts);
 /* Diagnostic, EXACT arithmetic only: the order in which the commits of one Jacobi phase are
  * folded into the shared window sums.  The reference leaves it to float atomics
@@ -139,6 +141,12 @@ int  vm_set_tuning(vm_ctx *ctx, int sweep_mode, int threads, int parts);
  * used to measure how far two legal runs drift apart (the chaos floor FAST is judged
  * against, tests/test_gpu_fullsize.py). */
 int  vm_set_commit_order(vm_ctx *ctx, int reversed);
+/* Diagnostic of the PASS schedule: on which XCD (0..7) each of the first `n` (<= 2048)
+ * workgroups of the most recent PASS launch ran (workgroup b belongs to tile group
+ * (b / 256) * 8 + b % 8; a group whose 32 workgroups report one XCD keeps its tile in one
+ * L2).  The first call only arms the recording (xcc_of_block is filled with 0xFF); placement
+ * is a matter of speed, never of correctness. */
+int  vm_dbg_pass_placement(vm_ctx *ctx, uint8_t *xcc_of_block, int n);
 /* device facts for reports: name (<=255 chars), CU count, HBM bytes */
 int  vm_device_info(vm_ctx *ctx, char *name256, int *cus, uint64_t *hbm_bytes);
 

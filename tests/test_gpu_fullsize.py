@@ -293,6 +293,109 @@ def test_step_schedule_is_bit_identical_to_split_on_a_long_run(gpu_ctx):
     assert np.abs(_box5(luma[..., 0] * luma[..., 1]) - cross).max() < 4.0 * 25
 
 
+@pytest.mark.parametrize("mode", [capi.MATH_FAST, capi.MATH_EXACT])
+def test_pass_schedule_is_bit_identical_to_step_on_long_runs(gpu_ctx, mode):
+    """The 120x68 and 240x135 levels of a 1080p pyramid, 150 fixed-work iterations (600 PASS
+    launches = 2400 phases behind tile-local barriers, against 2400 STEP launches): same bits in
+    every state array, same counters.  Any stale read across a tile barrier -- a record, a tag, a
+    folded window sum, a neighbour's v -- would surface here as a differing word."""
+    gpu_ctx.set_math_mode(mode)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    try:
+        for (w, h, cw, ch, iters) in [(120, 68, 60, 34, 150), (240, 135, 120, 68, 60 if mode == capi.MATH_EXACT else 150)]:
+            i0, i1 = synth.make_pair(w, h)
+            v0 = (0.9 * synth.displacement(w, h) + 0.05 * np.random.RandomState(3).randn(h, w, 2)).astype(np.float32)
+            out = []
+            # (PASS, parts = 1: the diagnostic form that stores write-through from the start, as a
+            # tile group spread over several XCDs does after its first barrier)
+            for sched, parts in ((capi.SWEEP_STEP, 0), (capi.SWEEP_PASS, 0), (capi.SWEEP_PASS, 1)):
+                gpu_ctx.set_tuning(sched, 0, parts)
+                pyr = morph.Pyramid(gpu_ctx)
+                pyr.build_levels([(w, h), (cw, ch)])
+                pyr.upload_luma(1, i0, i1)
+                pyr[1].v = v0
+                capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+                pr = capi.Progress()
+                capi.check(pyr._L.vm_optimize_level(pyr._h, 0, float(iters), None, 1, C.byref(pr)))
+                lv = pyr[1]
+                out.append(([lv.field(n).copy() for n in _STATE], (pr.commits, pr.candidates, pr.evaluations),
+                            pr.sched_launches[4], pr.launches))
+            assert out[0][1] == out[1][1] == out[2][1] and out[0][1][0] > 5000, (out[0][1], out[1][1], out[2][1])
+            assert out[0][2] == 0 and out[1][2] >= 4 * iters, out[1][2:]      # the PASS kernel really ran
+            assert out[1][3] < out[0][3] / 3                    # a quarter of the launches
+            for k in (1, 2):
+                for f, a, b in zip(_STATE, out[0][0], out[k][0]):
+                    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (w, h, f, k)
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+
+
+def test_pass_schedule_under_uneven_load_equals_step(gpu_ctx):
+    """PASS forced onto a BATCH of 6 pairs of the 120x68 level (48 tile groups = 1536 workgroups,
+    several rounds on the chip, groups of different pairs finishing their phases at different
+    times): every pair ends bit-identical to the STEP schedule -- the hand-offs hold when
+    workgroups wait for compute units, share them and arrive out of step."""
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    w, h, npairs, iters = 120, 68, 6, 40
+    frames = [synth.make_pair(w, h, frame=k) for k in range(npairs)]
+    rng = np.random.RandomState(8)
+    v0 = [(0.9 * synth.displacement(w, h) + 0.05 * rng.randn(h, w, 2)).astype(np.float32) for _ in range(npairs)]
+    out = {}
+    try:
+        for sched in (capi.SWEEP_STEP, capi.SWEEP_PASS):
+            gpu_ctx.set_tuning(sched, 0, 0)
+            batch = []
+            for k in range(npairs):
+                pyr = morph.Pyramid(gpu_ctx)
+                pyr.build_levels([(w, h), (60, 34)])
+                pyr.upload_luma(1, *frames[k])
+                pyr[1].v = v0[k]
+                capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+                batch.append(pyr)
+            arr = (C.c_void_p * npairs)(*[p._h for p in batch])
+            prog = (capi.Progress * npairs)()
+            capi.check(batch[0]._L.vm_optimize_level_batch(arr, npairs, 0, float(iters), None, 1, prog))
+            out[sched] = ([[b[1].field(n).copy() for n in _STATE] for b in batch],
+                          [(prog[k].commits, prog[k].candidates, prog[k].evaluations) for k in range(npairs)])
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    assert out[capi.SWEEP_STEP][1] == out[capi.SWEEP_PASS][1], (out[capi.SWEEP_STEP][1], out[capi.SWEEP_PASS][1])
+    for k in range(npairs):
+        for f, a, b in zip(_STATE, out[capi.SWEEP_STEP][0][k], out[capi.SWEEP_PASS][0][k]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, f)
+
+
+def test_pass_groups_land_on_one_xcd_each(gpu_ctx):
+    """speed, not correctness: under the dispatch order observed on MI355X the 32 workgroups of a
+    tile group (ids b, b + 8, ...) share an XCD -- recorded by the kernel itself (HW_REG_XCC_ID)"""
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    w, h = 120, 68
+    i0, i1 = synth.make_pair(w, h)
+    buf = (C.c_uint8 * 256)()
+    try:
+        capi.check(gpu_ctx._L.vm_dbg_pass_placement(gpu_ctx._h, buf, 256))       # arms the recording
+        gpu_ctx.set_tuning(capi.SWEEP_PASS, 0, 0)
+        pyr = morph.Pyramid(gpu_ctx)
+        pyr.build_levels([(w, h), (60, 34)])
+        pyr.upload_luma(1, i0, i1)
+        pyr[1].v = (0.9 * synth.displacement(w, h)).astype(np.float32)
+        capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+        capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 2.0, None, 1, None))
+        capi.check(gpu_ctx._L.vm_dbg_pass_placement(gpu_ctx._h, buf, 256))
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    xcc = np.frombuffer(buf, dtype=np.uint8).reshape(32, 8)       # [part][group]
+    assert (xcc < 8).all(), xcc
+    groups_on_one = sum(len(set(xcc[:, g])) == 1 for g in range(8))
+    print("XCD of each tile group's workgroups:", [sorted(set(int(x) for x in xcc[:, g])) for g in range(8)])
+    assert groups_on_one >= 6, xcc.T          # observed: all 8; a lost group costs time only
+
+
 def test_wave_wide_line_search_is_bit_identical_to_the_32_lane_one(gpu_ctx):
     """FAST, STEP schedule, 120x68 and 240x135 levels, 150 fixed-work iterations: with 32 workgroups
     per tile a workgroup holds <= 8 candidates and every candidate gets a whole wave (decide64: two

@@ -26,14 +26,14 @@ def _draw(rng, wmax, hmax):
 
 @pytest.mark.parametrize("seed", [11, 12])
 def test_exact_sweeps_equal_the_oracle_on_random_levels(gpu_ctx, oracle, seed):
-    """EXACT, TILE / SPLIT / STEP schedules, 1-3 sweeps: every state array bit-identical to the oracle"""
+    """EXACT, TILE / SPLIT / STEP / SPARSE / PASS schedules, 1-3 sweeps: every state array bit-identical to the oracle"""
     rng = np.random.RandomState(seed)
     gpu_ctx.set_math_mode(capi.MATH_EXACT)
     try:
         for trial in range(8):
             w, h, kw, cons = _draw(rng, 300, 120)
             iters = int(rng.randint(1, 4))
-            for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_SPARSE):
+            for sched in (capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_SPARSE, capi.SWEEP_PASS):
                 P = T._params(oracle, **kw)
                 lo, pyr, P = T._make_level(gpu_ctx, oracle, w, h, cons=cons, P=P, seed=trial)
                 for _ in range(iters):
@@ -47,7 +47,8 @@ def test_exact_sweeps_equal_the_oracle_on_random_levels(gpu_ctx, oracle, seed):
 
 @pytest.mark.parametrize("seed", [21, 22])
 def test_fast_step_equals_split_on_random_levels(gpu_ctx, oracle, seed):
-    """FAST: the one-launch-per-phase STEP schedule against the two-kernel SPLIT schedule, bitwise"""
+    """FAST: the one-launch-per-phase STEP schedule and the one-launch-per-pass PASS schedule (tile-local
+    barriers between the phases) against the two-kernel SPLIT schedule, bitwise, incl. the counters"""
     rng = np.random.RandomState(seed)
     gpu_ctx.set_math_mode(capi.MATH_FAST)
     try:
@@ -55,16 +56,17 @@ def test_fast_step_equals_split_on_random_levels(gpu_ctx, oracle, seed):
             w, h, kw, cons = _draw(rng, 420, 160)
             iters = float(rng.randint(1, 7))
             res = []
-            for sched in (capi.SWEEP_SPLIT, capi.SWEEP_STEP):
+            for sched in (capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_PASS):
                 P = T._params(oracle, **kw)
                 lo, pyr, P = T._make_level(gpu_ctx, oracle, w, h, cons=cons, P=P, seed=trial)
                 gpu_ctx.set_tuning(sched, 0, 0)
                 pr = capi.Progress()
                 capi.check(pyr._L.vm_optimize_level(pyr._h, 0, iters, None, 1, C.byref(pr)))
-                res.append(([pyr[1].field(n).copy() for n in STATE], pr.commits))
-            assert res[0][1] == res[1][1], (w, h, kw, iters)
-            for n, a, b in zip(STATE, res[0][0], res[1][0]):
-                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (n, w, h, kw, iters)
+                res.append(([pyr[1].field(n).copy() for n in STATE], (pr.commits, pr.candidates, pr.evaluations)))
+            assert res[0][1] == res[1][1] == res[2][1], (w, h, kw, iters, res[0][1], res[1][1], res[2][1])
+            for k in (1, 2):
+                for n, a, b in zip(STATE, res[0][0], res[k][0]):
+                    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (k, n, w, h, kw, iters)
     finally:
         gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
         gpu_ctx.set_math_mode(capi.MATH_EXACT)

@@ -14,7 +14,7 @@ VM_OK = 0
 VM_E_INVALID, VM_E_DEVICE, VM_E_STATE, VM_E_NUMERIC, VM_E_CANCELLED = -1, -2, -3, -4, -5
 BCOND_NONE, BCOND_CORNER, BCOND_BORDER = 0, 1, 2
 MATH_EXACT, MATH_FAST = 0, 1
-SWEEP_AUTO, SWEEP_TILE, SWEEP_SPLIT, SWEEP_STEP, SWEEP_SPARSE = 0, 1, 2, 3, 4
+SWEEP_AUTO, SWEEP_TILE, SWEEP_SPLIT, SWEEP_STEP, SWEEP_SPARSE, SWEEP_PASS = 0, 1, 2, 3, 4, 5
 
 FIELDS = {  # name -> (id, channels)
     "img0": (0, 1), "img1": (1, 1), "v": (2, 2), "luma": (3, 2), "mean": (4, 2), "var": (5, 2),
@@ -26,7 +26,7 @@ FIELDS = {  # name -> (id, channels)
 # every symbol include/vmorph.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "vm_last_error", "vm_version", "vm_ctx_create", "vm_ctx_destroy", "vm_ctx_sync",
-    "vm_set_params", "vm_get_params", "vm_set_math_mode", "vm_set_tuning", "vm_set_commit_order", "vm_device_info",
+    "vm_set_params", "vm_get_params", "vm_set_math_mode", "vm_set_tuning", "vm_set_commit_order", "vm_dbg_pass_placement", "vm_device_info",
     "vm_pyramid_create", "vm_pyramid_destroy", "vm_pyramid_levels", "vm_level_dims",
     "vm_level_upload_luma", "vm_pyramid_build_rgb", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
@@ -112,6 +112,7 @@ def load():
         "vm_set_math_mode": [vp, i],
         "vm_set_tuning": [vp, i, i, i],
         "vm_set_commit_order": [vp, i],
+        "vm_dbg_pass_placement": [vp, vp, i],
         "vm_device_info": [vp, C.c_char_p, C.POINTER(i), C.POINTER(C.c_uint64)],
         "vm_pyramid_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(vp)],
         "vm_pyramid_levels": [vp],

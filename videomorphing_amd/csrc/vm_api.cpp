@@ -11,6 +11,9 @@
 #ifndef VM_STEP_BIG_PARTS
 #define VM_STEP_BIG_PARTS 8
 #endif
+#ifndef VM_PASS_MAX_GROUPS
+#define VM_PASS_MAX_GROUPS 8 // AUTO: PASS instead of STEP while a pass has at most this many tiles (x pairs): one 256-workgroup chunk
+#endif
 #ifndef VM_SPARSE_TILES
 #define VM_SPARSE_TILES 12 // SPARSE takes a pruned level over once <= this many tiles per iteration were active
 #endif
@@ -165,6 +168,10 @@ static void ctx_free(vm_ctx *c)
     hipFree(c->stats);
     hipHostFree(c->stats_host);
     hipFree(c->step_slots);
+    hipFree(c->pass_bar);
+    hipFree(c->pass_err);
+    hipHostFree(c->pass_err_host);
+    hipFree(c->pass_dbg);
     hipFree(c->cons_dev);
     hipFree(c->views);
     hipFree(c->iter_dev);
@@ -227,9 +234,28 @@ extern "C" int vm_set_commit_order(vm_ctx *c, int reversed)
     return VM_OK;
 }
 
+extern "C" int vm_dbg_pass_placement(vm_ctx *c, uint8_t *xcc_of_block, int n)
+{
+    if (!c || !xcc_of_block || n < 1 || n > 2048) return vm_fail(VM_E_INVALID, "vm_dbg_pass_placement: bad argument");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    VM_ON_DEVICE(c);
+    if (!c->pass_dbg) { // arm: the next PASS launches record where their workgroups run
+        VM_HIP(hipMalloc((void **)&c->pass_dbg, 2048 * sizeof(uint32_t)));
+        VM_HIP(hipMemsetAsync(c->pass_dbg, 0xFF, 2048 * sizeof(uint32_t), c->stream));
+        VM_HIP(hipStreamSynchronize(c->stream));
+        memset(xcc_of_block, 0xFF, (size_t)n);
+        return VM_OK;
+    }
+    std::vector<uint32_t> h(2048);
+    VM_HIP(hipStreamSynchronize(c->stream));
+    VM_HIP(hipMemcpy(h.data(), c->pass_dbg, 2048 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; ++k) xcc_of_block[k] = (uint8_t)(h[k] & 0xFFu);
+    return VM_OK;
+}
+
 extern "C" int vm_set_tuning(vm_ctx *c, int sweep_mode, int threads, int parts)
 {
-    if (!c || sweep_mode < VM_SWEEP_AUTO || sweep_mode > VM_SWEEP_SPARSE || threads < 0 || parts < 0 ||
+    if (!c || sweep_mode < VM_SWEEP_AUTO || sweep_mode > VM_SWEEP_PASS || threads < 0 || parts < 0 ||
         (threads && (threads % 64 || threads < 256 || threads > 1024)) || parts > 64)
         return vm_fail(VM_E_INVALID, "vm_set_tuning: bad argument");
     c->sweep_mode = sweep_mode;
@@ -744,7 +770,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         // levels that may run the SPLIT / STEP schedules need their workspace before the views
         // are copied to the device
         const int tiles0 = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
-        if (c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP ||
+        if (c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP || c->sweep_mode == VM_SWEEP_PASS ||
             (c->sweep_mode == VM_SWEEP_AUTO && tiles0 * n <= VM_STEP_MAX_TILES))
             for (int i = 0; i < n; ++i) {
                 int rc = level_ensure_ws(c, *lv[i]);
@@ -790,12 +816,32 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     const bool may_split = c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= VM_STEP_MAX_TILES;
     double cand_prev = 1e9; // line searches per iteration in the previous batch (first batch: dense)
     double tiles_prev = 1e9; // active tile visits per iteration and pair in the previous batch
-    if (may_split || c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP) // epochs restart with every call: forget old records
+    if (may_split || c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP || c->sweep_mode == VM_SWEEP_PASS) // epochs restart with every call: forget old records
         for (int i = 0; i < n; ++i)
         {
             VM_HIP(hipMemsetAsync(lv[i]->view.rec_tag, 0, (size_t)l0.rs * l0.h * 4, s));
             VM_HIP(hipMemsetAsync(lv[i]->view.rec_tag2, 0, (size_t)l0.rs * l0.h * 4, s));
         }
+    // PASS: the workgroups of a tile group spin at a barrier of their own, so every group of a
+    // launch must become resident whatever else runs.  One 256-workgroup chunk (8 groups) always
+    // fits an idle MI355X; two PASS launches of different streams could starve each other's
+    // groups, so a device-wide token admits one context at a time (the others run STEP), and the
+    // barrier's spin is bounded: a timeout comes back as VM_E_DEVICE, never as a hang.
+    // VM_NO_PASS=1 (environment) turns the schedule off -- e.g. several processes on one device.
+    static const bool no_pass = getenv("VM_NO_PASS") != nullptr;
+    static std::mutex pass_token[64];
+    std::unique_lock<std::mutex> pass_lock;
+    const bool want_pass = !no_pass && (c->sweep_mode == VM_SWEEP_PASS ||
+                                        (c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= VM_PASS_MAX_GROUPS));
+    if (want_pass) {
+        pass_lock = std::unique_lock<std::mutex>(pass_token[c->device & 63], std::try_to_lock);
+        if (pass_lock.owns_lock() && !c->pass_err) {
+            VM_HIP(hipMalloc((void **)&c->pass_err, 256));
+            VM_HIP(hipMemsetAsync(c->pass_err, 0, 256, s));
+            VM_HIP(hipHostMalloc((void **)&c->pass_err_host, 256, hipHostMallocDefault));
+        }
+    }
+    const bool may_pass = want_pass && pass_lock.owns_lock();
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
     std::vector<int> executed(n, cap), improving(n, 1), stopped(n, 0), live(n, -1);
     std::vector<double> st_tiles(n, 0.0), st_cand(n, 0.0), st_commit(n, 0.0), st_eval(n, 0.0);
@@ -813,10 +859,12 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     int batch = 2; // a short first batch: the schedule of the rest depends on what it finds
     while (done < cap) {
         const int nb = std::min(batch, cap - done);
-        const bool split = c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP ||
+        const bool split = c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP || c->sweep_mode == VM_SWEEP_PASS ||
                            (may_split && cand_prev >= 200.0 * n);
-        // the one-launch-per-phase STEP schedule unless the two-kernel SPLIT is forced
-        const bool step = split && c->sweep_mode != VM_SWEEP_SPLIT;
+        // one launch per pass (PASS) where it is admitted, else one per phase (STEP), unless
+        // the two-kernel SPLIT is forced
+        const bool pass = split && may_pass;
+        const bool step = split && !pass && c->sweep_mode != VM_SWEEP_SPLIT;
         // TILE, FAST arithmetic: the register-light kernel variant once fewer than a tenth of the pixels
         // are searched per iteration (after the first sweep of a level, typically)
         const bool lean_regime = cand_prev < 0.1 * l0.w * l0.h * n;
@@ -827,16 +875,29 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         // one workgroup per pair serialises what the TILE grid runs side by side)
         const bool sparse = may_sparse && !split && lean_regime && !force_dense &&
                             (c->sweep_mode == VM_SWEEP_SPARSE || tiles_prev <= (double)VM_SPARSE_TILES);
-        const int sched = split ? 2 : (sparse ? 3 : (dense ? 0 : 1));
+        const int sched = pass ? 4 : (split ? 2 : (sparse ? 3 : (dense ? 0 : 1)));
         const int launches_before = launches;
         VM_HIP(hipEventRecord(c->ev0, s));
         uint32_t last_epoch = 0;
         int sb = 0; // step index inside this batch: parity = which copy of the sums is read
         int slot_iter = -1; // iteration whose counts the previous STEP launch left in its slots
-        if (step) {
-            // per-workgroup count slots of the last two launches (k_step folds them one launch late)
+        const int pass_groups = tiles_per_pass * n, pass_blocks = (pass_groups + 7) / 8 * 256;
+        if (pass) { // barrier counters of every launch of the batch, zeroed once
+            const size_t need_bar = (size_t)nb * 4 * pass_groups * VM_PASS_SYNC_WORDS;
+            if (c->pass_bar_words < need_bar) {
+                VM_HIP(hipStreamSynchronize(s));
+                hipFree(c->pass_bar);
+                c->pass_bar = nullptr;
+                c->pass_bar_words = 0;
+                VM_HIP(hipMalloc((void **)&c->pass_bar, std::max(need_bar, (size_t)64 * 4 * 8 * VM_PASS_SYNC_WORDS) * sizeof(uint32_t)));
+                c->pass_bar_words = std::max(need_bar, (size_t)64 * 4 * 8 * VM_PASS_SYNC_WORDS);
+            }
+            VM_HIP(hipMemsetAsync(c->pass_bar, 0, need_bar * sizeof(uint32_t), s));
+        }
+        if (step || pass) {
+            // per-workgroup count slots of the last two launches (k_step / k_pass fold them one launch late)
             const int gxs = (l0.w + VM_PITCH_X - 1) / VM_PITCH_X, gys = (l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y;
-            const size_t need = (size_t)gxs * gys * parts * n * 4;
+            const size_t need = pass ? (size_t)pass_blocks * 4 : (size_t)gxs * gys * parts * n * 4;
             if (c->step_slots_words < need) {
                 VM_HIP(hipStreamSynchronize(s));
                 hipFree(c->step_slots);
@@ -868,7 +929,17 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         }
         for (int it = it0; it < done + nb; ++it)
             for (int k = 0; k < 4; ++k) {
-                if (step) {
+                if (pass) {
+                    (exact ? vm_launch_optimize_pass_exact : vm_launch_optimize_pass_fast)(
+                        c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], 1u + (uint32_t)((it * 4 + k) * 4),
+                        c->pass_bar + (size_t)((it - done) * 4 + k) * pass_groups * VM_PASS_SYNC_WORDS, c->flags, c->stats, it, fixed_work,
+                        c->step_slots + (size_t)(sb & 1) * c->step_slots_words,
+                        c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, sb == 0 ? -1 : slot_iter, c->pass_err,
+                        c->pass_dbg, 1, c->sweep_mode == VM_SWEEP_PASS && c->sweep_parts == 1, s);
+                    slot_iter = it;
+                    ++sb;
+                    ++launches;
+                } else if (step) {
                     for (int ph = 0; ph < 4; ++ph, ++sb) {
                         const uint32_t epoch = 1u + (uint32_t)((it * 4 + k) * 4 + ph);
                         (exact ? vm_launch_optimize_step_exact : vm_launch_optimize_step_fast)(
@@ -897,14 +968,27 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
                 c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, sb == 0 ? -1 : slot_iter, s);
             ++launches;
         }
+        if (pass && sb > 0) { // the counts the last launch left in its slots
+            (exact ? vm_launch_optimize_pass_exact : vm_launch_optimize_pass_fast)(
+                c->views, n, cap, l0.w, l0.h, P, c->tables, 0, 0, 0u, nullptr, c->flags, c->stats, done + nb - 1, fixed_work,
+                nullptr, c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, slot_iter, c->pass_err, nullptr, 0, 0, s);
+            ++launches;
+        }
         VM_HIP(hipEventRecord(c->ev1, s));
         VM_HIP(hipGetLastError());
+        if (pass)
+            VM_HIP(hipMemcpyAsync(c->pass_err_host, c->pass_err, 4, hipMemcpyDeviceToHost, s));
         for (int i = 0; i < n; ++i) {
             VM_HIP(hipMemcpyAsync(c->flags_host + (size_t)i * cap + done, c->flags + (size_t)i * cap + done, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
             VM_HIP(hipMemcpyAsync(c->stats_host + ((size_t)i * cap + done) * VM_STAT_WORDS, c->stats + ((size_t)i * cap + done) * VM_STAT_WORDS,
                                   (size_t)nb * 4 * VM_STAT_WORDS, hipMemcpyDeviceToHost, s));
         }
         VM_HIP(hipStreamSynchronize(s));
+        if (pass && c->pass_err_host[0]) {
+            (void)hipMemsetAsync(c->pass_err, 0, 4, s);
+            return vm_fail(VM_E_DEVICE, "vm_optimize_level: a tile barrier of the PASS schedule timed out (is another process "
+                                        "competing for this device's compute units?  VM_NO_PASS=1 selects the STEP schedule)");
+        }
         float bms = 0;
         VM_HIP(hipEventElapsedTime(&bms, c->ev0, c->ev1));
         ms += bms;

@@ -70,6 +70,12 @@ struct vm_ctx {
     uint32_t *stats_host = nullptr;  // pinned mirror
     uint32_t *step_slots = nullptr;  // STEP schedule: per-workgroup activity counts of the last two launches
     size_t step_slots_words = 0;     // capacity of ONE of the two halves, in words
+    // PASS schedule: tile-barrier counters (one per tile group and launch of a batch), the
+    // error word a timed-out barrier raises (+ pinned mirror), optional XCD-placement record
+    uint32_t *pass_bar = nullptr;
+    size_t pass_bar_words = 0;
+    uint32_t *pass_err = nullptr, *pass_err_host = nullptr;
+    uint32_t *pass_dbg = nullptr;    // vm_dbg_pass_xcd: 256 words, XCC id per workgroup of the last launch
     int sweep_threads = 0;           // 0 = automatic
     int sweep_mode = 0;              // VM_SWEEP_AUTO / TILE / SPLIT
     int sweep_parts = 0;             // workgroups per tile in the SPLIT schedule, 0 = automatic

@@ -72,6 +72,10 @@ struct VmKParams {
 #define VM_TAB_IMP 625
 #define VM_TAB_WORDS (625 + 225)
 
+// PASS schedule: barrier words per tile group and launch (one 64-bit arrival counter with the
+// XCD census + 32 per-workgroup flag words, on lines of their own)
+#define VM_PASS_SYNC_WORDS 64
+
 // launchers implemented once per arithmetic mode (vm_morph_kernels.hip is
 // compiled twice: -DVM_EXACT=1 -ffp-contract=off and -DVM_EXACT=0)
 #define VM_DECL_LAUNCHERS(SUFFIX)                                                             \
@@ -100,6 +104,14 @@ struct VmKParams {
                                           int fixed_work, int threads, int parts,             \
                                           uint32_t *slots_cur, const uint32_t *slots_prev,    \
                                           int prev_iter_idx, hipStream_t s);                  \
+    void vm_launch_optimize_pass_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w,  \
+                                          int h, const VmKParams &P, const uint32_t *tables,  \
+                                          int offx, int offy, uint32_t epoch0, uint32_t *bar, \
+                                          uint32_t *flags, uint32_t *stats, int iter_idx,     \
+                                          int fixed_work, uint32_t *slots_cur,                \
+                                          const uint32_t *slots_prev, int prev_iter_idx,      \
+                                          uint32_t *err, uint32_t *dbg, int decide,           \
+                                          int force_wt, hipStream_t s);                       \
     void vm_launch_upsample_##SUFFIX(float2 *dst, int dw, int dh, int drs, const float2 *src, \
                                      int sw, int sh, int srs, hipStream_t s);                 \
     void vm_launch_splat_##SUFFIX(const VmLevelView &L, int w0, int h0,                       \

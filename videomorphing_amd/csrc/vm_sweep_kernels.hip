@@ -42,7 +42,13 @@
 
 #ifdef VM_PROF
 // dev-only stage stamps of k_decide (10 ns ticks), wave 0 lane 0 of each workgroup
-__device__ unsigned long long vm_prof_buf[512 * 16];
+__device__ unsigned long long vm_prof_buf[512 * 16 * 2];
+#define VM_PTSF(ph, k)                                         \
+    if (tid == 512 && b < 256)                                 \
+    vm_prof_buf[8192 + 512 + b * 8 + (ph) * 2 + (k)] = wall_clock64()
+#define VM_PTS(ph, k)                                          \
+    if (tid == 0 && b < 256)                                   \
+    vm_prof_buf[b * 32 + (ph) * 8 + (k)] = wall_clock64()
 #define VM_TS(i) ts[i] = wall_clock64()
 #define VM_TS_ARG , unsigned long long *ts
 #define VM_TS_PASS , ts
@@ -50,6 +56,8 @@ __device__ unsigned long long vm_prof_buf[512 * 16];
 #define VM_TS(i)
 #define VM_TS_ARG
 #define VM_TS_PASS
+#define VM_PTS(ph, k)
+#define VM_PTSF(ph, k)
 #endif
 
 namespace {
@@ -2080,13 +2088,22 @@ __device__ __forceinline__ uint32_t cell_hits(const uint32_t (*bits)[4], int bx0
 // are fetched in two batches of 5 and 4 -- all loads of a batch are issued before the first is
 // used, and a batch is skipped when no lane of the wave has a record left; one batch of 9 would
 // cost 72 VGPRs and with them a workgroup per CU.
+// Loads and stores of data that workgroups of ONE launch hand to each other (PASS schedule):
+// relaxed agent-scope atomics on GLOBAL-address-space pointers = global_load / global_store
+// ... sc1 (L1-bypassing loads, write-through stores).  Through generic pointers the compiler
+// emits flat_ instructions, which the hand-off rules exclude (MI355X_MICROARCH.md, Valid forms).
+typedef __attribute__((address_space(1))) const uint32_t vm_g_cu32;
+typedef __attribute__((address_space(1))) uint32_t vm_g_u32;
+typedef __attribute__((address_space(1))) const unsigned long long vm_g_cu64;
+typedef __attribute__((address_space(1))) unsigned long long vm_g_u64;
+
 // COH: the records were written by other workgroups of THIS launch (PASS schedule): L1-bypassing loads.
 template <bool COH>
 __device__ __forceinline__ float4 rec_load(const float4 *p)
 {
     if (!COH)
         return *p;
-    const unsigned long long *u = (const unsigned long long *)p;
+    vm_g_cu64 *u = (vm_g_cu64 *)p;
     const unsigned long long a = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long b = __hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_float4(__uint_as_float((uint32_t)a), __uint_as_float((uint32_t)(a >> 32)), __uint_as_float((uint32_t)b),
@@ -2515,59 +2532,76 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
 // 8000 dependent phases).  STEP pays a kernel boundary per phase: launch gap, three cold
 // dependent round trips at entry, the level re-staged into eight cold L2s.  Here the four
 // Jacobi phases of a tile stay inside one launch behind a TILE-LOCAL barrier:
-//  - a tile is worked by a GROUP of 32 workgroups of 8 waves: one wave per phase pixel
-//    (slot = part * 8 + wave), no candidate list, no workgroup-wide staging -- every wave
-//    tests its own pixel's mask bits, folds the last phase's records into the window cell
-//    each lane owns and runs the wave-wide line search (decide64 / decide_with64);
-//  - workgroup ids b, b + 8, b + 16, ... belong to one group: under the observed round-robin
-//    dispatch they share an XCD, so a tile's state stays in ONE L2 (speed only -- every
-//    hand-off below is valid wherever the workgroups land);
-//  - between phases the group meets at a counter of its own (32 arrivals, one agent-scope
-//    add per workgroup behind every wave's vmcnt(0) and the workgroup barrier; one lane polls
-//    with L1-bypassing loads, bounded: a timeout raises an error word instead of hanging);
-//    everything handed from phase to phase -- records, tags, v, the folded window sums, mask
-//    words -- is stored write-through and loaded L1-bypassing (relaxed agent-scope atomics =
-//    sc1), the acquire-free form of MI355X_MICROARCH.md "Valid forms";
-//  - the fold of phase s-1's records into the sums (tile + halo, 1360 cells) is shared out
-//    over the group (43 cells per workgroup, done by the first wave to finish its line
-//    search) and ping-pongs between the canonical arrays and the second copy:
-//        phase 0 reads C | 1: C + rec(0), folds C -> T | 2: T + rec(1), T -> C |
-//        3: C + rec(2), C -> T | after the last barrier: T + rec(3) -> C
+//  - a tile is worked by a GROUP of 32 workgroups of 8 waves, one wave per phase pixel
+//    (slot = part * 8 + wave): no candidate list, no workgroup-wide staging.  Per phase a wave
+//    fetches everything it needs in ONE round trip (mask words, the last phase's tags and
+//    records around its pixel, its pixel's state, the window cell each lane owns, the ring
+//    neighbours' v), passes the records through a wave-private LDS area, folds them into its
+//    window cells, tests its pixel's mask bits and runs the wave-wide line search (decide64 /
+//    decide_with64);
+//  - the fold of phase s-1's records into the window sums is a by-product of that: every cell
+//    of the tile + halo is OWNED by one slot (the 2 x 2 cells at its pixel, edge slots the
+//    halo beside them), whose wave stores the folded cell into the other copy of the sums:
+//        phase 0 reads C | 1: C + rec(0) -> T | 2: T + rec(1) -> C | 3: C + rec(2) -> T |
+//        closing step after the last barrier: T + rec(3) -> C
 //    so a pass leaves the canonical state complete and the next pass (other tile geometry)
-//    starts from it like any other schedule.
-// Same arithmetic, same fold order (fold_cell), same records as STEP: bit-identical to it.
+//    starts from it like any other schedule;
+//  - workgroup ids b, b + 8, b + 16, ... belong to one group: under the observed round-robin
+//    dispatch they share an XCD, so a tile's state stays in ONE L2.  That is checked, not
+//    assumed: every workgroup reports its XCC id with its first arrival; a group found on one
+//    XCD hands data over with plain stores (the XCD's L2 is the point of coherence of its
+//    CUs) + L1-bypassing loads and meets at flags in that L2; a group found spread over XCDs
+//    writes its phase-0 stores back (agent-scope release), meets once more and from then on
+//    stores write-through (sc1) and meets at an agent-scope counter -- the acquire-free form
+//    of MI355X_MICROARCH.md "Valid forms";
+//  - every wait is bounded: a timeout raises an error word instead of hanging the device.
+// Same arithmetic, same fold order, same records as STEP: bit-identical to it.
 struct PassLds {
     float tps[625];
     uint32_t imp[225];
-    uint32_t ticket[4];       // first wave to finish phase s takes the fold share of that phase
+    float4 rec[8][25][2]; // per wave: the last phase's records around the wave's pixel (rec_a, rec_b)
     uint32_t n_cand, n_commit, n_eval;
-    uint32_t go;
+    uint32_t go;          // 1: go on, 0: a barrier timed out
+    uint32_t wt;          // 1: the group spans XCDs: write-through stores, counter barrier
 };
 
 __device__ __forceinline__ uint32_t ldc(const uint32_t *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((vm_g_cu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float ldc(const float *p) { return __uint_as_float(ldc((const uint32_t *)p)); }
 __device__ __forceinline__ float2 ldc(const float2 *p)
 {
-    const unsigned long long u = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long u = __hip_atomic_load((vm_g_cu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_float2(__uint_as_float((uint32_t)u), __uint_as_float((uint32_t)(u >> 32)));
 }
-__device__ __forceinline__ void stc(uint32_t *p, uint32_t v)
+__device__ __forceinline__ float4 ldc(const float4 *p) { return rec_load<true>(p); }
+// stores of handed-off data: write-through (sc1) when the group spans XCDs, plain otherwise
+__device__ __forceinline__ void sth(uint32_t *p, uint32_t v, bool wt)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wt)
+        __hip_atomic_store((vm_g_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
 }
-__device__ __forceinline__ void stc(float *p, float v) { stc((uint32_t *)p, __float_as_uint(v)); }
-__device__ __forceinline__ void stc(float2 *p, float2 v)
+__device__ __forceinline__ void sth(float *p, float v, bool wt) { sth((uint32_t *)p, __float_as_uint(v), wt); }
+__device__ __forceinline__ void sth(float2 *p, float2 v, bool wt)
 {
-    const unsigned long long u = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
-    __hip_atomic_store((unsigned long long *)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wt) {
+        const unsigned long long u = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+        __hip_atomic_store((vm_g_u64 *)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = v;
+    }
 }
-__device__ __forceinline__ void stc(float4 *p, float4 v)
+__device__ __forceinline__ void sth(float4 *p, float4 v, bool wt)
 {
-    stc((float2 *)p, make_float2(v.x, v.y));
-    stc((float2 *)p + 1, make_float2(v.z, v.w));
+    if (wt) {
+        sth((float2 *)p, make_float2(v.x, v.y), true);
+        sth((float2 *)p + 1, make_float2(v.z, v.w), true);
+    } else {
+        *p = v;
+    }
 }
 
 // bits of mask word (bx, by) whose pixels lie inside [x0, x1] x [y0, y1]
@@ -2586,7 +2620,8 @@ __device__ __forceinline__ uint32_t block_bits_in(int bx, int by, int x0, int x1
 }
 
 #define VM_PASS_PARTS 32
-#define VM_PASS_CELLS ((VM_NCELL + VM_PASS_PARTS - 1) / VM_PASS_PARTS)
+#define VM_PASS_T 512
+#define VM_PASS_TIMEOUT_TICKS 200000000ull // 2 s of the 100 MHz wall clock
 
 // one wave adds the per-workgroup count slots of a finished PASS launch into the counters of
 // iteration `it`, pair by pair (slot k belongs to group (k >> 8) * 8 + (k & 7))
@@ -2620,20 +2655,23 @@ __device__ __forceinline__ void pass_sum_slots(uint32_t *stats0, const uint32_t 
         }
     }
 }
-#define VM_PASS_TIMEOUT_TICKS 200000000ull // 2 s of the 100 MHz wall clock
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4))) void SUF(k_pass)(
+__global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void SUF(k_pass)(
     const VmLevelView *__restrict__ views, int cap, VmKParams P, const uint32_t *__restrict__ tables, int offx, int offy,
-    uint32_t epoch0, int ngroups, int ntiles, uint32_t *__restrict__ bar, uint32_t *__restrict__ flags,
+    uint32_t epoch0, int ngroups, int ntiles, uint32_t *__restrict__ sync, uint32_t *__restrict__ flags,
     uint32_t *__restrict__ stats, int iter_idx, int fixed_work, uint32_t *__restrict__ slots_cur,
     const uint32_t *__restrict__ slots_prev, int prev_iter_idx, int nslot_prev, uint32_t *__restrict__ err,
-    uint32_t *__restrict__ dbg)
+    uint32_t *__restrict__ dbg, int force_wt)
 {
     __shared__ PassLds S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & 31;
     const bool hi = (tid & 32) != 0;
     // workgroup -> (group, part): ids b, b + 8, ... of a 256-block chunk form one group
     const int b = (int)blockIdx.x, within = b & 255;
+#ifdef VM_PROF
+    if (tid == 0 && b < 256)
+        vm_prof_buf[8192 + b * 2] = wall_clock64();
+#endif
     const int grp = (b >> 8) * 8 + (within & 7), part = within >> 3;
     uint4 *my_slot = (uint4 *)slots_cur + b; // read by the next launch: always written
     if (grp >= ngroups) {
@@ -2645,34 +2683,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     const VmLevelView L = views[pair];
     flags += (size_t)pair * cap;
     uint32_t *const stats0 = stats;
-    for (int k = tid; k < 625; k += 512)
+    unsigned long long *const bar = (unsigned long long *)(sync + (size_t)grp * VM_PASS_SYNC_WORDS);
+    uint32_t *const flg = sync + (size_t)grp * VM_PASS_SYNC_WORDS + 32;
+    for (int k = tid; k < 625; k += VM_PASS_T)
         S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
-    for (int k = tid; k < 225; k += 512)
+    for (int k = tid; k < 225; k += VM_PASS_T)
         S.imp[k] = tables[VM_TAB_IMP + k];
-    if (tid < 4)
-        S.ticket[tid] = 0;
     if (tid == 0) {
         S.n_cand = S.n_commit = S.n_eval = 0;
         S.go = 1;
+        S.wt = 0;
     }
-    if (dbg && tid == 0) // diagnostic: which XCD the workgroup runs on (HW_REG_XCC_ID, bits 3:0)
-        dbg[b] = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; // HW_REG_XCC_ID
+#ifndef VM_PASS_DEBUG
+    if (dbg && tid == 0 && b < 2048) // diagnostic: which XCD the workgroup runs on
+        dbg[b] = xcc;
+#else
+    uint32_t *const dbg_row = dbg ? dbg + 256 * (((epoch0 - 1u) >> 2) & 7u) : nullptr; // 8 launches x 256 workgroups
+#endif
     const int gxn = (L.w + VM_PITCH_X - 1) / VM_PITCH_X;
     const int ox = (tile % gxn) * VM_PITCH_X + offx, oy = (tile / gxn) * VM_PITCH_Y + offy;
     const MaskGeom g = mask_geom(L, ox, oy);
     // Group-wide early outs.  Every workgroup of the group must take the same decision from data
     // no workgroup of this launch can have changed yet: the flag of the previous iteration, and
-    // the mask bits of the pixels within +-2 of the tile (pixels of this tile or of the gaps: no
+    // the mask bits of the positions within +-2 of the tile (pixels of this tile or of the gaps: no
     // other tile of the pass owns them).  No set bit there = no candidate in phase 0, hence no
-    // commit, hence none in the later phases.
+    // commit, hence none in the later phases.  Positions past the right / bottom image edge
+    // count: init_improving_mask sets whole words, nothing ever clears the bits of pixels that
+    // do not exist, and the reference's test (get_improve_mask_idx) sees them -- a pixel within 2
+    // of such an edge stays a candidate for ever (measured: 684 line searches per iteration of a
+    // converged 120x68 level, in the oracle and in every schedule).
     bool live = ox < L.w && oy < L.h && !(!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0);
     {
         uint32_t mine = 0;
         if (live && tid < g.nbx * g.nby) {
             const int mx = tid % g.nbx, my = tid / g.nbx;
             mine = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)] &
-                   block_bits_in(g.bx0 + mx, g.by0 + my, max(ox - 2, 0), min(ox + VM_TILE_W + 1, L.w - 1), max(oy - 2, 0),
-                                 min(oy + VM_TILE_H + 1, L.h - 1));
+                   block_bits_in(g.bx0 + mx, g.by0 + my, ox - 2, min(ox + VM_TILE_W - 1, L.w - 1) + 2, oy - 2,
+                                 min(oy + VM_TILE_H - 1, L.h - 1) + 2);
         }
         if (!__syncthreads_or(mine != 0))
             live = false;
@@ -2684,95 +2732,95 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     if (!live) {
         if (tid == 0)
             *my_slot = make_uint4(0, 0, 0, 0);
+#ifdef VM_PASS_DEBUG
+        if (dbg_row && tid == 0 && b < 256)
+            dbg_row[b] = 0xFFu;
+#endif
         return;
     }
 
     // this wave's pixel slot of the tile: (tx, ty), pixel (ox + 2 tx + pj, oy + 2 ty + pi) in phase (pi, pj)
     const int slot = part * 8 + wave, tx = slot & 31, ty = slot >> 5;
-    // my share of the fold: cells of the tile + halo
-    const int cell = part * VM_PASS_CELLS + lane;
-    const int frx = cell % VM_HALO_W - 2, fry = cell / VM_HALO_W - 2;
-    const int fqx = ox + frx, fqy = oy + fry;
-    const bool fcell = lane < VM_PASS_CELLS && cell < VM_NCELL && fqx >= 0 && fqx < L.w && fqy >= 0 && fqy < L.h;
-    // ... and of the mask words the tile owns (blocks holding one of its pixels): word part, part + 32, ...
-    const int own_bx0 = ox / 5, own_by0 = oy / 5;
-    const int own_nx = min(ox + VM_TILE_W - 1, L.w - 1) / 5 - own_bx0 + 1, own_ny = min(oy + VM_TILE_H - 1, L.h - 1) / 5 - own_by0 + 1;
     const int tx1 = min(ox + VM_TILE_W, L.w), ty1 = min(oy + VM_TILE_H, L.h); // tile pixels: [ox, tx1) x [oy, ty1)
-
-    // fold of phase `fph`'s records (epoch epoch0 + fph) into the group's share of cells and mask
-    // words: src copy -> dst copy.  One wave.
-    auto fold_share = [&](int fph, bool src_t, bool dst_t) {
-        const uint32_t pe = epoch0 + (uint32_t)fph, want = (pe << 2) | 1u;
-        const int fpi = fph >> 1, fpj = fph & 1;
-        const uint32_t *r_tag = (pe & 1u) ? L.rec_tag2 : L.rec_tag;
-        const float4 *r_a = (pe & 1u) ? L.rec_a2 : L.rec_a, *r_b = (pe & 1u) ? L.rec_b2 : L.rec_b;
-        const float2 *s_mean = src_t ? L.mean2 : L.mean, *s_var = src_t ? L.var2 : L.var, *s_tpsb = src_t ? L.tps_b2 : L.tps_b;
-        const float *s_cross = src_t ? L.cross2 : L.cross, *s_value = src_t ? L.value2 : L.value;
-        float2 *d_mean = dst_t ? L.mean2 : L.mean, *d_var = dst_t ? L.var2 : L.var, *d_tpsb = dst_t ? L.tps_b2 : L.tps_b;
-        float *d_cross = dst_t ? L.cross2 : L.cross, *d_value = dst_t ? L.value2 : L.value;
-        const uint32_t *s_imp = src_t ? L.impmask2 : L.impmask;
-        uint32_t *d_imp = dst_t ? L.impmask2 : L.impmask;
-        {
-            const int gi = fcell ? fqy * L.rs + fqx : 0;
-            float2 m = make_float2(0, 0), q = m, tb = m;
-            float cr = 0, val = 0;
-            uint32_t hits = 0;
-            if (fcell) {
-                m = ldc(s_mean + gi);
-                q = ldc(s_var + gi);
-                tb = ldc(s_tpsb + gi);
-                cr = ldc(s_cross + gi);
-                val = ldc(s_value + gi);
-                // records of that phase within +-2 of the cell: the (at most 3 x 3) pixels of its
-                // parity class in the window, inside the tile
-                const int ax = (fpj - (fqx - 2 - ox)) & 1, ay = (fpi - (fqy - 2 - oy)) & 1;
-                uint32_t tg[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const int dx = ax + 2 * (k % 3), dy = ay + 2 * (k / 3);
-                    const int x = fqx + dx - 2, y = fqy + dy - 2;
-                    const bool ok = dx <= 4 && dy <= 4 && x >= ox && x < tx1 && y >= oy && y < ty1;
-                    tg[k] = ldc(r_tag + (ok ? y * L.rs + x : gi));
-                    if (!ok)
-                        tg[k] = 0;
-                }
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    if (tg[k] == want)
-                        hits |= 1u << ((ay + 2 * (k / 3)) * 5 + ax + 2 * (k % 3));
-            }
-            const bool touched = fold_cell<true>(L, r_a, r_b, S.tps, hits, fcell ? fqx : 0, fcell ? fqy : 0, m, q, cr, tb, P.rev_commit);
-            if (fcell) {
-                if (touched) {
-                    const float counter = (float)(window_count(fqy, L.h) * window_count(fqx, L.w));
-                    val = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
-                }
-                stc(d_mean + gi, m);
-                stc(d_var + gi, q);
-                stc(d_cross + gi, cr);
-                stc(d_tpsb + gi, tb);
-                stc(d_value + gi, val);
-            }
-        }
-        for (int wk = part; wk < own_nx * own_ny; wk += VM_PASS_PARTS) {
-            const int bx = own_bx0 + wk % own_nx, by = own_by0 + wk / own_nx;
-            const int wi = (by + 1) * L.imp_rs + (bx + 1);
-            const int x = 5 * bx + sub % 5, y = 5 * by + sub / 5;
-            uint32_t t = 0;
-            if (lane < 25 && x >= ox && x < tx1 && y >= oy && y < ty1)
-                t = ldc(r_tag + y * L.rs + x);
-            const uint32_t setb = (uint32_t)__ballot(lane < 25 && t == want);
-            const uint32_t clrb = (uint32_t)__ballot(lane < 25 && t == ((pe << 2) | 2u));
-            if (lane == 0)
-                stc(d_imp + wi, (ldc(s_imp + wi) | setb) & ~clrb);
-        }
-    };
+    // mask words the tile owns (blocks holding one of its pixels); word `slot` is folded by this wave
+    const int own_bx0 = ox / 5, own_by0 = oy / 5;
+    const int own_nx = (tx1 - 1) / 5 - own_bx0 + 1, own_ny = (ty1 - 1) / 5 - own_by0 + 1;
+    const bool has_word = slot < own_nx * own_ny;
+    const int wbx = own_bx0 + (has_word ? slot % own_nx : 0), wby = own_by0 + (has_word ? slot / own_nx : 0);
+    const int wword = (wby + 1) * L.imp_rs + (wbx + 1);
 
     uint32_t my_cand = 0, my_commit = 0, my_eval = 0; // of this wave, over the four phases
+    bool wt = force_wt != 0;                           // write-through stores, counter barrier
+    bool pure_known = false;                           // after the first barrier: the group's XCD census is in
+    uint32_t rounds = 0;                               // barrier rounds behind us
     bool timed_out = false;
-    for (int ph = 0; ph < 4; ++ph) {
-        const int pi = ph >> 1, pj = ph & 1;
-        const bool src_t = ph == 2; // which copy holds the sums before the last phase's records
+    int prof_ph = 0;
+    (void)prof_ph;
+
+    // Tile barrier: every store of this workgroup has left (vmcnt(0) per wave, then the workgroup
+    // barrier), then one arrival per workgroup.  First round (and every round of a group spread
+    // over XCDs): an agent-scope add on the group's counter, polled with L1-bypassing loads; the
+    // first arrival also carries the workgroup's XCD (a 6-bit arrival count per XCD above the
+    // total).  Later rounds of a group that sits on one XCD: a flag word per workgroup in that
+    // XCD's L2 (plain store, L1-bypassing polls of the 32 flags by one wave).
+    auto tile_barrier = [&](bool first) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        VM_PTS(prof_ph, 5);
+        if (wave == 0) {
+            const bool by_flags = pure_known && !wt;
+            const unsigned long long t0 = wall_clock64();
+            if (by_flags) {
+                if (lane == 0)
+                    flg[part] = rounds + 1u;
+                bool done = false;
+                for (uint32_t spin = 0; !done; ++spin) {
+                    const uint32_t v = lane < VM_PASS_PARTS ? ldc(flg + lane) : rounds + 1u;
+                    done = __all(v >= rounds + 1u);
+                    if (!done) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((spin & 63u) == 63u && wall_clock64() - t0 > VM_PASS_TIMEOUT_TICKS) {
+                            if (lane == 0) {
+                                S.go = 0;
+                                __hip_atomic_store((vm_g_u32 *)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            break;
+                        }
+                    }
+                }
+            } else if (lane == 0) {
+                const unsigned long long add = 1ull | (first ? 1ull << (8 + 6 * xcc) : 0ull);
+                __hip_atomic_fetch_add((vm_g_u64 *)bar, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t target = (uint32_t)VM_PASS_PARTS * (rounds + 1u);
+                unsigned long long seen;
+                while (((uint32_t)(seen = __hip_atomic_load((vm_g_cu64 *)bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFu) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > VM_PASS_TIMEOUT_TICKS) { // never hang the device: report and go on
+                        S.go = 0;
+                        __hip_atomic_store((vm_g_u32 *)err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                if (first) { // on how many XCDs does the group sit?
+                    int nx = 0;
+                    for (int k = 0; k < 8; ++k)
+                        nx += ((seen >> (8 + 6 * k)) & 63ull) != 0;
+                    S.wt = nx > 1 ? 1u : 0u;
+                }
+            }
+        }
+        VM_PTS(prof_ph, 6);
+        __syncthreads();
+        ++rounds;
+        if (S.go == 0)
+            timed_out = true;
+    };
+
+    // phases 0..3, then the closing step (ph == 4): the last phase's records, second copy -> canonical arrays
+    for (int ph = 0; ph < 5 && !timed_out; ++ph) {
+        const bool closing = ph == 4;
+        const int pi = closing ? 0 : ph >> 1, pj = closing ? 0 : ph & 1;
+        const bool src_t = ph == 2 || ph == 4; // which copy holds the sums before the last phase's records
         const uint32_t epoch = epoch0 + (uint32_t)ph, pe = epoch - 1u, want = (pe << 2) | 1u;
         const uint32_t *r_tag = (pe & 1u) ? L.rec_tag2 : L.rec_tag;
         const float4 *r_a = (pe & 1u) ? L.rec_a2 : L.rec_a, *r_b = (pe & 1u) ? L.rec_b2 : L.rec_b;
@@ -2780,16 +2828,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         float4 *w_a = (epoch & 1u) ? L.rec_a2 : L.rec_a, *w_b = (epoch & 1u) ? L.rec_b2 : L.rec_b;
         const float2 *s_mean = src_t ? L.mean2 : L.mean, *s_var = src_t ? L.var2 : L.var, *s_tpsb = src_t ? L.tps_b2 : L.tps_b;
         const float *s_cross = src_t ? L.cross2 : L.cross, *s_value = src_t ? L.value2 : L.value;
+        float2 *d_mean = src_t ? L.mean : L.mean2, *d_var = src_t ? L.var : L.var2, *d_tpsb = src_t ? L.tps_b : L.tps_b2;
+        float *d_cross = src_t ? L.cross : L.cross2, *d_value = src_t ? L.value : L.value2;
         const uint32_t *s_imp = src_t ? L.impmask2 : L.impmask;
-        const int ppi = (ph - 1) >> 1, ppj = (ph - 1) & 1; // parity class of the last phase's pixels (ph > 0)
+        uint32_t *d_imp = src_t ? L.impmask : L.impmask2;
+        const int ppi = ((ph - 1) & 3) >> 1, ppj = (ph - 1) & 1; // parity class of the last phase's pixels (ph > 0)
 
         const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
         const bool in_img = px < L.w && py < L.h;
-        const int spx = in_img ? px : ox, spy = in_img ? py : oy; // a safe pixel for the speculative loads
-        // ---- everything the phase needs from memory that does not depend on another load: one round trip
+        const int spx = in_img ? px : ox, spy = in_img ? py : oy; // a safe pixel for the loads of an idle wave
+        VM_PTS(ph, 0);
+        // ================= everything from memory in one round trip (no load depends on another) ===========
         // (a) mask words of the 2 x 2 blocks the pixel's window reaches + the last phase's tags in them
         const int oxb = spx % 5, oyb = spy % 5, pbx = spx / 5, pby = spy / 5;
         const int begi = oyb >= 2 ? 1 : 0, begj = oxb >= 2 ? 1 : 0;
+        const int pidx = spy * L.rs + spx;
         uint32_t mword[2], mtag[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) { // lanes 0-31: block column begj - 1, lanes 32-63: begj; round r: block row begi - 1 + r
@@ -2799,51 +2852,166 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             // concerned: always the canonical array (their owner may rewrite them, never those bits)
             mword[r] = ldc((owned ? s_imp : L.impmask) + (by + 1) * L.imp_rs + (bx + 1));
             const int x = 5 * bx + sub % 5, y = 5 * by + sub / 5;
-            mtag[r] = 0;
-            if (ph > 0 && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1)
-                mtag[r] = ldc(r_tag + y * L.rs + x);
+            const bool ok = ph > 0 && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1;
+            mtag[r] = ldc(r_tag + (ok ? y * L.rs + x : pidx));
+            if (!ok)
+                mtag[r] = 0;
         }
-        // (b) commits of the last phase within +-4 of the pixel (the records its window cells fold)
+        // (b) the mask word this wave folds for the group (word `slot` of the owned ones): its pixels' tags
+        uint32_t otag, oword;
+        {
+            const int x = 5 * wbx + sub % 5, y = 5 * wby + sub / 5;
+            const bool ok = ph > 0 && has_word && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1;
+            otag = ldc(r_tag + (ok ? y * L.rs + x : pidx));
+            if (!ok)
+                otag = 0;
+            oword = ldc(s_imp + wword);
+        }
+        // (c) the last phase's tags and records within +-4 of the pixel: position sub < 25 of the 5 x 5 grid
+        // of that phase's parity class; lanes 0-31 fetch rec_a, lanes 32-63 rec_b (speculatively: a record is
+        // used only where the tag says "committed in that phase")
         const int sx0 = -4 + ((ppj ^ pj) & 1), sy0 = -4 + ((ppi ^ pi) & 1);
-        uint32_t ctag = 0;
-        if (ph > 0 && sub < 25) {
+        uint32_t ctag;
+        float4 crec;
+        {
+            // (relative to the slot's pixel position even where that lies outside the image: the cells such a
+            // slot owns -- the halo beside a tile the border cuts down to a sliver -- still take records)
             const int dx = sx0 + 2 * (sub % 5), dy = sy0 + 2 * (sub / 5);
-            const int x = spx + dx, y = spy + dy;
-            if (dx <= 4 && dy <= 4 && x >= ox && x < tx1 && y >= oy && y < ty1)
-                ctag = ldc(r_tag + y * L.rs + x);
+            const int x = px + dx, y = py + dy;
+            const bool ok = ph > 0 && sub < 25 && dx <= 4 && dy <= 4 && x >= ox && x < tx1 && y >= oy && y < ty1;
+            const int ri = ok ? y * L.rs + x : pidx;
+            ctag = ldc(r_tag + ri);
+            crec = ldc((hi ? r_b : r_a) + ri);
+            if (!ok)
+                ctag = 0;
         }
-        // (c) the pixel's own state, (d) the window cell of this lane, (e) the ring neighbours' v
+        // (d) the pixel's own state
         PixelCtx c;
         c.px = spx;
         c.py = spy;
-        c.idx = spy * L.rs + spx;
-        c.v = ldc(L.v + c.idx);
-        c.old_luma = ldc(L.luma + c.idx);
-        c.ui_b = ldc(L.ui_b + c.idx);
-        c.ui_axy = L.ui_axy[c.idx];
+        c.idx = pidx;
+        c.v = ldc(L.v + pidx);
+        c.old_luma = ldc(L.luma + pidx);
+        c.ui_b = ldc(L.ui_b + pidx);
+        c.ui_axy = L.ui_axy[pidx];
         c.tps_axy = S.tps[(border_class(spy, L.h) * 5 + border_class(spx, L.w)) * 25 + 12] / 2;
         c.tref = make_float2(0, 0);
         c.tmask = 0.0f;
         if (L.temp_mask) { // uniform in the launch
-            c.tref = L.temp_ref[c.idx];
-            c.tmask = L.temp_mask[c.idx];
+            c.tref = L.temp_ref[pidx];
+            c.tmask = L.temp_mask[pidx];
         }
-        const int wi_ = (sub * 13) >> 6, wj_ = sub - wi_ * 5; // lane sub < 25 owns neighbour (sub % 5 - 2, sub / 5 - 2)
-        const int qx = spx + wj_ - 2, qy = spy + wi_ - 2;
-        const bool okc = sub < 25 && qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
-        const int cx = okc ? qx : spx, cy = okc ? qy : spy, gi = cy * L.rs + cx;
+        // (e) this lane's cell.  Lanes sub < 25: the window cell (sub % 5 - 2, sub / 5 - 2) of the pixel.
+        // Lanes sub >= 25 (7 per half): the cells this slot owns OUTSIDE its window -- an edge slot owns the
+        // halo column / row beside it, 3 away from its pixel (the records that reach such a cell are those of
+        // the tile's outermost pixels, within the +-4 this wave stages anyway).  Halo coordinates: (0, 0) =
+        // cell (ox - 2, oy - 2).
+        const int phx = 2 + 2 * tx + pj, phy = 2 + 2 * ty + pi;
+        const int ohx0 = tx == 0 ? 0 : phx, ohx1 = tx == 31 ? VM_HALO_W - 1 : phx + 1;
+        const int ohy0 = ty == 0 ? 0 : phy, ohy1 = ty == 7 ? VM_HALO_H - 1 : phy + 1;
+        const int wi_ = (sub * 13) >> 6, wj_ = sub - wi_ * 5;
+        int chx, chy;
+        if (sub < 25) {
+            chx = phx + wj_ - 2;
+            chy = phy + wi_ - 2;
+        } else {
+            const int xcol = (tx == 0 && pj == 1) ? 0 : ((tx == 31 && pj == 0) ? VM_HALO_W - 1 : -1);
+            const int xrow = (ty == 0 && pi == 1) ? 0 : ((ty == 7 && pi == 0) ? VM_HALO_H - 1 : -1);
+            const int ncol = xcol >= 0 ? ohy1 - ohy0 + 1 : 0;
+            const int e = (sub - 25) + (hi ? 7 : 0);
+            chx = chy = -1;
+            if (e < ncol) {
+                chx = xcol;
+                chy = ohy0 + e;
+            } else if (xrow >= 0) {
+                int k = ohx0 + (e - ncol);
+                if (xcol >= 0 && xcol == ohx0)
+                    ++k; // the corner cell went with the column
+                if (k <= ohx1 && k != xcol) {
+                    chx = k;
+                    chy = xrow;
+                }
+            }
+        }
+        const int qx = ox - 2 + chx, qy = oy - 2 + chy;
+        // (a cell can lie in the image while the slot's pixel does not -- the halo left of / above a
+        // tile cut down to a sliver by the image border: it is still owned, and copied, by that slot)
+        const bool cell_ok = chx >= 0 && qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
+        const bool okc = cell_ok && sub < 25; // a window neighbour of the pixel
+        const int gi = cell_ok ? qy * L.rs + qx : pidx;
         float2 m = ldc(s_mean + gi), q = ldc(s_var + gi), tb = ldc(s_tpsb + gi);
         float cr = ldc(s_cross + gi), val = ldc(s_value + gi);
+        // (f) the ring neighbours' v
         RingLanes ring;
         {
             const int k = sub & 7;
             const int rx = ((0x06A4 >> (2 * k)) & 3) - 1, ry = ((0x6A40 >> (2 * k)) & 3) - 1;
             const int nx = spx + rx, ny = spy + ry;
             const bool in = nx >= 0 && nx < L.w && ny >= 0 && ny < L.h;
-            ring.mine = ldc(L.v + (in ? ny * L.rs + nx : c.idx));
+            ring.mine = ldc(L.v + (in ? ny * L.rs + nx : pidx));
         }
 
-        // ---- mask test (get_improve_mask_idx, morph.cu:621-646) on the words + the last phase's tags
+        // ================= the group's mask word: a committed pixel sets its bit, a hit that did not move clears it
+        if (ph > 0) {
+            const uint32_t setb = (uint32_t)__ballot(!hi && otag == want);
+            const uint32_t clrb = (uint32_t)__ballot(!hi && otag == ((pe << 2) | 2u));
+            if (has_word && lane == 0)
+                sth(d_imp + wword, (oword | setb) & ~clrb, wt);
+        }
+        // ================= the last phase's records through LDS, folded into this lane's cell (fold_cell's order)
+        bool touched = false;
+        if (ph > 0) {
+            const uint32_t cset = (uint32_t)__ballot(!hi && ctag == want); // wave-uniform
+            if (cset) {
+                if (sub < 25 && ctag == want)
+                    S.rec[wave][sub][hi ? 1 : 0] = crec;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t todo = cset;
+                while (todo) { // wave-uniform; ascending position = row-major order of the committed pixels
+#if VM_EXACT
+                    // rev (vm_set_commit_order): the same records in reversed row-major order
+                    const int bk = P.rev_commit ? 31 - __clz(todo) : __ffs(todo) - 1;
+                    todo &= ~(1u << bk);
+#else
+                    const int bk = __ffs(todo) - 1;
+                    todo &= todo - 1;
+#endif
+                    const int rdx = sx0 + 2 * (bk % 5), rdy = sy0 + 2 * (bk / 5); // the record's pixel, relative to mine
+                    const int ex = rdx - (chx - phx), ey = rdy - (chy - phy);     // ... relative to this lane's cell
+                    if (cell_ok && ex >= -2 && ex <= 2 && ey >= -2 && ey <= 2) {
+                        const float4 ra = S.rec[wave][bk][0], rb = S.rec[wave][bk][1];
+                        const int x = px + rdx, y = py + rdy;
+                        touched = true;
+                        m.x += ra.x;
+                        m.y += ra.y;
+                        q.x += ra.z;
+                        q.y += ra.w;
+                        cr += rb.x;
+                        const float kk = S.tps[(border_class(y, L.h) * 5 + border_class(x, L.w)) * 25 + (2 - ey) * 5 + (2 - ex)];
+                        tb.x += rb.y * kk;
+                        tb.y += rb.z * kk;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (touched) {
+                const float counter = (float)(window_count(qy, L.h) * window_count(qx, L.w));
+                val = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
+            }
+            // the cells this slot owns go to the other copy of the sums
+            const bool owned = cell_ok && chx >= ohx0 && chx <= ohx1 && chy >= ohy0 && chy <= ohy1 && (sub >= 25 || !hi);
+            if (owned) {
+                sth(d_mean + gi, m, wt);
+                sth(d_var + gi, q, wt);
+                sth(d_cross + gi, cr, wt);
+                sth(d_tpsb + gi, tb, wt);
+                sth(d_value + gi, val, wt);
+            }
+        }
+        if (closing)
+            break;
+
+        // ================= mask test (get_improve_mask_idx, morph.cu:621-646) on the words + the last phase's tags
         bool hit = false;
         {
             const uint32_t *ib = S.imp + (oyb * 5 + oxb) * 9;
@@ -2860,32 +3028,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
             }
             hit = hit && in_img;
         }
-        uint32_t state = 0;
-        float2 step = make_float2(0, 0), luma = make_float2(0, 0);
-        uint32_t n_eval = 0;
+        VM_PTS(ph, 1);
         if (hit) { // wave-uniform
-            state = 2;
+            uint32_t state = 2;
+            float2 step = make_float2(0, 0), luma = make_float2(0, 0);
+            uint32_t n_eval = 0;
             ++my_cand;
             if (!pixel_locked(L, P.bcond, px, py)) {
-                // which window bits of this lane's cell hold a commit of the last phase
-                uint32_t hits = 0;
-                if (ph > 0) {
-                    uint32_t cset = (uint32_t)__ballot(sub < 25 && ctag == want && !hi);
-                    while (cset) { // wave-uniform
-                        const int bk = __ffs(cset) - 1;
-                        cset &= cset - 1;
-                        const int ex = sx0 + 2 * (bk % 5) - (wj_ - 2), ey = sy0 + 2 * (bk / 5) - (wi_ - 2);
-                        if (okc && ex >= -2 && ex <= 2 && ey >= -2 && ey <= 2)
-                            hits |= 1u << ((ey + 2) * 5 + (ex + 2));
-                    }
-                }
-                if (fold_cell<true>(L, r_a, r_b, S.tps, hits, cx, cy, m, q, cr, tb, P.rev_commit)) {
-                    const float counter = (float)(window_count(cy, L.h) * window_count(cx, L.w));
-                    val = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
-                }
                 // tps.b of the pixel itself is the folded value of its own cell (lane 12)
                 c.tps_b.x = __shfl(tb.x, 12, 32);
                 c.tps_b.y = __shfl(tb.y, 12, 32);
+                VM_PTS(ph, 2);
                 bool ok;
 #if VM_EXACT
                 NbX nb;
@@ -2915,57 +3068,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                 if (ok)
                     state = 1;
             }
+            VM_PTS(ph, 3);
             my_eval += n_eval;
             if (lane == 0) {
                 if (state == 1) {
                     const float2 ol = c.old_luma;
-                    stc(w_a + c.idx, make_float4(luma.x - ol.x, luma.y - ol.y, luma.x * luma.x - ol.x * ol.x,
-                                                 luma.y * luma.y - ol.y * ol.y));
-                    stc(w_b + c.idx, make_float4(luma.x * luma.y - ol.x * ol.y, step.x, step.y, 0.0f));
-                    stc(L.luma + c.idx, luma);
-                    stc(L.ui_b + c.idx, make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy));
-                    stc(L.v + c.idx, make_float2(c.v.x + step.x, c.v.y + step.y));
+                    sth(w_a + pidx, make_float4(luma.x - ol.x, luma.y - ol.y, luma.x * luma.x - ol.x * ol.x,
+                                                luma.y * luma.y - ol.y * ol.y), wt);
+                    sth(w_b + pidx, make_float4(luma.x * luma.y - ol.x * ol.y, step.x, step.y, 0.0f), wt);
+                    sth(L.luma + pidx, luma, wt);
+                    sth(L.ui_b + pidx, make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy), wt);
+                    sth(L.v + pidx, make_float2(c.v.x + step.x, c.v.y + step.y), wt);
                 }
-                stc(w_tag + c.idx, (epoch << 2) | state);
+                sth(w_tag + pidx, (epoch << 2) | state, wt);
             }
             if (state == 1)
                 ++my_commit;
         }
-        // ---- the group's fold of the LAST phase's records, by the first wave that gets here
-        if (ph > 0) {
-            uint32_t t = 0;
-            if (lane == 0)
-                t = atomicAdd(&S.ticket[ph], 1u);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if (t == 0)
-                fold_share(ph - 1, src_t, !src_t);
-        }
-        // ---- tile barrier: every store of this workgroup has left (vmcnt(0) per wave, then the
-        // workgroup barrier), one agent-scope arrival, one lane polls with L1-bypassing loads
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_fetch_add(bar + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t target = (uint32_t)VM_PASS_PARTS * (uint32_t)(ph + 1);
-            const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(bar + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > VM_PASS_TIMEOUT_TICKS) { // never hang the device: report and go on
-                    S.go = 0;
-                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
+        VM_PTS(ph, 4);
+        prof_ph = ph;
+        tile_barrier(ph == 0);
+        VM_PTS(ph, 7);
+        if (ph == 0 && !timed_out) {
+            pure_known = true;
+            if (!wt && S.wt) {
+                // The group turned out to sit on more than one XCD: its phase-0 stores were plain and
+                // may still be in another XCD's L2.  Write them back (agent-scope release), meet once
+                // more, and store write-through from now on.
+                if (tid == 0) // every wave's stores have left (the barrier above): one write-back for the workgroup
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                wt = true;
+                tile_barrier(false);
             }
         }
-        __syncthreads();
-        if (S.go == 0) {
-            timed_out = true;
-            break;
-        }
     }
-    // ---- the last phase's records: second copy + rec(3) -> canonical arrays (wave 0)
-    if (!timed_out && wave == 0)
-        fold_share(3, true, false);
     // ---- counts of the workgroup (plain stores; the next launch adds the slots up)
     if (lane == 0) {
         atomicAdd(&S.n_cand, my_cand);
@@ -2977,6 +3113,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         if (S.n_commit)
             flags[iter_idx] = 1u; // every writer stores the same 1 (see k_step)
         *my_slot = make_uint4(S.n_cand, S.n_commit, S.n_eval, part == 0 ? 1u : 0u);
+#ifdef VM_PASS_DEBUG
+        if (dbg_row && b < 256)
+            dbg_row[b] = S.n_cand;
+#endif
+#ifdef VM_PROF
+        if (b < 256)
+            vm_prof_buf[8192 + b * 2 + 1] = wall_clock64();
+#endif
     }
 }
 
@@ -3094,7 +3238,7 @@ void SUF(vm_launch_optimize_pass)(const VmLevelView *views, int nbatch, int cap,
                                   const uint32_t *tables, int offx, int offy, uint32_t epoch0, uint32_t *bar,
                                   uint32_t *flags, uint32_t *stats, int iter_idx, int fixed_work, uint32_t *slots_cur,
                                   const uint32_t *slots_prev, int prev_iter_idx, uint32_t *err, uint32_t *dbg,
-                                  int decide, hipStream_t s)
+                                  int decide, int force_wt, hipStream_t s)
 {
     const int gx = (w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (h + VM_PITCH_Y - 1) / VM_PITCH_Y;
     const int ntiles = gx * gy, ngroups = ntiles * nbatch;
@@ -3103,7 +3247,7 @@ void SUF(vm_launch_optimize_pass)(const VmLevelView *views, int nbatch, int cap,
         hipLaunchKernelGGL(SUF(k_pass_tail), dim3(1), dim3(64), 0, s, stats, slots_prev, prev_iter_idx, nblocks, ntiles, ngroups, cap);
         return;
     }
-    hipLaunchKernelGGL(SUF(k_pass), dim3(nblocks), dim3(512), 0, s, views, cap, P, tables, offx, offy, epoch0, ngroups,
+    hipLaunchKernelGGL(SUF(k_pass), dim3(nblocks), dim3(VM_PASS_T), 0, s, views, cap, P, tables, offx, offy, epoch0, ngroups,
                        ntiles, bar, flags, stats, iter_idx, fixed_work, slots_cur, slots_prev, prev_iter_idx, nblocks, err,
-                       dbg);
+                       dbg, force_wt);
 }
