@@ -29,14 +29,14 @@ se = buf[8192:8192 + 512].reshape(256, 2).astype(np.int64)
 ok = se[:, 0] > 0
 t0 = se[ok, 0].min()
 print("workgroups:", ok.sum(), " launch span first start -> last end: %.2f us; start skew %.2f us" % ((se[ok, 1].max() - t0) / 100.0, (se[ok, 0].max() - t0) / 100.0))
-names = ["phase start", "loads+fold+mask test", "(shfl)", "line search", "stores", "vmcnt+wg barrier", "tile barrier", "wg barrier 2"]
+names = ["phase start", "loads landed", "fold + owned stores", "mask test", "line search", "record stores + vmcnt + wg barrier", "tile barrier", "wg barrier 2"]
 sf = buf[8192 + 512:8192 + 512 + 2048].reshape(256, 4, 2).astype(np.int64)
 def pct(d):
     return "mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f" % (d.mean(), np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90), d.max())
 for ph in range(4):
     a = st[ok, ph]
-    own = (a[:, 4] - a[:, 0]) / 100.0
-    print("phase %d: wave 0 own work (start -> stores issued): %s" % (ph, pct(own)))
+    own = (np.where(a[:, 4] > a[:, 3], a[:, 4], a[:, 3]) - a[:, 0]) / 100.0
+    print("phase %d: wave 0 own work (start -> line search done): %s" % (ph, pct(own)))
     grp = np.arange(256)[ok] % 8
     arr = a[:, 5]
     last = np.array([arr[grp == g].max() for g in range(8)])
@@ -51,3 +51,6 @@ for ph in range(4):
         print("   %-20s n=%3d mean %6.2f min %6.2f max %6.2f" % (names[k], v.sum(), d.mean(), d.min(), d.max()))
 print("tail after the last barrier: %.2f us" % ((se[ok, 1] - st[ok, 3, 7]).mean() / 100.0))
 print("entry -> phase 0 start: %.2f us" % ((st[ok, 0, 0] - se[ok, 0]).mean() / 100.0))
+sx = buf[8192 + 512:8192 + 512 + 2048].reshape(256, 8).astype(np.int64)
+for k, nm in enumerate(["view struct loaded", "tables requested, geometry", "early-out test done (1 workgroup barrier)"]):
+    print("   entry -> %-45s %.2f us (mean), max %.2f" % (nm, ((sx[ok, k] - se[ok, 0]) / 100.0).mean(), ((sx[ok, k] - se[ok, 0]) / 100.0).max()))

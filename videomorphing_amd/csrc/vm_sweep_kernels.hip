@@ -43,11 +43,11 @@
 #ifdef VM_PROF
 // dev-only stage stamps of k_decide (10 ns ticks), wave 0 lane 0 of each workgroup
 __device__ unsigned long long vm_prof_buf[512 * 16 * 2];
-#define VM_PTSF(ph, k)                                         \
-    if (tid == 512 && b < 256)                                 \
-    vm_prof_buf[8192 + 512 + b * 8 + (ph) * 2 + (k)] = wall_clock64()
-#define VM_PTS(ph, k)                                          \
+#define VM_PTSF(k)                                             \
     if (tid == 0 && b < 256)                                   \
+    vm_prof_buf[8192 + 512 + b * 8 + (k)] = wall_clock64()
+#define VM_PTS(ph, k)                                          \
+    if (tid == 0 && b < 256 && (ph) < 4)                       \
     vm_prof_buf[b * 32 + (ph) * 8 + (k)] = wall_clock64()
 #define VM_TS(i) ts[i] = wall_clock64()
 #define VM_TS_ARG , unsigned long long *ts
@@ -57,7 +57,7 @@ __device__ unsigned long long vm_prof_buf[512 * 16 * 2];
 #define VM_TS_ARG
 #define VM_TS_PASS
 #define VM_PTS(ph, k)
-#define VM_PTSF(ph, k)
+#define VM_PTSF(k)
 #endif
 
 namespace {
@@ -2559,7 +2559,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
 struct PassLds {
     float tps[625];
     uint32_t imp[225];
-    float4 rec[8][25][2]; // per wave: the last phase's records around the wave's pixel (rec_a, rec_b)
+    float4 rec[8][49][2]; // per wave: the last phase's records around the wave's pixel (rec_a, rec_b), the
+                          // 5 x 5 grid of positions inside a border of one: entry (j + 1) * 7 + (i + 1)
     uint32_t n_cand, n_commit, n_eval;
     uint32_t go;          // 1: go on, 0: a barrier timed out
     uint32_t wt;          // 1: the group spans XCDs: write-through stores, counter barrier
@@ -2681,6 +2682,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
     const int pair = grp / ntiles, tile = grp - pair * ntiles;
     const VmLevelView L = views[pair];
+    VM_PTSF(0);
     flags += (size_t)pair * cap;
     uint32_t *const stats0 = stats;
     unsigned long long *const bar = (unsigned long long *)(sync + (size_t)grp * VM_PASS_SYNC_WORDS);
@@ -2713,6 +2715,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     // do not exist, and the reference's test (get_improve_mask_idx) sees them -- a pixel within 2
     // of such an edge stays a candidate for ever (measured: 684 line searches per iteration of a
     // converged 120x68 level, in the oracle and in every schedule).
+    VM_PTSF(1);
     bool live = ox < L.w && oy < L.h && !(!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0);
     {
         uint32_t mine = 0;
@@ -2725,6 +2728,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         if (!__syncthreads_or(mine != 0))
             live = false;
     }
+    VM_PTSF(2);
     // the activity counts of the previous launch, added up by one wave of workgroup 0 (a plain
     // read-modify-write by one thread: nothing else touches that iteration's counters now)
     if (b == 0 && wave == 7 && prev_iter_idx >= 0)
@@ -2951,6 +2955,10 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             ring.mine = ldc(L.v + (in ? ny * L.rs + nx : pidx));
         }
 
+#ifdef VM_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // profiling build only: when have the loads landed?
+#endif
+        VM_PTS(ph, 1);
         // ================= the group's mask word: a committed pixel sets its bit, a hit that did not move clears it
         if (ph > 0) {
             const uint32_t setb = (uint32_t)__ballot(!hi && otag == want);
@@ -2964,32 +2972,59 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             const uint32_t cset = (uint32_t)__ballot(!hi && ctag == want); // wave-uniform
             if (cset) {
                 if (sub < 25 && ctag == want)
-                    S.rec[wave][sub][hi ? 1 : 0] = crec;
+                    S.rec[wave][(sub / 5 + 1) * 7 + sub % 5 + 1][hi ? 1 : 0] = crec;
                 __builtin_amdgcn_wave_barrier();
-                uint32_t todo = cset;
-                while (todo) { // wave-uniform; ascending position = row-major order of the committed pixels
+                // The records that reach this lane's cell: the (at most 3 x 3) positions (i0 + a, j0 + b) of the
+                // staged grid within +-2 of it.  All LDS reads first, then the sums in row-major order of the
+                // committed pixels (fold_cell's order).
+                const int cdx = chx - phx, cdy = chy - phy;                             // my cell, relative to the pixel
+                const int i0 = (cdx - 2 - sx0 + 1) >> 1, j0 = (cdy - 2 - sy0 + 1) >> 1; // ceil((cd - 2 - s0) / 2): -1 .. 3
+                const int e0x = sx0 + 2 * i0 - cdx, e0y = sy0 + 2 * j0 - cdy;           // offset of position (i0, j0) from my cell: -2 or -1
+                const float4 *rbase = &S.rec[wave][(j0 + 1) * 7 + i0 + 1][0];
+                // which of the 3 x 3 hold a commit: row j of the census is bits 5 j .. 5 j + 4
+                uint32_t win[3];
+                int bcx[3], bcy[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int jj = j0 + t;
+                    const uint32_t row = (jj >= 0 && jj <= 4) ? (cset >> (5 * jj)) & 31u : 0u;
+                    win[t] = cell_ok ? ((row << 1) >> (i0 + 1)) & 7u : 0u; // bit a: position (i0 + a, jj); i0 + 1 >= 0
+                    if (e0y + 2 * t > 2)
+                        win[t] = 0;
+                    bcx[t] = border_class(px + sx0 + 2 * (i0 + t), L.w);
+                    bcy[t] = border_class(py + sy0 + 2 * jj, L.h);
+                }
+                if (e0x + 4 > 2) { // the third column is out of reach (e0x = -1)
+                    win[0] &= 3u;
+                    win[1] &= 3u;
+                    win[2] &= 3u;
+                }
+                float4 ra[9], rb[9];
+                float kk[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const int a = k % 3, t = k / 3;
+                    ra[k] = rbase[(t * 7 + a) * 2];
+                    rb[k] = rbase[(t * 7 + a) * 2 + 1];
+                    const bool u = (win[t] >> a) & 1u;
+                    kk[k] = S.tps[u ? (bcy[t] * 5 + bcx[a]) * 25 + (2 - e0y - 2 * t) * 5 + (2 - e0x - 2 * a) : 0];
+                }
+#pragma unroll
+                for (int k0 = 0; k0 < 9; ++k0) {
 #if VM_EXACT
-                    // rev (vm_set_commit_order): the same records in reversed row-major order
-                    const int bk = P.rev_commit ? 31 - __clz(todo) : __ffs(todo) - 1;
-                    todo &= ~(1u << bk);
+                    const int k = P.rev_commit ? 8 - k0 : k0; // rev (vm_set_commit_order): reversed row-major order
 #else
-                    const int bk = __ffs(todo) - 1;
-                    todo &= todo - 1;
+                    const int k = k0;
 #endif
-                    const int rdx = sx0 + 2 * (bk % 5), rdy = sy0 + 2 * (bk / 5); // the record's pixel, relative to mine
-                    const int ex = rdx - (chx - phx), ey = rdy - (chy - phy);     // ... relative to this lane's cell
-                    if (cell_ok && ex >= -2 && ex <= 2 && ey >= -2 && ey <= 2) {
-                        const float4 ra = S.rec[wave][bk][0], rb = S.rec[wave][bk][1];
-                        const int x = px + rdx, y = py + rdy;
+                    if ((win[k / 3] >> (k % 3)) & 1u) {
                         touched = true;
-                        m.x += ra.x;
-                        m.y += ra.y;
-                        q.x += ra.z;
-                        q.y += ra.w;
-                        cr += rb.x;
-                        const float kk = S.tps[(border_class(y, L.h) * 5 + border_class(x, L.w)) * 25 + (2 - ey) * 5 + (2 - ex)];
-                        tb.x += rb.y * kk;
-                        tb.y += rb.z * kk;
+                        m.x += ra[k].x;
+                        m.y += ra[k].y;
+                        q.x += ra[k].z;
+                        q.y += ra[k].w;
+                        cr += rb[k].x;
+                        tb.x += rb[k].y * kk[k];
+                        tb.y += rb[k].z * kk[k];
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -3008,6 +3043,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
                 sth(d_value + gi, val, wt);
             }
         }
+        VM_PTS(ph, 2);
         if (closing)
             break;
 
@@ -3028,7 +3064,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             }
             hit = hit && in_img;
         }
-        VM_PTS(ph, 1);
+        VM_PTS(ph, 3);
         if (hit) { // wave-uniform
             uint32_t state = 2;
             float2 step = make_float2(0, 0), luma = make_float2(0, 0);
@@ -3038,7 +3074,6 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
                 // tps.b of the pixel itself is the folded value of its own cell (lane 12)
                 c.tps_b.x = __shfl(tb.x, 12, 32);
                 c.tps_b.y = __shfl(tb.y, 12, 32);
-                VM_PTS(ph, 2);
                 bool ok;
 #if VM_EXACT
                 NbX nb;
@@ -3068,7 +3103,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
                 if (ok)
                     state = 1;
             }
-            VM_PTS(ph, 3);
+            VM_PTS(ph, 4);
             my_eval += n_eval;
             if (lane == 0) {
                 if (state == 1) {
@@ -3085,7 +3120,6 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             if (state == 1)
                 ++my_commit;
         }
-        VM_PTS(ph, 4);
         prof_ph = ph;
         tile_barrier(ph == 0);
         VM_PTS(ph, 7);
