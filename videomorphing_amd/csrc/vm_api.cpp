@@ -868,7 +868,17 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         // TILE, FAST arithmetic: the register-light kernel variant once fewer than a tenth of the pixels
         // are searched per iteration (after the first sweep of a level, typically)
         const bool lean_regime = cand_prev < 0.1 * l0.w * l0.h * n;
-        const int dense = exact || force_dense || !lean_regime;
+        // dense sweeps, FAST: the 128-VGPR form of the dense kernel (>= 4 lanes per candidate, two
+        // workgroups per CU) on levels of >= 512 tiles per pass -- measured on MI355X (r03,
+        // tools/dev_dense.py, us per dense pass, 256- vs 128-VGPR kernel): 1080p x 1 pair 1485 vs 1385,
+        // x 8 11404 vs 9998, x 30 42399 vs 37163; 960x540 x 8 2873 vs 2601; but 240x135 x 30 895 vs
+        // 974 and 120x68 x 30 277 vs 438: with about one workgroup per CU the second round of a
+        // 256-candidate phase costs more than the second workgroup hides.  The rule looks at the
+        // level only, never at the batch: a pair is solved by the same kernels alone and in a batch
+        // (FAST sums are ordered by the lane fan-out).  VM_DENSE128=0 / 1 forces it (dev switch).
+        static const char *d128 = getenv("VM_DENSE128");
+        const bool dense128 = !exact && (d128 ? atoi(d128) != 0 : tiles_per_pass >= 512);
+        const int dense = (exact || force_dense || !lean_regime) ? (dense128 ? 2 : 1) : 0;
         // SPARSE replaces the TILE launches of a pruned level once at most three tiles per pass
         // and pair are still active (measured on MI355X, 1080p: a no-op TILE iteration costs
         // 4 x 3.4 us, a no-op SPARSE iteration 4 x ~0.3 us; with more active tiles than that the

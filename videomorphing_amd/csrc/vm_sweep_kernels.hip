@@ -136,15 +136,17 @@ struct GlbSrc {
 // flag == false; one lane per pixel, neighbours visited in row-major order (dense
 // phases; sparse phases and the SPLIT schedule use energy_x32 below: same bits)
 #define VM_SWEEP_T 1024
+#define VM_SMAX 1
 #define VM_MIN_FANOUT 1
 #define VM_MAX_FANOUT 1
-struct NbCache {};
-template <bool INTERIOR, class Src>
-__device__ __forceinline__ void nb_load(NbCache &, const VmLevelView &, const Src &, const PixelCtx &, int, int) {}
+template <int SMAX>
+struct NbCacheT {};
+template <bool INTERIOR, int SMAX, class Src>
+__device__ __forceinline__ void nb_load(NbCacheT<SMAX> &, const VmLevelView &, const Src &, const PixelCtx &, int, int) {}
 
-template <bool INTERIOR, class Src>
+template <bool INTERIOR, int SMAX, class Src>
 __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKParams &P, const Src &src,
-                                               const NbCache &, const PixelCtx &c, float dx, float dy, int)
+                                               const NbCacheT<SMAX> &, const PixelCtx &c, float dx, float dy, int)
 {
     const float vx = c.v.x + dx, vy = c.v.y + dy;
     const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - vx + 0.5f, c.py - vy + 0.5f);
@@ -201,12 +203,15 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
 #ifndef VM_MAX_FANOUT
 #define VM_MAX_FANOUT 32
 #endif
-struct NbCache {
-    float A[VM_SMAX], B[VM_SMAX];                   // window means (sum / n)
-    float VX[VM_SMAX], VY[VM_SMAX], X[VM_SMAX];     // raw second-moment sums
-    float VAL[VM_SMAX];                             // current SSIM value (value - new is summed,
-                                                    // as the reference does: 1e-3..1e-6 of the values)
-    float N[VM_SMAX];                               // border waves only: window count, 0 = no such neighbour
+// SMAX = neighbours a lane may own: 13 with a fan-out of >= 2 lanes per pixel (the 256-VGPR dense
+// kernel), 7 with >= 4 (the 128-VGPR one: two workgroups per CU)
+template <int SMAX>
+struct NbCacheT {
+    float A[SMAX], B[SMAX];                   // window means (sum / n)
+    float VX[SMAX], VY[SMAX], X[SMAX];        // raw second-moment sums
+    float VAL[SMAX];                          // current SSIM value (value - new is summed,
+                                              // as the reference does: 1e-3..1e-6 of the values)
+    float N[SMAX];                            // border waves only: window count, 0 = no such neighbour
 };
 
 __device__ __forceinline__ float dpp_xor1(float x)
@@ -241,12 +246,12 @@ __device__ __forceinline__ float group_sum(float x, int Lf)
     return x;
 }
 
-template <bool INTERIOR, class Src>
-__device__ __forceinline__ void nb_load(NbCache &nb, const VmLevelView &L, const Src &src, const PixelCtx &c,
+template <bool INTERIOR, int SMAX, class Src>
+__device__ __forceinline__ void nb_load(NbCacheT<SMAX> &nb, const VmLevelView &L, const Src &src, const PixelCtx &c,
                                         int sub, int Lf)
 {
 #pragma unroll
-    for (int j = 0; j < VM_SMAX; ++j) {
+    for (int j = 0; j < SMAX; ++j) {
         if (j * Lf >= 25) // uniform in the workgroup: no lane has such a neighbour
             break;
         const int k = sub + j * Lf;
@@ -271,9 +276,9 @@ __device__ __forceinline__ void nb_load(NbCache &nb, const VmLevelView &L, const
     }
 }
 
-template <bool INTERIOR, class Src>
+template <bool INTERIOR, int SMAX, class Src>
 __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKParams &P, const Src &,
-                                               const NbCache &nb, const PixelCtx &c, float dx, float dy, int Lf)
+                                               const NbCacheT<SMAX> &nb, const PixelCtx &c, float dx, float dy, int Lf)
 {
     const float vx = c.v.x + dx, vy = c.v.y + dy;
     const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - vx + 0.5f, c.py - vy + 0.5f);
@@ -284,7 +289,7 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
     const float dcross = lx * ly - c.old_luma.x * c.old_luma.y;
     float acc = 0;
 #pragma unroll
-    for (int j = 0; j < VM_SMAX; ++j) {
+    for (int j = 0; j < SMAX; ++j) {
         if (j * Lf < 25) { // uniform in the workgroup
             if (INTERIOR) {
                 // the last slot of a lane may lie past the 25th neighbour: it then holds a copy
@@ -577,14 +582,14 @@ __device__ __forceinline__ bool decide_with64(const VmLevelView &L, const VmKPar
 }
 
 // one lane (EXACT) or L lanes (FAST dense path) per pixel
-template <bool INTERIOR, class Src>
+template <bool INTERIOR, int SMAX, class Src>
 __device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P, const Src &src,
                                        const PixelCtx &c, int sub, int Lf, float2 &step, uint32_t &n_eval VM_TS_ARG)
 {
-    NbCache nb;
-    nb_load<INTERIOR>(nb, L, src, c, sub, Lf);
+    NbCacheT<SMAX> nb;
+    nb_load<INTERIOR, SMAX>(nb, L, src, c, sub, Lf);
     return decide_with(
-        L, P, c, [&](float dx, float dy) { return energy_change<INTERIOR>(L, P, src, nb, c, dx, dy, Lf); },
+        L, P, c, [&](float dx, float dy) { return energy_change<INTERIOR, SMAX>(L, P, src, nb, c, dx, dy, Lf); },
         RingGlobal{L.v}, step, n_eval VM_TS_PASS);
 }
 
@@ -1305,7 +1310,7 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
 // DENSE = false (FAST only): the variant for pruned sweeps -- every phase runs the lean line
 // search, 16 candidates per round; without the dense path the kernel needs 134 instead of
 // 256 VGPRs (measured: pruned sweeps 5-8 % faster).
-template <bool DENSE>
+template <bool DENSE, int SMAX = VM_SMAX, int MINF = VM_MIN_FANOUT>
 __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, const VmKParams &P,
                                            const uint32_t *__restrict__ tables, bool tables_staged, int ox, int oy,
                                            int tid, int T, bool &improving, uint32_t &st_cand, uint32_t &st_commit)
@@ -1387,7 +1392,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 st_cand += n_act;
                 // ---- 2. line searches on the pre-phase state, L lanes per candidate ----
 #if !VM_EXACT
-                if (!DENSE || n_act * 32 <= T) {
+                if (!DENSE || (SMAX > 7 && n_act * 32 <= T)) { // (the 128-VGPR dense kernel keeps to the dense path: fewer live ranges)
                     // sparse phase: the lean 32-lane line search; with <= T / 64 candidates a whole
                     // wave each, two points of the search per round (decide64)
                     const bool wide = n_act * 64 <= T;
@@ -1471,7 +1476,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 } else
 #endif
                 if (DENSE) {
-                int Lf = VM_MIN_FANOUT;
+                int Lf = MINF;
                 while (Lf * 2 <= VM_MAX_FANOUT && Lf * 2 * n_act <= T)
                     Lf *= 2;
                 const int slots = T / Lf;
@@ -1494,8 +1499,8 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                         unsigned long long ts[16];
 #endif
                         uint32_t n_eval = 0;
-                        const bool ok = wave_interior ? decide<true>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS)
-                                                      : decide<false>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS);
+                        const bool ok = wave_interior ? decide<true, SMAX>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS)
+                                                      : decide<false, SMAX>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS);
                         if (sub == 0)
                             atomicAdd(&S.n_eval, n_eval);
                         if (ok && sub == 0) {
@@ -1577,8 +1582,13 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
     return true;
 }
 
-template <bool DENSE>
-__global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENSE ? 1 : 4))) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
+// DENSE, SMAX = VM_SMAX: the 256-VGPR kernel of dense sweeps (one workgroup per CU);
+// DENSE, SMAX = 7, MINF = 4: its 128-VGPR form -- every candidate gets >= 4 lanes, a phase of more than
+// T / 4 candidates takes two rounds, two workgroups share a CU (four waves per SIMD instead of two: the
+// dense line search is bound by the issue rate of a single wave, one VALU instruction per 4 cycles);
+// !DENSE: the lean kernel of pruned sweeps.
+template <bool DENSE, int SMAX = VM_SMAX, int MINF = VM_MIN_FANOUT>
+__global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENSE && SMAX > 7 ? 1 : 4))) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
                                                         VmKParams P, const uint32_t *__restrict__ tables,
                                                         int offx, int offy, uint32_t *__restrict__ flags,
                                                         uint32_t *__restrict__ stats, int iter_idx, int fixed_work,
@@ -1607,7 +1617,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
 
     bool improving = false;
     uint32_t st_cand = 0, st_commit = 0;
-    if (!tile_sweep<DENSE>(S, L, P, tables, false, ox, oy, tid, T, improving, st_cand, st_commit))
+    if (!tile_sweep<DENSE, SMAX, MINF>(S, L, P, tables, false, ox, oy, tid, T, improving, st_cand, st_commit))
         return;
     if (tid == 0) {
         if (improving)
@@ -3193,6 +3203,11 @@ void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int 
 #if !VM_EXACT
     if (!dense) {
         hipLaunchKernelGGL(SUF(k_optimize)<false>, g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats,
+                           iter_idx, fixed_work, iter_dev);
+        return;
+    }
+    if (dense == 2) { // the 128-VGPR form: two workgroups per CU
+        hipLaunchKernelGGL((SUF(k_optimize)<true, 7, 4>), g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats,
                            iter_idx, fixed_work, iter_dev);
         return;
     }
