@@ -522,6 +522,30 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         extras["temporal_video_%d_frames" % d] = {"mpix_iters_per_s": round(units / dt / 1e6, 1), "ms_per_video": round(dt * 1e3, 1),
                                                   "flow_pyramid_ms": round(t_flow * 1e3, 1),
                                                   "depth_per_level": [l[2] for l in levels]}
+        # ... and on to the screen (CMatchingThread::update_result for a video, then the compositor):
+        # per frame of the video its full-resolution field straight into a device-resident frame
+        # (vm_frame_set_v_from_video), Poisson extension of both sides, 9 rendered in-between frames;
+        # canvases uploaded once per frame (PCIe included)
+        exv = int(0.1 * max(w, h))
+        rv0, rv1 = synth.make_rgb_pair(w, h)
+        ev0, ev1 = morph.make_extended(rv0, exv), morph.make_extended(rv1, exv)
+        frv = morph.Frame(ctx, w, h, exv)
+        frv.upload(ev0, ev1, None, None)
+        frv.set_v_from_video(vid, 0, 0)
+        frv.poisson_extend(1, tol=1e-5)            # workspaces
+        ctx.sync(); t1 = time.perf_counter()
+        for fidx in range(d):
+            frv.upload(ev0, ev1, None, None)
+            frv.set_v_from_video(vid, 0, fidx)
+            frv.poisson_extend(1, tol=1e-5)
+            frv.poisson_extend(2, tol=1e-5)
+            for k in range(1, 10):
+                frv.render_halfway_dev(0.1 * k, 0.1 * k, 1)
+        ctx.sync(); dtv = time.perf_counter() - t1
+        frv.close()
+        extras["video_pipeline_%d_frames" % d] = {"compositor_ms_per_video_frame": round(dtv * 1e3 / d, 1),
+                                                  "rendered_frames_per_s": round(d * 9 / dtv, 1),
+                                                  "solve_plus_compositor_ms_per_video": round((dt + dtv) * 1e3, 1)}
         del vid
     except capi.VmError as e:
         extras["temporal_video_5_frames"] = {"error": str(e)[-160:]}

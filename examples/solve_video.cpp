@@ -2,7 +2,8 @@
 // (frames + optical flows), the temporally coupled Morph, the halfway field of every frame.
 //   solve_video W H D frames.u8 flows.f32 out_v.f32 [max_iter] [start_res] [exact|fast]
 // frames.u8: D x 2 RGB8 frames (video 0 frame t, video 1 frame t, ...), flows.f32: D x 4 fields
-// (f0, f1, b0, b1 of frame t), out: the finest level's v of every page.
+// (f0, f1, b0, b1 of frame t), out: the full-resolution halfway field of every frame
+// (Pyramid::_vector after CMatchingThread::update_result).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,14 +45,14 @@ int main(int argc, char **argv)
         }
         vmorph::VideoPyramid pyramid(ctx);
         pyramid.build(v0, v1, f0, f1, b0, b1, w, h, params.start_res);
-        volatile int run = 1;
-        vmorph::VideoMorph morph(params, pyramid, run);
-        morph.calculate_halfway_parametrization();
+        // class CMatchingThread over the video pair: the solve on a worker thread, then update_result()
+        vmorph::VideoMatchingThread thread(params, pyramid, w, h);
+        thread.start();
+        thread.wait();
+        vmorph::VideoMorph &morph = thread.gpu_morph;
         FILE *f = fopen(argv[6], "wb");
-        for (int t = 0; t < pyramid.levels[0].depth; ++t) {
-            std::vector<float> v = pyramid.get_v(0, t);
-            fwrite(v.data(), 4, v.size(), f);
-        }
+        for (int t = 0; t < d; ++t)
+            fwrite(pyramid._vector[t].data(), 4, pyramid._vector[t].size(), f);
         fclose(f);
         printf("levels %zu:", pyramid.levels.size());
         for (auto &l : pyramid.levels) printf(" %dx%dx%d", l.width, l.height, l.depth);

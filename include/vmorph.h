@@ -248,6 +248,14 @@ int  vm_video_build_flows(vm_video *v, const float *const *f0, const float *cons
 int  vm_video_set_v(vm_video *v, int lvl, int page, const float *v_xy, int pitch);
 int  vm_video_get_v(vm_video *v, int lvl, int page, float *v_xy, int pitch);
 int  vm_video_get_field(vm_video *v, int lvl, int page, int field, void *host);
+/* CMatchingThread::update_result for depth > 1, MatchingThread.cpp:22-84: every page of level
+ * `lvl` scaled by (w0 / w, h0 / h) and resized to w0 x h0 into frame min(page * factor,
+ * depth0 - 1), factor = factor_d[placeholder] / factor_d[lvl]; the frames the temporal
+ * pyramid skipped are blended linearly from the two frames around them.  vm_video_result
+ * delivers all depth0 frames (tight (depth0, h0, w0, 2) floats; a frame nothing writes stays
+ * zero); vm_frame_set_v_from_video leaves ONE of them in a compositor frame's v, on the
+ * device (w0 x h0 = the frame's size, depth0 = the depth the video was created with). */
+int  vm_video_result(vm_video *v, int lvl, int w0, int h0, float *v_xy_frames);
 /* Morph::cpu_optimize_level for every page of the coarsest level, morph.cu:419-590 */
 int  vm_video_coarse_solve(vm_video *v, const vm_video_constraint *c, int n);
 /* upsample(pyr[dst], pyr[dst+1]), upsample.cu:260-340: the spatial upsample of every coarse
@@ -287,6 +295,8 @@ int  vm_frame_download_ext(vm_frame *f, int side, uint8_t *ext_rgba);
 /* take v straight from a solved pyramid level (device to device, with the
  * update_result upscale) */
 int  vm_frame_set_v_from_level(vm_frame *f, vm_pyr *pyr, int lvl);
+/* ... and frame `frame` of vm_video_result (above), computed on the device */
+int  vm_frame_set_v_from_video(vm_frame *f, vm_video *v, int lvl, int frame);
 /* render_halfway_image, Algorithm/render.cu:62-96 (UI/RenderWidget.h:52-57);
  * rgb_out: h rows of w RGB8 pixels, pitch in bytes (0 = tight) */
 int  vm_render_halfway(vm_frame *f, float color_fa, float geo_fa, int color_from,
@@ -313,6 +323,8 @@ int  vm_frame_quadratic_path(vm_frame *f, float tol, int max_it,
                              int *iters, float *rel_res, float *elapsed_ms);
 /* the frame's quadratic path (Pyramid::_qpath, Pyramid.h:42), tight (h, w, 2) floats */
 int  vm_frame_download_qpath(vm_frame *f, float *u_xy);
+/* the frame's v (set by vm_frame_upload / _set_v_from_level / _set_v_from_video), tight (h, w, 2) floats */
+int  vm_frame_download_v(vm_frame *f, float *v_xy);
 
 /* ---- synchronisation stage ("(later)" row) ------------------ */
 /* Before the morph the reference's app aligns the two videos in time: the user

@@ -5,7 +5,10 @@
 #ifndef VMORPH_VIDEO_HPP
 #define VMORPH_VIDEO_HPP
 
+#include <chrono>
 #include <cmath>
+#include <exception>
+#include <thread>
 #include <vector>
 
 #include "pyramid.hpp"
@@ -58,6 +61,7 @@ public:
         for (const VideoLevel &l : table) { w.push_back(l.width); h.push_back(l.height); d.push_back(l.depth); ft.push_back(l.factor_t); }
         check(vm_video_create(ctx_.handle(), (int)table.size(), w.data(), h.data(), d.data(), ft.data(), depth0, &h_));
         levels = table;
+        depth0_ = depth0;
     }
 
     // Pyramid::build(video0, video1, f0, f1, b0, b1, start_res), pyramid.cu:166-485: RGB8 frames
@@ -82,11 +86,16 @@ public:
 
     vm_video *handle() const { return h_; }
     Context &context() const { return ctx_; }
+    int depth0() const { return depth0_; }
     std::vector<VideoLevel> levels; // level 0 finest ... back(): coarsest (v only)
+    // Pyramid::_vector (Pyramid.h:41): one full-resolution field per frame of the video, written by
+    // VideoMatchingThread::update_result
+    std::vector<std::vector<float>> _vector;
 
 private:
     Context &ctx_;
     vm_video *h_ = nullptr;
+    int depth0_ = 1;
 };
 
 // class Morph over a video pair: middle page first, then both chains with the temporal term
@@ -124,6 +133,61 @@ private:
     VideoPyramid &m_pyramid;
     Parameters &m_params;
     bool fixed_work_;
+};
+
+// class CMatchingThread (MatchingThread.h:7-37) over a video pair: the coupled solve on a worker
+// thread (QThread -> std::thread), then update_result(): pyramid._vector[frame] for EVERY frame of the
+// video at w0 x h0 -- pages scaled and resized, the frames the temporal pyramid skipped blended from
+// their neighbours (MatchingThread.cpp:22-84)
+class VideoMatchingThread {
+public:
+    VideoMatchingThread(Parameters &parameters, VideoPyramid &pyramids, int w0 = 0, int h0 = 0)
+        : runflag(1), _pyramids(pyramids), _parameters(parameters), gpu_morph(parameters, pyramids, runflag),
+          w0_(w0 ? w0 : pyramids.levels.at(0).width), h0_(h0 ? h0 : pyramids.levels.at(0).height) {}
+    ~VideoMatchingThread()
+    {
+        if (thread_.joinable()) thread_.join(); // a stored exception is dropped: wait() shows it
+    }
+
+    void run() // MatchingThread.cpp:138-150
+    {
+        auto t0 = std::chrono::steady_clock::now();
+        gpu_morph.calculate_halfway_parametrization();
+        run_time = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count();
+        update_result();
+    }
+    void start() { thread_ = std::thread([this] { try { run(); } catch (...) { error_ = std::current_exception(); } }); }
+    void wait()
+    {
+        if (thread_.joinable()) thread_.join();
+        if (error_) { auto e = error_; error_ = nullptr; std::rethrow_exception(e); }
+    }
+
+    // MatchingThread.cpp:22-84 from level `lvl` (after run(): the finest)
+    void update_result(int lvl = 0)
+    {
+        const size_t n = (size_t)w0_ * h0_ * 2;
+        std::vector<float> all(n * _pyramids.depth0());
+        check(vm_video_result(_pyramids.handle(), lvl, w0_, h0_, all.data()));
+        _pyramids._vector.assign(_pyramids.depth0(), std::vector<float>());
+        for (int f = 0; f < _pyramids.depth0(); ++f)
+            _pyramids._vector[f].assign(all.begin() + f * n, all.begin() + (f + 1) * n);
+        percentage = 100.0f;
+    }
+
+    float percentage = 0.0f;
+    float run_time = 0.0f;
+    volatile int runflag; // the reference's `bool runflag`, written by the UI thread
+
+private:
+    VideoPyramid &_pyramids;
+    Parameters &_parameters;
+public:
+    VideoMorph gpu_morph;
+private:
+    int w0_, h0_;
+    std::thread thread_;
+    std::exception_ptr error_;
 };
 
 } // namespace vmorph

@@ -34,6 +34,7 @@
 #ifndef VM_ORACLE_H
 #define VM_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -136,6 +137,7 @@ void vmo_render_halfway(uint8_t *out, int w, int h, int ex,
                         const float *v, const float *u);
 /* CMatchingThread::update_result/Resize, MatchingThread.cpp:22-136: scale v
  * by (W0/W,H0/H) and bilinearly resize to w0 x h0 */
+void vmo_blend_v(float *dst, const float *a, const float *b, float fa, size_t n_floats);
 void vmo_upscale_result(float *dst, int w0, int h0,
                         const float *v, int w, int h);
 /* CPoissonExt::prepare + poissonExtend, PoissonExt.cpp:49-362.  rgba_ext:

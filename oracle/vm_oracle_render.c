@@ -119,3 +119,16 @@ void vmo_upscale_result(float *dst, int w0, int h0, const float *v, int w, int h
     }
     free(tmp);
 }
+
+/* the temporal half of CMatchingThread::update_result (MatchingThread.cpp:62-78): the frames the
+ * temporal pyramid skipped, _vector[beg] * (1 - fa) + _vector[end] * fa.  A cv::Mat expression:
+ * OpenCV evaluates it as addWeighted in float -- two products and their sum per component (the
+ * binary is not in the reference tree: parity of this one line is unpinned). */
+void vmo_blend_v(float *dst, const float *a, const float *b, float fa, size_t n_floats)
+{
+    const float alpha = 1 - fa, beta = fa;
+    for (size_t i = 0; i < n_floats; ++i) {
+        const float t = a[i] * alpha, u = b[i] * beta;
+        dst[i] = t + u;
+    }
+}

@@ -103,6 +103,8 @@ def lib():
     L.vmo_render_halfway.restype = None
     L.vmo_upscale_result.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
     L.vmo_upscale_result.restype = None
+    L.vmo_blend_v.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_size_t]
+    L.vmo_blend_v.restype = None
     L.vmo_poisson_extend.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
     L.vmo_poisson_extend.restype = C.c_int
@@ -534,6 +536,29 @@ class Video:
             its[i] = pg[i].optimize(P, max_iter, stats)
         self.iters[lvl] = its
         return its
+
+    def update_result(self, lvl, w0=None, h0=None):
+        """CMatchingThread::update_result, MatchingThread.cpp:22-84: the depth0 full-resolution frames
+        of level `lvl`'s field -- the two loops of the reference, literally"""
+        w0 = int(w0 if w0 is not None else self.w0)
+        h0 = int(h0 if h0 is not None else self.h0)
+        d = self.levels[lvl][2]
+        factor = int(self.factor_d[0] / self.factor_d[lvl + 1])
+        vec = [np.zeros((h0, w0, 2), np.float32) for _ in range(self.depth0)]
+        for i in range(d):
+            vec[min(i * factor, self.depth0 - 1)] = upscale_result(self.pages[lvl][i].field("v"), w0, h0)
+        if factor > 1:
+            for i in range(d - 1):
+                for k in range(1, factor):
+                    if i * factor + k >= self.depth0 - 1:
+                        continue
+                    beg, end = i * factor, min((i + 1) * factor, self.depth0 - 1)
+                    fa = np.float32(k) / np.float32(end - beg)
+                    out = np.zeros((h0, w0, 2), np.float32)
+                    a, b = np.ascontiguousarray(vec[beg]), np.ascontiguousarray(vec[end])
+                    lib().vmo_blend_v(out.ctypes.data, a.ctypes.data, b.ctypes.data, float(fa), out.size)
+                    vec[i * factor + k] = out
+        return vec
 
     def solve(self, P, max_iter, drop=1.0, cons=(), stats=None):
         """Morph::calculate_halfway_parametrization, morph.cu:150-168"""

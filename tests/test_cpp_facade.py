@@ -76,8 +76,9 @@ def test_video_facade_builds(solve_video):
 
 @pytest.mark.gpu
 def test_video_facade_matches_python_mirror(solve_video, gpu_ctx, tmp_path):
-    """the C++ VideoPyramid / VideoMorph (device-side image + flow pyramid, coupled solve) and the
-    Python mirror over the same C-ABI produce the same bits"""
+    """the C++ VideoPyramid / VideoMatchingThread (device-side image + flow pyramid, coupled solve on a
+    worker thread, update_result for every frame) and the Python mirror over the same C-ABI produce
+    the same bits"""
     from videomorphing_amd import morph
     w, h, d = 96, 64, 4
     rgbs = [synth.make_rgb_pair(w, h, frame=t) for t in range(d)]
@@ -98,9 +99,11 @@ def test_video_facade_matches_python_mirror(solve_video, gpu_ctx, tmp_path):
     vid.build_flows(f0, f1, b0, b1)
     prm = morph.Parameters()
     prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 12, 1.0, 16
-    morph.VideoMorph(prm, vid).calculate_halfway_parametrization()
+    th = morph.VideoMatchingThread(prm, vid, w, h)
+    th.run()
     for t in range(d):
-        assert np.array_equal(v_cpp[t].view(np.uint32), vid.pages[0][t].v.view(np.uint32)), t
+        assert np.array_equal(v_cpp[t].view(np.uint32), vid._vector[t].view(np.uint32)), t
+        assert np.array_equal(v_cpp[t].view(np.uint32), vid.pages[0][t].v.view(np.uint32)), t     # ratio 1: the page itself
     assert np.abs(v_cpp).max() > 0.05
 
 

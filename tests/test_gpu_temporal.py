@@ -336,3 +336,112 @@ def test_temporal_video_at_1080p(gpu_ctx):
     # advected neighbour more closely than when every frame is solved on its own
     dev = lambda r: np.abs((r[2][8:-8, 8:-8] - np.float32([0.5, -0.25])) - r[1][8:-8, 7:-9]).mean()
     assert dev(res[10.0]) < dev(res[0.0]), (dev(res[10.0]), dev(res[0.0]))
+
+
+@pytest.mark.parametrize("levels,ft,depth0,full", [
+    ([(64, 48, 5), (32, 24, 5), (16, 12, 3)], [1, 1, 2], 5, (64, 48)),
+    ([(64, 48, 5), (32, 24, 5), (16, 12, 3)], [1, 1, 2], 5, (100, 75)),      # a decimated stage-2 pyramid: placeholder level larger
+    ([(40, 30, 6), (20, 15, 4), (10, 8, 3)], [1, 2, 2], 6, (40, 30)),         # 6 -> 4 -> 3 pages: factors 4, 2; clamped last frame
+    ([(40, 30, 4), (20, 15, 4)], [2, 1], 7, (40, 30)),                        # the finest level already skips frames (depth0 7 -> 4)
+])
+def test_video_result_delivery_exact(gpu_ctx, oracle, levels, ft, depth0, full):
+    """CMatchingThread::update_result for depth > 1 (MatchingThread.cpp:22-84) from every level: page i
+    scaled and resized into frame min(i * factor, depth0 - 1), the frames the temporal pyramid skipped
+    blended from the frames around them -- all depth0 frames bit-identical to the oracle's restatement
+    of the reference's two loops, as a host array and frame by frame in a device-resident vm_frame"""
+    vid = oracle.Video(levels, depth0)
+    dev = morph.VideoPyramid(gpu_ctx)
+    dev.build_levels(levels, ft, depth0)
+    rng = np.random.RandomState(17)
+    for l, (w, h, d) in enumerate(levels):
+        for t in range(d):
+            v = (rng.randn(h, w, 2) * 1.5).astype(np.float32)
+            vid.pages[l][t].field("v")[...] = v
+            dev.pages[l][t].v = v
+    w0, h0 = full
+    fr = morph.Frame(gpu_ctx, w0, h0, 0)
+    for l in range(len(levels)):
+        ref = vid.update_result(l, w0, h0)
+        got = dev.result(l, w0, h0)
+        assert got.shape == (depth0, h0, w0, 2)
+        for f in range(depth0):
+            assert np.array_equal(_bits(ref[f]), _bits(got[f])), (l, f, np.abs(ref[f] - got[f]).max())
+            fr.set_v_from_video(dev, l, f)
+            assert np.array_equal(_bits(ref[f]), _bits(fr.download_v())), (l, f)
+        factor = int(vid.factor_d[0] / vid.factor_d[l + 1])
+        if factor > 1 and depth0 > 2:       # a skipped frame really is the blend of its neighbours
+            assert np.allclose(got[1], got[0] * (1 - 1.0 / min(factor, depth0 - 1)) + got[min(factor, depth0 - 1)] / min(factor, depth0 - 1), atol=1e-5)
+    fr.close()
+
+
+def test_video_matching_thread_end_to_end(gpu_ctx, oracle):
+    """The temporally coupled path to the screen: VideoMatchingThread (solve on a worker thread, then
+    update_result) -> per frame the field into a device-resident vm_frame -> Poisson extension of
+    both sides -> rendered halfway frame.  The delivered fields equal the oracle's solve + its
+    restatement of update_result bit for bit (EXACT); the rendered frame of every video frame
+    equals the oracle's renderer on the oracle's extension within the Poisson solver's +-1 level."""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    P = _kp(gpu_ctx, oracle, w_temp=10.0)
+    levels, ft = [(64, 48, 5), (32, 24, 5), (16, 12, 3)], [1, 1, 2]
+    vid, dev = _make(oracle, gpu_ctx, levels, factor_t=ft, seed=31)
+    vid.solve(P, 12, 1.0)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor = 12, 1.0
+    th = morph.VideoMatchingThread(prm, dev)
+    th.start()
+    th.wait()
+    ref = vid.update_result(0)
+    assert len(dev._vector) == 5 and th.percentage == 100.0
+    for f in range(5):
+        assert np.array_equal(_bits(ref[f]), _bits(dev._vector[f])), f
+    assert max(np.abs(r).max() for r in ref) > 0.2
+    # compositor, frame by frame, v never leaving the device
+    w, h = levels[0][:2]
+    ex = int(0.1 * max(w, h))
+    rgb0, rgb1 = synth.make_rgb_pair(w, h)
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    for f in (0, 2, 4):
+        e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
+        fr.upload(e0, e1, None, None)
+        fr.set_v_from_video(dev, 0, f)
+        crops = {1: e1[ex:ex + h, ex:ex + w].copy(), 2: e0[ex:ex + h, ex:ex + w].copy()}
+        for side, ext in ((1, e0), (2, e1)):
+            r, _, _ = oracle.poisson_extend(ext, w, h, ex, crops[side], ref[f], side, tol=1e-9)
+            fr.poisson_extend(side, tol=1e-6)
+            ext[...] = r
+        img = fr.render_halfway(0.5, 0.5, 1)
+        want = oracle.render_halfway(w, h, ex, 0.5, 0.5, 1, e0.astype(np.float32), e1.astype(np.float32), ref[f], np.zeros_like(ref[f]))
+        d = np.abs(img.astype(int) - want.astype(int))
+        assert d.max() <= 1, (f, d.max())
+    fr.close()
+
+
+def test_video_result_at_1080p(gpu_ctx):
+    """update_result at full size, through properties: from a level whose temporal stride is 2 (3 pages of
+    960x540 for a 5-frame 1080p video) the key frames are exactly what the frame-pair path's
+    vm_upscale_result makes of the same page, the skipped frames exactly the mean of their neighbours,
+    and the device-resident vm_frame receives the same bits"""
+    w0, h0 = 1920, 1080
+    levels, ft = [(1920, 1080, 5), (960, 540, 3), (480, 270, 3)], [1, 2, 1]
+    dev = morph.VideoPyramid(gpu_ctx)
+    dev.build_levels(levels, ft, 5)
+    rng = np.random.RandomState(5)
+    pages = [(rng.randn(540, 960, 2) * 2).astype(np.float32) for _ in range(3)]
+    for t in range(3):
+        dev.pages[1][t].v = pages[t]
+    got = dev.result(1)
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build_levels([(w0, h0), (960, 540)])
+    for t in range(3):
+        pyr[2].v = pages[t]
+        want = np.zeros((h0, w0, 2), np.float32)
+        capi.check(pyr._L.vm_upscale_result(pyr._h, 1, w0, h0, want.ctypes.data, 0))
+        assert np.array_equal(_bits(want), _bits(got[2 * t])), t
+    half = np.float32(0.5)
+    for f in (1, 3):
+        assert np.array_equal(_bits(got[f - 1] * half + got[f + 1] * half), _bits(got[f])), f
+    fr = morph.Frame(gpu_ctx, w0, h0, 0)
+    for f in range(5):
+        fr.set_v_from_video(dev, 1, f)
+        assert np.array_equal(_bits(got[f]), _bits(fr.download_v())), f
+    fr.close()

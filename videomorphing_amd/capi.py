@@ -32,12 +32,12 @@ SYMBOLS = [
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
     "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
     "vm_frame_download_ext", "vm_frame_set_v_from_level", "vm_render_halfway",
-    "vm_render_halfway_dev", "vm_poisson_extend", "vm_frame_quadratic_path", "vm_frame_download_qpath",
+    "vm_render_halfway_dev", "vm_poisson_extend", "vm_frame_quadratic_path", "vm_frame_download_qpath", "vm_frame_download_v",
     "vm_rccl_bcast",
     "vm_video_create", "vm_video_destroy", "vm_video_levels", "vm_video_level_dims", "vm_video_upload_luma",
     "vm_video_upload_flows", "vm_video_build_rgb", "vm_video_build_flows", "vm_video_set_v", "vm_video_get_v",
     "vm_video_get_field", "vm_video_coarse_solve", "vm_video_upsample", "vm_video_init_level",
-    "vm_video_initialize_temp", "vm_video_optimize_level", "vm_video_solve",
+    "vm_video_initialize_temp", "vm_video_optimize_level", "vm_video_solve", "vm_video_result", "vm_frame_set_v_from_video",
     "vm_sync_level_table", "vm_sync_create", "vm_sync_destroy", "vm_sync_set_constraints", "vm_sync_load_identity",
     "vm_sync_upsample_level", "vm_sync_optimize_level", "vm_sync_solve", "vm_sync_get_field", "vm_sync_set_field",
     "vm_sync_result", "vm_sync_upload_frame", "vm_sync_upload_flow", "vm_sync_render", "vm_sync_render_dev",
@@ -140,6 +140,7 @@ def load():
         "vm_poisson_extend": [vp, i, f, i, C.POINTER(i), C.POINTER(f), C.POINTER(f)],
         "vm_frame_quadratic_path": [vp, f, i, C.POINTER(i), C.POINTER(f), C.POINTER(f)],
         "vm_frame_download_qpath": [vp, vp],
+        "vm_frame_download_v": [vp, vp],
         "vm_rccl_bcast": [vp, vp, vp, C.c_uint64, i],
         "vm_video_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i), i, C.POINTER(vp)],
         "vm_video_levels": [vp],
@@ -157,6 +158,8 @@ def load():
         "vm_video_initialize_temp": [vp, i, i, i],
         "vm_video_optimize_level": [vp, i, f, vp, i, vp],
         "vm_video_solve": [vp, f, f, vp, i, vp, i, vp],
+        "vm_video_result": [vp, i, i, i, vp],
+        "vm_frame_set_v_from_video": [vp, vp, i, i],
         "vm_sync_level_table": [i, i, i, i, vp, vp, vp, i, C.POINTER(i)],
         "vm_sync_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(vp)],
         "vm_sync_set_constraints": [vp, vp, i],

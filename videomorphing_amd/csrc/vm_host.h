@@ -153,6 +153,8 @@ struct vm_video {
     float2 *vcur = nullptr;
     float *weight = nullptr;
     std::vector<vm_video_lane> lanes;     // created by the first pipelined solve
+    float2 *result_tmp = nullptr;         // vm_frame_set_v_from_video: two full-resolution planes (blended frames)
+    size_t result_tmp_elems = 0;
 };
 
 struct vm_frame {

@@ -382,6 +382,19 @@ extern "C" int vm_frame_download_qpath(vm_frame *f, float *u_xy)
     return VM_OK;
 }
 
+// the frame's halfway field as the compositor holds it, tight (h, w, 2) floats (_vector[frame] of
+// the reference's Pyramid once update_result has run)
+extern "C" int vm_frame_download_v(vm_frame *f, float *v_xy)
+{
+    if (!f || !v_xy) return vm_fail(VM_E_INVALID, "vm_frame_download_v: bad argument");
+    if (!vm_ctx_alive(f->ctx)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__);
+    VM_ON_DEVICE(f->ctx);
+    hipStream_t s = f->ctx->stream;
+    VM_HIP(hipMemcpy2DAsync(v_xy, (size_t)f->w * 8, f->v, (size_t)f->rs * 8, (size_t)f->w * 8, f->h, hipMemcpyDeviceToHost, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}
+
 // RCCL is resolved at first use so that the library loads (and the CPU-side
 // tests run) on hosts without a usable librccl.
 extern "C" int vm_rccl_bcast(vm_ctx *c, void *comm, void *dev_buf, uint64_t bytes, int root)

@@ -141,7 +141,30 @@ __global__ __launch_bounds__(256) void k_upscale(float2 *__restrict__ dst, int w
     dst[(size_t)y * dpitch + x] = r;
 }
 
+// the frames the temporal pyramid skipped: _vector[beg] * (1 - fa) + _vector[end] * fa
+// (MatchingThread.cpp:62-78; a cv::Mat expression = addWeighted in float: two products, one sum)
+__global__ __launch_bounds__(256) void k_blend_v(float2 *__restrict__ dst, int dpitch, const float2 *__restrict__ a,
+                                                 const float2 *__restrict__ b, int spitch, int w0, int h0, float alpha,
+                                                 float beta)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w0 || y >= h0)
+        return;
+    const float2 p = a[(size_t)y * spitch + x], q = b[(size_t)y * spitch + x];
+    float2 r;
+    r.x = p.x * alpha + q.x * beta;
+    r.y = p.y * alpha + q.y * beta;
+    dst[(size_t)y * dpitch + x] = r;
+}
+
 } // namespace
+
+void vm_launch_blend_v(float2 *dst, int dpitch, const float2 *a, const float2 *b, int spitch, int w0, int h0,
+                       float alpha, float beta, hipStream_t s)
+{
+    dim3 blk(64, 4), g((w0 + 63) / 64, (h0 + 3) / 4);
+    hipLaunchKernelGGL(k_blend_v, g, blk, 0, s, dst, dpitch, a, b, spitch, w0, h0, alpha, beta);
+}
 
 void vm_launch_upscale(float2 *dst, int w0, int h0, int dpitch, const float2 *v, int w, int h,
                        int rs, hipStream_t s)

@@ -134,7 +134,7 @@ extern "C" void vm_video_destroy(vm_video *v)
                 vm_level_free(pg.lv);
                 hipFree(pg.tslab);
             }
-        hipFree(v->acc); hipFree(v->vcur); hipFree(v->weight);
+        hipFree(v->acc); hipFree(v->vcur); hipFree(v->weight); hipFree(v->result_tmp);
         (void)hipGetLastError();
     }
     delete v;
@@ -210,6 +210,87 @@ extern "C" int vm_video_get_v(vm_video *v, int lvl, int page, float *vxy, int pi
     VM_HIP(hipMemcpy2DAsync(vxy, (size_t)pitch * 4, l.view.v, l.rs * 8, (size_t)l.w * 8, l.h, hipMemcpyDeviceToHost, s));
     VM_HIP(hipStreamSynchronize(s));
     return VM_OK;
+}
+
+// CMatchingThread::update_result for one frame of the full-resolution result
+// (MatchingThread.cpp:22-84), on the device: `dst` (pitch in float2) receives frame f.  Which
+// page(s) a frame comes from follows the reference's two loops: page i goes to frame
+// min(i * factor, depth0 - 1) (a later page overwrites an earlier one that lands on the same
+// frame), then frame i * factor + k (0 < k < factor, below depth0 - 1) is the blend of frames
+// i * factor and min((i + 1) * factor, depth0 - 1).  tmp: two w0 x h0 float2 planes.
+static int video_result_frame(vm_video *v, int lvl, int w0, int h0, int f, float2 *dst, int dpitch, float2 *tmp)
+{
+    hipStream_t s = v->ctx->stream;
+    const int d = v->depth[lvl], depth0 = v->depth0;
+    const int factor = (int)(v->factor_d0 / v->factor_d[lvl]); // MatchingThread.cpp:27
+    auto key_page = [&](int frame) {
+        int key = -1;
+        for (int i = 0; i < d; ++i)
+            if (std::min(i * factor, depth0 - 1) == frame) key = i;
+        return key;
+    };
+    auto resize = [&](int page, float2 *out, int pitch) {
+        const vm_level &l = v->pages[lvl][page].lv;
+        vm_launch_upscale(out, w0, h0, pitch, l.view.v, l.w, l.h, l.rs, s);
+    };
+    if (factor > 1)
+        for (int i = 0; i < d - 1; ++i)
+            for (int k = 1; k < factor; ++k) {
+                if (i * factor + k >= depth0 - 1 || i * factor + k != f) continue;
+                const int beg = i * factor, end = std::min((i + 1) * factor, depth0 - 1);
+                const float fa = (float)k / (float)(end - beg);
+                const int pb = key_page(beg), pe = key_page(end);
+                float2 *ta = tmp, *tb = tmp + (size_t)w0 * h0;
+                if (pb >= 0) resize(pb, ta, w0); else VM_HIP(hipMemsetAsync(ta, 0, (size_t)w0 * h0 * 8, s));
+                if (pe >= 0) resize(pe, tb, w0); else VM_HIP(hipMemsetAsync(tb, 0, (size_t)w0 * h0 * 8, s));
+                vm_launch_blend_v(dst, dpitch, ta, tb, w0, w0, h0, 1 - fa, fa, s);
+                VM_HIP(hipGetLastError());
+                return VM_OK;
+            }
+    const int key = key_page(f);
+    if (key >= 0) resize(key, dst, dpitch);
+    else VM_HIP(hipMemset2DAsync(dst, (size_t)dpitch * 8, 0, (size_t)w0 * 8, h0, s)); // a frame nothing writes
+    VM_HIP(hipGetLastError());
+    return VM_OK;
+}
+
+extern "C" int vm_video_result(vm_video *v, int lvl, int w0, int h0, float *out)
+{
+    CHECK_VID(v, lvl, 0);
+    if (!out || w0 < 1 || h0 < 1) return vm_fail(VM_E_INVALID, "vm_video_result: bad argument");
+    std::lock_guard<std::recursive_mutex> lock(v->ctx->mu);
+    hipStream_t s = v->ctx->stream;
+    const size_t n = (size_t)w0 * h0;
+    float2 *buf = nullptr;
+    VM_HIP(hipMalloc((void **)&buf, 3 * n * 8));
+    int rc = VM_OK;
+    for (int f = 0; f < v->depth0 && rc == VM_OK; ++f) {
+        rc = video_result_frame(v, lvl, w0, h0, f, buf, w0, buf + n);
+        if (rc == VM_OK && hipMemcpyAsync(out + (size_t)f * n * 2, buf, n * 8, hipMemcpyDeviceToHost, s) != hipSuccess)
+            rc = vm_fail(VM_E_DEVICE, "vm_video_result: copy failed");
+        if (rc == VM_OK && hipStreamSynchronize(s) != hipSuccess) rc = vm_fail(VM_E_DEVICE, "vm_video_result: sync failed");
+    }
+    hipStreamSynchronize(s);
+    hipFree(buf);
+    return rc;
+}
+
+extern "C" int vm_frame_set_v_from_video(vm_frame *f, vm_video *v, int lvl, int frame)
+{
+    CHECK_VID(v, lvl, 0);
+    if (!f || f->ctx != v->ctx) return vm_fail(VM_E_INVALID, "vm_frame_set_v_from_video: the frame and the video must share a context");
+    if (frame < 0 || frame >= v->depth0) return vm_fail(VM_E_INVALID, "vm_frame_set_v_from_video: frame %d out of range (0..%d)", frame, v->depth0 - 1);
+    std::lock_guard<std::recursive_mutex> lock(v->ctx->mu);
+    const size_t n = (size_t)f->w * f->h;
+    if (!v->result_tmp || v->result_tmp_elems < 2 * n) {
+        VM_HIP(hipStreamSynchronize(v->ctx->stream));
+        hipFree(v->result_tmp);
+        v->result_tmp = nullptr;
+        v->result_tmp_elems = 0;
+        VM_HIP(hipMalloc((void **)&v->result_tmp, 2 * n * 8));
+        v->result_tmp_elems = 2 * n;
+    }
+    return video_result_frame(v, lvl, f->w, f->h, frame, f->v, f->rs, v->result_tmp);
 }
 
 extern "C" int vm_video_get_field(vm_video *v, int lvl, int page, int field, void *host)

@@ -458,6 +458,11 @@ class Frame(object):
     def set_v_from_level(self, pyramid, el):
         capi.check(self._L.vm_frame_set_v_from_level(self._h, pyramid._h, el - 1))
 
+    def set_v_from_video(self, video, lvl, frame):
+        """frame `frame` of CMatchingThread::update_result over a video pair, left in this frame's v on
+        the device (the frame's size is the result's w0 x h0)"""
+        capi.check(self._L.vm_frame_set_v_from_video(self._h, video._h, int(lvl), int(frame)))
+
     def download_ext(self, side):
         out = np.zeros((self.h + 2 * self.ex, self.w + 2 * self.ex, 4), dtype=np.uint8)
         capi.check(self._L.vm_frame_download_ext(self._h, side, out.ctypes.data))
@@ -481,6 +486,11 @@ class Frame(object):
         it, rr, ms = C.c_int(0), C.c_float(0), C.c_float(0)
         capi.check(self._L.vm_frame_quadratic_path(self._h, float(tol), int(max_it), C.byref(it), C.byref(rr), C.byref(ms)))
         return it.value, rr.value, ms.value
+
+    def download_v(self):
+        out = np.empty((self.h, self.w, 2), dtype=np.float32)
+        capi.check(self._L.vm_frame_download_v(self._h, out.ctypes.data))
+        return out
 
     def download_qpath(self):
         out = np.empty((self.h, self.w, 2), dtype=np.float32)
@@ -597,8 +607,20 @@ class VideoPyramid(object):
         capi.check(self._L.vm_video_create(self._ctx._h, n, ws, hs, ds, ft, int(depth0 if depth0 is not None else levels[0][2]), C.byref(h)))
         self._h = h
         self.levels = [tuple(int(x) for x in l) for l in levels]
+        self.depth0 = int(depth0 if depth0 is not None else levels[0][2])
+        self._vector = []
         self.factor_t = list(factor_t) if factor_t is not None else [1] + [2 if levels[i][2] != levels[i - 1][2] else 1 for i in range(1, n)]
         self.pages = [[VideoPage(self, l, t, levels[l][0], levels[l][1]) for t in range(levels[l][2])] for l in range(n)]
+
+    def result(self, lvl, w0=None, h0=None):
+        """CMatchingThread::update_result for depth > 1 (MatchingThread.cpp:22-84): the depth0
+        full-resolution frames of the halfway field from level `lvl` -- every page scaled and
+        resized, the frames the temporal pyramid skipped blended from their neighbours"""
+        w0 = int(w0 if w0 is not None else self.levels[0][0])
+        h0 = int(h0 if h0 is not None else self.levels[0][1])
+        out = np.zeros((self.depth0, h0, w0, 2), dtype=np.float32)
+        capi.check(self._L.vm_video_result(self._h, int(lvl), w0, h0, out.ctypes.data))
+        return out
 
     def factor_d(self, lvl):
         f = C.c_float(0)
@@ -670,6 +692,57 @@ class VideoMorph(object):
                                              candidates=pr.candidates, elapsed_ms=pr.elapsed_ms)
                 k += 1
         return True
+
+
+class VideoMatchingThread(object):
+    """class CMatchingThread (MatchingThread.h:7-37) over a video pair: the temporally coupled solve on
+    a worker thread, then update_result() -- pyramid._vector[frame] for every frame of the video,
+    at w0 x h0 (the size of the reference's placeholder level pyramid[0]; default: the finest level's)."""
+
+    def __init__(self, parameters, pyramids, w0=None, h0=None, fixed_work=False):
+        self._parameters, self._pyramids = parameters, pyramids
+        self._flag = C.c_int(1)
+        self.w0 = int(w0 if w0 is not None else pyramids.levels[0][0])
+        self.h0 = int(h0 if h0 is not None else pyramids.levels[0][1])
+        self.percentage = 0.0
+        self.run_time = 0.0
+        self.gpu_morph = VideoMorph(parameters, pyramids, self._flag, fixed_work)
+        self._thread = None
+        self.error = None
+
+    @property
+    def runflag(self):
+        return bool(self._flag.value)
+
+    @runflag.setter
+    def runflag(self, v):
+        self._flag.value = 1 if v else 0
+
+    def run(self):
+        """MatchingThread.cpp:138-150"""
+        t0 = time.time()
+        try:
+            self.gpu_morph.calculate_halfway_parametrization()
+        except Exception as e:  # surfaced to the caller of wait()
+            self.error = e
+        self.run_time = time.time() - t0
+        if self.error is None:
+            self.update_result()
+
+    def start(self):
+        self._thread = threading.Thread(target=self.run)
+        self._thread.start()
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+        if self.error is not None:
+            raise self.error
+
+    def update_result(self, lvl=0):
+        """MatchingThread.cpp:22-84 (the level the solver has reached; after run(): the finest)"""
+        self._pyramids._vector = list(self._pyramids.result(lvl, self.w0, self.h0))
+        self.percentage = 100.0
 
 
 # ---- synchronisation stage: CSyncThread (SyncThread.h:7-39) + the stage-1 renderer ------------
