@@ -91,6 +91,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--size", default=None, help="WxH override (development only)")
+    ap.add_argument("--as-rank", type=int, default=-1,
+                    help="config 2 on ONE GPU: solve the shard rank K of an --of G-rank job would get (static partition "
+                         "study: per-rank load without the G GPUs)")
+    ap.add_argument("--of", type=int, default=8)
     return ap.parse_args(argv)
 
 
@@ -116,6 +120,10 @@ def main():
     import torch
     import torch.distributed as dist
     if args.backend == "gloo":
+        if world > max(1, torch.cuda.device_count()):
+            # ranks share a device: the PASS schedule's tile groups of two processes could starve each
+            # other of compute units (their waits are bounded, the call would fail) -- one launch per phase
+            os.environ["VM_NO_PASS"] = "1"
         local_rank = local_rank % max(1, torch.cuda.device_count())    # test mode: ranks may share a device
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
@@ -168,7 +176,7 @@ def main():
 
     distinct_frames = None
     if config == 2:
-        mine = vdist.shard_pairs(args.pairs, world, rank)
+        mine = vdist.shard_pairs(args.pairs, world, rank) if args.as_rank < 0 else vdist.shard_pairs(args.pairs, args.of, args.as_rank)
         distinct = mine[:8]                       # 8 distinct frames per rank, reused cyclically
         distinct_frames = len(distinct)
         imgs = frames(distinct)
@@ -299,6 +307,9 @@ def main():
         out = report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, progs, step_ms, el_max, pix_total,
                      cpu, distinct_frames, len(pyrs) if config == 2 else None, pix_live_total)
         out.update(extras)
+        if args.as_rank >= 0:
+            out["as_rank"] = {"rank": args.as_rank, "of": args.of, "pairs": len(pyrs),
+                              "note": "the shard this rank of the job would solve, run alone on one GPU"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -36,6 +36,9 @@ void vm_mg_launch_resid_restrict(const VmMgLevel &F, const VmMgLevel &C, hipStre
 void vm_mg_launch_prolong_smooth(const VmMgLevel &F, const VmMgLevel &C, float omega, hipStream_t s);
 // coarsest grid (w h <= 1024): `sweeps` damped-Jacobi sweeps from zero inside one workgroup
 void vm_mg_launch_coarsest(const VmMgLevel &L, float omega, int sweeps, hipStream_t s);
+// the two coarsest grids of a cycle in one workgroup (F.w F.h <= 4096, C the coarsest): F's
+// pre-smoothing, restriction, C's sweeps, correction + post-smoothing; the result ends in F.t
+void vm_mg_launch_coarse_tail(const VmMgLevel &F, const VmMgLevel &C, float omega, int sweeps, hipStream_t s);
 
 // PCG on level 0 (vectors: X solution, B right-hand side, R residual, P direction, Q = A P)
 void vm_mg_launch_pcg_init(const VmMgLevel &L, const float4 *B, const float4 *X, float4 *R, VmPcgScalars *sc,

@@ -232,6 +232,91 @@ __global__ __launch_bounds__(1024) void k_coarsest(VmMgLevel L, float omega, int
         L.x[t] = cur;
 }
 
+// The two coarsest grids of the cycle in ONE workgroup (F: at most 4096 cells, C: the coarsest,
+// at most 1024): pre-smoothing of F, residual restriction, the Jacobi sweeps on C, coarse
+// correction + post-smoothing of F -- what k_jacobi0, k_resid_restrict, k_coarsest and
+// k_prolong_smooth do in four launches of a few workgroups each (on the 2304x1464 canvas: grids
+// 72x46 and 36x23, launch-bound).  F's iterate stays in LDS throughout.  Same arithmetic.
+__global__ __launch_bounds__(1024) void k_coarse_tail(VmMgLevel F, VmMgLevel C, float omega, int sweeps)
+{
+    __shared__ float4 xf[4096], xa[1024], xb[1024];
+    const int t = threadIdx.x, nF = F.w * F.h, nC = C.w * C.h;
+    for (int i = t; i < nF; i += 1024) { // x = omega b / dg
+        const float dg = F.dg[i];
+        float4 o = make_float4(0, 0, 0, 0);
+        if (dg > 0) {
+            const float k = omega / dg;
+            const float4 b = F.b[i];
+            o = make_float4(k * b.x, k * b.y, k * b.z, 0);
+        }
+        xf[i] = o;
+    }
+    __syncthreads();
+    // C.b = P^T (F.b - A x), then `sweeps` damped-Jacobi sweeps on C from zero
+    const int X = t % C.w, Y = t / C.w;
+    float dg = 0, wE = 0, wW = 0, wS = 0, wN = 0;
+    float4 b = make_float4(0, 0, 0, 0);
+    if (t < nC) {
+        for (int bb = 0; bb < 2; ++bb)
+            for (int a = 0; a < 2; ++a) {
+                const int x = 2 * X + a, y = 2 * Y + bb;
+                if (x >= F.w || y >= F.h)
+                    continue;
+                const size_t ii = (size_t)y * F.w + x;
+                const float fdg = F.dg[ii];
+                if (!(fdg > 0))
+                    continue;
+                const float4 ax = mg_apply(F, xf, x, y, ii, fdg), fb = F.b[ii];
+                b.x += fb.x - ax.x;
+                b.y += fb.y - ax.y;
+                b.z += fb.z - ax.z;
+            }
+        dg = C.dg[t];
+        if (X + 1 < C.w) wE = C.we[t];
+        if (X > 0) wW = C.we[t - 1];
+        if (Y + 1 < C.h) wS = C.ws[t];
+        if (Y > 0) wN = C.ws[t - C.w];
+    }
+    const float k = dg > 0 ? omega / dg : 0.0f;
+    float4 cur = make_float4(k * b.x, k * b.y, k * b.z, 0);
+    float4 *src = xa, *dst = xb;
+    src[t] = cur;
+    __syncthreads();
+    for (int it = 1; it < sweeps; ++it) {
+        if (t < nC && dg > 0) {
+            float4 s = make_float4(dg * cur.x, dg * cur.y, dg * cur.z, 0);
+            if (wE != 0.0f) s = f4_axpy(-wE, src[t + 1], s);
+            if (wW != 0.0f) s = f4_axpy(-wW, src[t - 1], s);
+            if (wS != 0.0f) s = f4_axpy(-wS, src[t + C.w], s);
+            if (wN != 0.0f) s = f4_axpy(-wN, src[t - C.w], s);
+            cur = make_float4(cur.x + k * (b.x - s.x), cur.y + k * (b.y - s.y), cur.z + k * (b.z - s.z), 0);
+        }
+        dst[t] = cur;
+        __syncthreads();
+        float4 *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    // x1 = x + P xc (in place), then F.t = x1 + omega (F.b - A x1) / dg
+    for (int i = t; i < nF; i += 1024) {
+        const int x = i % F.w, y = i / F.w;
+        const float4 c = src[(y >> 1) * C.w + (x >> 1)], f = xf[i];
+        xf[i] = make_float4(f.x + c.x, f.y + c.y, f.z + c.z, 0);
+    }
+    __syncthreads();
+    for (int i = t; i < nF; i += 1024) {
+        const int x = i % F.w, y = i / F.w;
+        const float fdg = F.dg[i];
+        float4 o = make_float4(0, 0, 0, 0);
+        if (fdg > 0) {
+            const float4 c = xf[i], s = mg_apply(F, xf, x, y, (size_t)i, fdg), fb = F.b[i];
+            const float kf = omega / fdg;
+            o = make_float4(c.x + kf * (fb.x - s.x), c.y + kf * (fb.y - s.y), c.z + kf * (fb.z - s.z), 0);
+        }
+        F.t[i] = o;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // PCG on level 0.  The kernels with a dot product give each thread VM_PCG_ROWS rows of the
 // 64x4 footprint: every block ends in three same-address double atomics, which the L2
@@ -433,6 +518,11 @@ void vm_mg_launch_prolong_smooth(const VmMgLevel &F, const VmMgLevel &C, float o
 void vm_mg_launch_coarsest(const VmMgLevel &L, float omega, int sweeps, hipStream_t s)
 {
     hipLaunchKernelGGL(k_coarsest, dim3(1), dim3(1024), 0, s, L, omega, sweeps);
+}
+
+void vm_mg_launch_coarse_tail(const VmMgLevel &F, const VmMgLevel &C, float omega, int sweeps, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_coarse_tail, dim3(1), dim3(1024), 0, s, F, C, omega, sweeps);
 }
 
 void vm_mg_launch_pcg_init(const VmMgLevel &L, const float4 *B, const float4 *X, float4 *R, VmPcgScalars *sc,

@@ -139,6 +139,11 @@ void mg_vcycle(MgHierarchy &H, size_t l, hipStream_t s)
         vm_mg_launch_coarsest(F, kMgOmega, kMgCoarseSweeps, s);
         return;
     }
+    if (l + 2 == H.lv.size() && (size_t)F.w * F.h <= 4096) { // the launch-bound tail of the cycle: one workgroup
+        vm_mg_launch_coarse_tail(F, H.lv[l + 1], kMgOmega, kMgCoarseSweeps, s);
+        std::swap(F.x, F.t);
+        return;
+    }
     vm_mg_launch_jacobi0(F, kMgOmega, s);
     vm_mg_launch_resid_restrict(F, H.lv[l + 1], s);
     mg_vcycle(H, l + 1, s);
