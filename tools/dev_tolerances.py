@@ -37,8 +37,36 @@ for tol in (1e-5, 1e-6, 1e-7, 1e-8, 1e-9):
             d = np.abs(out[..., :3].astype(int) - refs[(side, otol)][..., :3].astype(int))
             print("device tol %g side %d (%d its, resid %.2e) vs oracle %g: max %d, >1: %.6f, >0: %.4f" % (tol, side, it, rr, otol, d.max(), (d > 1).mean(), (d > 0).mean()))
 # (b)
+def gpu_solve(mode, rev, w2, h2, i0, i1, v0, P):
+    ctx.set_math_mode(mode); ctx.set_commit_order(rev)
+    kp = capi.KernParams()
+    for f, _ in capi.KernParams._fields_:
+        setattr(kp, f, getattr(P, f))
+    ctx.set_params(kp)
+    p2 = morph.Pyramid(ctx); p2.build_levels([(w2, h2), ((w2 + 1) // 2, (h2 + 1) // 2)])
+    p2.upload_luma(1, i0, i1); p2[1].v = v0
+    capi.check(p2._L.vm_init_level(p2._h, 0, w2, h2, None, 0))
+    pr = capi.Progress()
+    capi.check(p2._L.vm_optimize_level(p2._h, 0, 2000.0, None, 0, C.byref(pr)))
+    ctx.set_commit_order(0)
+    return p2[1].v, pr.iters
+def total_energy(w2, h2, i0, i1, v, P):
+    lg = O.Level(w2, h2); lg.set_images(i0, i1); lg.field("v")[...] = v; lg.init(0.0)
+    e = lg.energy(P)
+    return P.w_ssim * e[0] / (w2 * h2) + P.w_tps * e[1], e[0]
+for (w2, h2) in ((160, 120), (128, 96), (200, 150)):
+    i0, i1 = synth.make_pair(w2, h2)
+    v0 = (0.8 * synth.displacement(w2, h2) + 0.05 * np.random.RandomState(0).randn(h2, w2, 2)).astype(np.float32)
+    P = O.default_params()
+    runs = {"exact": gpu_solve(capi.MATH_EXACT, 0, w2, h2, i0, i1, v0, P), "exact_rev": gpu_solve(capi.MATH_EXACT, 1, w2, h2, i0, i1, v0, P),
+            "fast": gpu_solve(capi.MATH_FAST, 0, w2, h2, i0, i1, v0, P)}
+    E = {k: total_energy(w2, h2, i0, i1, v, P) for k, (v, it) in runs.items()}
+    rms = lambda a, b: float(np.sqrt(((runs[a][0] - runs[b][0]) ** 2).sum(-1).mean()))
+    print("%dx%d converged (its %s): total energy exact %.6f rev %.6f fast %.6f -> floor |rev-exact| %.3f %%, |fast-exact| %.3f %%; ssim sums %s; rms dv floor %.4f fast %.4f" % (
+        w2, h2, {k: it for k, (v, it) in runs.items()}, E["exact"][0], E["exact_rev"][0], E["fast"][0], 100 * abs(E["exact_rev"][0] - E["exact"][0]) / E["exact"][0],
+        100 * abs(E["fast"][0] - E["exact"][0]) / E["exact"][0], {k: round(float(e[1]), 3) for k, e in E.items()}, rms("exact", "exact_rev"), rms("exact", "fast")))
 ctx.set_math_mode(capi.MATH_FAST)
-for (w2, h2) in ((160, 120), (128, 96)):
+for (w2, h2) in ():
     i0, i1 = synth.make_pair(w2, h2)
     v0 = (0.8 * synth.displacement(w2, h2) + 0.05 * np.random.RandomState(0).randn(h2, w2, 2)).astype(np.float32)
     P = O.default_params()

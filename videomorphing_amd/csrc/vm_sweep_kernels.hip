@@ -288,6 +288,9 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
     const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
     const float dcross = lx * ly - c.old_luma.x * c.old_luma.y;
     float acc = 0;
+    // (the packed f32 pipe -- v_pk_fma_f32 & co., two windows per instruction -- was tried here in
+    // round 3: bit-identical, and no faster: 36.4 vs 37.2 ms per dense 30-pair 1080p pass; on gfx950 a
+    // packed f32 instruction occupies the SIMD twice as long as a plain one)
 #pragma unroll
     for (int j = 0; j < SMAX; ++j) {
         if (j * Lf < 25) { // uniform in the workgroup
@@ -1587,6 +1590,9 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
 // T / 4 candidates takes two rounds, two workgroups share a CU (four waves per SIMD instead of two: the
 // dense line search is bound by the issue rate of a single wave, one VALU instruction per 4 cycles);
 // !DENSE: the lean kernel of pruned sweeps.
+// (The same 128-VGPR form as ONE 1024-thread workgroup per tile -- 4 lanes per candidate in a single
+// round, for batches over levels of few tiles -- was measured slower than the 256-VGPR kernel at
+// every batch size: 30 x 120x68 310 vs 280 us per pass, 30 x 240x135 970 vs 905; removed.)
 template <bool DENSE, int SMAX = VM_SMAX, int MINF = VM_MIN_FANOUT>
 __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENSE && SMAX > 7 ? 1 : 4))) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
                                                         VmKParams P, const uint32_t *__restrict__ tables,
@@ -2697,6 +2703,14 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     uint32_t *const stats0 = stats;
     unsigned long long *const bar = (unsigned long long *)(sync + (size_t)grp * VM_PASS_SYNC_WORDS);
     uint32_t *const flg = sync + (size_t)grp * VM_PASS_SYNC_WORDS + 32;
+    const int gxn = (L.w + VM_PITCH_X - 1) / VM_PITCH_X;
+    const int ox = (tile % gxn) * VM_PITCH_X + offx, oy = (tile / gxn) * VM_PITCH_Y + offy;
+    const MaskGeom g = mask_geom(L, ox, oy);
+    // (requested before the tables are copied: one round trip for both)
+    uint32_t early_word = 0;
+    if (ox < L.w && oy < L.h && tid < g.nbx * g.nby)
+        early_word = L.impmask[(g.by0 + tid / g.nbx + 1) * L.imp_rs + (g.bx0 + tid % g.nbx + 1)];
+    const uint32_t prev_flag = (!fixed_work && iter_idx > 0) ? flags[iter_idx - 1] : 1u;
     for (int k = tid; k < 625; k += VM_PASS_T)
         S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
     for (int k = tid; k < 225; k += VM_PASS_T)
@@ -2713,9 +2727,6 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
 #else
     uint32_t *const dbg_row = dbg ? dbg + 256 * (((epoch0 - 1u) >> 2) & 7u) : nullptr; // 8 launches x 256 workgroups
 #endif
-    const int gxn = (L.w + VM_PITCH_X - 1) / VM_PITCH_X;
-    const int ox = (tile % gxn) * VM_PITCH_X + offx, oy = (tile / gxn) * VM_PITCH_Y + offy;
-    const MaskGeom g = mask_geom(L, ox, oy);
     // Group-wide early outs.  Every workgroup of the group must take the same decision from data
     // no workgroup of this launch can have changed yet: the flag of the previous iteration, and
     // the mask bits of the positions within +-2 of the tile (pixels of this tile or of the gaps: no
@@ -2726,12 +2737,12 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     // of such an edge stays a candidate for ever (measured: 684 line searches per iteration of a
     // converged 120x68 level, in the oracle and in every schedule).
     VM_PTSF(1);
-    bool live = ox < L.w && oy < L.h && !(!fixed_work && iter_idx > 0 && flags[iter_idx - 1] == 0);
+    bool live = ox < L.w && oy < L.h && prev_flag != 0;
     {
         uint32_t mine = 0;
         if (live && tid < g.nbx * g.nby) {
             const int mx = tid % g.nbx, my = tid / g.nbx;
-            mine = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)] &
+            mine = early_word &
                    block_bits_in(g.bx0 + mx, g.by0 + my, ox - 2, min(ox + VM_TILE_W - 1, L.w - 1) + 2, oy - 2,
                                  min(oy + VM_TILE_H - 1, L.h - 1) + 2);
         }
@@ -2857,7 +2868,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         const int oxb = spx % 5, oyb = spy % 5, pbx = spx / 5, pby = spy / 5;
         const int begi = oyb >= 2 ? 1 : 0, begj = oxb >= 2 ? 1 : 0;
         const int pidx = spy * L.rs + spx;
-        uint32_t mword[2], mtag[2];
+        uint32_t mword[2] = {0, 0}, mtag[2] = {0, 0};
 #pragma unroll
         for (int r = 0; r < 2; ++r) { // lanes 0-31: block column begj - 1, lanes 32-63: begj; round r: block row begi - 1 + r
             const int bx = pbx + begj - 1 + (hi ? 1 : 0), by = pby + begi - 1 + r;
