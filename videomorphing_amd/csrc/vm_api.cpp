@@ -831,8 +831,17 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     static const bool no_pass = getenv("VM_NO_PASS") != nullptr;
     static std::mutex pass_token[64];
     std::unique_lock<std::mutex> pass_lock;
-    const bool want_pass = !no_pass && (c->sweep_mode == VM_SWEEP_PASS ||
-                                        (c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= VM_PASS_MAX_GROUPS));
+    bool want_pass = !no_pass && (c->sweep_mode == VM_SWEEP_PASS ||
+                                  (c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= VM_PASS_MAX_GROUPS));
+    if (want_pass) { // a 256-workgroup chunk of the launch must fit the device at once
+        int &res = c->pass_resident[c->math_mode == VM_MATH_EXACT ? 0 : 1];
+        if (res < 0) res = c->math_mode == VM_MATH_EXACT ? vm_pass_resident_blocks_exact(c->device) : vm_pass_resident_blocks_fast(c->device);
+        if (res < 256) {
+            if (c->sweep_mode == VM_SWEEP_PASS)
+                return vm_fail(VM_E_STATE, "vm_optimize_level: the PASS schedule needs 256 co-resident workgroups, this device holds %d", res);
+            want_pass = false;
+        }
+    }
     if (want_pass) {
         pass_lock = std::unique_lock<std::mutex>(pass_token[c->device & 63], std::try_to_lock);
         if (pass_lock.owns_lock() && !c->pass_err) {

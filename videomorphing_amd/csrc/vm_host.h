@@ -75,6 +75,7 @@ struct vm_ctx {
     uint32_t *pass_bar = nullptr;
     size_t pass_bar_words = 0;
     uint32_t *pass_err = nullptr, *pass_err_host = nullptr;
+    int pass_resident[2] = {-1, -1}; // co-resident k_pass workgroups on this device (EXACT, FAST build); -1: not asked yet
     uint32_t *pass_dbg = nullptr;    // vm_dbg_pass_xcd: 256 words, XCC id per workgroup of the last launch
     int sweep_threads = 0;           // 0 = automatic
     int sweep_mode = 0;              // VM_SWEEP_AUTO / TILE / SPLIT

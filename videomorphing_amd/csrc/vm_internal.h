@@ -112,6 +112,7 @@ struct VmKParams {
                                           const uint32_t *slots_prev, int prev_iter_idx,      \
                                           uint32_t *err, uint32_t *dbg, int decide,           \
                                           int force_wt, hipStream_t s);                       \
+    int vm_pass_resident_blocks_##SUFFIX(int device);                                         \
     void vm_launch_upsample_##SUFFIX(float2 *dst, int dw, int dh, int drs, const float2 *src, \
                                      int sw, int sh, int srs, hipStream_t s);                 \
     void vm_launch_splat_##SUFFIX(const VmLevelView &L, int w0, int h0,                       \

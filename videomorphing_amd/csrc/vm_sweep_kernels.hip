@@ -3311,3 +3311,18 @@ void SUF(vm_launch_optimize_pass)(const VmLevelView *views, int nbatch, int cap,
                        ntiles, bar, flags, stats, iter_idx, fixed_work, slots_cur, slots_prev, prev_iter_idx, nblocks, err,
                        dbg, force_wt);
 }
+
+// how many workgroups of k_pass the device holds at once: a tile group's 32 workgroups wait for each other
+// inside a launch, so a 256-workgroup chunk (8 groups) must be co-resident -- an MI355X in its default
+// mode holds 256 (one per CU); a partitioned or smaller device does not, and gets the STEP schedule
+int SUF(vm_pass_resident_blocks)(int device)
+{
+    hipDeviceProp_t pr;
+    int per_cu = 0;
+    if (hipGetDeviceProperties(&pr, device) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, SUF(k_pass), VM_PASS_T, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return per_cu * pr.multiProcessorCount;
+}
