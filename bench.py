@@ -46,7 +46,9 @@ SCHED = ("k_optimize<true> (TILE schedule, dense kernel)", "k_optimize<false> (T
          "k_step (STEP schedule, one launch per phase)",
          "k_sparse (SPARSE schedule: one launch per batch of iterations of a pruned level)",
          "k_pass (PASS schedule: one launch per pass, the four phases of a tile behind tile-local barriers)")
-SCHED_PMC = ("k_optimize_fast<true>", "k_optimize_fast<false>", "k_step_fast<512>", "k_sparse_fast<false>", "k_pass_fast")
+# kernel-name prefixes of each schedule in the PMC summaries (template variants of one schedule are
+# combined, weighted by their launches in the profiled run)
+SCHED_PMC = ("k_optimize_fast<true", "k_optimize_fast<false", "k_step_fast", "k_sparse_fast<", "k_pass_fast")
 NSCHED = 5
 # launches per iteration of each schedule (a SPARSE launch covers a batch of iterations)
 SCHED_LAUNCHES_PER_ITER = (4.0, 4.0, 16.0, None, 4.0)
@@ -324,12 +326,43 @@ def load_pmc(config, pairs_per_launch):
     try:
         tj = json.load(open(tp))
     except Exception:
-        return {}, None
+        return {}, {}, None, {}
     for e in tj.get("entries", []):
         if e.get("config") == config and e.get("pairs_per_launch") == pairs_per_launch:
-            return e.get("per_kernel", {}) or {}, "profiles/traffic_latest.json[config %d, %d pair(s) per launch]: %s" % (
-                config, pairs_per_launch, e.get("source", "")[:200])
-    return {}, None
+            return e.get("per_kernel", {}) or {}, e.get("per_kernel_launches", {}) or {}, \
+                "profiles/traffic_latest.json[config %d, %d pair(s) per launch]: %s" % (
+                    config, pairs_per_launch, e.get("source", "")[:200]), e.get("sq_per_kernel", {}) or {}
+    return {}, {}, None, {}
+
+
+def sq_measured(sq, prefix):
+    """SQ counters of the committed profile of this workload shape for the kernels of one schedule
+    (template variants weighted by their launches): how busy the vector ALUs were, MEASURED --
+    valu_frac above is a flop count divided by a peak."""
+    ks = [k for k in sq if k.startswith(prefix) and sq[k].get("SQ_WAVE_CYCLES")]
+    if not ks:
+        return None
+    tot = lambda c: sum(sq[k].get(c, 0.0) * sq[k].get("calls", 1.0) for k in ks)
+    wc, grbm = tot("SQ_WAVE_CYCLES"), tot("GRBM_GUI_ACTIVE")
+    out = {"valu_active_of_wave_cycles": round(tot("SQ_ACTIVE_INST_VALU") / wc, 4),
+           "wait_any_of_wave_cycles": round(tot("SQ_WAIT_ANY") / wc, 4),
+           "wait_inst_any_of_wave_cycles": round(tot("SQ_WAIT_INST_ANY") / wc, 4),
+           "valu_insts_per_wave": round(tot("SQ_INSTS_VALU") / max(tot("SQ_WAVES"), 1.0), 1)}
+    if grbm > 0:
+        # 1024 SIMDs issue one wave64 VALU instruction per 4 cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        out["valu_issue_slots_used"] = round(tot("SQ_INSTS_VALU") * 4.0 / (1024.0 * grbm / 8.0), 4)
+    if tot("SQ_LDS_IDX_ACTIVE") > 0:
+        out["lds_bank_conflict_of_lds_active"] = round(tot("SQ_LDS_BANK_CONFLICT") / tot("SQ_LDS_IDX_ACTIVE"), 4)
+    return out
+
+
+def pmc_bytes(pmc_k, pmc_n, prefix):
+    """launch-weighted mean of the PMC bytes per launch over the kernels whose name starts with prefix"""
+    ks = [k for k in pmc_k if k.startswith(prefix)]
+    if not ks:
+        return None
+    n = sum(pmc_n.get(k, 1) for k in ks)
+    return sum(pmc_k[k] * pmc_n.get(k, 1) for k in ks) / max(n, 1)
 
 
 def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, progs, step_ms, el_max, pix_total, cpu,
@@ -350,7 +383,7 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
     achieved = alg_nominal / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     # ---- HBM traffic per launch from the PMC passes of the committed profile of this workload
     # shape (not of this run: counters need rocprofv3)
-    pmc_k, traffic_src = load_pmc(config, B)
+    pmc_k, pmc_n, traffic_src, sq_k = load_pmc(config, B)
     # ---- per kernel: launches, average duration (HIP events around each batch of launches on
     # the context's stream), algorithmic bytes per launch, nominal and real fraction of HBM peak
     per_kernel = []
@@ -377,12 +410,15 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
         ent = {"kernel": SCHED[k], "launches": n, "avg_us": round(avg_us, 2), "share_of_sweep_time": round(ms / max(kern_ms, 1e-9), 3),
                "alg_bytes_per_launch": round(nbytes / n), "nominal_GBs": round(nbytes / n / (avg_us * 1e-6) / 1e9, 2),
                "nominal_frac": round(nbytes / n / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)}
-        pb = pmc_k.get(SCHED_PMC[k])
+        pb = pmc_bytes(pmc_k, pmc_n, SCHED_PMC[k])
         if pb is not None:
             ent["pmc_bytes_per_launch"] = round(pb)
             ent["real_GBs"] = round(pb / (avg_us * 1e-6) / 1e9, 2)
             ent["real_frac"] = round(pb / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
             ent["traffic_over_algorithmic"] = round(pb / max(nbytes / n, 1.0), 2)
+        sqm = sq_measured(sq_k, SCHED_PMC[k])
+        if sqm is not None:
+            ent["sq_measured"] = sqm
         per_kernel.append(ent)
     avg_launch_us = kern_ms * 1e3 / max(launches, 1)
     # the kernel the job spends most of its sweep time in: the roofline line is ITS
@@ -436,6 +472,8 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
                      "alg_bytes_per_pixel_visit": ALG_BYTES_PER_VISIT,
                      "valu_frac": round(evals * FLOP_PER_EVAL / (kern_ms * 1e-3) / VALU_PEAK_FLOPS, 5) if kern_ms > 0 else None,
                      "flop_per_evaluation": FLOP_PER_EVAL,
+                     # MEASURED (SQ counters of the committed profile of this workload shape) for the dominant kernel
+                     "valu_busy_measured": dom.get("sq_measured") if dom else None,
                      "active_pixel_ratio": round(line_searches / max(pixel_visits, 1), 6),
                      "per_kernel": per_kernel},
         "cpu_baseline": cpu,

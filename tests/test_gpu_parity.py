@@ -87,14 +87,16 @@ def test_sweep_exact(gpu_ctx, oracle, w, h, iters):
 @pytest.mark.parametrize("w,h,parts,threads", [(96, 64, 8, 1024), (150, 97, 3, 256), (69, 21, 1, 512), (200, 40, 5, 1024)])
 def test_sweep_exact_split_schedule(gpu_ctx, oracle, w, h, parts, threads):
     """the SPLIT schedule (decide/commit kernels, a tile's candidates spread over `parts`
-    workgroups) and the STEP schedule (one launch per phase) give the same bits as the oracle,
-    and mixing schedules between calls is seamless (all work on the same state in HBM)"""
+    workgroups), the STEP schedule (one launch per phase) and the PASS schedule (one launch per
+    pass, tile-local barriers; parts == 1: its write-through hand-off) give the same bits as the
+    oracle, and mixing schedules between calls is seamless (all work on the same state in HBM)"""
     gpu_ctx.set_math_mode(capi.MATH_EXACT)
     cons = synth.make_constraints(w, h, 4)
     P = _params(oracle, bcond=capi.BCOND_BORDER)
     lo, pyr, P = _make_level(gpu_ctx, oracle, w, h, cons=cons, P=P)
     try:
-        for it, mode in enumerate([capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_TILE, capi.SWEEP_STEP, capi.SWEEP_SPLIT]):
+        for it, mode in enumerate([capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_PASS, capi.SWEEP_TILE, capi.SWEEP_PASS, capi.SWEEP_STEP,
+                                   capi.SWEEP_SPLIT, capi.SWEEP_PASS]):
             gpu_ctx.set_tuning(mode, threads, parts)
             imp_o = lo.optimize_iter(P)
             pr = capi.Progress()
@@ -119,7 +121,7 @@ def test_fast_step_schedule_is_bit_identical_to_split(gpu_ctx, oracle, w, h, bco
     cons = synth.make_constraints(w, h, ncons) if ncons else ()
     out = []
     try:
-        for sched in (capi.SWEEP_SPLIT, capi.SWEEP_STEP):
+        for sched in (capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_PASS):
             P = _params(oracle, bcond=bcond)
             lo, pyr, P = _make_level(gpu_ctx, oracle, w, h, cons=cons, P=P)
             trace = []
@@ -132,10 +134,11 @@ def test_fast_step_schedule_is_bit_identical_to_split(gpu_ctx, oracle, w, h, bco
     finally:
         gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
         gpu_ctx.set_math_mode(capi.MATH_EXACT)
-    for (sa, ca, na), (sb, cb, nb) in zip(*out):
-        assert ca == cb and ca > 0 and na == nb
-        for a, b in zip(sa, sb):
-            assert np.array_equal(a, b)
+    for other in out[1:]:
+        for (sa, ca, na), (sb, cb, nb) in zip(out[0], other):
+            assert ca == cb and ca > 0 and na == nb
+            for a, b in zip(sa, sb):
+                assert np.array_equal(a, b)
 
 
 def test_fast_split_matches_fast_tile_statistically(gpu_ctx, oracle):
@@ -306,7 +309,7 @@ def test_batched_solve_equals_individual_solves(gpu_ctx):
     assert len({tuple(i) for i in iters}) > 1, iters
 
 
-@pytest.mark.parametrize("sched", [capi.SWEEP_STEP, capi.SWEEP_TILE, capi.SWEEP_SPARSE])
+@pytest.mark.parametrize("sched", [capi.SWEEP_STEP, capi.SWEEP_TILE, capi.SWEEP_SPARSE, capi.SWEEP_PASS])
 def test_fast_batched_solve_equals_individual_solves(gpu_ctx, sched):
     """FAST, a fixed schedule: the batch dimension (grid.z = pair; STEP: per-pair ping-pong copies
     and record sets, TILE: graph replays with the device iteration counter) changes no bit"""
@@ -580,7 +583,7 @@ def test_context_driven_from_fresh_threads(gpu_ctx):
     ctx.close()
 
 
-@pytest.mark.parametrize("sched", [capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP])
+@pytest.mark.parametrize("sched", [capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_PASS])
 def test_reversed_commit_order_matches_the_oracle_switch(gpu_ctx, oracle, sched):
     """vm_set_commit_order: the commits of a phase folded in reversed row-major order -- another
     order the reference's atomics may produce -- equals the oracle run with the same switch bit

@@ -118,7 +118,7 @@ def test_video_upsample_with_depth_doubling_exact(gpu_ctx, oracle):
     assert not dev.pages[0][3].v.any() and dev.pages[0][2].v.any()
 
 
-@pytest.mark.parametrize("sched", [capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP])
+@pytest.mark.parametrize("sched", [capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_PASS])
 def test_sweeps_with_the_temporal_term_exact(gpu_ctx, oracle, sched):
     """flag == true in every schedule: one page tied to its neighbour, 3 iterations, bit-identical"""
     gpu_ctx.set_math_mode(capi.MATH_EXACT)

@@ -16,4 +16,7 @@ cp $S/config2_1gpu_bench.json profiles/${R}_config2_1gpu_bench.json
 python3 tools/pmc_summary.py --merge profiles/traffic_latest.json $S/n1_traffic.json 1 1
 python3 tools/pmc_summary.py --merge profiles/traffic_latest.json $S/b8_traffic.json 2 4
 python3 tools/pmc_summary.py --merge profiles/traffic_latest.json $S/c2_traffic.json 2 30
+python3 tools/pmc_summary.py --merge-sq profiles/traffic_latest.json profiles/${R}_n1_sq_counters.csv 1 1
+python3 tools/pmc_summary.py --merge-sq profiles/traffic_latest.json profiles/${R}_batch8_sq_counters.csv 2 4
+python3 tools/pmc_summary.py --merge-sq profiles/traffic_latest.json profiles/${R}_config2_60_sq_counters.csv 2 30
 ls profiles | grep $R

@@ -35,7 +35,7 @@ def pct(d):
     return "mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f" % (d.mean(), np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90), d.max())
 for ph in range(4):
     a = st[ok, ph]
-    own = (np.where(a[:, 4] > a[:, 3], a[:, 4], a[:, 3]) - a[:, 0]) / 100.0
+    own = (np.where((a[:, 4] > a[:, 3]) & (a[:, 4] < a[:, 5]), a[:, 4], a[:, 3]) - a[:, 0]) / 100.0
     print("phase %d: wave 0 own work (start -> line search done): %s" % (ph, pct(own)))
     grp = np.arange(256)[ok] % 8
     arr = a[:, 5]
@@ -43,8 +43,14 @@ for ph in range(4):
     print("         workgroup arrival (after its slowest wave) -> group's last arrival: %s" % pct((last[grp] - arr) / 100.0))
     print("         last arrival -> released (poll saw it): %s" % pct((a[:, 6] - last[grp]) / 100.0))
     print("phase %d: start at %.2f us (mean over workgroups), end %.2f" % (ph, (a[:, 0].mean() - t0) / 100.0, (a[:, 7].mean() - t0) / 100.0))
+    # a stamp older than the phase's start is left over from an earlier launch (wave 0 had no
+    # candidate: no line-search stamp): such a stage took no time in this workgroup
+    a = a.copy()
+    fresh = a >= a[:, :1]
     for k in range(1, 8):
-        v = (a[:, k] > 0) & (a[:, k - 1] > 0)
+        a[:, k] = np.where(fresh[:, k], a[:, k], a[:, k - 1])
+    for k in range(1, 8):
+        v = fresh[:, k]
         if v.sum() == 0:
             continue
         d = (a[v, k] - a[v, k - 1]) / 100.0

@@ -32,15 +32,36 @@ def merge():
     except Exception:
         cur = {}
     ents = [e for e in cur.get("entries", []) if not (e.get("config") == config and e.get("pairs_per_launch") == pairs)]
-    ents.append({"config": config, "pairs_per_launch": pairs, "per_kernel": entry["per_kernel"], "source": entry["source"]})
+    ents.append({"config": config, "pairs_per_launch": pairs, "per_kernel": entry["per_kernel"],
+                 "per_kernel_launches": entry.get("per_kernel_launches", {}), "source": entry["source"]})
     ents.sort(key=lambda e: (e["config"], e["pairs_per_launch"]))
     json.dump({"entries": ents, "correction": entry["correction"]}, open(path, "w"), indent=1)
+
+
+def merge_sq():
+    """adds the per-kernel SQ / GRBM counters of a tools/pmc_table.py table to the entry of a workload shape"""
+    path, table, config, pairs = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+    cur = json.load(open(path))
+    lines = open(table).read().splitlines()
+    cols = lines[0].split(",")
+    sq = {}
+    for ln in lines[1:]:
+        parts = ln.rsplit(",", len(cols) - 1)          # kernel names may hold commas
+        name = parts[0].strip('"')
+        sq[name] = {c.replace("_per_launch", ""): float(v) for c, v in zip(cols[1:], parts[1:]) if v != ""}
+    for e in cur["entries"]:
+        if e.get("config") == config and e.get("pairs_per_launch") == pairs:
+            e["sq_per_kernel"] = sq
+            e["sq_source"] = "rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE (separate passes, --kernel-trace only), per launch; table: " + os.path.basename(table)
+    json.dump(cur, open(path, "w"), indent=1)
 
 
 def main():
     global SWEEP
     if sys.argv[1] == "--merge":
         return merge()
+    if sys.argv[1] == "--merge-sq":
+        return merge_sq()
     fd, wd, out_csv, out_json, cmd = sys.argv[1:6]
     if len(sys.argv) > 6:
         SWEEP = tuple(sys.argv[6].split(","))
@@ -59,14 +80,16 @@ def main():
     with open(out_csv, "w") as fo:
         fo.write("kernel,launches,FETCH_SIZE_KB_per_launch_raw,WRITE_SIZE_KB_per_launch_raw,HBM_bytes_per_launch_corrected\n")
         for k, n, f, w in rows:
-            fo.write("%s,%d,%.3f,%.3f,%.0f\n" % (k, n, f, w, (2 * f + w) * 1024))
+            fo.write("\"%s\",%d,%.3f,%.3f,%.0f\n" % (k, n, f, w, (2 * f + w) * 1024))
     fk, wk = tot_f / max(tot_l, 1), tot_w / max(tot_l, 1)
-    per_kernel = {}
+    per_kernel, per_kernel_launches = {}, {}
     for k, n, f, w in rows:
         name = k.replace("void ", "").strip()
         per_kernel[name] = (2 * f + w) * 1024
+        per_kernel_launches[name] = n
     json.dump({
         "per_kernel": per_kernel,
+        "per_kernel_launches": per_kernel_launches,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `%s`; kernels summed below (%s), %d launches" % (cmd, ", ".join(SWEEP), tot_l),
         "fetch_size_kb_per_launch_raw": fk, "write_size_kb_per_launch_raw": wk,
         "hbm_bytes_per_launch": (2 * fk + wk) * 1024,

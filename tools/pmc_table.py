@@ -17,4 +17,4 @@ names = sorted({c for v in tab.values() for c in v})
 print("kernel,calls,avg_us,pct," + ",".join(n + "_per_launch" for n in names))
 for k in sorted(tab, key=lambda k: -stats.get(k, (0, 0, 0))[2]):
     s = stats.get(k, (0, 0.0, 0.0))
-    print("%s,%d,%.2f,%.2f," % (k, s[0], s[1], s[2]) + ",".join("%.1f" % (tab[k][n][1] / max(tab[k][n][0], 1)) if n in tab[k] else "" for n in names))
+    print("\"%s\",%d,%.2f,%.2f," % (k, s[0], s[1], s[2]) + ",".join("%.1f" % (tab[k][n][1] / max(tab[k][n][0], 1)) if n in tab[k] else "" for n in names))
