@@ -833,6 +833,13 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     std::unique_lock<std::mutex> pass_lock;
     bool want_pass = !no_pass && (c->sweep_mode == VM_SWEEP_PASS ||
                                   (c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= VM_PASS_MAX_GROUPS));
+    // k_pass addresses a level's arrays by 32-bit byte offsets from its slab and from its schedule
+    // workspace (72 + 104 B per pixel)
+    if ((size_t)l0.rs * l0.h * 128 >= ((size_t)1 << 32)) {
+        if (c->sweep_mode == VM_SWEEP_PASS)
+            return vm_fail(VM_E_STATE, "vm_optimize_level: the PASS schedule addresses levels of up to 32 Mpixel");
+        want_pass = false;
+    }
     if (want_pass) { // a 256-workgroup chunk of the launch must fit the device at once
         int &res = c->pass_resident[c->math_mode == VM_MATH_EXACT ? 0 : 1];
         if (res < 0) res = c->math_mode == VM_MATH_EXACT ? vm_pass_resident_blocks_exact(c->device) : vm_pass_resident_blocks_fast(c->device);

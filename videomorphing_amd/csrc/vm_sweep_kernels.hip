@@ -40,6 +40,19 @@
 // uses 75 shared + 25 global float atomics per accepted pixel, morph.cu:951-1015).
 #include "vm_morph_common.h"
 
+// Pointers in the level views come from memory, so the compiler knows them as generic and emits
+// flat_ loads; global-address-space pointers give global_ instructions (vmcnt only, and the
+// SGPR-base + 32-bit-offset addressing form).
+// Loads and stores of data that workgroups of ONE launch hand to each other (PASS schedule):
+// relaxed agent-scope atomics on GLOBAL-address-space pointers = global_load / global_store
+// ... sc1 (L1-bypassing loads, write-through stores).  Through generic pointers the compiler
+// emits flat_ instructions, which the hand-off rules exclude (MI355X_MICROARCH.md, Valid forms).
+typedef __attribute__((address_space(1))) const uint32_t vm_g_cu32;
+typedef __attribute__((address_space(1))) uint32_t vm_g_u32;
+typedef __attribute__((address_space(1))) const unsigned long long vm_g_cu64;
+typedef __attribute__((address_space(1))) unsigned long long vm_g_u64;
+typedef __attribute__((address_space(1))) const float vm_g_cf32;
+
 #ifdef VM_PROF
 // dev-only stage stamps of k_decide (10 ns ticks), wave 0 lane 0 of each workgroup
 __device__ unsigned long long vm_prof_buf[512 * 16 * 2];
@@ -791,7 +804,9 @@ __device__ __forceinline__ void taps32_issue(const VmLevelView &L, const TapLane
     fi = __builtin_amdgcn_fmed3f(fi, -1.0f, (float)L.w);
     fj = __builtin_amdgcn_fmed3f(fj, -1.0f, (float)L.h);
     const int i = med3i((int)fi + t.cx, 0, L.w - 1), j = med3i((int)fj + t.cy, 0, L.h - 1);
-    texel = L.img0[t.imgoff + j * L.rs + i];
+    // (a global load off the image base + an unsigned 32-bit byte offset: the images are read-only,
+    // both sit in the level's slab)
+    texel = *(vm_g_cf32 *)((const char *)L.img0 + ((uint32_t)(t.imgoff + j * L.rs + i) << 2));
     wgt = fmaf(t.wxs, a, t.wxo) * fmaf(t.wys, b, t.wyo);
 }
 // ... then the quad sums and the exchange between the two images' quads
@@ -2104,14 +2119,6 @@ __device__ __forceinline__ uint32_t cell_hits(const uint32_t (*bits)[4], int bx0
 // are fetched in two batches of 5 and 4 -- all loads of a batch are issued before the first is
 // used, and a batch is skipped when no lane of the wave has a record left; one batch of 9 would
 // cost 72 VGPRs and with them a workgroup per CU.
-// Loads and stores of data that workgroups of ONE launch hand to each other (PASS schedule):
-// relaxed agent-scope atomics on GLOBAL-address-space pointers = global_load / global_store
-// ... sc1 (L1-bypassing loads, write-through stores).  Through generic pointers the compiler
-// emits flat_ instructions, which the hand-off rules exclude (MI355X_MICROARCH.md, Valid forms).
-typedef __attribute__((address_space(1))) const uint32_t vm_g_cu32;
-typedef __attribute__((address_space(1))) uint32_t vm_g_u32;
-typedef __attribute__((address_space(1))) const unsigned long long vm_g_cu64;
-typedef __attribute__((address_space(1))) unsigned long long vm_g_u64;
 
 // COH: the records were written by other workgroups of THIS launch (PASS schedule): L1-bypassing loads.
 template <bool COH>
@@ -2621,6 +2628,16 @@ __device__ __forceinline__ void sth(float4 *p, float4 v, bool wt)
     }
 }
 
+// Addressing of k_pass: a uniform base (SGPR pair) + an unsigned 32-bit byte offset per lane -- the
+// global_load / global_store form "vdst, voffset, s[base]": one v_lshl_add_u32 per address instead
+// of a sign extension + a 64-bit shift-add, and half the SGPRs per array (an offset instead of a
+// pointer; with 28 pointers of the level view live the kernel spilled 118 SGPRs).
+template <class T> __device__ __forceinline__ T ldo(const char *base, uint32_t byte_off) { return ldc((const T *)(base + byte_off)); }
+template <class T> __device__ __forceinline__ void sto(const char *base, uint32_t byte_off, T v, bool wt)
+{
+    sth((T *)const_cast<char *>(base + byte_off), v, wt);
+}
+
 // bits of mask word (bx, by) whose pixels lie inside [x0, x1] x [y0, y1]
 __device__ __forceinline__ uint32_t block_bits_in(int bx, int by, int x0, int x1, int y0, int y1)
 {
@@ -2774,6 +2791,22 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     const int wbx = own_bx0 + (has_word ? slot % own_nx : 0), wby = own_by0 + (has_word ? slot / own_nx : 0);
     const int wword = (wby + 1) * L.imp_rs + (wbx + 1);
 
+    // addressing (ldo / sto): the level's slab (vm_level_alloc: v first) and the schedule workspace
+    // (level_ensure_ws: rec_tag first) as bases, the arrays as byte offsets from them (both
+    // allocations are far below 4 GB: the host admits PASS only then)
+    const char *const sb = (const char *)L.v, *const wb = (const char *)L.rec_tag;
+#define VM_SO(p) ((uint32_t)((const char *)(p) - sb))
+#define VM_WO(p) ((uint32_t)((const char *)(p) - wb))
+    const uint32_t o_luma = VM_SO(L.luma), o_uib = VM_SO(L.ui_b), o_uiaxy = VM_SO(L.ui_axy), o_imp = VM_SO(L.impmask);
+    const uint32_t o_mean = VM_SO(L.mean), o_var = VM_SO(L.var), o_tpsb = VM_SO(L.tps_b), o_cross = VM_SO(L.cross),
+                   o_value = VM_SO(L.value);
+    const uint32_t o_mean2 = VM_WO(L.mean2), o_var2 = VM_WO(L.var2), o_tpsb2 = VM_WO(L.tps_b2), o_cross2 = VM_WO(L.cross2),
+                   o_value2 = VM_WO(L.value2), o_imp2 = VM_WO(L.impmask2);
+    const uint32_t o_tag2 = VM_WO(L.rec_tag2), o_a = VM_WO(L.rec_a), o_b = VM_WO(L.rec_b), o_a2 = VM_WO(L.rec_a2),
+                   o_b2 = VM_WO(L.rec_b2);
+#undef VM_SO
+#undef VM_WO
+
     uint32_t my_cand = 0, my_commit = 0, my_eval = 0; // of this wave, over the four phases
     bool wt = force_wt != 0;                           // write-through stores, counter barrier
     bool pure_known = false;                           // after the first barrier: the group's XCD census is in
@@ -2847,84 +2880,66 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         const int pi = closing ? 0 : ph >> 1, pj = closing ? 0 : ph & 1;
         const bool src_t = ph == 2 || ph == 4; // which copy holds the sums before the last phase's records
         const uint32_t epoch = epoch0 + (uint32_t)ph, pe = epoch - 1u, want = (pe << 2) | 1u;
-        const uint32_t *r_tag = (pe & 1u) ? L.rec_tag2 : L.rec_tag;
-        const float4 *r_a = (pe & 1u) ? L.rec_a2 : L.rec_a, *r_b = (pe & 1u) ? L.rec_b2 : L.rec_b;
-        uint32_t *w_tag = (epoch & 1u) ? L.rec_tag2 : L.rec_tag;
-        float4 *w_a = (epoch & 1u) ? L.rec_a2 : L.rec_a, *w_b = (epoch & 1u) ? L.rec_b2 : L.rec_b;
-        const float2 *s_mean = src_t ? L.mean2 : L.mean, *s_var = src_t ? L.var2 : L.var, *s_tpsb = src_t ? L.tps_b2 : L.tps_b;
-        const float *s_cross = src_t ? L.cross2 : L.cross, *s_value = src_t ? L.value2 : L.value;
-        float2 *d_mean = src_t ? L.mean : L.mean2, *d_var = src_t ? L.var : L.var2, *d_tpsb = src_t ? L.tps_b : L.tps_b2;
-        float *d_cross = src_t ? L.cross : L.cross2, *d_value = src_t ? L.value : L.value2;
-        const uint32_t *s_imp = src_t ? L.impmask2 : L.impmask;
-        uint32_t *d_imp = src_t ? L.impmask : L.impmask2;
+        // records of the last phase (read) and of this one (written): both sets live in the workspace
+        const uint32_t o_rtag = (pe & 1u) ? o_tag2 : 0u, o_ra = (pe & 1u) ? o_a2 : o_a, o_rb = (pe & 1u) ? o_b2 : o_b;
+        const uint32_t o_wtag = (epoch & 1u) ? o_tag2 : 0u, o_wa = (epoch & 1u) ? o_a2 : o_a, o_wb = (epoch & 1u) ? o_b2 : o_b;
+        // the copy of the sums and of the mask that is read (s) and the one that is written (d)
+        const char *const sbase = src_t ? wb : sb, *const dbase = src_t ? sb : wb;
+        const uint32_t os_mean = src_t ? o_mean2 : o_mean, os_var = src_t ? o_var2 : o_var, os_tpsb = src_t ? o_tpsb2 : o_tpsb,
+                       os_cross = src_t ? o_cross2 : o_cross, os_value = src_t ? o_value2 : o_value, os_imp = src_t ? o_imp2 : o_imp;
+        const uint32_t od_mean = src_t ? o_mean : o_mean2, od_var = src_t ? o_var : o_var2, od_tpsb = src_t ? o_tpsb : o_tpsb2,
+                       od_cross = src_t ? o_cross : o_cross2, od_value = src_t ? o_value : o_value2, od_imp = src_t ? o_imp : o_imp2;
         const int ppi = ((ph - 1) & 3) >> 1, ppj = (ph - 1) & 1; // parity class of the last phase's pixels (ph > 0)
 
         const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
         const bool in_img = px < L.w && py < L.h;
         const int spx = in_img ? px : ox, spy = in_img ? py : oy; // a safe pixel for the loads of an idle wave
         VM_PTS(ph, 0);
-        // ================= everything from memory in one round trip (no load depends on another) ===========
-        // (a) mask words of the 2 x 2 blocks the pixel's window reaches + the last phase's tags in them
+        // ================= everything from memory in one round trip (no load depends on another): first every
+        // byte offset, then the loads back to back.  (Address arithmetic between the loads costs a round trip
+        // of its own as soon as it touches a register a load is still to fill -- the compiler's 32-bit
+        // multiply-adds are v_mad_u64_u32 with an undefined high half: measured, a vmcnt(0) after six loads.)
         const int oxb = spx % 5, oyb = spy % 5, pbx = spx / 5, pby = spy / 5;
         const int begi = oyb >= 2 ? 1 : 0, begj = oxb >= 2 ? 1 : 0;
         const int pidx = spy * L.rs + spx;
-        uint32_t mword[2] = {0, 0}, mtag[2] = {0, 0};
+        // (a) mask words of the 2 x 2 blocks the pixel's window reaches + the last phase's tags in them
+        // (lanes 0-31: block column begj - 1, lanes 32-63: begj; round r: block row begi - 1 + r)
+        uint32_t a_word[2], a_tag[2];
+        bool a_owned[2], a_ok[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) { // lanes 0-31: block column begj - 1, lanes 32-63: begj; round r: block row begi - 1 + r
+        for (int r = 0; r < 2; ++r) {
             const int bx = pbx + begj - 1 + (hi ? 1 : 0), by = pby + begi - 1 + r;
-            const bool owned = bx >= own_bx0 && bx < own_bx0 + own_nx && by >= own_by0 && by < own_by0 + own_ny;
             // words the tile does not own hold bits of gap pixels only as far as this pixel is
             // concerned: always the canonical array (their owner may rewrite them, never those bits)
-            mword[r] = ldc((owned ? s_imp : L.impmask) + (by + 1) * L.imp_rs + (bx + 1));
+            a_owned[r] = bx >= own_bx0 && bx < own_bx0 + own_nx && by >= own_by0 && by < own_by0 + own_ny;
+            a_word[r] = (uint32_t)((by + 1) * L.imp_rs + (bx + 1)) << 2;
             const int x = 5 * bx + sub % 5, y = 5 * by + sub / 5;
-            const bool ok = ph > 0 && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1;
-            mtag[r] = ldc(r_tag + (ok ? y * L.rs + x : pidx));
-            if (!ok)
-                mtag[r] = 0;
+            a_ok[r] = ph > 0 && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1;
+            a_tag[r] = o_rtag + ((uint32_t)(a_ok[r] ? y * L.rs + x : pidx) << 2);
         }
         // (b) the mask word this wave folds for the group (word `slot` of the owned ones): its pixels' tags
-        uint32_t otag, oword;
+        bool b_ok;
+        uint32_t b_tag;
         {
             const int x = 5 * wbx + sub % 5, y = 5 * wby + sub / 5;
-            const bool ok = ph > 0 && has_word && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1;
-            otag = ldc(r_tag + (ok ? y * L.rs + x : pidx));
-            if (!ok)
-                otag = 0;
-            oword = ldc(s_imp + wword);
+            b_ok = ph > 0 && has_word && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1;
+            b_tag = o_rtag + ((uint32_t)(b_ok ? y * L.rs + x : pidx) << 2);
         }
         // (c) the last phase's tags and records within +-4 of the pixel: position sub < 25 of the 5 x 5 grid
         // of that phase's parity class; lanes 0-31 fetch rec_a, lanes 32-63 rec_b (speculatively: a record is
         // used only where the tag says "committed in that phase")
         const int sx0 = -4 + ((ppj ^ pj) & 1), sy0 = -4 + ((ppi ^ pi) & 1);
-        uint32_t ctag;
-        float4 crec;
+        bool c_ok;
+        uint32_t c_tag, c_rec;
         {
             // (relative to the slot's pixel position even where that lies outside the image: the cells such a
             // slot owns -- the halo beside a tile the border cuts down to a sliver -- still take records)
             const int dx = sx0 + 2 * (sub % 5), dy = sy0 + 2 * (sub / 5);
             const int x = px + dx, y = py + dy;
-            const bool ok = ph > 0 && sub < 25 && dx <= 4 && dy <= 4 && x >= ox && x < tx1 && y >= oy && y < ty1;
-            const int ri = ok ? y * L.rs + x : pidx;
-            ctag = ldc(r_tag + ri);
-            crec = ldc((hi ? r_b : r_a) + ri);
-            if (!ok)
-                ctag = 0;
-        }
-        // (d) the pixel's own state
-        PixelCtx c;
-        c.px = spx;
-        c.py = spy;
-        c.idx = pidx;
-        c.v = ldc(L.v + pidx);
-        c.old_luma = ldc(L.luma + pidx);
-        c.ui_b = ldc(L.ui_b + pidx);
-        c.ui_axy = L.ui_axy[pidx];
-        c.tps_axy = S.tps[(border_class(spy, L.h) * 5 + border_class(spx, L.w)) * 25 + 12] / 2;
-        c.tref = make_float2(0, 0);
-        c.tmask = 0.0f;
-        if (L.temp_mask) { // uniform in the launch
-            c.tref = L.temp_ref[pidx];
-            c.tmask = L.temp_mask[pidx];
+            c_ok = ph > 0 && sub < 25 && dx <= 4 && dy <= 4 && x >= ox && x < tx1 && y >= oy && y < ty1;
+            const uint32_t ri = (uint32_t)(c_ok ? y * L.rs + x : pidx);
+            c_tag = o_rtag + (ri << 2);
+            c_rec = (hi ? o_rb : o_ra) + (ri << 4);
         }
         // (e) this lane's cell.  Lanes sub < 25: the window cell (sub % 5 - 2, sub / 5 - 2) of the pixel.
         // Lanes sub >= 25 (7 per half): the cells this slot owns OUTSIDE its window -- an edge slot owns the
@@ -2963,18 +2978,64 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         // tile cut down to a sliver by the image border: it is still owned, and copied, by that slot)
         const bool cell_ok = chx >= 0 && qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
         const bool okc = cell_ok && sub < 25; // a window neighbour of the pixel
-        const int gi = cell_ok ? qy * L.rs + qx : pidx;
-        float2 m = ldc(s_mean + gi), q = ldc(s_var + gi), tb = ldc(s_tpsb + gi);
-        float cr = ldc(s_cross + gi), val = ldc(s_value + gi);
+        const uint32_t gi = (uint32_t)(cell_ok ? qy * L.rs + qx : pidx);
         // (f) the ring neighbours' v
-        RingLanes ring;
+        uint32_t f_ring;
         {
             const int k = sub & 7;
             const int rx = ((0x06A4 >> (2 * k)) & 3) - 1, ry = ((0x6A40 >> (2 * k)) & 3) - 1;
             const int nx = spx + rx, ny = spy + ry;
             const bool in = nx >= 0 && nx < L.w && ny >= 0 && ny < L.h;
-            ring.mine = ldc(L.v + (in ? ny * L.rs + nx : pidx));
+            f_ring = (uint32_t)(in ? ny * L.rs + nx : pidx) << 3;
         }
+        const uint32_t p4 = (uint32_t)pidx << 2, p8 = (uint32_t)pidx << 3, g4 = gi << 2, g8 = gi << 3;
+        const uint32_t w4 = (uint32_t)wword << 2;
+        const float tps_axy = S.tps[(border_class(spy, L.h) * 5 + border_class(spx, L.w)) * 25 + 12] / 2;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the loads
+        uint32_t mword[2], mcanon[2], mtag[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            mword[r] = ldo<uint32_t>(sbase, os_imp + a_word[r]);
+            mcanon[r] = ldo<uint32_t>(sb, o_imp + a_word[r]);
+            mtag[r] = ldo<uint32_t>(wb, a_tag[r]);
+        }
+        uint32_t otag = ldo<uint32_t>(wb, b_tag);
+        const uint32_t oword = ldo<uint32_t>(sbase, os_imp + w4);
+        uint32_t ctag = ldo<uint32_t>(wb, c_tag);
+        const float4 crec = ldo<float4>(wb, c_rec);
+        // (d) the pixel's own state
+        PixelCtx c;
+        c.px = spx;
+        c.py = spy;
+        c.idx = pidx;
+        c.v = ldo<float2>(sb, p8);
+        c.old_luma = ldo<float2>(sb, o_luma + p8);
+        c.ui_b = ldo<float2>(sb, o_uib + p8);
+        c.ui_axy = *(vm_g_cf32 *)(sb + (o_uiaxy + p4));
+        float2 m = ldo<float2>(sbase, os_mean + g8), q = ldo<float2>(sbase, os_var + g8), tb = ldo<float2>(sbase, os_tpsb + g8);
+        float cr = ldo<float>(sbase, os_cross + g4), val = ldo<float>(sbase, os_value + g4);
+        RingLanes ring;
+        ring.mine = ldo<float2>(sb, f_ring);
+        c.tref = make_float2(0, 0);
+        c.tmask = 0.0f;
+        if (L.temp_mask) { // uniform in the launch
+            c.tref = L.temp_ref[pidx];
+            c.tmask = L.temp_mask[pidx];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c.tps_axy = tps_axy;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (!a_owned[r])
+                mword[r] = mcanon[r];
+            if (!a_ok[r])
+                mtag[r] = 0;
+        }
+        if (!b_ok)
+            otag = 0;
+        if (!c_ok)
+            ctag = 0;
 
 #ifdef VM_PROF
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // profiling build only: when have the loads landed?
@@ -2985,7 +3046,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             const uint32_t setb = (uint32_t)__ballot(!hi && otag == want);
             const uint32_t clrb = (uint32_t)__ballot(!hi && otag == ((pe << 2) | 2u));
             if (has_word && lane == 0)
-                sth(d_imp + wword, (oword | setb) & ~clrb, wt);
+                sto<uint32_t>(dbase, od_imp + w4, (oword | setb) & ~clrb, wt);
         }
         // ================= the last phase's records through LDS, folded into this lane's cell (fold_cell's order)
         bool touched = false;
@@ -3057,11 +3118,11 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             // the cells this slot owns go to the other copy of the sums
             const bool owned = cell_ok && chx >= ohx0 && chx <= ohx1 && chy >= ohy0 && chy <= ohy1 && (sub >= 25 || !hi);
             if (owned) {
-                sth(d_mean + gi, m, wt);
-                sth(d_var + gi, q, wt);
-                sth(d_cross + gi, cr, wt);
-                sth(d_tpsb + gi, tb, wt);
-                sth(d_value + gi, val, wt);
+                sto<float2>(dbase, od_mean + g8, m, wt);
+                sto<float2>(dbase, od_var + g8, q, wt);
+                sto<float>(dbase, od_cross + g4, cr, wt);
+                sto<float2>(dbase, od_tpsb + g8, tb, wt);
+                sto<float>(dbase, od_value + g4, val, wt);
             }
         }
         VM_PTS(ph, 2);
@@ -3129,14 +3190,14 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             if (lane == 0) {
                 if (state == 1) {
                     const float2 ol = c.old_luma;
-                    sth(w_a + pidx, make_float4(luma.x - ol.x, luma.y - ol.y, luma.x * luma.x - ol.x * ol.x,
-                                                luma.y * luma.y - ol.y * ol.y), wt);
-                    sth(w_b + pidx, make_float4(luma.x * luma.y - ol.x * ol.y, step.x, step.y, 0.0f), wt);
-                    sth(L.luma + pidx, luma, wt);
-                    sth(L.ui_b + pidx, make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy), wt);
-                    sth(L.v + pidx, make_float2(c.v.x + step.x, c.v.y + step.y), wt);
+                    sto<float4>(wb, o_wa + (p4 << 2), make_float4(luma.x - ol.x, luma.y - ol.y, luma.x * luma.x - ol.x * ol.x,
+                                                                luma.y * luma.y - ol.y * ol.y), wt);
+                    sto<float4>(wb, o_wb + (p4 << 2), make_float4(luma.x * luma.y - ol.x * ol.y, step.x, step.y, 0.0f), wt);
+                    sto<float2>(sb, o_luma + p8, luma, wt);
+                    sto<float2>(sb, o_uib + p8, make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy), wt);
+                    sto<float2>(sb, p8, make_float2(c.v.x + step.x, c.v.y + step.y), wt);
                 }
-                sth(w_tag + pidx, (epoch << 2) | state, wt);
+                sto<uint32_t>(wb, o_wtag + p4, (epoch << 2) | state, wt);
             }
             if (state == 1)
                 ++my_commit;
