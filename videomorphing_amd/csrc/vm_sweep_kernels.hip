@@ -53,6 +53,11 @@ typedef __attribute__((address_space(1))) const unsigned long long vm_g_cu64;
 typedef __attribute__((address_space(1))) unsigned long long vm_g_u64;
 typedef __attribute__((address_space(1))) const float vm_g_cf32;
 
+// a * b + c for operands below 2^23 (pixel coordinates, row strides): v_mad_i32_i24, full rate and
+// 32 bits wide (the compiler's choice for a 32-bit a * b + c is v_mad_u64_u32 with an undefined high
+// half of c -- a register that may be the destination of a load in flight)
+__device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+
 #ifdef VM_PROF
 // dev-only stage stamps of k_decide (10 ns ticks), wave 0 lane 0 of each workgroup
 __device__ unsigned long long vm_prof_buf[512 * 16 * 2];
@@ -2901,7 +2906,32 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         // multiply-adds are v_mad_u64_u32 with an undefined high half: measured, a vmcnt(0) after six loads.)
         const int oxb = spx % 5, oyb = spy % 5, pbx = spx / 5, pby = spy / 5;
         const int begi = oyb >= 2 ? 1 : 0, begj = oxb >= 2 ? 1 : 0;
-        const int pidx = spy * L.rs + spx;
+        const int pidx = mad24(spy, L.rs, spx);
+        const uint32_t p4 = (uint32_t)pidx << 2, p8 = (uint32_t)pidx << 3;
+        const uint32_t w4 = (uint32_t)wword << 2;
+        // first the loads whose addresses are cheap: (d) the pixel's own state, (f) the ring neighbours' v,
+        // the group's mask word -- in flight while the other offsets are worked out
+        uint32_t f_ring;
+        {
+            const int k = sub & 7;
+            const int rx = ((0x06A4 >> (2 * k)) & 3) - 1, ry = ((0x6A40 >> (2 * k)) & 3) - 1;
+            const int nx = spx + rx, ny = spy + ry;
+            const bool in = nx >= 0 && nx < L.w && ny >= 0 && ny < L.h;
+            f_ring = (uint32_t)(in ? mad24(ny, L.rs, nx) : pidx) << 3;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PixelCtx c;
+        c.px = spx;
+        c.py = spy;
+        c.idx = pidx;
+        c.v = ldo<float2>(sb, p8);
+        c.old_luma = ldo<float2>(sb, o_luma + p8);
+        c.ui_b = ldo<float2>(sb, o_uib + p8);
+        c.ui_axy = *(vm_g_cf32 *)(sb + (o_uiaxy + p4));
+        RingLanes ring;
+        ring.mine = ldo<float2>(sb, f_ring);
+        const uint32_t oword = ldo<uint32_t>(sbase, os_imp + w4);
+        __builtin_amdgcn_sched_barrier(0);
         // (a) mask words of the 2 x 2 blocks the pixel's window reaches + the last phase's tags in them
         // (lanes 0-31: block column begj - 1, lanes 32-63: begj; round r: block row begi - 1 + r)
         uint32_t a_word[2], a_tag[2];
@@ -2912,10 +2942,10 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             // words the tile does not own hold bits of gap pixels only as far as this pixel is
             // concerned: always the canonical array (their owner may rewrite them, never those bits)
             a_owned[r] = bx >= own_bx0 && bx < own_bx0 + own_nx && by >= own_by0 && by < own_by0 + own_ny;
-            a_word[r] = (uint32_t)((by + 1) * L.imp_rs + (bx + 1)) << 2;
+            a_word[r] = (uint32_t)mad24(by + 1, L.imp_rs, bx + 1) << 2;
             const int x = 5 * bx + sub % 5, y = 5 * by + sub / 5;
             a_ok[r] = ph > 0 && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1;
-            a_tag[r] = o_rtag + ((uint32_t)(a_ok[r] ? y * L.rs + x : pidx) << 2);
+            a_tag[r] = o_rtag + ((uint32_t)(a_ok[r] ? mad24(y, L.rs, x) : pidx) << 2);
         }
         // (b) the mask word this wave folds for the group (word `slot` of the owned ones): its pixels' tags
         bool b_ok;
@@ -2923,7 +2953,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         {
             const int x = 5 * wbx + sub % 5, y = 5 * wby + sub / 5;
             b_ok = ph > 0 && has_word && sub < 25 && x >= ox && x < tx1 && y >= oy && y < ty1;
-            b_tag = o_rtag + ((uint32_t)(b_ok ? y * L.rs + x : pidx) << 2);
+            b_tag = o_rtag + ((uint32_t)(b_ok ? mad24(y, L.rs, x) : pidx) << 2);
         }
         // (c) the last phase's tags and records within +-4 of the pixel: position sub < 25 of the 5 x 5 grid
         // of that phase's parity class; lanes 0-31 fetch rec_a, lanes 32-63 rec_b (speculatively: a record is
@@ -2937,7 +2967,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             const int dx = sx0 + 2 * (sub % 5), dy = sy0 + 2 * (sub / 5);
             const int x = px + dx, y = py + dy;
             c_ok = ph > 0 && sub < 25 && dx <= 4 && dy <= 4 && x >= ox && x < tx1 && y >= oy && y < ty1;
-            const uint32_t ri = (uint32_t)(c_ok ? y * L.rs + x : pidx);
+            const uint32_t ri = (uint32_t)(c_ok ? mad24(y, L.rs, x) : pidx);
             c_tag = o_rtag + (ri << 2);
             c_rec = (hi ? o_rb : o_ra) + (ri << 4);
         }
@@ -2978,18 +3008,8 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         // tile cut down to a sliver by the image border: it is still owned, and copied, by that slot)
         const bool cell_ok = chx >= 0 && qx >= 0 && qx < L.w && qy >= 0 && qy < L.h;
         const bool okc = cell_ok && sub < 25; // a window neighbour of the pixel
-        const uint32_t gi = (uint32_t)(cell_ok ? qy * L.rs + qx : pidx);
-        // (f) the ring neighbours' v
-        uint32_t f_ring;
-        {
-            const int k = sub & 7;
-            const int rx = ((0x06A4 >> (2 * k)) & 3) - 1, ry = ((0x6A40 >> (2 * k)) & 3) - 1;
-            const int nx = spx + rx, ny = spy + ry;
-            const bool in = nx >= 0 && nx < L.w && ny >= 0 && ny < L.h;
-            f_ring = (uint32_t)(in ? ny * L.rs + nx : pidx) << 3;
-        }
-        const uint32_t p4 = (uint32_t)pidx << 2, p8 = (uint32_t)pidx << 3, g4 = gi << 2, g8 = gi << 3;
-        const uint32_t w4 = (uint32_t)wword << 2;
+        const uint32_t gi = (uint32_t)(cell_ok ? mad24(qy, L.rs, qx) : pidx);
+        const uint32_t g4 = gi << 2, g8 = gi << 3;
         const float tps_axy = S.tps[(border_class(spy, L.h) * 5 + border_class(spx, L.w)) * 25 + 12] / 2;
         __builtin_amdgcn_sched_barrier(0);
         // ---- the loads
@@ -3001,22 +3021,10 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             mtag[r] = ldo<uint32_t>(wb, a_tag[r]);
         }
         uint32_t otag = ldo<uint32_t>(wb, b_tag);
-        const uint32_t oword = ldo<uint32_t>(sbase, os_imp + w4);
         uint32_t ctag = ldo<uint32_t>(wb, c_tag);
         const float4 crec = ldo<float4>(wb, c_rec);
-        // (d) the pixel's own state
-        PixelCtx c;
-        c.px = spx;
-        c.py = spy;
-        c.idx = pidx;
-        c.v = ldo<float2>(sb, p8);
-        c.old_luma = ldo<float2>(sb, o_luma + p8);
-        c.ui_b = ldo<float2>(sb, o_uib + p8);
-        c.ui_axy = *(vm_g_cf32 *)(sb + (o_uiaxy + p4));
         float2 m = ldo<float2>(sbase, os_mean + g8), q = ldo<float2>(sbase, os_var + g8), tb = ldo<float2>(sbase, os_tpsb + g8);
         float cr = ldo<float>(sbase, os_cross + g4), val = ldo<float>(sbase, os_value + g4);
-        RingLanes ring;
-        ring.mine = ldo<float2>(sb, f_ring);
         c.tref = make_float2(0, 0);
         c.tmask = 0.0f;
         if (L.temp_mask) { // uniform in the launch
