@@ -67,6 +67,13 @@ __device__ unsigned long long vm_prof_buf[512 * 16 * 2];
 #define VM_PTS(ph, k)                                          \
     if (tid == 0 && b < 256 && (ph) < 4)                       \
     vm_prof_buf[b * 32 + (ph) * 8 + (k)] = wall_clock64()
+// ... and of tile_sweep (TILE schedule): thread 0 of tiles 0..255 of the first pair
+#define VM_TTS(ph, k)                                                              \
+    if (threadIdx.x == 0 && blockIdx.x < 256 && blockIdx.z == 0)                   \
+    vm_prof_buf[blockIdx.x * 32 + (ph) * 8 + (k)] = wall_clock64()
+#define VM_TTSF(k)                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 256 && blockIdx.z == 0)                   \
+    vm_prof_buf[8192 + 512 + blockIdx.x * 8 + (k)] = wall_clock64()
 #define VM_TS(i) ts[i] = wall_clock64()
 #define VM_TS_ARG , unsigned long long *ts
 #define VM_TS_PASS , ts
@@ -76,6 +83,8 @@ __device__ unsigned long long vm_prof_buf[512 * 16 * 2];
 #define VM_TS_PASS
 #define VM_PTS(ph, k)
 #define VM_PTSF(k)
+#define VM_TTS(ph, k)
+#define VM_TTSF(k)
 #endif
 
 namespace {
@@ -1338,6 +1347,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                                            const uint32_t *__restrict__ tables, bool tables_staged, int ox, int oy,
                                            int tid, int T, bool &improving, uint32_t &st_cand, uint32_t &st_commit)
 {
+    VM_TTSF(0);
     // --- improving-mask words of the tile and its ring of neighbour blocks ---
     const MaskGeom g = mask_geom(L, ox, oy);
     uint32_t mymask = 0;
@@ -1393,11 +1403,13 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
         }
     }
     __syncthreads();
+    VM_TTSF(1);
 
     bool tile_improving = false;
 
     for (int pi = 0; pi < 2; ++pi) {
         for (int pj = 0; pj < 2; ++pj) {
+            VM_TTS(pi * 2 + pj, 0);
             // ---- 1. candidates of this phase ----
             bool cand = false;
             if (tid < 256) {
@@ -1410,6 +1422,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 S.d_ok[tid] = state;
             }
             const int n_act = compact256(cand, tid, S.list, S.wave_cnt);
+            VM_TTS(pi * 2 + pj, 1);
 
             if (n_act > 0) {
                 st_cand += n_act;
@@ -1534,7 +1547,9 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 }
                 }
             }
+            VM_TTS(pi * 2 + pj, 2);
             __syncthreads();
+            VM_TTS(pi * 2 + pj, 3);
 
             // ---- 3. commits ----
             const bool ok = tid < 256 && commit_own(S, L, g, tid, ox, oy, pi, pj);
@@ -1546,6 +1561,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 }
             }
             const int ncommit = __syncthreads_count(ok);
+            VM_TTS(pi * 2 + pj, 4);
             if (ncommit) {
                 tile_improving = true;
                 st_commit += ncommit;
@@ -1578,8 +1594,10 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 }
             }
             __syncthreads();
+            VM_TTS(pi * 2 + pj, 5);
         }
     }
+    VM_TTSF(2);
 
     // ---- SaveSSIM (morph.cu:1236-1256), tps.b and the owned mask words ----
     if (tile_improving) {
@@ -1602,6 +1620,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
             L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)] = S.mask[my][mx];
     }
     improving = improving || tile_improving;
+    VM_TTSF(3);
     return true;
 }
 
