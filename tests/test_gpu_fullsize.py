@@ -396,6 +396,43 @@ def test_pass_groups_land_on_one_xcd_each(gpu_ctx):
     assert groups_on_one >= 6, xcc.T          # observed: all 8; a lost group costs time only
 
 
+def test_auto_policy_admits_pass_for_a_single_small_level_only(gpu_ctx):
+    """VM_SWEEP_AUTO: the 120x68 level of ONE pair (8 tile groups = one 256-workgroup chunk) is swept by
+    the PASS schedule, a batch of four such levels by STEP (32 groups would run as four chunks in
+    turn), a 1080p level by neither; vm_progress.sched_launches says which kernels ran"""
+    if os.environ.get("VM_NO_PASS"):
+        pytest.skip("VM_NO_PASS set")
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+    try:
+        def make(w, h, k):
+            i0, i1 = synth.make_pair(w, h, frame=k)
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build_levels([(w, h), ((w + 1) // 2, (h + 1) // 2)])
+            pyr.upload_luma(1, i0, i1)
+            pyr[1].v = (0.9 * synth.displacement(w, h)).astype(np.float32)
+            capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+            return pyr
+        one = make(120, 68, 0)
+        pr = capi.Progress()
+        capi.check(one._L.vm_optimize_level(one._h, 0, 12.0, None, 1, C.byref(pr)))
+        # 4 launches per iteration + one tail launch per batch of iterations
+        assert 48 <= pr.sched_launches[4] <= 60 and pr.sched_launches[2] == 0, list(pr.sched_launches)
+        batch = [make(120, 68, k) for k in range(4)]
+        arr = (C.c_void_p * 4)(*[p._h for p in batch])
+        prog = (capi.Progress * 4)()
+        capi.check(batch[0]._L.vm_optimize_level_batch(arr, 4, 0, 12.0, None, 1, prog))
+        assert prog[0].sched_launches[4] == 0 and prog[0].sched_launches[2] > 0, list(prog[0].sched_launches)
+        # ... and the batch's first pair ends where the same pair ends alone (the schedule is not part of the result)
+        assert np.array_equal(batch[0][1].v.view(np.uint32), one[1].v.view(np.uint32))
+        big = make(1920, 1080, 0)
+        capi.check(big._L.vm_optimize_level(big._h, 0, 3.0, None, 1, C.byref(pr)))
+        assert pr.sched_launches[4] == 0 and pr.sched_launches[2] == 0 and pr.sched_launches[0] > 0, list(pr.sched_launches)
+    finally:
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+
+
 def test_wave_wide_line_search_is_bit_identical_to_the_32_lane_one(gpu_ctx):
     """FAST, STEP schedule, 120x68 and 240x135 levels, 150 fixed-work iterations: with 32 workgroups
     per tile a workgroup holds <= 8 candidates and every candidate gets a whole wave (decide64: two

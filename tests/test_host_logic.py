@@ -120,3 +120,25 @@ def test_param_block_roundtrip_and_sharding():
     assert set(len(s) for s in shards) <= {7, 8}
     assert all(s == list(range(s[0], s[-1] + 1)) for s in shards)
     assert dist.shard_pairs(30, 4, 3) == list(range(23, 30))
+
+
+def test_bench_reads_the_committed_counters_of_its_own_workload_shape():
+    """profiles/traffic_latest.json holds one entry per (config, pairs per launch); bench.py quotes PMC
+    bytes and SQ ratios only from the entry of the workload it runs, template variants of one
+    schedule's kernel combined by their launches"""
+    k, n, src, sq = bench.load_pmc(1, 1)
+    assert src and "config 1, 1 pair" in src
+    for prefix in bench.SCHED_PMC:
+        b = bench.pmc_bytes(k, n, prefix)
+        assert b is not None and b > 0, prefix
+    ks = [x for x in k if x.startswith("k_optimize_fast<true")]
+    assert len(ks) == 2          # the 256- and the 128-VGPR form of the dense kernel
+    lo, hi = min(k[x] for x in ks), max(k[x] for x in ks)
+    assert lo <= bench.pmc_bytes(k, n, "k_optimize_fast<true") <= hi
+    m = bench.sq_measured(sq, "k_pass_fast")
+    assert 0 < m["valu_active_of_wave_cycles"] < 1 and 0 < m["wait_any_of_wave_cycles"] < 1
+    assert 0 < m["valu_issue_slots_used"] < 1
+    # a batch line never borrows the single pair's counters
+    k30, n30, _, sq30 = bench.load_pmc(2, 30)
+    assert bench.pmc_bytes(k30, n30, "k_pass_fast") is None and bench.pmc_bytes(k30, n30, "k_optimize_fast<true") > 1e8
+    assert bench.load_pmc(2, 17) == ({}, {}, None, {})
