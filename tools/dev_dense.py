@@ -24,4 +24,5 @@ for rep in range(2):
     capi.check(batch[0]._L.vm_optimize_level_batch(arr, npairs, 0, 2.0, None, 1, prog))
 print("pairs %d %dx%d: dense sweeps %.3f ms per iteration (%.1f us per pass launch), sched ms %s, evals %.3g, commits %d" % (
     npairs, w, h, prog[0].elapsed_ms / 2, prog[0].elapsed_ms * 1e3 / 8, [round(x, 2) for x in prog[0].sched_ms], sum(p.evaluations for p in prog), sum(p.commits for p in prog)))
-print("v checksum", float(np.abs(batch[-1][1].v).sum()))
+import hashlib
+print("v checksum", float(np.abs(batch[-1][1].v).sum()), "sha1", hashlib.sha1(np.ascontiguousarray(batch[-1][1].v).tobytes()).hexdigest()[:16], hashlib.sha1(np.ascontiguousarray(batch[0][1].v).tobytes()).hexdigest()[:16])

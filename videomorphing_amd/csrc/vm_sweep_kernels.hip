@@ -261,6 +261,26 @@ __device__ __forceinline__ float swz_xor16(float x)
 {
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));
 }
+// tap() (vm_morph_common.h) on the image `off` elements behind img0 (both images sit in the level's
+// slab): the same arithmetic, the texels as global loads off a uniform base + 32-bit offsets
+__device__ __forceinline__ float tap_g(const float *img0, int off, int w, int h, int rs, float x, float y)
+{
+    float xb = x - 0.5f, yb = y - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float a = xb - fi, b = yb - fj;
+    fi = fminf(fmaxf(fi, -1.0f), (float)w);
+    fj = fminf(fmaxf(fj, -1.0f), (float)h);
+    int i0 = (int)fi, j0 = (int)fj;
+    int i1 = min(max(i0 + 1, 0), w - 1), j1 = min(max(j0 + 1, 0), h - 1);
+    i0 = min(max(i0, 0), w - 1);
+    j0 = min(max(j0, 0), h - 1);
+    const char *base = (const char *)img0;
+    const int r0 = off + j0 * rs, r1 = off + j1 * rs;
+    const float t00 = *(vm_g_cf32 *)(base + ((uint32_t)(r0 + i0) << 2)), t10 = *(vm_g_cf32 *)(base + ((uint32_t)(r0 + i1) << 2));
+    const float t01 = *(vm_g_cf32 *)(base + ((uint32_t)(r1 + i0) << 2)), t11 = *(vm_g_cf32 *)(base + ((uint32_t)(r1 + i1) << 2));
+    return (1 - a) * (1 - b) * t00 + a * (1 - b) * t10 + (1 - a) * b * t01 + a * b * t11;
+}
+
 // sum over the aligned group of Lf lanes (Lf = 2, 4, 8, 16 or 32, uniform in the
 // workgroup); every lane of the group ends with the same bits
 __device__ __forceinline__ float group_sum(float x, int Lf)
@@ -308,8 +328,16 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
                                                const NbCacheT<SMAX> &nb, const PixelCtx &c, float dx, float dy, int Lf)
 {
     const float vx = c.v.x + dx, vy = c.v.y + dy;
-    const float lx = tap(L.img0, L.w, L.h, L.rs, c.px - vx + 0.5f, c.py - vy + 0.5f);
-    const float ly = tap(L.img1, L.w, L.h, L.rs, c.px + vx + 0.5f, c.py + vy + 0.5f);
+    // The two bilinear taps of the pixel are shared by its lanes: a fan-out is >= 2 and groups are
+    // aligned, so lanes 2k and 2k + 1 belong to one pixel -- the even lane samples image 0 at p - v,
+    // the odd one image 1 at p + v (tap()'s arithmetic, one tap per lane instead of two), and a
+    // quad-permute hands each the other's.  Same values in every lane as before, bit for bit.
+    const bool odd = (threadIdx.x & 1) != 0;
+    const float sx = odd ? vx : -vx, sy = odd ? vy : -vy;
+    const float mine = tap_g(L.img0, odd ? (int)(L.img1 - L.img0) : 0, L.w, L.h, L.rs, (float)c.px + sx + 0.5f,
+                             (float)c.py + sy + 0.5f);
+    const float other = dpp_xor1(mine);
+    const float lx = odd ? other : mine, ly = odd ? mine : other;
     const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
     const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
     const float dvy = ly * ly - c.old_luma.y * c.old_luma.y;
