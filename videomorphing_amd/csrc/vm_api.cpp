@@ -885,15 +885,16 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         // are searched per iteration (after the first sweep of a level, typically)
         const bool lean_regime = cand_prev < 0.1 * l0.w * l0.h * n;
         // dense sweeps, FAST: the 128-VGPR form of the dense kernel (>= 4 lanes per candidate, two
-        // workgroups per CU) on levels of >= 512 tiles per pass -- measured on MI355X (r03,
-        // tools/dev_dense.py, us per dense pass, 256- vs 128-VGPR kernel): 1080p x 1 pair 1485 vs 1385,
-        // x 8 11404 vs 9998, x 30 42399 vs 37163; 960x540 x 8 2873 vs 2601; but 240x135 x 30 895 vs
-        // 974 and 120x68 x 30 277 vs 438: with about one workgroup per CU the second round of a
-        // 256-candidate phase costs more than the second workgroup hides.  The rule looks at the
-        // level only, never at the batch: a pair is solved by the same kernels alone and in a batch
-        // (FAST sums are ordered by the lane fan-out).  VM_DENSE128=0 / 1 forces it (dev switch).
+        // workgroups per CU) on levels of >= 256 tiles per pass (960x540 and up) -- measured on MI355X
+        // (r03, tools/dev_dense.py, us per dense pass, 256- vs 128-VGPR kernel, with the taps shared by
+        // lane pairs): 1080p x 1 pair 1399 vs 1290; 960x540 x 1 468 vs 466, x 8 2711 vs 2362, x 30 9946 vs
+        // 8272; but 480x270 x 1 228 vs 306, x 8 726 vs 798 (x 30 2509 vs 2254), 240x135 x 30 875 vs 960,
+        // 120x68 x 30 277 vs 438: with about one workgroup per CU the second round of a 256-candidate
+        // phase costs more than the second workgroup hides.  The rule looks at the level only, never
+        // at the batch: a pair is solved by the same kernels alone and in a batch (FAST sums are
+        // ordered by the lane fan-out).  VM_DENSE128=0 / 1 forces it (dev switch).
         static const char *d128 = getenv("VM_DENSE128");
-        const bool dense128 = !exact && (d128 ? atoi(d128) != 0 : tiles_per_pass >= 512);
+        const bool dense128 = !exact && (d128 ? atoi(d128) != 0 : tiles_per_pass >= 256);
         const int dense = (exact || force_dense || !lean_regime) ? (dense128 ? 2 : 1) : 0;
         // SPARSE replaces the TILE launches of a pruned level once at most three tiles per pass
         // and pair are still active (measured on MI355X, 1080p: a no-op TILE iteration costs
