@@ -33,5 +33,8 @@ for name, sched in (("step", capi.SWEEP_STEP), ("pass", capi.SWEEP_PASS), ("auto
             name, lv.width, lv.height, pr.elapsed_ms, pr.iters, pr.elapsed_ms / pr.iters, pr.elapsed_ms * 1e3 / pr.iters / 16, pr.launches,
             [round(x, 1) for x in pr.sched_ms], pr.candidates / pr.iters, pr.commits), flush=True)
         res[(name, el)] = pyr[el].v
+import hashlib
+for k in sorted(res):
+    print("sha1", k, hashlib.sha1(np.ascontiguousarray(res[k]).tobytes()).hexdigest()[:16])
 for el in (nl - 1, nl - 2):
     print("level", el, "pass == step:", np.array_equal(res[("step", el)].view(np.uint32), res[("pass", el)].view(np.uint32)))

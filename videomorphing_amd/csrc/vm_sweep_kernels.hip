@@ -1370,7 +1370,7 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
 // DENSE = false (FAST only): the variant for pruned sweeps -- every phase runs the lean line
 // search, 16 candidates per round; without the dense path the kernel needs 134 instead of
 // 256 VGPRs (measured: pruned sweeps 5-8 % faster).
-template <bool DENSE, int SMAX = VM_SMAX, int MINF = VM_MIN_FANOUT>
+template <bool DENSE, int SMAX = VM_SMAX, int MINF = VM_MIN_FANOUT, bool INTV = true>
 __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, const VmKParams &P,
                                            const uint32_t *__restrict__ tables, bool tables_staged, int ox, int oy,
                                            int tid, int T, bool &improving, uint32_t &st_cand, uint32_t &st_commit)
@@ -1552,7 +1552,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                     const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
                     // the constant-count fast path is taken per WAVE (all its pixels interior):
                     // a per-pixel choice would make mixed waves run both line searches
-                    const bool wave_interior = __all(li >= n_act || is_interior(L, px, py));
+                    const bool wave_interior = INTV && __all(li >= n_act || is_interior(L, px, py));
                     if (li < n_act) {
                         PixelCtx c;
                         ctx_load(c, L, S.tps, px, py);
@@ -1660,7 +1660,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
 // (The same 128-VGPR form as ONE 1024-thread workgroup per tile -- 4 lanes per candidate in a single
 // round, for batches over levels of few tiles -- was measured slower than the 256-VGPR kernel at
 // every batch size: 30 x 120x68 310 vs 280 us per pass, 30 x 240x135 970 vs 905; removed.)
-template <bool DENSE, int SMAX = VM_SMAX, int MINF = VM_MIN_FANOUT>
+template <bool DENSE, int SMAX = VM_SMAX, int MINF = VM_MIN_FANOUT, bool INTV = true>
 __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENSE && SMAX > 7 ? 1 : 4))) void SUF(k_optimize)(const VmLevelView *__restrict__ views, int cap,
                                                         VmKParams P, const uint32_t *__restrict__ tables,
                                                         int offx, int offy, uint32_t *__restrict__ flags,
@@ -1690,7 +1690,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
 
     bool improving = false;
     uint32_t st_cand = 0, st_commit = 0;
-    if (!tile_sweep<DENSE, SMAX, MINF>(S, L, P, tables, false, ox, oy, tid, T, improving, st_cand, st_commit))
+    if (!tile_sweep<DENSE, SMAX, MINF, INTV>(S, L, P, tables, false, ox, oy, tid, T, improving, st_cand, st_commit))
         return;
     if (tid == 0) {
         if (improving)
@@ -3336,6 +3336,18 @@ void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int 
     if (dense == 2) { // the 128-VGPR form: two workgroups per CU
         hipLaunchKernelGGL((SUF(k_optimize)<true, 7, 4>), g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats,
                            iter_idx, fixed_work, iter_dev);
+        return;
+    }
+    // Levels of at most 8 tiles per pass (120x68 and below): every tile touches the image border, so
+    // every tile runs the border form of the dense line search in some of its waves and waits for
+    // them; the interior form beside it only doubles the code the CU's waves execute at once.
+    // Without it (bit-identical: the border form computes the same window counts at run time) a
+    // 30-pair pass over 120x68 takes 258 instead of 275 us (r03, tools/dev_dense.py); from 240x135 up
+    // the interior form pays (1080p x 8 pairs: 36.6 ms per pass with it, 50.5 without).  A rule on
+    // the level, never on the batch.
+    if (g.x * g.y <= 8) {
+        hipLaunchKernelGGL((SUF(k_optimize)<true, VM_SMAX, VM_MIN_FANOUT, false>), g, b, 0, s, views, cap, P, tables, offx, offy,
+                           flags, stats, iter_idx, fixed_work, iter_dev);
         return;
     }
 #endif
