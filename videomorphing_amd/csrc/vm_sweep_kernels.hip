@@ -165,13 +165,12 @@ struct GlbSrc {
 #define VM_SWEEP_T 1024
 #define VM_SMAX 1
 #define VM_MIN_FANOUT 1
-#define VM_MAX_FANOUT 1
 template <int SMAX>
 struct NbCacheT {};
-template <bool INTERIOR, int SMAX, class Src>
+template <bool INTERIOR, int SMAX, int LF = 0, class Src>
 __device__ __forceinline__ void nb_load(NbCacheT<SMAX> &, const VmLevelView &, const Src &, const PixelCtx &, int, int) {}
 
-template <bool INTERIOR, int SMAX, class Src>
+template <bool INTERIOR, int SMAX, int LF = 0, class Src>
 __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKParams &P, const Src &src,
                                                const NbCacheT<SMAX> &, const PixelCtx &c, float dx, float dy, int)
 {
@@ -226,9 +225,6 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
 #else
 #define VM_SMAX 13
 #define VM_MIN_FANOUT 2
-#endif
-#ifndef VM_MAX_FANOUT
-#define VM_MAX_FANOUT 32
 #endif
 // SMAX = neighbours a lane may own: 13 with a fan-out of >= 2 lanes per pixel (the 256-VGPR dense
 // kernel), 7 with >= 4 (the 128-VGPR one: two workgroups per CU)
@@ -293,10 +289,13 @@ __device__ __forceinline__ float group_sum(float x, int Lf)
     return x;
 }
 
-template <bool INTERIOR, int SMAX, class Src>
+// LF: the fan-out as a compile-time constant (0: the run-time value Lf_rt).  The generic form carries a
+// uniform branch per window slot and per reduction stage; with the fan-out known the loops unroll flat.
+template <bool INTERIOR, int SMAX, int LF = 0, class Src>
 __device__ __forceinline__ void nb_load(NbCacheT<SMAX> &nb, const VmLevelView &L, const Src &src, const PixelCtx &c,
-                                        int sub, int Lf)
+                                        int sub, int Lf_rt)
 {
+    const int Lf = LF ? LF : Lf_rt;
 #pragma unroll
     for (int j = 0; j < SMAX; ++j) {
         if (j * Lf >= 25) // uniform in the workgroup: no lane has such a neighbour
@@ -323,10 +322,11 @@ __device__ __forceinline__ void nb_load(NbCacheT<SMAX> &nb, const VmLevelView &L
     }
 }
 
-template <bool INTERIOR, int SMAX, class Src>
+template <bool INTERIOR, int SMAX, int LF = 0, class Src>
 __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKParams &P, const Src &,
-                                               const NbCacheT<SMAX> &nb, const PixelCtx &c, float dx, float dy, int Lf)
+                                               const NbCacheT<SMAX> &nb, const PixelCtx &c, float dx, float dy, int Lf_rt)
 {
+    const int Lf = LF ? LF : Lf_rt;
     const float vx = c.v.x + dx, vy = c.v.y + dy;
     // The two bilinear taps of the pixel are shared by its lanes: a fan-out is >= 2 and groups are
     // aligned, so lanes 2k and 2k + 1 belong to one pixel -- the even lane samples image 0 at p - v,
@@ -640,14 +640,14 @@ __device__ __forceinline__ bool decide_with64(const VmLevelView &L, const VmKPar
 }
 
 // one lane (EXACT) or L lanes (FAST dense path) per pixel
-template <bool INTERIOR, int SMAX, class Src>
+template <bool INTERIOR, int SMAX, int LF = 0, class Src>
 __device__ __forceinline__ bool decide(const VmLevelView &L, const VmKParams &P, const Src &src,
                                        const PixelCtx &c, int sub, int Lf, float2 &step, uint32_t &n_eval VM_TS_ARG)
 {
     NbCacheT<SMAX> nb;
-    nb_load<INTERIOR, SMAX>(nb, L, src, c, sub, Lf);
+    nb_load<INTERIOR, SMAX, LF>(nb, L, src, c, sub, Lf);
     return decide_with(
-        L, P, c, [&](float dx, float dy) { return energy_change<INTERIOR, SMAX>(L, P, src, nb, c, dx, dy, Lf); },
+        L, P, c, [&](float dx, float dy) { return energy_change<INTERIOR, SMAX, LF>(L, P, src, nb, c, dx, dy, Lf); },
         RingGlobal{L.v}, step, n_eval VM_TS_PASS);
 }
 
@@ -1540,9 +1540,16 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 } else
 #endif
                 if (DENSE) {
-                int Lf = MINF;
-                while (Lf * 2 <= VM_MAX_FANOUT && Lf * 2 * n_act <= T)
-                    Lf *= 2;
+                // A FIXED fan-out of MINF lanes per candidate (2 in the 256-VGPR kernel, 4 in the 128-VGPR one),
+                // known at compile time.  Rounds 1-2 grew it with the free lanes (2 ... 16: "sparse phases
+                // fill the CU with neighbours"); measured in round 3 that was a loss everywhere: the
+                // generic code carries a uniform branch per window slot and per reduction stage, every
+                // extra lane of a candidate repeats the taps and the line-search bookkeeping, and a phase
+                // of few candidates is the lean path's anyway.  Same workloads, us per dense pass, adaptive
+                // vs fixed: 30 x 120x68 258 -> 184, 30 x 240x135 881 -> 619, 30 x 480x270 2504 -> 1912,
+                // 8 x 960x540 2358 -> 2026, 8 x 1080p 36.6 -> 31.1 ms (tools/dev_dense.py); 60 pairs on
+                // one GPU 68.1 -> 82.2 G pixel*iters/s.
+                constexpr int Lf = MINF;
                 const int slots = T / Lf;
                 const int sub = tid & (Lf - 1), grp = tid / Lf;
                 for (int base = 0; base < n_act; base += slots) {
@@ -1563,8 +1570,8 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                         unsigned long long ts[16];
 #endif
                         uint32_t n_eval = 0;
-                        const bool ok = wave_interior ? decide<true, SMAX>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS)
-                                                      : decide<false, SMAX>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS);
+                        const bool ok = wave_interior ? decide<true, SMAX, MINF>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS)
+                                                      : decide<false, SMAX, MINF>(L, P, src, c, sub, Lf, step, n_eval VM_TS_PASS);
                         if (sub == 0)
                             atomicAdd(&S.n_eval, n_eval);
                         if (ok && sub == 0) {
@@ -3338,14 +3345,15 @@ void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int 
                            iter_idx, fixed_work, iter_dev);
         return;
     }
-    // Levels of at most 8 tiles per pass (120x68 and below): every tile touches the image border, so
-    // every tile runs the border form of the dense line search in some of its waves and waits for
+    // Levels of at most 32 tiles per pass (240x135 and below): most tiles touch the image border, so
+    // most tiles run the border form of the dense line search in some of their waves and wait for
     // them; the interior form beside it only doubles the code the CU's waves execute at once.
-    // Without it (bit-identical: the border form computes the same window counts at run time) a
-    // 30-pair pass over 120x68 takes 258 instead of 275 us (r03, tools/dev_dense.py); from 240x135 up
-    // the interior form pays (1080p x 8 pairs: 36.6 ms per pass with it, 50.5 without).  A rule on
-    // the level, never on the batch.
-    if (g.x * g.y <= 8) {
+    // Without it (bit-identical: the border form computes the same window counts at run time), us per
+    // dense pass (r03, tools/dev_dense.py): 30 x 120x68 187.5 -> 183.6, 30 x 240x135 623 -> 604, 3 x 240x135
+    // 182 -> 175; on large levels the interior form is what most waves run (1080p x 8 pairs, before the
+    // fixed fan-out: 36.6 ms per pass with it, 50.5 without).  A rule on the level, never on the batch.
+    static const char *noint = getenv("VM_DENSE_NOINT"); // dev switch: 0 / 1 = never / always
+    if (noint ? atoi(noint) != 0 : g.x * g.y <= 32) {
         hipLaunchKernelGGL((SUF(k_optimize)<true, VM_SMAX, VM_MIN_FANOUT, false>), g, b, 0, s, views, cap, P, tables, offx, offy,
                            flags, stats, iter_idx, fixed_work, iter_dev);
         return;
