@@ -8,6 +8,13 @@
 #ifndef VM_STEP_MAX_TILES
 #define VM_STEP_MAX_TILES 64 // AUTO: levels of a batch with at most this many tiles per pass may run STEP
 #endif
+// (VM_STEP_MAX_TILES in the environment overrides it: dev switch)
+static int vm_step_max_tiles()
+{
+    static const char *e = getenv("VM_STEP_MAX_TILES");
+    static const int v = e ? atoi(e) : VM_STEP_MAX_TILES;
+    return v;
+}
 #ifndef VM_STEP_BIG_PARTS
 #define VM_STEP_BIG_PARTS 8
 #endif
@@ -771,7 +778,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         // are copied to the device
         const int tiles0 = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
         if (c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP || c->sweep_mode == VM_SWEEP_PASS ||
-            (c->sweep_mode == VM_SWEEP_AUTO && tiles0 * n <= VM_STEP_MAX_TILES))
+            (c->sweep_mode == VM_SWEEP_AUTO && tiles0 * n <= vm_step_max_tiles()))
             for (int i = 0; i < n; ++i) {
                 int rc = level_ensure_ws(c, *lv[i]);
                 if (rc != VM_OK) return rc;
@@ -813,7 +820,11 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     // 0.32 (STEP) vs 0.64 ms (TILE) per iteration; 240x135 with 900 line searches per
     // iteration 0.22 vs 0.36; with 90: 0.24 vs 0.23; converged 0.08 vs 0.024.  All schedules
     // work on the same state in HBM, so the choice can change from batch to batch.
-    const bool may_split = c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= VM_STEP_MAX_TILES;
+    // (levels of more than 12 tiles per pass -- 240x135 -- only for a single pair: measured r03, two
+    // streams x 2 pairs, 56 tiles per launch: 274 ms per job with STEP there, 206 with TILE; the 120x68
+    // level of batches up to 8 pairs stays: 346 vs 480 ms for 2 x 4 pairs, 477 vs 531 for 8 + 7)
+    const bool may_split = c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= vm_step_max_tiles() &&
+                           (tiles_per_pass <= 12 || n == 1);
     double cand_prev = 1e9; // line searches per iteration in the previous batch (first batch: dense)
     double tiles_prev = 1e9; // active tile visits per iteration and pair in the previous batch
     if (may_split || c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP || c->sweep_mode == VM_SWEEP_PASS) // epochs restart with every call: forget old records
