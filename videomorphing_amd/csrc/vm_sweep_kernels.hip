@@ -9,17 +9,17 @@
 // per candidate pixel an improving-mask test, a finite-difference gradient, the
 // fold-over bound, a golden-section line search and an accept-if-lower commit.
 //
-// How it is computed is CDNA4-first.  Three schedules share the device functions and
+// How it is computed is CDNA4-first.  Five schedules share the device functions and
 // the state in HBM (the host may switch between them from batch to batch):
 //
 //  TILE schedule (k_optimize, one launch per pass): one workgroup of T threads
 //  owns one tile; window sums, SSIM values, tps.b and the tile's improving-mask
 //  words live in LDS for the four phases.  Per phase the candidates are compacted;
-//  a DENSE phase gives each L = 2..16 consecutive lanes (L = largest power of two
-//  <= T/#candidates) that split the 25 window neighbours, keep their share of the
-//  sums in registers for the whole line search and combine SSIM terms with DPP
-//  butterflies; a SPARSE phase (<= T/32 candidates) runs the LEAN line search:
-//  32 lanes per pixel, one neighbour per lane, the bilinear taps spread over
+//  a DENSE phase gives each a fixed, compile-time number of consecutive lanes (2 in the
+//  256-VGPR kernel, 4 in the 128-VGPR one) that split the 25 window neighbours, keep
+//  their share of the sums in registers for the whole line search, share the pixel's two
+//  bilinear taps and combine SSIM terms with DPP permutes; a SPARSE phase (<= T/32
+//  candidates) runs the LEAN line search: 32 lanes per pixel, one neighbour per lane, the bilinear taps spread over
 //  quads, a branch-free golden-section loop (~105 instructions per evaluation --
 //  in this regime the instruction count of one evaluation IS the time).  Tiles
 //  without a set mask bit return after one 96-word load, so a pruned level costs
@@ -34,6 +34,12 @@
 //  STEP schedule (k_step, one launch per phase): the commit of phase s-1 is
 //  folded into the launch of phase s from a second copy of the sums (ping-pong),
 //  see the comment at k_step.  Bit-identical to SPLIT.
+//
+//  SPARSE schedule (k_sparse, one launch per batch of iterations of a pruned level): one
+//  workgroup per pair walks the iterations, sweeping only the tiles whose mask words are set.
+//
+//  PASS schedule (k_pass, one launch per pass): a tile = a group of 32 workgroups on one XCD,
+//  the four phases behind a tile-local barrier; see the comment at PassLds.
 //
 // Commits are applied by a per-cell gather of the committed pixels' records in a
 // fixed order: deterministic, one owner per cell, no float atomics (the reference
