@@ -1267,6 +1267,47 @@ __device__ __forceinline__ int compact256(bool flag, int tid, int *list, int *wa
 
 // commit_pixel_motion (morph.cu:990-1026) for the pixel of slot `tid`: own-pixel state,
 // the record the per-cell gather reads, the mask bit.  Returns true for a commit.
+// gather_cell with the committed slots given as bitmap rows (rowbits[t]: bit sx of slot row sy0 + t,
+// already cut down to the slots within +-2 of the cell): no d_ok reads, no loop over empty slots;
+// the same records in the same row-major order
+template <class LdsT>
+__device__ __forceinline__ void gather_cell_bits(const LdsT &S, const VmLevelView &L, int ox, int oy, int rx, int ry,
+                                                 int pi, int pj, int sy0, const uint32_t (&rowbits)[3], float2 &m,
+                                                 float2 &q, float &cr, float2 &tb, int rev)
+{
+#pragma unroll
+    for (int t0 = 0; t0 < 3; ++t0) {
+#if VM_EXACT
+        const int t = rev ? 2 - t0 : t0; // rev (vm_set_commit_order): reversed row-major order
+#else
+        const int t = t0;
+        (void)rev;
+#endif
+        uint32_t bits = rowbits[t];
+        const int y = 2 * (sy0 + t) + pi;
+        while (bits) {
+#if VM_EXACT
+            const int sx = rev ? 31 - __clz(bits) : __ffs(bits) - 1;
+#else
+            const int sx = __ffs(bits) - 1;
+#endif
+            bits &= ~(1u << sx);
+            const int x = 2 * sx + pj;
+            const int rec = (sy0 + t) * 32 + sx;
+            const float2 dm = S.d_mean[rec], dv = S.d_var[rec], st = S.d_step[rec];
+            m.x += dm.x;
+            m.y += dm.y;
+            q.x += dv.x;
+            q.y += dv.y;
+            cr += S.d_cross[rec];
+            const int By = border_class(oy + y, L.h), Bx = border_class(ox + x, L.w);
+            const float k = S.tps[(By * 5 + Bx) * 25 + (ry - y + 2) * 5 + (rx - x + 2)];
+            tb.x += st.x * k;
+            tb.y += st.y * k;
+        }
+    }
+}
+
 template <class LdsT>
 __device__ __forceinline__ bool commit_own(LdsT &S, const VmLevelView &L, const MaskGeom &g, int tid, int ox,
                                            int oy, int pi, int pj)
@@ -1611,20 +1652,26 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                     const int qx = ox + rx, qy = oy + ry;
                     if (qx < 0 || qx >= L.w || qy < 0 || qy >= L.h)
                         continue;
-                    {
-                        // any committed pixel within +-2?  (three words of the commit bitmap)
-                        const int sy0 = max(ry - 2, 0) >> 1, sy1 = min(ry + 2, VM_TILE_H - 1) >> 1;
-                        const int sx0 = max(rx - 2, 0) >> 1, sx1 = min(rx + 2, VM_TILE_W - 1) >> 1;
-                        const uint32_t colmask = (0xFFFFFFFFu >> (31 - (sx1 - sx0))) << sx0;
-                        uint32_t any = 0;
-                        for (int sy = sy0; sy <= sy1; ++sy)
-                            any |= S.cbits[sy] & colmask;
-                        if (!any)
-                            continue;
-                    }
+                    // the committed pixels of this phase within +-2 of the cell, straight from the commit bitmap
+                    // (bit tx of word ty): at most 3 x 3 slots, visited in gather_cell's order
+                    int ylo = max(ry - 2, 0), xlo = max(rx - 2, 0);
+                    const int yhi = min(ry + 2, VM_TILE_H - 1), xhi = min(rx + 2, VM_TILE_W - 1);
+                    ylo += (ylo & 1) ^ pi;
+                    xlo += (xlo & 1) ^ pj;
+                    if (ylo > yhi || xlo > xhi)
+                        continue;
+                    const int sx0 = xlo >> 1, nx = ((xhi - xlo) >> 1) + 1, sy0 = ylo >> 1, ny = ((yhi - ylo) >> 1) + 1;
+                    const uint32_t colmask = ((1u << nx) - 1u) << sx0; // nx <= 3
+                    uint32_t rowbits[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        rowbits[t] = t < ny ? S.cbits[sy0 + t] & colmask : 0u;
+                    if (!(rowbits[0] | rowbits[1] | rowbits[2]))
+                        continue;
                     float2 m = S.mean[cell], q = S.var[cell], tb = S.tpsb[cell];
                     float cr = S.cross[cell];
-                    if (gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb, P.rev_commit)) {
+                    gather_cell_bits(S, L, ox, oy, rx, ry, pi, pj, sy0, rowbits, m, q, cr, tb, P.rev_commit);
+                    {
                         S.mean[cell] = m;
                         S.var[cell] = q;
                         S.cross[cell] = cr;
