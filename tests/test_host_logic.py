@@ -132,7 +132,7 @@ def test_bench_reads_the_committed_counters_of_its_own_workload_shape():
         b = bench.pmc_bytes(k, n, prefix)
         assert b is not None and b > 0, prefix
     ks = [x for x in k if x.startswith("k_optimize_fast<true")]
-    assert len(ks) == 2          # the 256- and the 128-VGPR form of the dense kernel
+    assert len(ks) >= 2          # the 256- and the 128-VGPR forms of the dense kernel
     lo, hi = min(k[x] for x in ks), max(k[x] for x in ks)
     assert lo <= bench.pmc_bytes(k, n, "k_optimize_fast<true") <= hi
     m = bench.sq_measured(sq, "k_pass_fast")
@@ -140,5 +140,5 @@ def test_bench_reads_the_committed_counters_of_its_own_workload_shape():
     assert 0 < m["valu_issue_slots_used"] < 1
     # a batch line never borrows the single pair's counters
     k30, n30, _, sq30 = bench.load_pmc(2, 30)
-    assert bench.pmc_bytes(k30, n30, "k_pass_fast") is None and bench.pmc_bytes(k30, n30, "k_optimize_fast<true") > 1e8
+    assert bench.pmc_bytes(k30, n30, "k_pass_fast") is None and bench.pmc_bytes(k30, n30, "k_optimize_fast<true") > 1e7
     assert bench.load_pmc(2, 17) == ({}, {}, None, {})

@@ -1503,7 +1503,11 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                 st_cand += n_act;
                 // ---- 2. line searches on the pre-phase state, L lanes per candidate ----
 #if !VM_EXACT
-                if (!DENSE || (SMAX > 7 && n_act * 32 <= T)) { // (the 128-VGPR dense kernel keeps to the dense path: fewer live ranges)
+                // (the 128-VGPR dense kernel keeps to the dense path: fewer live ranges; so does the kernel of
+                // the small levels, INTV == false: their phases are full for hundreds of iterations, and the
+                // four lean line-search bodies beside the dense one cost 2-3 % per dense pass and 6 % of the
+                // 60-pair job even though they never run -- r03, 82.1 -> 87.1 G pixel*iters/s)
+                if (!DENSE || (SMAX > 7 && INTV && n_act * 32 <= T)) {
                     // sparse phase: the lean 32-lane line search; with <= T / 64 candidates a whole
                     // wave each, two points of the search per round (decide64)
                     const bool wide = n_act * 64 <= T;
