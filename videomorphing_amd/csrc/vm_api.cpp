@@ -820,11 +820,10 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     // 0.32 (STEP) vs 0.64 ms (TILE) per iteration; 240x135 with 900 line searches per
     // iteration 0.22 vs 0.36; with 90: 0.24 vs 0.23; converged 0.08 vs 0.024.  All schedules
     // work on the same state in HBM, so the choice can change from batch to batch.
-    // (levels of more than 12 tiles per pass -- 240x135 -- only for a single pair: measured r03, two
-    // streams x 2 pairs, 56 tiles per launch: 274 ms per job with STEP there, 206 with TILE; the 120x68
-    // level of batches up to 8 pairs stays: 346 vs 480 ms for 2 x 4 pairs, 477 vs 531 for 8 + 7)
-    const bool may_split = c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= vm_step_max_tiles() &&
-                           (tiles_per_pass <= 12 || n == 1);
+    // (r03: restricting levels of more than 12 tiles per pass -- 240x135 -- to single pairs helped two
+    // streams x 2 independent pairs, 274 -> 206 ms per job, and cost the coupled 5-frame video, whose
+    // chain steps are batches of two pages, 354 -> 417 ms: not done)
+    const bool may_split = c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= vm_step_max_tiles();
     double cand_prev = 1e9; // line searches per iteration in the previous batch (first batch: dense)
     double tiles_prev = 1e9; // active tile visits per iteration and pair in the previous batch
     if (may_split || c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP || c->sweep_mode == VM_SWEEP_PASS) // epochs restart with every call: forget old records
