@@ -24,6 +24,12 @@ static int vm_step_max_tiles()
 #ifndef VM_SPARSE_TILES
 #define VM_SPARSE_TILES 12 // SPARSE takes a pruned level over once <= this many tiles per iteration were active
 #endif
+static int vm_sparse_tiles()
+{
+    static const char *e = getenv("VM_SPARSE_TILES"); // dev switch
+    static const int v = e ? atoi(e) : VM_SPARSE_TILES;
+    return v;
+}
 
 #include <algorithm>
 #include <cmath>
@@ -911,7 +917,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         // 4 x 3.4 us, a no-op SPARSE iteration 4 x ~0.3 us; with more active tiles than that the
         // one workgroup per pair serialises what the TILE grid runs side by side)
         const bool sparse = may_sparse && !split && lean_regime && !force_dense &&
-                            (c->sweep_mode == VM_SWEEP_SPARSE || tiles_prev <= (double)VM_SPARSE_TILES);
+                            (c->sweep_mode == VM_SWEEP_SPARSE || tiles_prev <= (double)vm_sparse_tiles());
         const int sched = pass ? 4 : (split ? 2 : (sparse ? 3 : (dense ? 0 : 1)));
         const int launches_before = launches;
         VM_HIP(hipEventRecord(c->ev0, s));
