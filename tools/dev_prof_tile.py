@@ -1,15 +1,21 @@
 """dev: stage stamps of one dense TILE launch (k_optimize<true, 13, 2>) over a batch of 120x68 levels,
 every pixel a candidate -- the launch the 60-pair job spends its time in (needs a build with
 VM_DEFS=-DVM_PROF: thread 0 of each tile of the first pair stamps its phases)
-   python tools/dev_prof_tile.py [pairs=30] [w=120] [h=68]"""
+   python tools/dev_prof_tile.py [pairs=30] [w=120] [h=68] [iters=3] [lean]
+with `lean`: the TILE schedule as AUTO would run it (the lean kernel once the level is pruned): stamps of
+the tiles that were still active in the last pass"""
 import sys, os, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["VM_TILE_DENSE"] = "1"
+LEAN = "lean" in sys.argv
+if not LEAN:
+    os.environ["VM_TILE_DENSE"] = "1"
+os.environ["VM_NO_GRAPH"] = "1"
 from videomorphing_amd import capi, morph, synth
 npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (120, 68)
+iters = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4].isdigit() else 3
 ctx = morph.Context(0, capi.MATH_FAST)
 ctx.set_params(morph.KernParameters(morph.Parameters()))
 ctx.set_tuning(capi.SWEEP_TILE, 0, 0)
@@ -26,16 +32,16 @@ for rep in range(2):
     for p in batch:
         capi.check(L.vm_init_level(p._h, 0, w, h, None, 0))
     prog = (capi.Progress * npairs)()
-    capi.check(L.vm_optimize_level_batch(arr, npairs, 0, 3.0, None, 1, prog))
+    capi.check(L.vm_optimize_level_batch(arr, npairs, 0, float(iters), None, 1, prog))
 print("pairs %d %dx%d: %.1f us per pass launch, sched ms %s, line searches per iteration and pair %.0f" % (
-    npairs, w, h, prog[0].elapsed_ms * 1e3 / 12, [round(x, 2) for x in prog[0].sched_ms], prog[0].candidates / 3))
+    npairs, w, h, prog[0].elapsed_ms * 1e3 / (4 * iters), [round(x, 2) for x in prog[0].sched_ms], prog[0].candidates / iters))
 buf = np.zeros(512 * 16 * 2, np.uint64)
 L.vm_dbg_prof_read.argtypes = [C.c_void_p, C.c_size_t]
 assert L.vm_dbg_prof_read(buf.ctypes.data, buf.nbytes) == 0
 ntile = ((w + 68) // 69) * ((h + 20) // 21)
 st = buf[:8192].reshape(256, 4, 8).astype(np.int64)[:ntile]
 sf = buf[8192 + 512:8192 + 512 + 2048].reshape(256, 8).astype(np.int64)[:ntile]
-ok = sf[:, 3] > sf[:, 0]
+ok = (sf[:, 3] > sf[:, 0]) & (sf[:, 0] >= sf[:, 0].max() - 2000000)   # this launch's (20 ms window)
 st, sf = st[ok], sf[ok]
 us = lambda d: "mean %6.2f  min %6.2f  max %6.2f" % (d.mean() / 100.0, d.min() / 100.0, d.max() / 100.0)
 print("tiles stamped (last pass of the last iteration):", ok.sum())
