@@ -1249,14 +1249,20 @@ __device__ __forceinline__ bool mask_hit(const uint32_t (*mask)[16], const uint3
 // ordered compaction of the (at most 256) flagged phase pixels of a workgroup into
 // list[]: slot order, hence identical in every workgroup that looks at the same tile.
 // Every thread of the workgroup calls it; returns the number of entries.
-__device__ __forceinline__ int compact256(bool flag, int tid, int *list, int *wave_cnt)
+// (`also`: a second flag of the same threads; *any_also = it is set somewhere -- bit 16 of the counts)
+__device__ __forceinline__ int compact256(bool flag, int tid, int *list, int *wave_cnt, bool also = false,
+                                          bool *any_also = nullptr)
 {
     const unsigned long long b = __ballot(flag);
+    const unsigned long long b2 = __ballot(also);
     const int lane = tid & 63, wave = tid >> 6;
     if (tid < 256 && lane == 0)
-        wave_cnt[wave] = __popcll(b);
+        wave_cnt[wave] = __popcll(b) | (b2 ? 1 << 16 : 0);
     __syncthreads();
-    const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+    const int w0 = wave_cnt[0], w1 = wave_cnt[1], w2 = wave_cnt[2], w3 = wave_cnt[3];
+    const int c0 = w0 & 0xFFFF, c1 = w1 & 0xFFFF, c2 = w2 & 0xFFFF, c3 = w3 & 0xFFFF;
+    if (any_also)
+        *any_also = ((w0 | w1 | w2 | w3) >> 16) != 0;
     if (tid < 256 && flag) {
         const int off = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
         list[off + __popcll(b & ((1ull << lane) - 1ull))] = tid;
@@ -1486,17 +1492,29 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
         for (int pj = 0; pj < 2; ++pj) {
             VM_TTS(pi * 2 + pj, 0);
             // ---- 1. candidates of this phase ----
-            bool cand = false;
+            bool cand = false, hit = false;
             if (tid < 256) {
                 const int px = ox + (tid & 31) * 2 + pj, py = oy + (tid >> 5) * 2 + pi;
                 int state = 0;
                 if (px < L.w && py < L.h && mask_hit(S.mask, S.imp, g, px, py)) {
                     state = 2; // in the mask: its bit is cleared unless it commits
+                    hit = true;
                     cand = !pixel_locked(L, P.bcond, px, py);
                 }
                 S.d_ok[tid] = state;
             }
-            const int n_act = compact256(cand, tid, S.list, S.wave_cnt);
+            bool any_hit;
+            const int n_act = compact256(cand, tid, S.list, S.wave_cnt, hit, &any_hit);
+            // no pixel of this phase in the mask: nothing to search, nothing to commit, no bit to clear
+            // (a pruned tile visit is mostly such phases: 1.6 -> 0.9 us each)
+            if (!any_hit) {
+                VM_TTS(pi * 2 + pj, 1);
+                VM_TTS(pi * 2 + pj, 2);
+                VM_TTS(pi * 2 + pj, 3);
+                VM_TTS(pi * 2 + pj, 4);
+                VM_TTS(pi * 2 + pj, 5);
+                continue;
+            }
             VM_TTS(pi * 2 + pj, 1);
 
             if (n_act > 0) {
