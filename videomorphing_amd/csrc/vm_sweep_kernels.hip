@@ -2872,12 +2872,8 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         S.wt = 0;
     }
     const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; // HW_REG_XCC_ID
-#ifndef VM_PASS_DEBUG
     if (dbg && tid == 0 && b < 2048) // diagnostic: which XCD the workgroup runs on
         dbg[b] = xcc;
-#else
-    uint32_t *const dbg_row = dbg ? dbg + 256 * (((epoch0 - 1u) >> 2) & 7u) : nullptr; // 8 launches x 256 workgroups
-#endif
     // Group-wide early outs.  Every workgroup of the group must take the same decision from data
     // no workgroup of this launch can have changed yet: the flag of the previous iteration, and
     // the mask bits of the positions within +-2 of the tile (pixels of this tile or of the gaps: no
@@ -2908,10 +2904,6 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     if (!live) {
         if (tid == 0)
             *my_slot = make_uint4(0, 0, 0, 0);
-#ifdef VM_PASS_DEBUG
-        if (dbg_row && tid == 0 && b < 256)
-            dbg_row[b] = 0xFFu;
-#endif
         return;
     }
 
@@ -3366,10 +3358,6 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         if (S.n_commit)
             flags[iter_idx] = 1u; // every writer stores the same 1 (see k_step)
         *my_slot = make_uint4(S.n_cand, S.n_commit, S.n_eval, part == 0 ? 1u : 0u);
-#ifdef VM_PASS_DEBUG
-        if (dbg_row && b < 256)
-            dbg_row[b] = S.n_cand;
-#endif
 #ifdef VM_PROF
         if (b < 256)
             vm_prof_buf[8192 + b * 2 + 1] = wall_clock64();
