@@ -28,6 +28,7 @@ import pytest
 from videomorphing_amd import capi, morph, synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _all_cpus():
@@ -635,3 +636,51 @@ def test_sparse_schedule_equals_tile_at_1080p(gpu_ctx, npairs):
         assert np.array_equal(out[capi.SWEEP_TILE][0][k].view(np.uint32), out[capi.SWEEP_SPARSE][0][k].view(np.uint32)), k
         assert np.array_equal(out[capi.SWEEP_TILE][1][k], out[capi.SWEEP_SPARSE][1][k]), k
     assert out[capi.SWEEP_SPARSE][2] < out[capi.SWEEP_TILE][2], (out[capi.SWEEP_TILE][2], out[capi.SWEEP_SPARSE][2])
+
+
+_FORM_SCRIPT = r"""
+import sys, ctypes as C
+import numpy as np
+sys.path.insert(0, %r)
+from videomorphing_amd import capi, morph, synth
+ctx = morph.Context(0, capi.MATH_FAST)
+ctx.set_params(morph.KernParameters(morph.Parameters()))
+ctx.set_tuning(capi.SWEEP_TILE, 0, 0)
+w, h = 150, 97
+i0, i1 = synth.make_pair(w, h)
+pyr = morph.Pyramid(ctx); pyr.build_levels([(w, h), ((w + 1) // 2, (h + 1) // 2)])
+pyr.upload_luma(1, i0, i1)
+pyr[1].v = (0.9 * synth.displacement(w, h)).astype(np.float32)
+capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+pr = capi.Progress()
+capi.check(pyr._L.vm_optimize_level(pyr._h, 0, float(sys.argv[1]), None, 1, C.byref(pr)))
+np.save(sys.argv[2], pyr[1].v)
+print(pr.commits, pr.candidates)
+"""
+
+
+def test_small_level_dense_kernel_against_the_general_one(tmp_path):
+    """FAST, dense TILE sweeps: the kernel form of the small levels (VM_DENSE_NOINT=1 forces it, =0
+    forbids it; in processes of their own, the switch is read once) has no interior form of the line
+    search -- the border form computes at run time the window counts the interior form has as
+    constants: the same bits -- and no lean bodies: a phase of <= 16 candidates takes the two-lane
+    dense search, whose sums are ordered differently.  One sweep from a fresh level (every phase
+    full): bit-identical; 12 sweeps: the FAST rounding band (RMS <= 0.01 px, counters within 2 %)."""
+    import subprocess
+    import sys
+    res = {}
+    for iters in (1, 12):
+        for form in ("0", "1"):
+            env = dict(os.environ, VM_DENSE_NOINT=form, VM_TILE_DENSE="1")
+            out = str(tmp_path / ("v_%s_%d.npy" % (form, iters)))
+            r = subprocess.run([sys.executable, "-c", _FORM_SCRIPT % ROOT, str(iters), out], capture_output=True, text=True,
+                               timeout=300, env=env)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[(form, iters)] = (np.load(out), [int(float(x)) for x in r.stdout.split()[-2:]])
+    a, b = res[("0", 1)], res[("1", 1)]
+    assert a[1] == b[1] and a[1][0] > 1000, (a[1], b[1])
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    a, b = res[("0", 12)], res[("1", 12)]
+    rms = float(np.sqrt(np.mean((a[0] - b[0]) ** 2)))
+    assert rms <= 0.01, rms
+    assert abs(a[1][0] - b[1][0]) <= 0.02 * a[1][0] and abs(a[1][1] - b[1][1]) <= 0.02 * a[1][1], (a[1], b[1])

@@ -3411,10 +3411,13 @@ void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int 
     // Levels of at most 32 tiles per pass (240x135 and below): most tiles touch the image border, so
     // most tiles run the border form of the dense line search in some of their waves and wait for
     // them; the interior form beside it only doubles the code the CU's waves execute at once.
-    // Without it (bit-identical: the border form computes the same window counts at run time), us per
+    // Without it (the same bits: the border form computes the same window counts at run time), us per
     // dense pass (r03, tools/dev_dense.py): 30 x 120x68 187.5 -> 183.6, 30 x 240x135 623 -> 604, 3 x 240x135
     // 182 -> 175; on large levels the interior form is what most waves run (1080p x 8 pairs, before the
     // fixed fan-out: 36.6 ms per pass with it, 50.5 without).  A rule on the level, never on the batch.
+    // (This form also has no lean bodies, see tile_sweep: a phase of <= 16 candidates takes the two-lane
+    // search, so against the general kernel its results move by FAST rounding -- the same for a pair
+    // alone and in a batch, since the form follows from the level.)
     static const char *noint = getenv("VM_DENSE_NOINT"); // dev switch: 0 / 1 = never / always
     if (noint ? atoi(noint) != 0 : g.x * g.y <= 32) {
         hipLaunchKernelGGL((SUF(k_optimize)<true, VM_SMAX, VM_MIN_FANOUT, false>), g, b, 0, s, views, cap, P, tables, offx, offy,
