@@ -13,8 +13,10 @@ Metric (BASELINE.json): Mpixel*iters/s of the halfway optimizer.
               batch relaxed by the same launches).  Total work is fixed: strong scaling.
   --config 3  config[3]: one 3840x2160 pair, 7-level pyramid, otherwise as config 1.
 
-value = sum over levels of W*H*iterations (the reference's own progress unit,
-morph.cu:1389) over all ranks / max-over-ranks wall time.  No collective sits on the data
+value = sum over levels of W*H*EXECUTED iterations (the reference's own progress unit,
+`_current_iter += W*H` per sweep that runs, morph.cu:1389: sweeps up to and including a level's
+first without an accepted move) over all ranks / max-over-ranks wall time; value_nominal credits
+max_iter sweeps per level whether they ran or not and is quoted beside it, never as the headline.  No collective sits on the data
 path; the only exchanges are one RCCL broadcast of the parameter block and one all-gather of
 two scalars per rank for the report.
 
@@ -92,6 +94,10 @@ def parse_args(argv=None):
                          "gloo lets a box with fewer GPUs than ranks exercise the N > 1 code (ranks then share devices)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-extras-but-scale-ref", action="store_true", help="no extras except scale_reference")
+    ap.add_argument("--no-scale-ref", action="store_true",
+                    help="N = 1, config 1: skip `scale_reference` (config[2]'s job -- the workload an N > 1 run shards -- on this one GPU)")
+    ap.add_argument("--scale-ref-pairs", type=int, default=60, help="frame pairs of the scale_reference job")
     ap.add_argument("--size", default=None, help="WxH override (development only)")
     ap.add_argument("--as-rank", type=int, default=-1,
                     help="config 2 on ONE GPU: solve the shard rank K of an --of G-rank job would get (static partition "
@@ -122,11 +128,9 @@ def main():
     import torch
     import torch.distributed as dist
     if args.backend == "gloo":
-        if world > max(1, torch.cuda.device_count()):
-            # ranks share a device: the PASS schedule's tile groups of two processes could starve each
-            # other of compute units (their waits are bounded, the call would fail) -- one launch per phase
-            os.environ["VM_NO_PASS"] = "1"
-        local_rank = local_rank % max(1, torch.cuda.device_count())    # test mode: ranks may share a device
+        # test mode: ranks may share a device.  Nothing to configure for that: the PASS schedule's token is a
+        # per-device lock file (one holder at a time across processes, the others run STEP), vm_api.cpp
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     coll_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
@@ -179,18 +183,7 @@ def main():
     distinct_frames = None
     if config == 2:
         mine = vdist.shard_pairs(args.pairs, world, rank) if args.as_rank < 0 else vdist.shard_pairs(args.pairs, args.of, args.as_rank)
-        distinct = mine[:8]                       # 8 distinct frames per rank, reused cyclically
-        distinct_frames = len(distinct)
-        imgs = frames(distinct)
-        # the rank's pairs in nctx contiguous chunks, one context (HIP stream + host thread) each;
-        # a chunk is solved in even batches of <= max_batch pairs per launch
-        nctx = min(nctx, max(1, len(mine)))
-        chunk_of = [k * nctx // max(len(mine), 1) for k in range(len(mine))]
-        pyrs = [pyramid(ctxs[chunk_of[k]], imgs[k % len(imgs)]) for k in range(len(mine))]
-        per_ctx = (len(mine) + nctx - 1) // nctx
-        B = max(1, min(args.max_batch, per_ctx))
-        nb = (per_ctx + B - 1) // B
-        B = (per_ctx + nb - 1) // nb              # even batches: 60 pairs on one GPU and stream = 2 x 30
+        pyrs, B, nctx, distinct_frames = config2_setup(mine, ctxs, frames, pyramid, args.max_batch)
         step_sets = [pyrs] * (args.steps + args.warmup)       # every step re-solves the rank's shard
     else:
         B = max(1, args.batch)
@@ -227,18 +220,9 @@ def main():
     def run_step(ps):
         """one step; with several contexts, one host thread per context (a vm_ctx is
         single-threaded by contract)"""
-        if config == 2 and nctx > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            chunks = [[p for p in ps if p._ctx is c] for c in ctxs]
-
-            def work(chunk):
-                res = []
-                for g0 in range(0, len(chunk), B):
-                    res += solve_group(chunk[g0:g0 + B])
-                return res
-            with ThreadPoolExecutor(max_workers=nctx) as ex:           # ctypes calls release the GIL
-                return [r for res in ex.map(work, chunks) for r in res]
-        if B > 1 or config == 2:
+        if config == 2:
+            return config2_step(ps, ctxs[:nctx], B, solve_group)
+        if B > 1:
             out = []
             for g0 in range(0, len(ps), B):
                 out += solve_group(ps[g0:g0 + B])
@@ -298,8 +282,11 @@ def main():
         el_max, pix_total, pix_live_total = el, pix_iters, pix_live
 
     extras = {}
-    if rank == 0 and not args.no_extras and config != 2:
+    if rank == 0 and not (args.no_extras or args.no_extras_but_scale_ref) and config != 2:
         extras = run_extras(args, np, capi, morph, synth, L, blk, ctx, pyrs[0], w, h, nlev, FIXED, B, solve, solve_group)
+
+    if rank == 0 and world == 1 and config == 1 and not args.size and not (args.no_extras or args.no_scale_ref):
+        extras["scale_reference"] = scale_reference(args, morph, blk, local_rank, frames, solve_group, sizes, nlev, FIXED)
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -318,11 +305,79 @@ def main():
         dist.destroy_process_group()
 
 
-def load_pmc(config, pairs_per_launch):
+def config2_setup(mine, ctxs, frames, pyramid, max_batch):
+    """config[2] on one rank: the rank's pairs `mine` as pyramids resident in HBM, in len(ctxs) contiguous
+    chunks -- one context (HIP stream + host thread) each --, a chunk solved in even batches of <= max_batch
+    pairs per launch.  8 distinct frames per rank, reused cyclically.  Returns (pyrs, B, nctx, distinct)."""
+    distinct = mine[:8]
+    imgs = frames(distinct)
+    nctx = min(len(ctxs), max(1, len(mine)))
+    chunk_of = [k * nctx // max(len(mine), 1) for k in range(len(mine))]
+    pyrs = [pyramid(ctxs[chunk_of[k]], imgs[k % len(imgs)]) for k in range(len(mine))]
+    per_ctx = (len(mine) + nctx - 1) // nctx
+    B = max(1, min(max_batch, per_ctx))
+    nb = (per_ctx + B - 1) // B
+    B = (per_ctx + nb - 1) // nb              # even batches: 60 pairs on one GPU and stream = 2 x 30
+    return pyrs, B, nctx, len(distinct)
+
+
+def config2_step(ps, ctxs, B, solve_group):
+    """one step of config[2] on one rank: every context's chunk in batches of B pairs, one host thread per
+    context (a vm_ctx is single-threaded by contract; ctypes calls release the GIL)"""
+    def work(chunk):
+        res = []
+        for g0 in range(0, len(chunk), B):
+            res += solve_group(chunk[g0:g0 + B])
+        return res
+    chunks = [[p for p in ps if p._ctx is c] for c in ctxs]
+    if len(ctxs) == 1:
+        return work(chunks[0])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(ctxs)) as ex:
+        return [r for res in ex.map(work, chunks) for r in res]
+
+
+def scale_reference(args, morph, blk, local_rank, frames, solve_group, sizes, nlev, fixed):
+    """The workload an N > 1 run of this script shards (config[2]: --scale-ref-pairs independent 1080p
+    pairs, two streams, batches of <= --max-batch pairs per launch) on THIS one GPU: the same-workload
+    denominator of a scaling curve whose N = 1 point is config[1]."""
+    ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(2)]
+    for c in ctxs:
+        c.set_params(blk.kp)
+
+    def pyramid(c, imgs):
+        p = morph.Pyramid(c)
+        p.build(imgs[0], imgs[1], blk.start_res, nlevels=nlev)
+        return p
+    mine = list(range(args.scale_ref_pairs))
+    pyrs, B, nctx, distinct = config2_setup(mine, ctxs, frames, pyramid, args.max_batch)
+    config2_step(pyrs, ctxs[:nctx], B, solve_group)                    # warm-up (workspaces, graphs)
+    for c in ctxs:
+        c.sync()
+    t0 = time.perf_counter()
+    progs = config2_step(pyrs, ctxs[:nctx], B, solve_group)
+    for c in ctxs:
+        c.sync()
+    dt = time.perf_counter() - t0
+    R = range(nlev - 1)
+    nominal = sum(pr[i].pixel_iters for pr in progs for i in R)
+    live = sum(float(pr[i].iters_live) * sizes[i][0] * sizes[i][1] for pr in progs for i in R)
+    for p in pyrs:
+        p.clear()
+    for c in ctxs:
+        c.close()
+    return {"workload": "config[2] on this one GPU: %d independent 1080p pairs (%d distinct frames), %d stream(s) x batches of %d pairs per "
+                        "launch, one step" % (len(mine), distinct, nctx, B),
+            "value": round(live / dt / 1e6, 2), "value_nominal": round(nominal / dt / 1e6, 2), "unit": "Mpixel*iters/s",
+            "ms_per_step": round(dt * 1e3, 2), "executed_pixel_iters": round(live),
+            "note": "`python bench.py --gpus N` (N > 1) shards exactly this job over N ranks: divide its value by this one"}
+
+
+def load_pmc(config, pairs_per_launch, path=None):
     """HBM bytes per launch of the sweep kernels from the committed PMC profile of THIS workload
     shape (config, pairs per launch); counters need rocprofv3, so they are never of this run.
     No matching entry: no PMC figures (a figure taken at another batch size would be wrong)."""
-    tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    tp = path or os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         tj = json.load(open(tp))
     except Exception:
@@ -330,8 +385,8 @@ def load_pmc(config, pairs_per_launch):
     for e in tj.get("entries", []):
         if e.get("config") == config and e.get("pairs_per_launch") == pairs_per_launch:
             return e.get("per_kernel", {}) or {}, e.get("per_kernel_launches", {}) or {}, \
-                "profiles/traffic_latest.json[config %d, %d pair(s) per launch]: %s" % (
-                    config, pairs_per_launch, e.get("source", "")[:200]), e.get("sq_per_kernel", {}) or {}
+                "%s[config %d, %d pair(s) per launch]: %s" % (
+                    os.path.relpath(tp, ROOT), config, pairs_per_launch, e.get("source", "")[:200]), e.get("sq_per_kernel", {}) or {}
     return {}, {}, None, {}
 
 
@@ -429,7 +484,9 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
     out = {
         "metric": "Mpixel*iters/s (halfway optimizer, 1080p pair, 6-level pyramid, 500 iters/level)" if config != 3 else
                   "Mpixel*iters/s (halfway optimizer, 3840x2160 pair, 7-level pyramid, 500 iters/level)",
-        "value": round(pix_total / el_max / 1e6, 2),
+        # EXECUTED pixel*iters / wall time: the reference's own progress unit (`_current_iter += W*H` per sweep that
+        # runs, morph.cu:1389) -- sweeps up to and including each level's first without an accepted move
+        "value": round(pix_live_total / el_max / 1e6, 2),
         "unit": "Mpixel*iters/s",
         "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(el_max / steps * 1e3, 2),
@@ -438,17 +495,18 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
         "data": "synthetic" if config != 2 else "synthetic (%d distinct frames per rank, reused cyclically over its pairs)" % distinct_frames,
         "config": {"workload": workload_name(config, w, h, nlev, blk, B, args, world, pairs_this_rank),
                    "math_mode": "fast" if blk.math_mode == capi.MATH_FAST else "exact",
-                   "semantics": ("fixed iteration count per level: value credits max_iter sweeps of every level (the BASELINE "
-                                 "config, '500 iters/level'); sweeps past a level's convergence are provable no-ops that the device "
-                                 "skips -- value_executed counts only the sweeps up to convergence") if FIXED
+                   "semantics": ("every level gets max_iter = 500 sweeps ('500 iters/level'); a level that stops improving needs no more "
+                                 "of them -- the remaining sweeps are provable no-ops the device skips -- so `value` counts the EXECUTED "
+                                 "sweeps only (up to and including each level's first without an accepted move: what the reference's loop "
+                                 "runs, morph.cu:1378-1390); value_nominal credits all 500 per level and is NOT a throughput") if FIXED
                                 else "reference: a level stops when no pixel improved",
                    "iters_per_level_fine_to_coarse": [progs[0][i].iters for i in R],
                    "iters_executed_per_level_fine_to_coarse": [progs[0][i].iters_live for i in R],
                    "pairs_in_flight_per_gpu": nctx, "pairs_per_launch": B,
                    "parallelism": "independent frame pairs, %d rank(s), 1 RCCL broadcast + 1 all-gather of the report" % world},
-        # what actually ran: sweeps up to and including each level's first without an accepted move
         "executed_pixel_iters": round(pix_live_total),
-        "value_executed": round(pix_live_total / el_max / 1e6, 2),
+        # max_iter sweeps credited for every level whether they ran or not (rounds 1-3 quoted this one)
+        "value_nominal": round(pix_total / el_max / 1e6, 2),
         "roofline": {"bound": "hbm",
                      # the dominant sweep kernel (largest share of sweep time): ALGORITHMIC bytes of one
                      # launch (100 B per pixel-visit x the visits one launch covers) / its
@@ -462,9 +520,13 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
                      "launch_us": dom["avg_us"] if dom else None,
                      "alg_bytes_per_launch": dom["alg_bytes_per_launch"] if dom else None,
                      "share_of_sweep_time": dom["share_of_sweep_time"] if dom else None,
-                     # SURVEY 8(d)'s aggregate over all sweep kernels: NOMINAL algorithmic bytes of every
-                     # credited iteration (skipped no-op sweeps included) / HIP-event time -- not DRAM throughput
-                     "achieved_nominal": round(achieved, 2), "frac_nominal": round(achieved / HBM_PEAK_GBS, 5),
+                     # SURVEY 8(d)'s formula on the EXECUTED rate: value x 282.7 B per pixel*iter / 8 TB/s.  Algorithmic
+                     # bytes INCLUDING the tile visits the improving mask skips (2.827 visits per pixel and sweep are
+                     # counted whether or not a tile has a candidate): not a bandwidth statement -- hbm_real_frac is
+                     "survey_formula_executed": round(pix_live_total / el_max * ALG_BYTES_PER_VISIT * 2.827 / 1e9 / HBM_PEAK_GBS, 5),
+                     # the same formula over every CREDITED sweep (skipped no-op sweeps included) / HIP-event time:
+                     # bytes that were never moved (it exceeds 1 on batched jobs); kept only to read older rounds' lines
+                     "credited_not_moved": {"GBs": round(achieved, 2), "frac_of_peak": round(achieved / HBM_PEAK_GBS, 5)},
                      "achieved_executed": round(alg_executed / (kern_ms * 1e-3) / 1e9, 2) if kern_ms > 0 else None,
                      "frac_executed": round(alg_executed / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kern_ms > 0 else None,
                      "hbm_real_frac": round(hbm_real_frac, 5) if hbm_real_frac is not None else None,
@@ -487,9 +549,15 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
                           "max": round(ms[-1], 2),
                           "note": "every step is a different frame of the synthetic video; whether the finest level converges or "
                                   "keeps exchanging rounding-level moves differs per frame" if config != 2 else "every step re-solves the rank's pairs"}
-        med = statistics.median(ms)
-        # the same units per step (fixed work), the median step instead of the mean
-        out["value_median_step"] = round(pix_total / world / len(step_ms) / (med * 1e-3) / 1e6 * world, 2) if FIXED else None
+        # executed units of each step / that step's time: the median step instead of the mean
+        per = max(len(progs) // max(len(step_ms), 1), 1)
+        rates = []
+        for k, t_ms in enumerate(step_ms):
+            live = sum(float(pr[i].iters_live) * sizes[i][0] * sizes[i][1] for pr in progs[k * per:(k + 1) * per] for i in R)
+            rates.append(live * world / (t_ms * 1e-3) / 1e6)
+        out["value_median_step"] = round(statistics.median(rates), 2)
+        out["step_executed_mpix_iters"] = [round(sum(float(pr[i].iters_live) * sizes[i][0] * sizes[i][1] for pr in progs[k * per:(k + 1) * per]
+                                                     for i in R) / 1e6, 2) for k in range(len(step_ms))]
     return out
 
 
@@ -509,16 +577,19 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
     capi.check(L.vm_get_params(ctx._h, C.byref(saved_kp)))
     extras = {}
     R = range(nlev - 1)
+    sz = [(p[el].width, p[el].height) for el in range(1, nlev)]
+    executed = lambda prs: sum(float(q[i].iters_live) * sz[i][0] * sz[i][1] for q in prs for i in R)
     ctx.sync(); t1 = time.perf_counter(); pr = solve(p, fixed=1 - FIXED); ctx.sync(); dt = time.perf_counter() - t1
     extras["%s_semantics" % ("reference" if FIXED else "fixed")] = {
-        "mpix_iters_per_s": round(sum(pr[i].pixel_iters for i in R) / dt / 1e6, 2),
+        "mpix_iters_per_s": round(executed([pr]) / dt / 1e6, 2),
         "ms_per_solve": round(dt * 1e3, 2),
         "iters_per_level_fine_to_coarse": [pr[i].iters for i in R]}
     other = capi.MATH_EXACT if blk.math_mode == capi.MATH_FAST else capi.MATH_FAST
     ctx.set_math_mode(other)
     ctx.sync(); t1 = time.perf_counter(); pr = solve(p); ctx.sync(); dt = time.perf_counter() - t1
-    extras["%s_math_mpix_iters_per_s" % ("exact" if other == capi.MATH_EXACT else "fast")] = round(
-        sum(pr[i].pixel_iters for i in R) / dt / 1e6, 2)
+    extras["%s_math" % ("exact" if other == capi.MATH_EXACT else "fast")] = {
+        "mpix_iters_per_s": round(executed([pr]) / dt / 1e6, 2), "ms_per_solve": round(dt * 1e3, 2),
+        "iters_executed_per_level_fine_to_coarse": [pr[i].iters_live for i in R]}
     ctx.set_math_mode(blk.math_mode)
     if w * h > 1920 * 1080:
         return extras
@@ -537,10 +608,11 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
             ctx.sync(); t1 = time.perf_counter(); pr = solve_group(group); ctx.sync()
             dt = time.perf_counter() - t1
             bt["pairs_%d" % nb] = {
-                "mpix_iters_per_s": round(sum(q2[i].pixel_iters for q2 in pr for i in R) / dt / 1e6, 1),
+                "mpix_iters_per_s": round(executed(pr) / dt / 1e6, 1),
+                "nominal_mpix_iters_per_s": round(sum(q2[i].pixel_iters for q2 in pr for i in R) / dt / 1e6, 1),
                 "ms_per_batch": round(dt * 1e3, 1)}
             del group
-        extras["batched_throughput_fixed_work"] = bt
+        extras["batched_throughput"] = bt
     # the temporally coupled path: a 5-frame 1080p video pair with analytic
     # flows, every frame tied to its solved neighbour (middle page, then both chains, two pages
     # per launch); the device-side flow pyramid included, lumas uploaded per page
@@ -567,8 +639,10 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         ctx.sync(); t1 = time.perf_counter()
         vm.calculate_halfway_parametrization()
         ctx.sync(); dt = time.perf_counter() - t1
-        units = sum(l[0] * l[1] * pr["iters"] for (lv, t), pr in vm.progress.items() for l in [levels[lv]])
-        extras["temporal_video_%d_frames" % d] = {"mpix_iters_per_s": round(units / dt / 1e6, 1), "ms_per_video": round(dt * 1e3, 1),
+        units = sum(l[0] * l[1] * pr["iters_live"] for (lv, t), pr in vm.progress.items() for l in [levels[lv]])
+        nominal = sum(l[0] * l[1] * pr["iters"] for (lv, t), pr in vm.progress.items() for l in [levels[lv]])
+        extras["temporal_video_%d_frames" % d] = {"mpix_iters_per_s": round(units / dt / 1e6, 1), "nominal_mpix_iters_per_s": round(nominal / dt / 1e6, 1),
+                                                  "ms_per_video": round(dt * 1e3, 1),
                                                   "flow_pyramid_ms": round(t_flow * 1e3, 1),
                                                   "depth_per_level": [l[2] for l in levels]}
         # ... and on to the screen (CMatchingThread::update_result for a video, then the compositor):

@@ -137,10 +137,20 @@ int  vm_set_tuning(vm_ctx *ctx, int sweep_mode, int threads, int parts);
 /* Diagnostic, EXACT arithmetic only: the order in which the commits of one Jacobi phase are
  * folded into the shared window sums.  The reference leaves it to float atomics
  * (morph.cu:951-1015); the oracle and this library fix it as row-major over the committing
- * pixels.  reversed != 0 applies them in the opposite order -- an equally legal trajectory,
- * used to measure how far two legal runs drift apart (the chaos floor FAST is judged
- * against, tests/test_gpu_fullsize.py). */
-int  vm_set_commit_order(vm_ctx *ctx, int reversed);
+ * pixels (order 0).  order 1 applies that sequence reversed, 2 column-major, 3 column-major
+ * reversed -- equally legal trajectories, used to measure how far legal runs drift apart
+ * (the per-frame chaos floor FAST is judged against, tests/test_gpu_fullsize.py).  Other
+ * values: VM_E_INVALID. */
+int  vm_set_commit_order(vm_ctx *ctx, int order);
+/* Test hooks of the PASS schedule's safety net.  k_pass spins at tile-local barriers with a bounded
+ * wait; under VM_SWEEP_AUTO a timeout (compute units masked away or held by someone else) restores the
+ * level to where the batch of iterations started, reruns the batch with the STEP schedule and keeps the
+ * context off PASS from then on; a forced VM_SWEEP_PASS reports VM_E_DEVICE.  force_timeout(on != 0)
+ * makes one workgroup of every following PASS launch walk away from its tile group, so that the rest
+ * times out for real (2 s); on == 0 ends that and re-admits PASS.  fallbacks = how many batches this
+ * context has rerun with STEP. */
+int  vm_dbg_pass_force_timeout(vm_ctx *ctx, int on);
+int  vm_dbg_pass_fallbacks(vm_ctx *ctx);
 /* Diagnostic of the PASS schedule: on which XCD (0..7) each of the first `n` (<= 2048)
  * workgroups of the most recent PASS launch ran (workgroup b belongs to tile group
  * (b / 256) * 8 + b % 8; a group whose 32 workgroups report one XCD keeps its tile in one
@@ -252,8 +262,10 @@ int  vm_video_get_field(vm_video *v, int lvl, int page, int field, void *host);
  * `lvl` scaled by (w0 / w, h0 / h) and resized to w0 x h0 into frame min(page * factor,
  * depth0 - 1), factor = factor_d[placeholder] / factor_d[lvl]; the frames the temporal
  * pyramid skipped are blended linearly from the two frames around them.  vm_video_result
- * delivers all depth0 frames (tight (depth0, h0, w0, 2) floats; a frame nothing writes stays
- * zero); vm_frame_set_v_from_video leaves ONE of them in a compositor frame's v, on the
+ * delivers all depth0 frames (tight (depth0, h0, w0, 2) floats).  A level whose last page
+ * stops short of the last frame ((depth - 1) * factor < depth0 - 1: never with the reference's
+ * own depth tables) is refused with VM_E_STATE -- the reference would leave those frames as an
+ * earlier delivery wrote them; vm_frame_set_v_from_video leaves ONE of them in a compositor frame's v, on the
  * device (w0 x h0 = the frame's size, depth0 = the depth the video was created with). */
 int  vm_video_result(vm_video *v, int lvl, int w0, int h0, float *v_xy_frames);
 /* Morph::cpu_optimize_level for every page of the coarsest level, morph.cu:419-590 */

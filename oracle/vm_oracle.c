@@ -672,8 +672,11 @@ float vmo_dbg_energy_change(const vmo_level *l, const vmo_params *P, int px, int
  * state, commits applied in row-major order of the committing pixels
  * (commit_pixel_motion :990-1026, ssim_update :951-988), then the SSIM value
  * of every tile+halo cell recomputed (UpdateSSIM :1258-1279). */
-static int g_commit_reversed = 0;
-void vmo_set_commit_order(int reversed) { g_commit_reversed = reversed != 0; }
+/* Diagnostic: the order in which the commits of a phase are applied.  The reference leaves it to
+ * float atomics (morph.cu:951-1015).  0 = row-major over the committing pixels (the order this
+ * oracle fixes), bit 0 = that sequence reversed, bit 1 = column-major (tx outer, ty inner). */
+static int g_commit_order = 0;
+void vmo_set_commit_order(int order) { g_commit_order = order & 3; }
 
 static int optimize_tile(vmo_level *l, const vmo_params *P, int ox, int oy, sweep_stats *st)
 {
@@ -688,7 +691,10 @@ static int optimize_tile(vmo_level *l, const vmo_params *P, int ox, int oy, swee
                     optimize_pixel(l, P, ox + tx * 2 + j, oy + ty * 2 + i, &dec[nd++], st);
             /* __syncthreads(); commits (row-major: ty outer, tx inner) */
             for (int kk = 0; kk < nd; ++kk) {
-                decision *d = &dec[g_commit_reversed ? nd - 1 - kk : kk];
+                int ks = (g_commit_order & 1) ? nd - 1 - kk : kk;
+                if (g_commit_order & 2) /* column-major: position ks of the sequence tx outer, ty inner */
+                    ks = (ks % OPT_BH) * OPT_BW + ks / OPT_BH;
+                decision *d = &dec[ks];
                 if (d->ok) {
                     int px = d->px, py = d->py, idx = py * w + px;
                     float lx = vmo_tex2d(l->img0, w, h, px - d->nvx + 0.5f, py - d->nvy + 0.5f);

@@ -194,10 +194,11 @@ void vmo_temporal_fill(int w, int h, const float *v_prev, const float *f0_prev, 
 void vmo_flow_scale(const float *flow, int w, int h, int wout, int hout, float *out);
 /* temporal concatenation (pyramid.cu:406-442): f(p) += BiLinear(f_next, p + f(p)) */
 void vmo_flow_concat(float *f, const float *f_next, int w, int h);
-/* order in which the commits of a phase are applied (the reference leaves it to atomics):
- * 0 = row-major over the committing pixels (the oracle's definition), 1 = reversed -- an
- * equally legal order, used to measure how far two legal trajectories drift apart */
-void vmo_set_commit_order(int reversed);
+/* order in which the commits of a phase are applied (the reference leaves it to atomics,
+ * morph.cu:951-1015): 0 = row-major over the committing pixels (the oracle's definition), 1 = that
+ * sequence reversed, 2 = column-major, 3 = column-major reversed -- equally legal orders, used to
+ * measure how far legal trajectories drift apart */
+void vmo_set_commit_order(int order);
 
 void vmo_set_threads(int n);   /* OpenMP threads for the timed CPU baseline */
 int  vmo_get_threads(void);

@@ -11,12 +11,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def total_credit(d):
-    return d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * d["steps"] * 1.01
+SIZES = [(1920, 1080), (960, 540), (480, 270), (240, 135), (120, 68)]
 
 
 def test_bench_json_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--no-extras"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-extras"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -25,7 +24,7 @@ def test_bench_json_line():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
@@ -35,10 +34,13 @@ def test_bench_json_line():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     # the line is the DOMINANT sweep kernel's (named, with its share of the sweep time); the
     # nominal aggregate, the executed-work figure and the PMC traffic sit beside it
-    for k in ("kernel", "launch_us", "alg_bytes_per_launch", "share_of_sweep_time", "frac_nominal", "achieved_executed",
-              "frac_executed", "traffic_source", "hbm_real_frac", "valu_frac", "active_pixel_ratio", "per_kernel"):
+    for k in ("kernel", "launch_us", "alg_bytes_per_launch", "share_of_sweep_time", "survey_formula_executed", "credited_not_moved",
+              "achieved_executed", "frac_executed", "traffic_source", "hbm_real_frac", "valu_frac", "active_pixel_ratio", "per_kernel"):
         assert k in rf, k
-    assert rf["frac_executed"] <= rf["frac_nominal"] and 0 < rf["valu_frac"] < 1 and 0 < rf["active_pixel_ratio"] <= 1
+    assert "frac_nominal" not in rf and "achieved_nominal" not in rf
+    assert rf["frac_executed"] <= rf["credited_not_moved"]["frac_of_peak"] and 0 < rf["valu_frac"] < 1 and 0 < rf["active_pixel_ratio"] <= 1
+    # SURVEY 8(d)'s formula on the executed rate: value x 282.7 B / 8 TB/s
+    assert abs(rf["survey_formula_executed"] - d["value"] * 1e6 * 282.7 / 8e12) < 2e-5
     assert len(rf["per_kernel"]) >= 2
     for e in rf["per_kernel"]:
         for k in ("kernel", "launches", "avg_us", "alg_bytes_per_launch", "nominal_frac"):
@@ -46,11 +48,16 @@ def test_bench_json_line():
     dom = max(rf["per_kernel"], key=lambda e: e["share_of_sweep_time"])
     assert rf["kernel"] == dom["kernel"] and rf["frac"] == dom["nominal_frac"] and rf["launch_us"] == dom["avg_us"]
     assert abs(rf["achieved"] - rf["alg_bytes_per_launch"] / (rf["launch_us"] * 1e-6) / 1e9) < 0.02 * rf["achieved"] + 0.01
-    # what ran vs what is credited: fixed work credits 500 sweeps per level, executed counts the
-    # sweeps up to each level's convergence
-    assert "skips" in d["config"]["semantics"]
-    assert 0 < d["executed_pixel_iters"] <= total_credit(d) and 0 < d["value_executed"] <= d["value"]
-    assert d["config"]["iters_executed_per_level_fine_to_coarse"][-1] <= 500
+    # the headline is what RAN: executed pixel*iters / wall time; the 500-sweeps-per-level credit sits beside it
+    assert "EXECUTED" in d["config"]["semantics"] and "value_executed" not in d
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 * d["steps"] / d["executed_pixel_iters"] - 1.0) < 0.01
+    ex = d["config"]["iters_executed_per_level_fine_to_coarse"]
+    assert len(ex) == 5 and all(1 <= k <= 500 for k in ex)
+    # (two different frames per run: each contributes between one sweep and 500 sweeps of every level)
+    assert 2 * sum(w * h for w, h in SIZES) <= d["executed_pixel_iters"] <= 2 * 500 * sum(w * h for w, h in SIZES)
+    assert d["value"] <= d["value_nominal"]
+    assert abs(d["value_nominal"] * 1e6 * d["ms_per_step"] * 1e-3 / (500 * sum(w * h for w, h in SIZES)) - 1.0) < 0.01
+    assert abs(sum(d["step_executed_mpix_iters"]) * 1e6 / d["executed_pixel_iters"] - 1.0) < 0.01
     assert abs(sum(e["share_of_sweep_time"] for e in rf["per_kernel"]) - 1.0) < 0.02
     assert abs(sum(e["launches"] for e in rf["per_kernel"]) - rf["launches"]) <= 0
     cb = d["cpu_baseline"]
@@ -60,11 +67,20 @@ def test_bench_json_line():
     assert cb["gpu_same_sample"]["value"] > cb["value"]        # like for like: same levels, starts, iteration counts
     # ... and the EXACT arithmetic on that sample is the oracle's result bit for bit
     assert cb["parity_same_sample"]["bit_identical"] is True and cb["parity_same_sample"]["max_abs_dv"] == 0.0
-    # value = pixel-iterations of one fixed-work 1080p solve / time of the step
-    sizes = [(1920, 1080), (960, 540), (480, 270), (240, 135), (120, 68)]
-    total = 500 * sum(w * h for w, h in sizes)
-    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 / total - 1.0) < 0.01
     assert d["value"] > 50 * cb["value"] / cb["cores"]      # sanity: the GPU path is not the CPU path
+
+
+def test_bench_scale_reference_in_the_n1_line():
+    """the N = 1 line carries config[2]'s job -- what an N > 1 run shards -- on this one GPU (here: 6 pairs)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-extras-but-scale-ref", "--scale-ref-pairs", "6"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+    sr = d["scale_reference"]
+    assert "config[2]" in sr["workload"] and "6 independent" in sr["workload"] and "2 stream(s) x batches of 3" in sr["workload"]
+    assert 0 < sr["value"] <= sr["value_nominal"] and sr["unit"] == d["unit"]
+    assert abs(sr["value"] * 1e6 * sr["ms_per_step"] * 1e-3 / sr["executed_pixel_iters"] - 1.0) < 0.01
+    assert abs(sr["value_nominal"] * 1e6 * sr["ms_per_step"] * 1e-3 / (6 * 500 * sum(w * h for w, h in SIZES)) - 1.0) < 0.01
 
 
 def test_bench_gpus_2_self_launches_two_ranks():
@@ -82,9 +98,31 @@ def test_bench_gpus_2_self_launches_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert "config[2]" in d["config"]["workload"] and d["config"]["pairs_per_launch"] == 2
-    sizes = [(1920, 1080), (960, 540), (480, 270), (240, 135), (120, 68)]
-    total = 4 * 500 * sum(w * h for w, h in sizes)          # all 4 pairs of the job, both ranks
-    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 / total - 1.0) < 0.01
+    total = 4 * 500 * sum(w * h for w, h in SIZES)          # all 4 pairs of the job, both ranks
+    assert abs(d["value_nominal"] * 1e6 * d["ms_per_step"] * 1e-3 / total - 1.0) < 0.01
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 / d["executed_pixel_iters"] - 1.0) < 0.01
+
+
+def test_bench_gpus_8_gloo_one_device():
+    """N = 8 readiness without the hardware: `bench.py --gpus 8` as the driver starts it (self-launch: eight
+    ranks, config[2]'s 60 pairs sharded 8/7/8/7/..., two streams per rank), the two collectives over gloo,
+    all eight ranks sharing this box's one device -- one JSON line, n_gpus 8, every pair of the job
+    accounted for, no environment switch needed for the shared device."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VM_NO_PASS")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--config", "2", "--pairs", "60",
+                        "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["steps"] == 1
+    assert "60 independent" in d["config"]["workload"] and "rank 0: 8 pairs" in d["config"]["workload"]
+    assert d["config"]["pairs_per_launch"] == 4 and d["config"]["pairs_in_flight_per_gpu"] == 2
+    total = 60 * 500 * sum(w * h for w, h in SIZES)          # all 60 pairs, all eight ranks
+    assert abs(d["value_nominal"] * 1e6 * d["ms_per_step"] * 1e-3 / total - 1.0) < 0.01
+    assert abs(d["value"] * 1e6 * d["ms_per_step"] * 1e-3 / d["executed_pixel_iters"] - 1.0) < 0.01
+    assert 60 * sum(w * h for w, h in SIZES) <= d["executed_pixel_iters"] <= total
 
 
 def test_bench_refuses_a_world_size_mismatch():

@@ -585,9 +585,10 @@ def test_context_driven_from_fresh_threads(gpu_ctx):
 
 @pytest.mark.parametrize("sched", [capi.SWEEP_TILE, capi.SWEEP_SPLIT, capi.SWEEP_STEP, capi.SWEEP_PASS])
 def test_reversed_commit_order_matches_the_oracle_switch(gpu_ctx, oracle, sched):
-    """vm_set_commit_order: the commits of a phase folded in reversed row-major order -- another
-    order the reference's atomics may produce -- equals the oracle run with the same switch bit
-    for bit, and differs from the row-major trajectory (so the switch measures something)"""
+    """vm_set_commit_order: the commits of a phase folded in reversed row-major, column-major and
+    reversed column-major order -- other orders the reference's atomics may produce -- equal the
+    oracle run with the same switch bit for bit, and every one differs from the row-major
+    trajectory and from the others (so the switch measures something)"""
     gpu_ctx.set_math_mode(capi.MATH_EXACT)
     w, h = 138, 84
     i0, i1 = synth.make_pair(w, h)
@@ -600,7 +601,7 @@ def test_reversed_commit_order_matches_the_oracle_switch(gpu_ctx, oracle, sched)
     res = {}
     try:
         gpu_ctx.set_tuning(sched, 0, 0)
-        for rev in (0, 1):
+        for rev in (0, 1, 2, 3):
             oracle.lib().vmo_set_commit_order(rev)
             gpu_ctx.set_commit_order(rev)
             lo = oracle.Level(w, h)
@@ -623,7 +624,11 @@ def test_reversed_commit_order_matches_the_oracle_switch(gpu_ctx, oracle, sched)
         oracle.lib().vmo_set_commit_order(0)
         gpu_ctx.set_commit_order(0)
         gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
-    assert not np.array_equal(res[0], res[1])
+    for a in range(4):
+        for b in range(a + 1, 4):
+            assert not np.array_equal(res[a], res[b]), (a, b)
+    with pytest.raises(capi.VmError):
+        gpu_ctx.set_commit_order(4)
 
 
 def test_fast_energy_on_converged_solves_sits_at_the_chaos_floor(gpu_ctx, oracle):

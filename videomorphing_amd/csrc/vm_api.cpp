@@ -39,6 +39,9 @@ static int vm_sparse_tiles()
 #include <cstring>
 #include <string>
 #include <vector>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 static thread_local std::string g_err;
 
@@ -183,6 +186,7 @@ static void ctx_free(vm_ctx *c)
     hipFree(c->step_slots);
     hipFree(c->pass_bar);
     hipFree(c->pass_err);
+    hipFree(c->pass_snap);
     hipHostFree(c->pass_err_host);
     hipFree(c->pass_dbg);
     hipFree(c->cons_dev);
@@ -240,11 +244,25 @@ extern "C" int vm_set_math_mode(vm_ctx *c, int mode)
     return VM_OK;
 }
 
-extern "C" int vm_set_commit_order(vm_ctx *c, int reversed)
+extern "C" int vm_set_commit_order(vm_ctx *c, int order)
 {
     if (!c) return vm_fail(VM_E_INVALID, "vm_set_commit_order: ctx is NULL");
-    c->commit_reversed = reversed ? 1 : 0;
+    if (order < 0 || order > 3) return vm_fail(VM_E_INVALID, "vm_set_commit_order: order %d (0 row-major, 1 reversed, 2 column-major, 3 column-major reversed)", order);
+    c->commit_reversed = order;
     return VM_OK;
+}
+
+extern "C" int vm_dbg_pass_force_timeout(vm_ctx *c, int on)
+{
+    if (!c) return vm_fail(VM_E_INVALID, "vm_dbg_pass_force_timeout: ctx is NULL");
+    c->pass_test_timeout = on ? 1 : 0;
+    if (!on) c->pass_latched_off = false;
+    return VM_OK;
+}
+
+extern "C" int vm_dbg_pass_fallbacks(vm_ctx *c)
+{
+    return c ? c->pass_fallbacks : -1;
 }
 
 extern "C" int vm_dbg_pass_placement(vm_ctx *c, uint8_t *xcc_of_block, int n)
@@ -706,6 +724,60 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
     return exec;
 }
 
+// The PASS token of a device.  k_pass spins at tile-local barriers, so the workgroups of all its tile
+// groups must become co-resident; two PASS launches at once -- of two contexts, or of two PROCESSES
+// sharing the device -- could hold part of the compute units each and starve each other's groups.  One
+// holder at a time: inside the process a mutex per device, across processes an advisory flock() on a lock
+// file named after the device's PCI bus id (so that HIP_VISIBLE_DEVICES renumbering cannot split it);
+// whoever does not get the token runs STEP for that call.  Kernels that do not spin (every other
+// schedule, any other program) only delay a PASS launch: they finish and free their compute units.
+// VM_LOCK_DIR (default /tmp) holds the files; if one cannot be opened the token is process-local and the
+// bounded barrier wait + the STEP rerun below remain the safety net.
+namespace {
+struct PassDevice {
+    std::mutex mu;
+    int fd = -2; // -2: not opened yet, -1: no lock file (process-local token)
+};
+PassDevice g_pass_dev[64];
+
+struct PassToken {
+    PassDevice *d = nullptr;
+    bool owns = false;
+    bool try_acquire(int device)
+    {
+        d = &g_pass_dev[device & 63];
+        if (!d->mu.try_lock()) return false;
+        if (d->fd == -2) {
+            char bus[64] = "";
+            if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+                (void)hipGetLastError();
+                snprintf(bus, sizeof(bus), "ordinal%d", device);
+            }
+            for (char *q = bus; *q; ++q)
+                if (*q == ':' || *q == '/' || *q == '.') *q = '_';
+            const char *dir = getenv("VM_LOCK_DIR");
+            const std::string path = std::string(dir && *dir ? dir : "/tmp") + "/vmorph-pass-" + bus + ".lock";
+            d->fd = open(path.c_str(), O_RDONLY | O_CREAT | O_CLOEXEC, 0666);
+            if (d->fd < 0) d->fd = -1;
+        }
+        if (d->fd >= 0 && flock(d->fd, LOCK_EX | LOCK_NB) != 0) {
+            d->mu.unlock();
+            return false;
+        }
+        owns = true;
+        return true;
+    }
+    void release()
+    {
+        if (!owns) return;
+        if (d->fd >= 0) (void)flock(d->fd, LOCK_UN);
+        d->mu.unlock();
+        owns = false;
+    }
+    ~PassToken() { release(); }
+};
+} // namespace
+
 // Morph::optimize_level for a BATCH of frame pairs of identical geometry on one context:
 // every sweep launch covers the same level of all pairs (grid.z = pair), so a level with
 // too few tiles to occupy 256 CUs is filled by the batch instead -- the natural parallelism
@@ -840,15 +912,16 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         }
     // PASS: the workgroups of a tile group spin at a barrier of their own, so every group of a
     // launch must become resident whatever else runs.  One 256-workgroup chunk (8 groups) always
-    // fits an idle MI355X; two PASS launches of different streams could starve each other's
-    // groups, so a device-wide token admits one context at a time (the others run STEP), and the
-    // barrier's spin is bounded: a timeout comes back as VM_E_DEVICE, never as a hang.
-    // VM_NO_PASS=1 (environment) turns the schedule off -- e.g. several processes on one device.
+    // fits an idle MI355X; two PASS launches at once could starve each other's groups, so a
+    // device-wide token (PassToken: across contexts AND processes) admits one holder at a time --
+    // the others run STEP -- and the barrier's spin is bounded: in AUTO a timeout (a device whose
+    // compute units are masked or otherwise not all ours) puts the level back to where the batch
+    // started, reruns the batch with STEP and keeps this context off PASS from then on; only a
+    // FORCED PASS schedule reports it as VM_E_DEVICE.  VM_NO_PASS=1 (environment) turns PASS off.
     static const bool no_pass = getenv("VM_NO_PASS") != nullptr;
-    static std::mutex pass_token[64];
-    std::unique_lock<std::mutex> pass_lock;
+    PassToken pass_token;
     bool want_pass = !no_pass && (c->sweep_mode == VM_SWEEP_PASS ||
-                                  (c->sweep_mode == VM_SWEEP_AUTO && tiles_per_pass * n <= VM_PASS_MAX_GROUPS));
+                                  (c->sweep_mode == VM_SWEEP_AUTO && !c->pass_latched_off && tiles_per_pass * n <= VM_PASS_MAX_GROUPS));
     // k_pass addresses a level's arrays by 32-bit byte offsets from its slab and from its schedule
     // workspace (72 + 104 B per pixel)
     if ((size_t)l0.rs * l0.h * 128 >= ((size_t)1 << 32)) {
@@ -865,15 +938,30 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
             want_pass = false;
         }
     }
-    if (want_pass) {
-        pass_lock = std::unique_lock<std::mutex>(pass_token[c->device & 63], std::try_to_lock);
-        if (pass_lock.owns_lock() && !c->pass_err) {
-            VM_HIP(hipMalloc((void **)&c->pass_err, 256));
-            VM_HIP(hipMemsetAsync(c->pass_err, 0, 256, s));
-            VM_HIP(hipHostMalloc((void **)&c->pass_err_host, 256, hipHostMallocDefault));
+    if (want_pass && pass_token.try_acquire(c->device) && !c->pass_err) {
+        VM_HIP(hipMalloc((void **)&c->pass_err, 256));
+        VM_HIP(hipMemsetAsync(c->pass_err, 0, 256, s));
+        VM_HIP(hipHostMalloc((void **)&c->pass_err_host, 256, hipHostMallocDefault));
+    }
+    bool may_pass = want_pass && pass_token.owns;
+    // diagnostic forms of a FORCED PASS schedule (vm_set_tuning(VM_SWEEP_PASS, 0, parts)): parts == 1 stores
+    // write-through from the start, parts == 2 maps 32 consecutive workgroup ids to a tile group, so that
+    // every group spans all XCDs and takes the census -> write-back -> write-through route for real
+    const int pass_switches = (c->sweep_mode == VM_SWEEP_PASS && c->sweep_parts == 1 ? 1 : 0) | (c->pass_test_timeout ? 2 : 0) |
+                              (c->sweep_mode == VM_SWEEP_PASS && c->sweep_parts == 2 ? 4 : 0);
+    // AUTO only: the levels as they stand before a PASS batch, to rerun it with STEP should a barrier time out
+    const bool pass_guard = may_pass && c->sweep_mode == VM_SWEEP_AUTO;
+    if (pass_guard) {
+        size_t need = 0;
+        for (int i = 0; i < n; ++i) need += lv[i]->slab_bytes;
+        if (c->pass_snap_bytes < need) {
+            hipFree(c->pass_snap);
+            c->pass_snap = nullptr;
+            c->pass_snap_bytes = 0;
+            VM_HIP(hipMalloc(&c->pass_snap, need));
+            c->pass_snap_bytes = need;
         }
     }
-    const bool may_pass = want_pass && pass_lock.owns_lock();
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}}; // morph.cu:1382-1385
     std::vector<int> executed(n, cap), improving(n, 1), stopped(n, 0), live(n, -1);
     std::vector<double> st_tiles(n, 0.0), st_cand(n, 0.0), st_commit(n, 0.0), st_eval(n, 0.0);
@@ -925,6 +1013,13 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         int sb = 0; // step index inside this batch: parity = which copy of the sums is read
         int slot_iter = -1; // iteration whose counts the previous STEP launch left in its slots
         const int pass_groups = tiles_per_pass * n, pass_blocks = (pass_groups + 7) / 8 * 256;
+        if (pass && pass_guard) {
+            size_t off = 0;
+            for (int i = 0; i < n; ++i) {
+                VM_HIP(hipMemcpyAsync((char *)c->pass_snap + off, lv[i]->slab, lv[i]->slab_bytes, hipMemcpyDeviceToDevice, s));
+                off += lv[i]->slab_bytes;
+            }
+        }
         if (pass) { // barrier counters of every launch of the batch, zeroed once
             const size_t need_bar = (size_t)nb * 4 * pass_groups * VM_PASS_SYNC_WORDS;
             if (c->pass_bar_words < need_bar) {
@@ -978,7 +1073,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
                         c->pass_bar + (size_t)((it - done) * 4 + k) * pass_groups * VM_PASS_SYNC_WORDS, c->flags, c->stats, it, fixed_work,
                         c->step_slots + (size_t)(sb & 1) * c->step_slots_words,
                         c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, sb == 0 ? -1 : slot_iter, c->pass_err,
-                        c->pass_dbg, 1, c->sweep_mode == VM_SWEEP_PASS && c->sweep_parts == 1, s);
+                        c->pass_dbg, 1, pass_switches, s);
                     slot_iter = it;
                     ++sb;
                     ++launches;
@@ -1014,7 +1109,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         if (pass && sb > 0) { // the counts the last launch left in its slots
             (exact ? vm_launch_optimize_pass_exact : vm_launch_optimize_pass_fast)(
                 c->views, n, cap, l0.w, l0.h, P, c->tables, 0, 0, 0u, nullptr, c->flags, c->stats, done + nb - 1, fixed_work,
-                nullptr, c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, slot_iter, c->pass_err, nullptr, 0, 0, s);
+                nullptr, c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, slot_iter, c->pass_err, nullptr, 0, pass_switches, s);
             ++launches;
         }
         VM_HIP(hipEventRecord(c->ev1, s));
@@ -1028,9 +1123,26 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         }
         VM_HIP(hipStreamSynchronize(s));
         if (pass && c->pass_err_host[0]) {
-            (void)hipMemsetAsync(c->pass_err, 0, 4, s);
-            return vm_fail(VM_E_DEVICE, "vm_optimize_level: a tile barrier of the PASS schedule timed out (is another process "
-                                        "competing for this device's compute units?  VM_NO_PASS=1 selects the STEP schedule)");
+            VM_HIP(hipMemsetAsync(c->pass_err, 0, 4, s));
+            if (!pass_guard)
+                return vm_fail(VM_E_DEVICE, "vm_optimize_level: a tile barrier of the PASS schedule timed out (are all of this device's "
+                                            "compute units available to this process?  VM_SWEEP_AUTO falls back to the STEP schedule by itself)");
+            // AUTO: the batch never happened -- state, records, flags and counters as before it -- and runs again with STEP
+            size_t off = 0;
+            for (int i = 0; i < n; ++i) {
+                VM_HIP(hipMemcpyAsync(lv[i]->slab, (char *)c->pass_snap + off, lv[i]->slab_bytes, hipMemcpyDeviceToDevice, s));
+                off += lv[i]->slab_bytes;
+                VM_HIP(hipMemsetAsync(lv[i]->view.rec_tag, 0, (size_t)l0.rs * l0.h * 4, s));
+                VM_HIP(hipMemsetAsync(lv[i]->view.rec_tag2, 0, (size_t)l0.rs * l0.h * 4, s));
+                VM_HIP(hipMemsetAsync(c->flags + (size_t)i * cap + done, 0, (size_t)nb * 4, s));
+                VM_HIP(hipMemsetAsync(c->stats + ((size_t)i * cap + done) * VM_STAT_WORDS, 0, (size_t)nb * 4 * VM_STAT_WORDS, s));
+            }
+            launches = launches_before;
+            may_pass = false;
+            c->pass_latched_off = true;
+            ++c->pass_fallbacks;
+            pass_token.release();
+            continue;
         }
         float bms = 0;
         VM_HIP(hipEventElapsedTime(&bms, c->ev0, c->ev1));

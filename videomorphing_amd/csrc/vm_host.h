@@ -77,6 +77,11 @@ struct vm_ctx {
     uint32_t *pass_err = nullptr, *pass_err_host = nullptr;
     int pass_resident[2] = {-1, -1}; // co-resident k_pass workgroups on this device (EXACT, FAST build); -1: not asked yet
     uint32_t *pass_dbg = nullptr;    // vm_dbg_pass_xcd: 256 words, XCC id per workgroup of the last launch
+    void *pass_snap = nullptr;       // AUTO: the levels' slabs as they stood before the current PASS batch
+    size_t pass_snap_bytes = 0;
+    bool pass_latched_off = false;   // AUTO: a tile barrier timed out once on this context: STEP from then on
+    int pass_fallbacks = 0;          // how often that happened (vm_dbg_pass_fallbacks)
+    int pass_test_timeout = 0;       // vm_dbg_pass_force_timeout: the next PASS launches behave as if a barrier timed out
     int sweep_threads = 0;           // 0 = automatic
     int sweep_mode = 0;              // VM_SWEEP_AUTO / TILE / SPLIT
     int sweep_parts = 0;             // workgroups per tile in the SPLIT schedule, 0 = automatic
@@ -95,7 +100,7 @@ struct vm_ctx {
         hipGraphExec_t exec;
     };
     std::vector<SweepGraph> graphs;
-    int commit_reversed = 0;         // vm_set_commit_order (EXACT, diagnostic)
+    int commit_reversed = 0;         // vm_set_commit_order (EXACT, diagnostic): order 0..3
     int use_graphs = -1;             // -1: not decided yet, 0: off (VM_NO_GRAPH or a failed capture), 1: on
 };
 

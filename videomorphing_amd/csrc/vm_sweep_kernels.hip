@@ -1278,38 +1278,47 @@ __device__ __forceinline__ int compact256(bool flag, int tid, int *list, int *wa
 // the same records in the same row-major order
 template <class LdsT>
 __device__ __forceinline__ void gather_cell_bits(const LdsT &S, const VmLevelView &L, int ox, int oy, int rx, int ry,
-                                                 int pi, int pj, int sy0, const uint32_t (&rowbits)[3], float2 &m,
-                                                 float2 &q, float &cr, float2 &tb, int rev)
+                                                 int pi, int pj, int sy0, int sx0, const uint32_t (&rowbits)[3], float2 &m,
+                                                 float2 &q, float &cr, float2 &tb, int order)
 {
+    auto add = [&](int t, int sx) {
+        const int y = 2 * (sy0 + t) + pi, x = 2 * sx + pj;
+        const int rec = (sy0 + t) * 32 + sx;
+        const float2 dm = S.d_mean[rec], dv = S.d_var[rec], st = S.d_step[rec];
+        m.x += dm.x;
+        m.y += dm.y;
+        q.x += dv.x;
+        q.y += dv.y;
+        cr += S.d_cross[rec];
+        const int By = border_class(oy + y, L.h), Bx = border_class(ox + x, L.w);
+        const float k = S.tps[(By * 5 + Bx) * 25 + (ry - y + 2) * 5 + (rx - x + 2)];
+        tb.x += st.x * k;
+        tb.y += st.y * k;
+    };
+#if VM_EXACT
+    // order (vm_set_commit_order): bit 0 = reversed, bit 1 = column-major over the committing pixels --
+    // equally legal orders of the commits the reference leaves to atomics
+    if (order) {
+        for (int k0 = 0; k0 < 9; ++k0) {
+            const int k = (order & 1) ? 8 - k0 : k0;
+            const int t = (order & 2) ? k % 3 : k / 3, a = (order & 2) ? k / 3 : k % 3;
+            const int sx = sx0 + a;
+            if (sx < 32 && ((rowbits[t] >> sx) & 1u))
+                add(t, sx);
+        }
+        return;
+    }
+#else
+    (void)order;
+#endif
+    (void)sx0;
 #pragma unroll
-    for (int t0 = 0; t0 < 3; ++t0) {
-#if VM_EXACT
-        const int t = rev ? 2 - t0 : t0; // rev (vm_set_commit_order): reversed row-major order
-#else
-        const int t = t0;
-        (void)rev;
-#endif
+    for (int t = 0; t < 3; ++t) {
         uint32_t bits = rowbits[t];
-        const int y = 2 * (sy0 + t) + pi;
         while (bits) {
-#if VM_EXACT
-            const int sx = rev ? 31 - __clz(bits) : __ffs(bits) - 1;
-#else
             const int sx = __ffs(bits) - 1;
-#endif
             bits &= ~(1u << sx);
-            const int x = 2 * sx + pj;
-            const int rec = (sy0 + t) * 32 + sx;
-            const float2 dm = S.d_mean[rec], dv = S.d_var[rec], st = S.d_step[rec];
-            m.x += dm.x;
-            m.y += dm.y;
-            q.x += dv.x;
-            q.y += dv.y;
-            cr += S.d_cross[rec];
-            const int By = border_class(oy + y, L.h), Bx = border_class(ox + x, L.w);
-            const float k = S.tps[(By * 5 + Bx) * 25 + (ry - y + 2) * 5 + (rx - x + 2)];
-            tb.x += st.x * k;
-            tb.y += st.y * k;
+            add(t, sx);
         }
     }
 }
@@ -1366,28 +1375,31 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
     xlo += (xlo & 1) ^ pj;
     bool touched = false;
 #if VM_EXACT
-    // diagnostic (vm_set_commit_order): the same records in reversed row-major order -- an
-    // equally legal order of the commits the reference leaves to atomics
+    // diagnostic (vm_set_commit_order): the same records in another order -- bit 0 = reversed, bit 1 =
+    // column-major over the committing pixels; equally legal orders of the commits the reference
+    // leaves to atomics
     if (rev) {
-        yhi -= (yhi & 1) ^ pi;
-        xhi -= (xhi & 1) ^ pj;
-        for (int y = yhi; y >= ylo; y -= 2)
-            for (int x = xhi; x >= xlo; x -= 2) {
-                const int rec = (y >> 1) * 32 + (x >> 1);
-                if (S.d_ok[rec] != 1)
-                    continue;
-                touched = true;
-                const float2 dm = S.d_mean[rec], dv = S.d_var[rec], st = S.d_step[rec];
-                m.x += dm.x;
-                m.y += dm.y;
-                q.x += dv.x;
-                q.y += dv.y;
-                cr += S.d_cross[rec];
-                const int By = border_class(oy + y, L.h), Bx = border_class(ox + x, L.w);
-                const float k = S.tps[(By * 5 + Bx) * 25 + (ry - y + 2) * 5 + (rx - x + 2)];
-                tb.x += st.x * k;
-                tb.y += st.y * k;
-            }
+        const int ny = yhi >= ylo ? ((yhi - ylo) >> 1) + 1 : 0, nx = xhi >= xlo ? ((xhi - xlo) >> 1) + 1 : 0;
+        const int n = ny * nx;
+        for (int k0 = 0; k0 < n; ++k0) {
+            const int k = (rev & 1) ? n - 1 - k0 : k0;
+            const int iy = (rev & 2) ? k % ny : k / nx, ix = (rev & 2) ? k / ny : k % nx;
+            const int y = ylo + 2 * iy, x = xlo + 2 * ix;
+            const int rec = (y >> 1) * 32 + (x >> 1);
+            if (S.d_ok[rec] != 1)
+                continue;
+            touched = true;
+            const float2 dm = S.d_mean[rec], dv = S.d_var[rec], st = S.d_step[rec];
+            m.x += dm.x;
+            m.y += dm.y;
+            q.x += dv.x;
+            q.y += dv.y;
+            cr += S.d_cross[rec];
+            const int By = border_class(oy + y, L.h), Bx = border_class(ox + x, L.w);
+            const float k2 = S.tps[(By * 5 + Bx) * 25 + (ry - y + 2) * 5 + (rx - x + 2)];
+            tb.x += st.x * k2;
+            tb.y += st.y * k2;
+        }
         return touched;
     }
 #else
@@ -1692,7 +1704,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                         continue;
                     float2 m = S.mean[cell], q = S.var[cell], tb = S.tpsb[cell];
                     float cr = S.cross[cell];
-                    gather_cell_bits(S, L, ox, oy, rx, ry, pi, pj, sy0, rowbits, m, q, cr, tb, P.rev_commit);
+                    gather_cell_bits(S, L, ox, oy, rx, ry, pi, pj, sy0, sx0, rowbits, m, q, cr, tb, P.rev_commit);
                     {
                         S.mean[cell] = m;
                         S.var[cell] = q;
@@ -2267,6 +2279,16 @@ __device__ __forceinline__ float4 rec_load(const float4 *p)
                        __uint_as_float((uint32_t)(b >> 32)));
 }
 
+// bit dy * 5 + dx of a 5 x 5 window field -> bit dx * 5 + dy
+__device__ __forceinline__ uint32_t transpose5(uint32_t h)
+{
+    uint32_t t = 0;
+#pragma unroll
+    for (int k = 0; k < 25; ++k)
+        t |= ((h >> k) & 1u) << ((k % 5) * 5 + k / 5);
+    return t;
+}
+
 template <bool COH = false>
 __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__restrict__ r_a,
                                           const float4 *__restrict__ r_b, const float *s_tps, uint32_t hits, int qx,
@@ -2289,10 +2311,19 @@ __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__
                 continue;
             }
 #if VM_EXACT
-            // rev (vm_set_commit_order): the highest window bit first = reversed row-major order
-            const int b = hits ? (rev ? 31 - __clz(hits) : __ffs(hits) - 1) : -1;
-            if (b >= 0)
+            // rev (vm_set_commit_order): bit 0 = the last window position first, bit 1 = positions in
+            // column-major order (picked from the transposed 5 x 5 bit field)
+            int b = -1;
+            if (hits) {
+                if (!(rev & 2)) {
+                    b = (rev & 1) ? 31 - __clz(hits) : __ffs(hits) - 1;
+                } else {
+                    const uint32_t ht = transpose5(hits);
+                    const int bt = (rev & 1) ? 31 - __clz(ht) : __ffs(ht) - 1;
+                    b = (bt % 5) * 5 + bt / 5;
+                }
                 hits &= ~(1u << b);
+            }
 #else
             const int b = hits ? __ffs(hits) - 1 : -1;
             hits &= hits - 1;
@@ -2794,14 +2825,14 @@ __device__ __forceinline__ uint32_t block_bits_in(int bx, int by, int x0, int x1
 // one wave adds the per-workgroup count slots of a finished PASS launch into the counters of
 // iteration `it`, pair by pair (slot k belongs to group (k >> 8) * 8 + (k & 7))
 __device__ __forceinline__ void pass_sum_slots(uint32_t *stats0, const uint32_t *slots, int it, int nslot, int ntiles,
-                                               int ngroups, int cap, int lane)
+                                               int ngroups, int cap, int lane, bool spread)
 {
     const uint4 *sl = (const uint4 *)slots;
     const int npairs = ngroups / ntiles;
     for (int p = 0; p < npairs; ++p) {
         uint32_t acc[4] = {0, 0, 0, 0};
         for (int k = lane; k < nslot; k += 64) {
-            const int grp = (k >> 8) * 8 + (k & 7);
+            const int grp = (k >> 8) * 8 + (spread ? (k & 255) >> 5 : k & 7);
             if (grp >= ngroups || grp / ntiles != p)
                 continue;
             const uint4 q = sl[k];
@@ -2840,7 +2871,10 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     if (tid == 0 && b < 256)
         vm_prof_buf[8192 + b * 2] = wall_clock64();
 #endif
-    const int grp = (b >> 8) * 8 + (within & 7), part = within >> 3;
+    // (force_wt & 4, a test switch: groups of 32 CONSECUTIVE ids instead -- every group then spans all eight
+    // XCDs, which is what exercises the census, the write-back fence and the write-through hand-offs)
+    const bool spread = (force_wt & 4) != 0;
+    const int grp = (b >> 8) * 8 + (spread ? within >> 5 : within & 7), part = spread ? within & 31 : within >> 3;
     uint4 *my_slot = (uint4 *)slots_cur + b; // read by the next launch: always written
     if (grp >= ngroups) {
         if (tid == 0)
@@ -2862,6 +2896,8 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     if (ox < L.w && oy < L.h && tid < g.nbx * g.nby)
         early_word = L.impmask[(g.by0 + tid / g.nbx + 1) * L.imp_rs + (g.bx0 + tid % g.nbx + 1)];
     const uint32_t prev_flag = (!fixed_work && iter_idx > 0) ? flags[iter_idx - 1] : 1u;
+    // a barrier of an earlier launch of this batch timed out: the host will discard the batch -- do not wait again
+    const uint32_t err_before = ldc(err);
     for (int k = tid; k < 625; k += VM_PASS_T)
         S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
     for (int k = tid; k < 225; k += VM_PASS_T)
@@ -2884,7 +2920,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     // of such an edge stays a candidate for ever (measured: 684 line searches per iteration of a
     // converged 120x68 level, in the oracle and in every schedule).
     VM_PTSF(1);
-    bool live = ox < L.w && oy < L.h && prev_flag != 0;
+    bool live = ox < L.w && oy < L.h && prev_flag != 0 && err_before == 0;
     {
         uint32_t mine = 0;
         if (live && tid < g.nbx * g.nby) {
@@ -2900,7 +2936,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
     // the activity counts of the previous launch, added up by one wave of workgroup 0 (a plain
     // read-modify-write by one thread: nothing else touches that iteration's counters now)
     if (b == 0 && wave == 7 && prev_iter_idx >= 0)
-        pass_sum_slots(stats0, slots_prev, prev_iter_idx, nslot_prev, ntiles, ngroups, cap, lane);
+        pass_sum_slots(stats0, slots_prev, prev_iter_idx, nslot_prev, ntiles, ngroups, cap, lane, spread);
     if (!live) {
         if (tid == 0)
             *my_slot = make_uint4(0, 0, 0, 0);
@@ -2934,7 +2970,7 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
 #undef VM_WO
 
     uint32_t my_cand = 0, my_commit = 0, my_eval = 0; // of this wave, over the four phases
-    bool wt = force_wt != 0;                           // write-through stores, counter barrier
+    bool wt = (force_wt & 1) != 0;                     // write-through stores, counter barrier
     bool pure_known = false;                           // after the first barrier: the group's XCD census is in
     uint32_t rounds = 0;                               // barrier rounds behind us
     bool timed_out = false;
@@ -3017,6 +3053,10 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
                        od_cross = src_t ? o_cross : o_cross2, od_value = src_t ? o_value : o_value2, od_imp = src_t ? o_imp : o_imp2;
         const int ppi = ((ph - 1) & 3) >> 1, ppj = (ph - 1) & 1; // parity class of the last phase's pixels (ph > 0)
 
+        // test hook (vm_dbg_pass_force_timeout): one workgroup of group 0 walks away before the second barrier;
+        // the rest of its group waits in vain, times out and raises the error word
+        if ((force_wt & 2) && grp == 0 && part == 3 && ph == 1)
+            break;
         const int px = ox + tx * 2 + pj, py = oy + ty * 2 + pi;
         const bool in_img = px < L.w && py < L.h;
         const int spx = in_img ? px : ox, spy = in_img ? py : oy; // a safe pixel for the loads of an idle wave
@@ -3223,7 +3263,9 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
                 for (int k0 = 0; k0 < 9; ++k0) {
 #if VM_EXACT
-                    const int k = P.rev_commit ? 8 - k0 : k0; // rev (vm_set_commit_order): reversed row-major order
+                    // vm_set_commit_order: bit 0 = reversed, bit 1 = column-major (k = row * 3 + column)
+                    const int kr = (P.rev_commit & 1) ? 8 - k0 : k0;
+                    const int k = (P.rev_commit & 2) ? (kr % 3) * 3 + kr / 3 : kr;
 #else
                     const int k = k0;
 #endif
@@ -3367,9 +3409,9 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
 
 // closes a batch of PASS launches: the counts the last launch left in its slots
 __global__ __launch_bounds__(64) void SUF(k_pass_tail)(uint32_t *__restrict__ stats, const uint32_t *__restrict__ slots_prev,
-                                                        int prev_iter_idx, int nslot_prev, int ntiles, int ngroups, int cap)
+                                                        int prev_iter_idx, int nslot_prev, int ntiles, int ngroups, int cap, int spread)
 {
-    pass_sum_slots(stats, slots_prev, prev_iter_idx, nslot_prev, ntiles, ngroups, cap, (int)threadIdx.x);
+    pass_sum_slots(stats, slots_prev, prev_iter_idx, nslot_prev, ntiles, ngroups, cap, (int)threadIdx.x, spread != 0);
 }
 
 __global__ void SUF(k_next_iter)(int *iter_dev, int set, int value)
@@ -3506,7 +3548,8 @@ void SUF(vm_launch_optimize_pass)(const VmLevelView *views, int nbatch, int cap,
     const int ntiles = gx * gy, ngroups = ntiles * nbatch;
     const int nblocks = (ngroups + 7) / 8 * 256;
     if (!decide) {
-        hipLaunchKernelGGL(SUF(k_pass_tail), dim3(1), dim3(64), 0, s, stats, slots_prev, prev_iter_idx, nblocks, ntiles, ngroups, cap);
+        hipLaunchKernelGGL(SUF(k_pass_tail), dim3(1), dim3(64), 0, s, stats, slots_prev, prev_iter_idx, nblocks, ntiles, ngroups, cap,
+                           force_wt & 4);
         return;
     }
     hipLaunchKernelGGL(SUF(k_pass), dim3(nblocks), dim3(VM_PASS_T), 0, s, views, cap, P, tables, offx, offy, epoch0, ngroups,

@@ -223,6 +223,14 @@ static int video_result_frame(vm_video *v, int lvl, int w0, int h0, int f, float
     hipStream_t s = v->ctx->stream;
     const int d = v->depth[lvl], depth0 = v->depth0;
     const int factor = (int)(v->factor_d0 / v->factor_d[lvl]); // MatchingThread.cpp:27
+    // The reference's two loops write frames 0 .. min((d - 1) factor, depth0 - 1); with its own depth tables
+    // (d = ceil((d_finer + 1) / 2), pyramid.cu:237) that is every frame.  A table whose last page stops
+    // short of the last frame would leave the tail frames with whatever an EARLIER delivery put into
+    // Pyramid::_vector there -- content this library does not have: refused instead of returned as zeros.
+    if ((d - 1) * factor < depth0 - 1)
+        return vm_fail(VM_E_STATE, "vm_video_result: level %d delivers frames 0..%d of %d (%d pages, stride %d): the reference would "
+                                   "leave the rest as an earlier update_result wrote them; deliver a level that reaches the last frame",
+                       lvl, (d - 1) * factor, depth0, d, factor);
     auto key_page = [&](int frame) {
         int key = -1;
         for (int i = 0; i < d; ++i)

@@ -109,9 +109,10 @@ class Context(object):
     def set_tuning(self, sweep_mode=0, threads=0, parts=0):
         capi.check(self._L.vm_set_tuning(self._h, int(sweep_mode), int(threads), int(parts)))
 
-    def set_commit_order(self, reversed_=False):
-        """diagnostic (EXACT): fold a phase's commits in reversed row-major order"""
-        capi.check(self._L.vm_set_commit_order(self._h, int(bool(reversed_))))
+    def set_commit_order(self, order=0):
+        """diagnostic (EXACT): the order a phase's commits are folded in -- 0 row-major (the oracle's),
+        1 reversed, 2 column-major, 3 column-major reversed (vm_set_commit_order)"""
+        capi.check(self._L.vm_set_commit_order(self._h, int(order)))
 
     def sync(self):
         capi.check(self._L.vm_ctx_sync(self._h))
@@ -330,7 +331,7 @@ class Morph(object):
                 lv = pyr[el]
                 # morph.cu:1389-1391: the level is accounted as max_iter sweeps
                 self._current_iter += lv.width * lv.height * self._max_iter
-                self.progress[el] = dict(iters=pr.iters, improving=pr.improving,
+                self.progress[el] = dict(iters=pr.iters, iters_live=pr.iters_live, improving=pr.improving,
                                          pixel_iters=pr.pixel_iters, elapsed_ms=pr.elapsed_ms,
                                          launches=pr.launches, active_tiles=pr.active_tiles,
                                          candidates=pr.candidates, commits=pr.commits,
@@ -356,7 +357,7 @@ def solve_batch(pyramids, max_iter, max_iter_drop_factor=1.0, fixed_work=False, 
                                 int(bool(fixed_work)), prog))
     out = []
     for i in range(n):
-        out.append([dict(iters=prog[i * nl + k].iters, improving=prog[i * nl + k].improving,
+        out.append([dict(iters=prog[i * nl + k].iters, iters_live=prog[i * nl + k].iters_live, improving=prog[i * nl + k].improving,
                          pixel_iters=prog[i * nl + k].pixel_iters, elapsed_ms=prog[i * nl + k].elapsed_ms,
                          launches=prog[i * nl + k].launches, commits=prog[i * nl + k].commits,
                          candidates=prog[i * nl + k].candidates, active_tiles=prog[i * nl + k].active_tiles,
@@ -388,13 +389,13 @@ class MatchingThread(object):
     def run(self):
         """MatchingThread.cpp:138-150"""
         t0 = time.time()
-        try:
+        try:   # the whole body: an error of the delivery must reach wait() like one of the solve
             self.gpu_morph.calculate_halfway_parametrization()
+            self.run_time = time.time() - t0
+            self.update_result()
         except Exception as e:  # surfaced to the caller of wait()
             self.error = e
-        self.run_time = time.time() - t0
-        if self.error is None:
-            self.update_result()
+            self.run_time = time.time() - t0
 
     def start(self):
         self._thread = threading.Thread(target=self.run)
@@ -688,7 +689,7 @@ class VideoMorph(object):
         for l in range(len(vid.levels) - 1):
             for t in range(vid.levels[l][2]):
                 pr = prog[k]
-                self.progress[(l, t)] = dict(iters=pr.iters, improving=pr.improving, commits=pr.commits,
+                self.progress[(l, t)] = dict(iters=pr.iters, iters_live=pr.iters_live, improving=pr.improving, commits=pr.commits,
                                              candidates=pr.candidates, elapsed_ms=pr.elapsed_ms)
                 k += 1
         return True
@@ -721,13 +722,13 @@ class VideoMatchingThread(object):
     def run(self):
         """MatchingThread.cpp:138-150"""
         t0 = time.time()
-        try:
+        try:   # the whole body: an error of the delivery (vm_video_result) must reach wait() like one of the solve
             self.gpu_morph.calculate_halfway_parametrization()
+            self.run_time = time.time() - t0
+            self.update_result()
         except Exception as e:  # surfaced to the caller of wait()
             self.error = e
-        self.run_time = time.time() - t0
-        if self.error is None:
-            self.update_result()
+            self.run_time = time.time() - t0
 
     def start(self):
         self._thread = threading.Thread(target=self.run)
