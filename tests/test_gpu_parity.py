@@ -674,3 +674,38 @@ def test_fast_energy_on_converged_solves_sits_at_the_chaos_floor(gpu_ctx, oracle
     msg = dict(fast=dev_fast, floor=dev_floor, rms=rms_fast)
     assert np.mean(dev_fast) <= max(0.005, 1.5 * np.mean(dev_floor)), msg
     assert max(dev_fast) <= 0.012 and max(rms_fast) <= 0.02, msg
+
+
+@pytest.mark.parametrize("sched", [capi.SWEEP_TILE, capi.SWEEP_STEP, capi.SWEEP_PASS, capi.SWEEP_AUTO])
+def test_exact_fma_mode_is_a_rounding_level_variant_of_exact(gpu_ctx, oracle, sched):
+    """VM_MATH_EXACT_FMA (diagnostic): the EXACT source with fused multiply-adds -- what nvcc's default
+    --fmad=true makes of the reference source.  Every schedule runs under it; after three sweeps from the
+    same start it agrees with EXACT to rounding level -- >= 97 % of the pixels within 0.01 px, the same
+    activity to 3 % -- and is not identical to it (so it does perturb the trajectory)."""
+    w, h = 138, 84
+    i0, i1 = synth.make_pair(w, h)
+    v0 = (0.8 * synth.displacement(w, h)).astype(np.float32)
+    P = _params(oracle)
+    out = {}
+    try:
+        gpu_ctx.set_tuning(sched, 0, 0)
+        for mode in (capi.MATH_EXACT, capi.MATH_EXACT_FMA):
+            gpu_ctx.set_math_mode(mode)
+            gpu_ctx.set_params(_kp(P))
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build_levels([(w, h), (69, 42)])
+            pyr.upload_luma(1, i0, i1)
+            pyr[1].v = v0
+            capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+            pr = capi.Progress()
+            capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 3.0, None, 1, C.byref(pr)))
+            out[mode] = (pyr[1].v, pr.commits, pr.candidates)
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    a, b = out[capi.MATH_EXACT], out[capi.MATH_EXACT_FMA]
+    d = np.sqrt(((a[0] - b[0]) ** 2).sum(-1))
+    assert (d < 0.01).mean() >= 0.97, (d < 0.01).mean()
+    assert abs(a[1] - b[1]) <= 0.03 * a[1] and abs(a[2] - b[2]) <= 0.03 * a[2], (a[1:], b[1:])
+    assert not np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert np.abs(b[0] - v0).max() > 0

@@ -1,6 +1,6 @@
 """dev: the per-frame chaos floor of config[1] (1080p, 6 levels, 500 iterations per level, reference
-stopping rule): four equally legal EXACT trajectories (commit orders 0..3, vm_set_commit_order) and
-FAST under the automatic schedule, per frame; energies from the oracle's vmo_energy on the host.
+stopping rule): the family of equally legal runs (four commit orders in EXACT arithmetic, two of them with fused
+multiply-adds, tests/test_gpu_fullsize.py::CHAOS_FAMILY) and FAST under the automatic schedule, per frame; energies from the oracle's vmo_energy on the host.
 The measurement is tests/test_gpu_fullsize.py::chaos_floor_measure; this prints it as JSON lines.
 usage: tools/dev_chaos_floor.py [frame ...]"""
 import json
@@ -21,6 +21,6 @@ signed = []
 for f in frames:
     r = T.chaos_floor_measure(ctx, frames=(f,))[f]
     signed.append(r["e_fast_signed"])
-    print(json.dumps({"frame": f, **{k: (np.round(v, 5).tolist() if not isinstance(v, dict) else v) for k, v in r.items()}}), flush=True)
+    print(json.dumps({"frame": f, **T.chaos_round(r)}), flush=True)
 s = np.array(signed)
 print(json.dumps({"signed_energy_mean": float(s.mean()), "sem": float(s.std(ddof=1) / np.sqrt(len(s))) if len(s) > 1 else None}))

@@ -24,6 +24,9 @@ UNITS = [
     ("vm_morph_kernels.hip", "vm_morph_kernels_exact.o", ["-DVM_EXACT=1", "-ffp-contract=off"]),
     ("vm_morph_kernels.hip", "vm_morph_kernels_fast.o", ["-DVM_EXACT=0", "-ffp-contract=fast"]),
     ("vm_sweep_kernels.hip", "vm_sweep_kernels_exact.o", ["-DVM_EXACT=1", "-ffp-contract=off"]),
+    # VM_MATH_EXACT_FMA (diagnostic): the EXACT source with contraction on -- what nvcc's default --fmad=true
+    # makes of the reference source; one more legal rounding of the algorithm for the chaos-floor tests
+    ("vm_sweep_kernels.hip", "vm_sweep_kernels_exactf.o", ["-DVM_EXACT=2", "-ffp-contract=fast"]),
     # FAST fuses multiply-adds where the source says fmaf(), nowhere else: with -ffp-contract=fast
     # two inlined copies of one expression (a*b + c*d) may be contracted differently, and the
     # schedules would agree bit for bit only while their code is laid out alike (measured cost of

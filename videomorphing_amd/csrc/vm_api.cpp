@@ -238,7 +238,7 @@ extern "C" int vm_get_params(vm_ctx *c, vm_kern_params *p)
 
 extern "C" int vm_set_math_mode(vm_ctx *c, int mode)
 {
-    if (!c || (mode != VM_MATH_EXACT && mode != VM_MATH_FAST))
+    if (!c || (mode != VM_MATH_EXACT && mode != VM_MATH_FAST && mode != VM_MATH_EXACT_FMA))
         return vm_fail(VM_E_INVALID, "vm_set_math_mode: bad argument");
     c->math_mode = mode;
     return VM_OK;
@@ -633,7 +633,7 @@ extern "C" int vm_coarse_solve(vm_pyr *p, int lvl, int w0, int h0, const vm_cons
 // upsample(PyramidLevel&dest, PyramidLevel&orig) for one page, upsample.cu:260-286
 int vm_level_upsample(vm_ctx *c, vm_level &d, const vm_level &s)
 {
-    if (c->math_mode == VM_MATH_EXACT)
+    if (c->math_mode != VM_MATH_FAST)
         vm_launch_upsample_exact(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, c->stream);
     else
         vm_launch_upsample_fast(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, c->stream);
@@ -661,7 +661,7 @@ int vm_level_init(vm_ctx *c, vm_level &l, int w0, int h0, const vm_constraint *c
     if (n < 0 || (n > 0 && !cons)) return vm_fail(VM_E_INVALID, "vm_init_level: constraints");
     int rc = upload_constraints(c, cons, n);
     if (rc != VM_OK) return rc;
-    if (c->math_mode == VM_MATH_EXACT) {
+    if (c->math_mode != VM_MATH_FAST) {
         vm_launch_init_level_exact(l.view, c->kp.ssim_clamp, c->tables, c->stream);
         if (n > 0) vm_launch_splat_exact(l.view, w0, h0, c->cons_dev, n, c->stream);
     } else {
@@ -673,6 +673,32 @@ int vm_level_init(vm_ctx *c, vm_level &l, int w0, int h0, const vm_constraint *c
     return VM_OK;
 }
 
+// the sweep launchers of one arithmetic build of vm_sweep_kernels.hip
+struct SweepLaunchers {
+    decltype(&vm_launch_optimize_exact) optimize;
+    decltype(&vm_launch_next_iter_exact) next_iter;
+    decltype(&vm_launch_optimize_sparse_exact) sparse;
+    decltype(&vm_launch_optimize_split_exact) split;
+    decltype(&vm_launch_optimize_step_exact) step;
+    decltype(&vm_launch_optimize_pass_exact) pass;
+    decltype(&vm_pass_resident_blocks_exact) pass_resident;
+};
+static const SweepLaunchers &sweep_launchers(int math_mode)
+{
+    static const SweepLaunchers exact = {vm_launch_optimize_exact, vm_launch_next_iter_exact, vm_launch_optimize_sparse_exact,
+                                         vm_launch_optimize_split_exact, vm_launch_optimize_step_exact, vm_launch_optimize_pass_exact,
+                                         vm_pass_resident_blocks_exact};
+    static const SweepLaunchers fast = {vm_launch_optimize_fast, vm_launch_next_iter_fast, vm_launch_optimize_sparse_fast,
+                                        vm_launch_optimize_split_fast, vm_launch_optimize_step_fast, vm_launch_optimize_pass_fast,
+                                        vm_pass_resident_blocks_fast};
+    // VM_MATH_EXACT_FMA: the EXACT source with -ffp-contract=fast (fused multiply-adds wherever the compiler
+    // contracts, IEEE division and square root): what nvcc's default --fmad=true makes of the reference source
+    static const SweepLaunchers exactf = {vm_launch_optimize_exactf, vm_launch_next_iter_exactf, vm_launch_optimize_sparse_exactf,
+                                          vm_launch_optimize_split_exactf, vm_launch_optimize_step_exactf, vm_launch_optimize_pass_exactf,
+                                          vm_pass_resident_blocks_exactf};
+    return math_mode == VM_MATH_FAST ? fast : (math_mode == VM_MATH_EXACT_FMA ? exactf : exact);
+}
+
 // A hipGraph of VM_GRAPH_ITERS TILE-schedule iterations (4 pass launches each, one counter bump)
 // for the given geometry, instantiated once per context and replayed: pruned sweeps last 2-3 us
 // on the GPU, less than the 4-6 us the host needs per eager launch, so the sweep loop of a
@@ -680,13 +706,13 @@ int vm_level_init(vm_ctx *c, vm_level &l, int w0, int h0, const vm_constraint *c
 // a kernel argument there but a device counter.  Returns nullptr when graphs are unavailable
 // (VM_NO_GRAPH set, or capture/instantiation failed once): the caller launches eagerly.
 #define VM_GRAPH_ITERS 8
-static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, int cap, int fixed_work, int threads,
+static hipGraphExec_t sweep_graph(vm_ctx *c, int math_mode, int n, int w, int h, int cap, int fixed_work, int threads,
                                   int dense, const VmKParams &P)
 {
     if (c->use_graphs < 0) c->use_graphs = getenv("VM_NO_GRAPH") ? 0 : 1;
     if (!c->use_graphs) return nullptr;
     for (auto &g : c->graphs)
-        if (g.exact == exact && g.n == n && g.w == w && g.h == h && g.cap == cap && g.fixed_work == fixed_work &&
+        if (g.math_mode == math_mode && g.n == n && g.w == w && g.h == h && g.cap == cap && g.fixed_work == fixed_work &&
             g.threads == threads && g.dense == dense && g.rev == c->commit_reversed && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
             memcmp(&g.kp, &c->kp, sizeof(c->kp)) == 0)
             return g.exec;
@@ -695,18 +721,17 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
         return nullptr;
     }
     const int offs[4][2] = {{0, 0}, {VM_TILE_W, 0}, {0, VM_TILE_H}, {VM_TILE_W, VM_TILE_H}};
+    const SweepLaunchers &SL = sweep_launchers(math_mode);
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (ok) {
         for (int it = 0; it < VM_GRAPH_ITERS; ++it) {
             for (int k = 0; k < 4; ++k) {
-                if (exact) vm_launch_optimize_exact(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, c->iter_dev, dense, c->stream);
-                else vm_launch_optimize_fast(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, c->iter_dev, dense, c->stream);
+                SL.optimize(c->views, n, cap, w, h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, c->iter_dev, dense, c->stream);
             }
         }
-        if (exact) vm_launch_next_iter_exact(c->iter_dev, 0, VM_GRAPH_ITERS, c->stream);
-        else vm_launch_next_iter_fast(c->iter_dev, 0, VM_GRAPH_ITERS, c->stream);
+        SL.next_iter(c->iter_dev, 0, VM_GRAPH_ITERS, c->stream);
         ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && graph;
     }
     if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -720,7 +745,7 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, bool exact, int n, int w, int h, in
         for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
         c->graphs.clear();
     }
-    c->graphs.push_back({exact, n, w, h, cap, fixed_work, threads, dense, c->commit_reversed, c->views, c->flags, c->stats, c->kp, exec});
+    c->graphs.push_back({math_mode, n, w, h, cap, fixed_work, threads, dense, c->commit_reversed, c->views, c->flags, c->stats, c->kp, exec});
     return exec;
 }
 
@@ -875,7 +900,8 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     }
     VM_HIP(hipMemsetAsync(c->flags, 0, words * 4, s));
     VM_HIP(hipMemsetAsync(c->stats, 0, words * 4 * VM_STAT_WORDS, s));
-    const bool exact = c->math_mode == VM_MATH_EXACT;
+    const bool exact = c->math_mode != VM_MATH_FAST; // EXACT and its FMA-contracted diagnostic build
+    const SweepLaunchers &SL = sweep_launchers(c->math_mode);
     // FAST kernels are built for at most 512 threads (256-VGPR budget: the register-cached
     // window sums must not spill), EXACT ones for up to 1024
     const int threads = std::min(c->sweep_threads ? c->sweep_threads : 512, exact ? 1024 : 512);
@@ -930,8 +956,8 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         want_pass = false;
     }
     if (want_pass) { // a 256-workgroup chunk of the launch must fit the device at once
-        int &res = c->pass_resident[c->math_mode == VM_MATH_EXACT ? 0 : 1];
-        if (res < 0) res = c->math_mode == VM_MATH_EXACT ? vm_pass_resident_blocks_exact(c->device) : vm_pass_resident_blocks_fast(c->device);
+        int &res = c->pass_resident[c->math_mode == VM_MATH_EXACT ? 0 : (c->math_mode == VM_MATH_FAST ? 1 : 2)];
+        if (res < 0) res = SL.pass_resident(c->device);
         if (res < 256) {
             if (c->sweep_mode == VM_SWEEP_PASS)
                 return vm_fail(VM_E_STATE, "vm_optimize_level: the PASS schedule needs 256 co-resident workgroups, this device holds %d", res);
@@ -1049,16 +1075,15 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         if (sparse) {
             for (int i = 0; i < n; ++i)
                 VM_HIP(hipMemsetAsync(lv[i]->view.sp_cnt, 0, 8, s));
-            (exact ? vm_launch_optimize_sparse_exact : vm_launch_optimize_sparse_fast)(
+            SL.sparse(
                 c->views, n, cap, l0.w, l0.h, P, c->tables, c->flags, c->stats, done, nb, fixed_work, threads, dense, s);
             launches += 2;
             it0 = done + nb;
         }
         if (!split && !sparse && nb >= VM_GRAPH_ITERS) {
             // TILE batch: whole groups of VM_GRAPH_ITERS iterations are graph replays
-            if (hipGraphExec_t ge = sweep_graph(c, exact, n, l0.w, l0.h, cap, fixed_work, threads, dense, P)) {
-                if (exact) vm_launch_next_iter_exact(c->iter_dev, 1, done, s);
-                else vm_launch_next_iter_fast(c->iter_dev, 1, done, s);
+            if (hipGraphExec_t ge = sweep_graph(c, c->math_mode, n, l0.w, l0.h, cap, fixed_work, threads, dense, P)) {
+                SL.next_iter(c->iter_dev, 1, done, s);
                 for (; it0 + VM_GRAPH_ITERS <= done + nb; it0 += VM_GRAPH_ITERS) {
                     VM_HIP(hipGraphLaunch(ge, s));
                     launches += 4 * VM_GRAPH_ITERS;
@@ -1068,7 +1093,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         for (int it = it0; it < done + nb; ++it)
             for (int k = 0; k < 4; ++k) {
                 if (pass) {
-                    (exact ? vm_launch_optimize_pass_exact : vm_launch_optimize_pass_fast)(
+                    SL.pass(
                         c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], 1u + (uint32_t)((it * 4 + k) * 4),
                         c->pass_bar + (size_t)((it - done) * 4 + k) * pass_groups * VM_PASS_SYNC_WORDS, c->flags, c->stats, it, fixed_work,
                         c->step_slots + (size_t)(sb & 1) * c->step_slots_words,
@@ -1080,7 +1105,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
                 } else if (step) {
                     for (int ph = 0; ph < 4; ++ph, ++sb) {
                         const uint32_t epoch = 1u + (uint32_t)((it * 4 + k) * 4 + ph);
-                        (exact ? vm_launch_optimize_step_exact : vm_launch_optimize_step_fast)(
+                        SL.step(
                             c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], ph >> 1, ph & 1, epoch,
                             sb == 0 ? 0u : epoch - 1u, sb & 1, 1, c->flags, c->stats, it, fixed_work, threads, parts,
                             c->step_slots + (size_t)(sb & 1) * c->step_slots_words,
@@ -1090,24 +1115,22 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
                     }
                     launches += 4;
                 } else if (split) {
-                    if (exact) vm_launch_optimize_split_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
-                    else vm_launch_optimize_split_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
+                    SL.split(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
                     launches += 8;
                 } else {
-                    if (exact) vm_launch_optimize_exact(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, s);
-                    else vm_launch_optimize_fast(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, s);
+                    SL.optimize(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, s);
                     ++launches;
                 }
             }
         if (step) { // fold the last phase's records in place: copy 0 is complete again
-            (exact ? vm_launch_optimize_step_exact : vm_launch_optimize_step_fast)(
+            SL.step(
                 c->views, n, cap, l0.w, l0.h, P, c->tables, 0, 0, 0, 0, 0u, last_epoch, 2, 0, c->flags, c->stats,
                 done + nb - 1, fixed_work, threads, parts, c->step_slots + (size_t)(sb & 1) * c->step_slots_words,
                 c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, sb == 0 ? -1 : slot_iter, s);
             ++launches;
         }
         if (pass && sb > 0) { // the counts the last launch left in its slots
-            (exact ? vm_launch_optimize_pass_exact : vm_launch_optimize_pass_fast)(
+            SL.pass(
                 c->views, n, cap, l0.w, l0.h, P, c->tables, 0, 0, 0u, nullptr, c->flags, c->stats, done + nb - 1, fixed_work,
                 nullptr, c->step_slots + (size_t)((sb + 1) & 1) * c->step_slots_words, slot_iter, c->pass_err, nullptr, 0, pass_switches, s);
             ++launches;

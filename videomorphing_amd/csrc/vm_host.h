@@ -75,7 +75,7 @@ struct vm_ctx {
     uint32_t *pass_bar = nullptr;
     size_t pass_bar_words = 0;
     uint32_t *pass_err = nullptr, *pass_err_host = nullptr;
-    int pass_resident[2] = {-1, -1}; // co-resident k_pass workgroups on this device (EXACT, FAST build); -1: not asked yet
+    int pass_resident[3] = {-1, -1, -1}; // co-resident k_pass workgroups on this device (EXACT, FAST, EXACT_FMA build); -1: not asked yet
     uint32_t *pass_dbg = nullptr;    // vm_dbg_pass_xcd: 256 words, XCC id per workgroup of the last launch
     void *pass_snap = nullptr;       // AUTO: the levels' slabs as they stood before the current PASS batch
     size_t pass_snap_bytes = 0;
@@ -93,7 +93,7 @@ struct vm_ctx {
     // hipGraph replay of launch-bound TILE sweeps (vm_api.cpp): 8 iterations per graph
     int *iter_dev = nullptr;         // device iteration counter read by the replayed kernels
     struct SweepGraph {
-        bool exact;
+        int math_mode;
         int n, w, h, cap, fixed_work, threads, dense, rev;
         const void *views, *flags, *stats;
         vm_kern_params kp;

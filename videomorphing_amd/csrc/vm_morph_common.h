@@ -11,7 +11,11 @@
 #error "define VM_EXACT to 0 or 1"
 #endif
 
-#if VM_EXACT
+#if VM_EXACT == 2
+// the EXACT source compiled with -ffp-contract=fast (VM_MATH_EXACT_FMA, sweeps only): fused multiply-adds
+// wherever the compiler contracts, IEEE division and square root
+#define SUF(name) name##_exactf
+#elif VM_EXACT
 #define SUF(name) name##_exact
 #else
 #define SUF(name) name##_fast
