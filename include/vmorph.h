@@ -72,13 +72,18 @@ enum {
     VM_MATH_FAST  = 1,  /* fused multiply-add, v_rcp/v_sqrt approximations: the
                            analogue of the reference's --use_fast_math build
                            (MdiEditor.vcxproj:208-213) */
-    VM_MATH_EXACT_FMA = 2 /* diagnostic: the EXACT source compiled with -ffp-contract=fast --
+    VM_MATH_EXACT_FMA = 2, /* diagnostic: the EXACT source compiled with -ffp-contract=fast --
                            fused multiply-adds wherever the compiler contracts, IEEE division
                            and square root -- i.e. what nvcc's default --fmad=true makes of the
                            reference source WITHOUT --use_fast_math: one more legal rounding of
                            the same algorithm (sweep kernels only; not bit-comparable to the
                            oracle), used to measure the reproducibility floor FAST is judged
                            against (tests/test_gpu_fullsize.py) */
+    VM_MATH_REF_FASTMATH = 3 /* diagnostic: the EXACT source as the reference's project file compiles
+                           it -- --use_fast_math (MdiEditor.vcxproj:208-213): contraction plus
+                           approximate division (x * rcp(y), CUDA's __fdividef) and square root.  The
+                           reference's own expressions in the reference's own arithmetic: the third
+                           member of the family of legal builds */
 };
 
 /* progress of one optimize_level call; mirrors the public progress members of

@@ -591,12 +591,15 @@ def _oracle_energy(i0, i1, v):
 
 
 CHAOS_FRAMES = (0, 3, 6, 9, 12, 15)      # r03's bench: frames 6 and 12 are the ones whose finest level cycles in FAST
-# The family of equally legal runs of the reference algorithm: EXACT arithmetic with the four commit orders of
-# vm_set_commit_order (row-major = the oracle, reversed, column-major, c.-m. reversed: the reference leaves the order
-# to float atomics, morph.cu:951-1015), and the same source with fused multiply-adds (VM_MATH_EXACT_FMA: what nvcc's
-# default --fmad=true makes of the reference source) under two of the orders
+# The family of equally legal runs of the reference algorithm -- the reference's own expressions in the reference's own
+# order, every member: IEEE arithmetic without contraction under the four commit orders of vm_set_commit_order
+# (row-major = the oracle, reversed, column-major, c.-m. reversed: the reference leaves the order to float atomics,
+# morph.cu:951-1015); with fused multiply-adds (VM_MATH_EXACT_FMA: nvcc's default --fmad=true); and as the reference's
+# project file really compiles it, --use_fast_math (VM_MATH_REF_FASTMATH: contraction + approximate division and
+# square root, MdiEditor.vcxproj:208-213), each under two of the orders
 CHAOS_FAMILY = (("x0", capi.MATH_EXACT, 0), ("x1", capi.MATH_EXACT, 1), ("x2", capi.MATH_EXACT, 2), ("x3", capi.MATH_EXACT, 3),
-                ("f0", capi.MATH_EXACT_FMA, 0), ("f2", capi.MATH_EXACT_FMA, 2))
+                ("f0", capi.MATH_EXACT_FMA, 0), ("f2", capi.MATH_EXACT_FMA, 2),
+                ("r0", capi.MATH_REF_FASTMATH, 0), ("r2", capi.MATH_REF_FASTMATH, 2))
 
 
 def chaos_floor_measure(ctx, frames=CHAOS_FRAMES, family=CHAOS_FAMILY, w=1920, h=1080, keep_fields_of=None):
@@ -626,6 +629,7 @@ def chaos_floor_measure(ctx, frames=CHAOS_FRAMES, family=CHAOS_FAMILY, w=1920, h
             ex = [f[0] for f in family]
             pairs = [(a, b) for k, a in enumerate(ex) for b in ex[k + 1:]]
             opairs = [(a, b) for a, b in pairs if a[0] == "x" and b[0] == "x"]      # commit orders only
+            rpairs = [(a, b) for a, b in pairs if (a[0] == "r") != (b[0] == "r")]    # --use_fast_math against IEEE builds
             E = {k: _oracle_energy(i0, i1, out[k]) for k in out}
             Ex = [E[k] for k in ex]
             r = {
@@ -637,6 +641,7 @@ def chaos_floor_measure(ctx, frames=CHAOS_FRAMES, family=CHAOS_FAMILY, w=1920, h
                 "E_family": Ex, "E_fast": E["fast"],
                 # the quantities SURVEY 8(d) names: FAST against the oracle's run (x0), the floor = the family's range
                 "rms_floor": max(rms(a, b) for a, b in pairs), "rms_floor_orders_only": max(rms(a, b) for a, b in opairs),
+                "rms_fastmath_vs_ieee": [rms(a, b) for a, b in rpairs] if rpairs else None,
                 "rms_fast0": rms("fast", ex[0]),
                 "within_floor": min(within(a, b) for a, b in pairs), "within_fast0": within("fast", ex[0]),
                 "e_floor": (max(Ex) - min(Ex)) / Ex[0], "e_fast0": abs(E["fast"] - Ex[0]) / Ex[0],

@@ -676,12 +676,15 @@ def test_fast_energy_on_converged_solves_sits_at_the_chaos_floor(gpu_ctx, oracle
     assert max(dev_fast) <= 0.012 and max(rms_fast) <= 0.02, msg
 
 
+@pytest.mark.parametrize("variant", [capi.MATH_EXACT_FMA, capi.MATH_REF_FASTMATH])
 @pytest.mark.parametrize("sched", [capi.SWEEP_TILE, capi.SWEEP_STEP, capi.SWEEP_PASS, capi.SWEEP_AUTO])
-def test_exact_fma_mode_is_a_rounding_level_variant_of_exact(gpu_ctx, oracle, sched):
-    """VM_MATH_EXACT_FMA (diagnostic): the EXACT source with fused multiply-adds -- what nvcc's default
-    --fmad=true makes of the reference source.  Every schedule runs under it; after three sweeps from the
-    same start it agrees with EXACT to rounding level -- >= 97 % of the pixels within 0.01 px, the same
-    activity to 3 % -- and is not identical to it (so it does perturb the trajectory)."""
+def test_legal_arithmetic_variants_are_rounding_level_variants_of_exact(gpu_ctx, oracle, sched, variant):
+    """VM_MATH_EXACT_FMA (the EXACT source with fused multiply-adds: nvcc's default --fmad=true) and
+    VM_MATH_REF_FASTMATH (the same as the reference's project compiles it, --use_fast_math: contraction +
+    approximate division and square root) -- diagnostic builds of the sweep kernels.  Every schedule runs
+    under them; after three sweeps from the same start they agree with EXACT to rounding level -- >= 97 % of
+    the pixels within 0.01 px, the same activity to 3 % -- and are not identical to it (so they do perturb
+    the trajectory)."""
     w, h = 138, 84
     i0, i1 = synth.make_pair(w, h)
     v0 = (0.8 * synth.displacement(w, h)).astype(np.float32)
@@ -689,7 +692,7 @@ def test_exact_fma_mode_is_a_rounding_level_variant_of_exact(gpu_ctx, oracle, sc
     out = {}
     try:
         gpu_ctx.set_tuning(sched, 0, 0)
-        for mode in (capi.MATH_EXACT, capi.MATH_EXACT_FMA):
+        for mode in (capi.MATH_EXACT, variant):
             gpu_ctx.set_math_mode(mode)
             gpu_ctx.set_params(_kp(P))
             pyr = morph.Pyramid(gpu_ctx)
@@ -703,7 +706,7 @@ def test_exact_fma_mode_is_a_rounding_level_variant_of_exact(gpu_ctx, oracle, sc
     finally:
         gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
         gpu_ctx.set_math_mode(capi.MATH_EXACT)
-    a, b = out[capi.MATH_EXACT], out[capi.MATH_EXACT_FMA]
+    a, b = out[capi.MATH_EXACT], out[variant]
     d = np.sqrt(((a[0] - b[0]) ** 2).sum(-1))
     assert (d < 0.01).mean() >= 0.97, (d < 0.01).mean()
     assert abs(a[1] - b[1]) <= 0.03 * a[1] and abs(a[2] - b[2]) <= 0.03 * a[2], (a[1:], b[1:])

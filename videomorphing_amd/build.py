@@ -27,6 +27,9 @@ UNITS = [
     # VM_MATH_EXACT_FMA (diagnostic): the EXACT source with contraction on -- what nvcc's default --fmad=true
     # makes of the reference source; one more legal rounding of the algorithm for the chaos-floor tests
     ("vm_sweep_kernels.hip", "vm_sweep_kernels_exactf.o", ["-DVM_EXACT=2", "-ffp-contract=fast"]),
+    # VM_MATH_REF_FASTMATH (diagnostic): the same source as the reference's project compiles it -- --use_fast_math:
+    # contraction, approximate division and square root
+    ("vm_sweep_kernels.hip", "vm_sweep_kernels_reffm.o", ["-DVM_EXACT=3", "-ffp-contract=fast"]),
     # FAST fuses multiply-adds where the source says fmaf(), nowhere else: with -ffp-contract=fast
     # two inlined copies of one expression (a*b + c*d) may be contracted differently, and the
     # schedules would agree bit for bit only while their code is laid out alike (measured cost of

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvmorph_hip.so")
 VM_OK = 0
 VM_E_INVALID, VM_E_DEVICE, VM_E_STATE, VM_E_NUMERIC, VM_E_CANCELLED = -1, -2, -3, -4, -5
 BCOND_NONE, BCOND_CORNER, BCOND_BORDER = 0, 1, 2
-MATH_EXACT, MATH_FAST, MATH_EXACT_FMA = 0, 1, 2
+MATH_EXACT, MATH_FAST, MATH_EXACT_FMA, MATH_REF_FASTMATH = 0, 1, 2, 3
 SWEEP_AUTO, SWEEP_TILE, SWEEP_SPLIT, SWEEP_STEP, SWEEP_SPARSE, SWEEP_PASS = 0, 1, 2, 3, 4, 5
 
 FIELDS = {  # name -> (id, channels)

@@ -238,7 +238,7 @@ extern "C" int vm_get_params(vm_ctx *c, vm_kern_params *p)
 
 extern "C" int vm_set_math_mode(vm_ctx *c, int mode)
 {
-    if (!c || (mode != VM_MATH_EXACT && mode != VM_MATH_FAST && mode != VM_MATH_EXACT_FMA))
+    if (!c || mode < VM_MATH_EXACT || mode > VM_MATH_REF_FASTMATH)
         return vm_fail(VM_E_INVALID, "vm_set_math_mode: bad argument");
     c->math_mode = mode;
     return VM_OK;
@@ -696,7 +696,11 @@ static const SweepLaunchers &sweep_launchers(int math_mode)
     static const SweepLaunchers exactf = {vm_launch_optimize_exactf, vm_launch_next_iter_exactf, vm_launch_optimize_sparse_exactf,
                                           vm_launch_optimize_split_exactf, vm_launch_optimize_step_exactf, vm_launch_optimize_pass_exactf,
                                           vm_pass_resident_blocks_exactf};
-    return math_mode == VM_MATH_FAST ? fast : (math_mode == VM_MATH_EXACT_FMA ? exactf : exact);
+    // VM_MATH_REF_FASTMATH: that source as the reference's project file compiles it (--use_fast_math)
+    static const SweepLaunchers reffm = {vm_launch_optimize_reffm, vm_launch_next_iter_reffm, vm_launch_optimize_sparse_reffm,
+                                         vm_launch_optimize_split_reffm, vm_launch_optimize_step_reffm, vm_launch_optimize_pass_reffm,
+                                         vm_pass_resident_blocks_reffm};
+    return math_mode == VM_MATH_FAST ? fast : (math_mode == VM_MATH_EXACT_FMA ? exactf : (math_mode == VM_MATH_REF_FASTMATH ? reffm : exact));
 }
 
 // A hipGraph of VM_GRAPH_ITERS TILE-schedule iterations (4 pass launches each, one counter bump)
@@ -956,7 +960,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         want_pass = false;
     }
     if (want_pass) { // a 256-workgroup chunk of the launch must fit the device at once
-        int &res = c->pass_resident[c->math_mode == VM_MATH_EXACT ? 0 : (c->math_mode == VM_MATH_FAST ? 1 : 2)];
+        int &res = c->pass_resident[c->math_mode & 3];
         if (res < 0) res = SL.pass_resident(c->device);
         if (res < 256) {
             if (c->sweep_mode == VM_SWEEP_PASS)

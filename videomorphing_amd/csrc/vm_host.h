@@ -75,7 +75,7 @@ struct vm_ctx {
     uint32_t *pass_bar = nullptr;
     size_t pass_bar_words = 0;
     uint32_t *pass_err = nullptr, *pass_err_host = nullptr;
-    int pass_resident[3] = {-1, -1, -1}; // co-resident k_pass workgroups on this device (EXACT, FAST, EXACT_FMA build); -1: not asked yet
+    int pass_resident[4] = {-1, -1, -1, -1}; // co-resident k_pass workgroups on this device, per arithmetic build (math_mode); -1: not asked yet
     uint32_t *pass_dbg = nullptr;    // vm_dbg_pass_xcd: 256 words, XCC id per workgroup of the last launch
     void *pass_snap = nullptr;       // AUTO: the levels' slabs as they stood before the current PASS batch
     size_t pass_snap_bytes = 0;

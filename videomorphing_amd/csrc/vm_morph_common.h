@@ -11,7 +11,12 @@
 #error "define VM_EXACT to 0 or 1"
 #endif
 
-#if VM_EXACT == 2
+#if VM_EXACT == 3
+// VM_MATH_REF_FASTMATH (sweeps only): the EXACT source -- the reference's own expressions in its own order --
+// with what its project file compiles it with, --use_fast_math (MdiEditor.vcxproj:208-213): fused
+// multiply-adds, approximate division (x * rcp(y), CUDA: __fdividef) and approximate square root
+#define SUF(name) name##_reffm
+#elif VM_EXACT == 2
 // the EXACT source compiled with -ffp-contract=fast (VM_MATH_EXACT_FMA, sweeps only): fused multiply-adds
 // wherever the compiler contracts, IEEE division and square root
 #define SUF(name) name##_exactf
@@ -26,7 +31,7 @@ namespace {
 
 __device__ __forceinline__ float fdiv(float a, float b)
 {
-#if VM_EXACT
+#if VM_EXACT && VM_EXACT != 3
     return a / b;
 #else
     return a * __builtin_amdgcn_rcpf(b);
@@ -35,7 +40,7 @@ __device__ __forceinline__ float fdiv(float a, float b)
 
 __device__ __forceinline__ float fsqrt(float a)
 {
-#if VM_EXACT
+#if VM_EXACT && VM_EXACT != 3
     return sqrtf(a);
 #else
     return __builtin_amdgcn_sqrtf(a);

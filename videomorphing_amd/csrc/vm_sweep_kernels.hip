@@ -875,10 +875,10 @@ __device__ __forceinline__ void taps32(const VmLevelView &L, const TapLane &t, c
     taps32_finish(t, texel, wgt, lx, ly);
 }
 
-// sum over the window of (stored SSIM value - value with the pixel's lumas replaced by
-// lx, ly): ssim_change (morph.cu:671-728) on 32 lanes
+// one lane's term of ssim_change (morph.cu:671-728): stored SSIM value - value with the pixel's lumas
+// replaced by lx, ly, for the window neighbour whose sums `nb` holds (0 where there is none)
 template <bool INTERIOR>
-__device__ __forceinline__ float change32(const VmKParams &P, const Nb1 &nb, const PixelCtx &c, float lx, float ly)
+__device__ __forceinline__ float change_term(const VmKParams &P, const Nb1 &nb, const PixelCtx &c, float lx, float ly)
 {
     const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
     const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
@@ -897,7 +897,38 @@ __device__ __forceinline__ float change32(const VmKParams &P, const Nb1 &nb, con
                                     nb.X + dcross, n, P.ssim_clamp);
         acc = valid ? nb.VAL - val : 0.0f;
     }
-    return group_sum(acc, 32);
+    return acc;
+}
+
+// sum over the window: ssim_change on 32 lanes, one neighbour per lane
+template <bool INTERIOR>
+__device__ __forceinline__ float change32(const VmKParams &P, const Nb1 &nb, const PixelCtx &c, float lx, float ly)
+{
+    return group_sum(change_term<INTERIOR>(P, nb, c, lx, ly), 32);
+}
+
+// ... on 16 lanes, two neighbours per lane (k and k + 16): the two 16-lane trees of group_sum(., 32)
+// side by side, then its last stage -- the same additions in the same order, bit for bit
+__device__ __forceinline__ float tree16(float x)
+{
+    x += dpp_xor1(x);
+    x += dpp_xor2(x);
+    x += dpp_half_mirror(x);
+    x += dpp_mirror(x);
+    return x;
+}
+template <bool INTERIOR>
+__device__ __forceinline__ float change16x2(const VmKParams &P, const Nb1 &lo, const Nb1 &hi, const PixelCtx &c, float lx,
+                                            float ly)
+{
+    const float s_lo = tree16(change_term<INTERIOR>(P, lo, c, lx, ly));
+    const float s_hi = tree16(change_term<INTERIOR>(P, hi, c, lx, ly));
+    return s_lo + s_hi;
+}
+
+__device__ __forceinline__ float bcast_lane(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
 // prevent_foldover (morph.cu:872-883): lane s < 16 tests segment s & 7 of ring s >> 3
@@ -1043,59 +1074,70 @@ __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &
     return true;
 }
 
-// decide32 with a whole wave per pixel: the line search is a chain of dependent energy
-// evaluations (the only thing a launch-bound small level waits for), and the chip is idle there,
-// so the two halves of the wave evaluate two points at once --
-//   gradient: +eps and -eps of an axis side by side (2 rounds instead of 4),
-//   the two initial points of the golden section side by side,
-//   then per round the point the search needs now AND the point it will need next if the coming
-//   comparison goes the way the last one went (the next point's position depends only on that one
-//   bit).  When the guess holds the round completes two steps of the search.
-// Every evaluation that is USED is the one decide32 makes at that step (same point, same
-// arithmetic, same lanes' roles), so the result is bit-identical to decide32's; n_eval counts
-// the search's evaluations, not the speculative ones.
+// decide32 with a whole wave per pixel: the line search is a chain of dependent energy evaluations (the
+// only thing a launch-bound small level waits for), and the chip is idle there, so the wave's four
+// 16-lane rows evaluate FOUR points at once (round 4; rounds 2-3 took two, one per half):
+//   gradient: +eps / -eps of both axes side by side (one round instead of four),
+//   golden section, first round: its two initial points AND the two points its first step can ask for;
+//   then per round the point the search needs now, BOTH points the step after it can ask for (that
+//   step's position depends on one comparison only), and the point of a third step under the guess
+//   that the comparisons repeat (measured on the 120x68 level of a 1080p pair: they do for 99 % of the
+//   steps -- most accepted moves are small, the search keeps shrinking towards 0): two steps of the
+//   search per round for certain, three when the guess holds.
+// A row holds two window neighbours per lane (k and k + 16, fetched from the other half-row of the
+// 32-lane layout by one swizzle per sum); its taps, its 16 fold-over lanes and the two 16-lane trees
+// of the window sum are the 32-lane search's own instructions on the same values, and every
+// evaluation that is USED is the one decide32 makes at that step -- same point, same arithmetic -- so the
+// result is bit-identical to decide32's; n_eval counts the search's evaluations, not the speculative ones.
 template <bool INTERIOR, class Ring>
 __device__ __forceinline__ bool decide64(const VmLevelView &L, const VmKParams &P, const Nb1 &nb, const Ring &ring,
-                                         const PixelCtx &c, int sub, bool hi, float2 &step, float2 &luma,
+                                         const PixelCtx &c, int sub, bool, float2 &step, float2 &luma,
                                          uint32_t &n_eval)
 {
     n_eval += 4;
     const bool has_temp = L.temp_mask != nullptr; // uniform in the launch
     const float WT = has_temp ? P.w_temp * c.tmask * L.factor_d * L.inv_wh : 0.0f;
     const TapLane tl = tap_lane_make(L, sub);
+    const int row = (threadIdx.x >> 4) & 3; // which of the round's four points this lane works on
+    // window neighbours sub & 15 and (sub & 15) + 16: one is the lane's own, the other its partner's
+    Nb1 lo, hi;
+    {
+        Nb1 o;
+        o.A = swz_xor16(nb.A);
+        o.B = swz_xor16(nb.B);
+        o.VX = swz_xor16(nb.VX);
+        o.VY = swz_xor16(nb.VY);
+        o.X = swz_xor16(nb.X);
+        o.VAL = swz_xor16(nb.VAL);
+        o.N = swz_xor16(nb.N);
+        const bool low = sub < 16;
+        lo.A = low ? nb.A : o.A; hi.A = low ? o.A : nb.A;
+        lo.B = low ? nb.B : o.B; hi.B = low ? o.B : nb.B;
+        lo.VX = low ? nb.VX : o.VX; hi.VX = low ? o.VX : nb.VX;
+        lo.VY = low ? nb.VY : o.VY; hi.VY = low ? o.VY : nb.VY;
+        lo.X = low ? nb.X : o.X; hi.X = low ? o.X : nb.X;
+        lo.VAL = low ? nb.VAL : o.VAL; hi.VAL = low ? o.VAL : nb.VAL;
+        lo.N = low ? nb.N : o.N; hi.N = low ? o.N : nb.N;
+    }
     float lx, ly;
     float gx = 0, gy = 0;
     {
-        // compute_gradient (morph.cu:763-778): half 0 takes +eps (k = 0, 2), half 1 -eps (k = 1, 3)
-        const float sgn = hi ? -1.0f : 1.0f;
-        float g_tex[2], g_wgt[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const float dx = r == 0 ? sgn * P.eps : 0.0f, dy = r == 0 ? 0.0f : sgn * P.eps;
-            taps32_issue(L, tl, c, c.v.x + dx, c.v.y + dy, g_tex[r], g_wgt[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const float dx = r == 0 ? sgn * P.eps : 0.0f, dy = r == 0 ? 0.0f : sgn * P.eps;
-            taps32_finish(tl, g_tex[r], g_wgt[r], lx, ly);
-            const float change = change32<INTERIOR>(P, nb, c, lx, ly);
-            const float dd = dx * dx + dy * dy;
-            const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
-            const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
-            float e = (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
-            if (has_temp)
-                e = fmaf(WT, temp_change(c, dx, dy), e);
-            e *= sgn;
-            float e_lo, e_hi;
-            halves(e, e_lo, e_hi);
-            if (r == 0) {
-                gx += e_lo;
-                gx += e_hi;
-            } else {
-                gy += e_lo;
-                gy += e_hi;
-            }
-        }
+        // compute_gradient (morph.cu:763-778): row k takes evaluation k of decide32's loop
+        const float sgn = (row & 1) ? -1.0f : 1.0f;
+        const float dx = row < 2 ? sgn * P.eps : 0.0f, dy = row < 2 ? 0.0f : sgn * P.eps;
+        taps32(L, tl, c, c.v.x + dx, c.v.y + dy, lx, ly);
+        const float change = change16x2<INTERIOR>(P, lo, hi, c, lx, ly);
+        const float dd = dx * dx + dy * dy;
+        const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
+        const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
+        float e = (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
+        if (has_temp)
+            e = fmaf(WT, temp_change(c, dx, dy), e);
+        e *= sgn;
+        gx += bcast_lane(e, 0); // (0 + E+) + (-E-), as decide32
+        gx += bcast_lane(e, 16);
+        gy += bcast_lane(e, 32);
+        gy += bcast_lane(e, 48);
     }
     gx = -gx;
     gy = -gy;
@@ -1110,74 +1152,120 @@ __device__ __forceinline__ bool decide64(const VmLevelView &L, const VmKParams &
     const float Q2 = (WU * c.ui_axy + P.w_tps * c.tps_axy) * gg;
     const float Q1 = WU * (c.ui_b.x * gx + c.ui_b.y * gy) + P.w_tps * (c.tps_b.x * gx + c.tps_b.y * gy);
     const float T0 = fabsf(c.v.x - c.tref.x) + fabsf(c.v.y - c.tref.y);
-    // the energy at t of this half; f and the lumas of both halves come back
-#define ELINE2(T_, FLO_, FHI_, LLO_, LHI_)                                              \
+    // the energy along the line at this row's t; f and the lumas of all four rows come back
+    float f4[4];
+    float2 l4[4];
+#define ELINE4(T_)                                                                     \
     {                                                                                  \
         const float nvx_ = fmaf(gx, (T_), c.v.x), nvy_ = fmaf(gy, (T_), c.v.y);        \
         taps32(L, tl, c, nvx_, nvy_, lx, ly);                                          \
-        float f_ = fmaf(WS, change32<INTERIOR>(P, nb, c, lx, ly), (T_) * fmaf(Q2, (T_), Q1)); \
+        float f_ = fmaf(WS, change16x2<INTERIOR>(P, lo, hi, c, lx, ly), (T_) * fmaf(Q2, (T_), Q1)); \
         if (has_temp)                                                                  \
             f_ = fmaf(WT, (fabsf(nvx_ - c.tref.x) + fabsf(nvy_ - c.tref.y)) - T0, f_); \
-        halves(f_, (FLO_), (FHI_));                                                    \
-        halves(lx, (LLO_).x, (LHI_).x);                                                \
-        halves(ly, (LLO_).y, (LHI_).y);                                                \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                             \
+            f4[r_] = bcast_lane(f_, 16 * r_);                                          \
+            l4[r_] = make_float2(bcast_lane(lx, 16 * r_), bcast_lane(ly, 16 * r_));    \
+        }                                                                              \
     }
-    // golden_section_search, morph.cu:885-947
+    // golden_section_search, morph.cu:885-947.  One step of it, positions only: under the comparison `lt`
+    // [a, cc] <- [b, cc], b <- x  or  [a, cc] <- [a, x], x <- b, and one new point xn
     const float R = 0.618033989f, C = 1.0f - R;
+#define GS_POS(A_, B_, X_, CC_, LT_, A1_, B1_, X1_, CC1_, XN_)                         \
+    {                                                                                  \
+        const float p_ = (LT_) ? (X_) : (B_), q_ = (LT_) ? (CC_) : (A_);               \
+        (XN_) = p_ * R + q_ * C;                                                       \
+        (A1_) = (LT_) ? (B_) : (A_);                                                   \
+        (CC1_) = (LT_) ? (CC_) : (X_);                                                 \
+        (B1_) = (LT_) ? (X_) : (XN_);                                                  \
+        (X1_) = (LT_) ? (XN_) : (B_);                                                  \
+    }
+    // ... and its values: the new point's energy and lumas take the place decide32 gives them
+#define GS_VAL(LT_, F_, LF_)                                                           \
+    {                                                                                  \
+        const float ofb_ = fb;                                                         \
+        const float2 olb_ = lb;                                                        \
+        fb = (LT_) ? fx : (F_);                                                        \
+        fx = (LT_) ? (F_) : ofb_;                                                      \
+        lb = (LT_) ? lq : (LF_);                                                       \
+        lq = (LT_) ? (LF_) : olb_;                                                     \
+        ++n_eval;                                                                      \
+    }
     float a = 0;
     float b = cc * C, x = b * R + cc * C;
     float fb, fx;
     float2 lb, lq; // lumas at b and at x
-    ELINE2(hi ? x : b, fb, fx, lb, lq);
-    n_eval += 2;
+    {
+        // first round: b, x and both points the first step can ask for
+        float aT, bT, xT, ccT, nT, aF, bF, xF, ccF, nF;
+        GS_POS(a, b, x, cc, true, aT, bT, xT, ccT, nT);
+        GS_POS(a, b, x, cc, false, aF, bF, xF, ccF, nF);
+        const float t = row == 0 ? b : (row == 1 ? x : (row == 2 ? nT : nF));
+        ELINE4(t);
+        fb = f4[0];
+        fx = f4[1];
+        lb = l4[0];
+        lq = l4[1];
+        n_eval += 2;
+        if (cc - a > P.eps) {
+            const bool lt = fx < fb;
+            const float f = lt ? f4[2] : f4[3];
+            const float2 lf = lt ? l4[2] : l4[3];
+            a = lt ? aT : aF;
+            b = lt ? bT : bF;
+            x = lt ? xT : xF;
+            cc = lt ? ccT : ccF;
+            GS_VAL(lt, f, lf);
+        }
+    }
 #pragma unroll 1
     for (;;) {
         if (!(cc - a > P.eps))
             break;
+        // step 1 of the round: its comparison is known, its point A is not evaluated yet
         const bool lt = fx < fb;
-        // this step: [a, cc] <- [b, cc], b <- x  or  [a, cc] <- [a, x], x <- b;  one new point xn
-        const float p = lt ? x : b, qv = lt ? cc : a;
-        const float a1 = lt ? b : a, cc1 = lt ? cc : x;
-        const float xn = p * R + qv * C;
-        const float b1 = lt ? x : xn, x1 = lt ? xn : b;
-        // the step after it, should its comparison fall like this one did
-        // The guess: the comparison repeats.  Measured on the 120x68 level of the 1080p pair it
-        // holds for 99 % of the steps (most accepted moves are small: the search keeps shrinking
-        // towards 0); a parabola through the three known points predicted no better and cost more.
+        float a1, b1, x1, cc1, nA;
+        GS_POS(a, b, x, cc, lt, a1, b1, x1, cc1, nA);
+        // step 2: both points it can ask for
+        float aT, bT, xT, ccT, nT, aF, bF, xF, ccF, nF;
+        GS_POS(a1, b1, x1, cc1, true, aT, bT, xT, ccT, nT);
+        GS_POS(a1, b1, x1, cc1, false, aF, bF, xF, ccF, nF);
+        // step 3 under the guess that both comparisons fall like this one
         const bool G = lt;
-        const float p2 = G ? x1 : b1, q2 = G ? cc1 : a1;
-        const float xn2 = p2 * R + q2 * C;
-        float f1, f2;
-        float2 l1, l2;
-        ELINE2(hi ? xn2 : xn, f1, f2, l1, l2);
-        ++n_eval;
+        float a3, b3, x3, cc3, nG;
         {
-            const float nfb = lt ? fx : f1, nfx = lt ? f1 : fb;
-            const float2 nlb = lt ? lq : l1, nlq = lt ? l1 : lb;
-            a = a1;
-            cc = cc1;
-            b = b1;
-            x = x1;
-            fb = nfb;
-            fx = nfx;
-            lb = nlb;
-            lq = nlq;
+            const float ag = G ? aT : aF, bg = G ? bT : bF, xg = G ? xT : xF, ccg = G ? ccT : ccF;
+            GS_POS(ag, bg, xg, ccg, G, a3, b3, x3, cc3, nG);
         }
-        if (cc - a > P.eps && (fx < fb) == G) { // the guess held: f2 is the next step's evaluation
-            const float ob = b, ofb = fb;
-            const float2 olb = lb;
-            a = G ? b : a;
-            cc = G ? cc : x;
-            b = G ? x : xn2;
-            x = G ? xn2 : ob;
-            fb = G ? fx : f2;
-            fx = G ? f2 : ofb;
-            lb = G ? lq : l2;
-            lq = G ? l2 : olb;
-            ++n_eval;
+        const float t = row == 0 ? nA : (row == 1 ? nT : (row == 2 ? nF : nG));
+        ELINE4(t);
+        a = a1;
+        b = b1;
+        x = x1;
+        cc = cc1;
+        GS_VAL(lt, f4[0], l4[0]);
+        if (!(cc - a > P.eps))
+            break;
+        const bool lt2 = fx < fb;
+        {
+            const float f = lt2 ? f4[1] : f4[2];
+            const float2 lf = lt2 ? l4[1] : l4[2];
+            a = lt2 ? aT : aF;
+            b = lt2 ? bT : bF;
+            x = lt2 ? xT : xF;
+            cc = lt2 ? ccT : ccF;
+            GS_VAL(lt2, f, lf);
+        }
+        if (lt2 == G && cc - a > P.eps && (fx < fb) == G) { // the guess held: row 3 evaluated the third step's point
+            a = a3;
+            b = b3;
+            x = x3;
+            cc = cc3;
+            GS_VAL(G, f4[3], l4[3]);
         }
     }
-#undef ELINE2
+#undef ELINE4
+#undef GS_POS
+#undef GS_VAL
     const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
     if (!(fmin < 0))
         return false;
