@@ -1079,8 +1079,11 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         if (sparse) {
             for (int i = 0; i < n; ++i)
                 VM_HIP(hipMemsetAsync(lv[i]->view.sp_cnt, 0, 8, s));
+            // (forced SPARSE schedule with parts given: the LDS capacity of the word list, 0 < parts; parts = 1 is
+            // "as good as none": the list then lives in memory from the first pass it holds two words -- tests)
             SL.sparse(
-                c->views, n, cap, l0.w, l0.h, P, c->tables, c->flags, c->stats, done, nb, fixed_work, threads, dense, s);
+                c->views, n, cap, l0.w, l0.h, P, c->tables, c->flags, c->stats, done, nb, fixed_work, threads, dense,
+                c->sweep_mode == VM_SWEEP_SPARSE && c->sweep_parts > 0 ? c->sweep_parts : 1 << 20, s);
             launches += 2;
             it0 = done + nb;
         }

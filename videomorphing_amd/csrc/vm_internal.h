@@ -90,7 +90,8 @@ struct VmKParams {
     void vm_launch_optimize_sparse_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w, \
                                             int h, const VmKParams &P, const uint32_t *tables, \
                                             uint32_t *flags, uint32_t *stats, int it0, int nit, \
-                                            int fixed_work, int threads, int dense, hipStream_t s); \
+                                            int fixed_work, int threads, int dense, int lds_cap,   \
+                                            hipStream_t s);                                    \
     void vm_launch_optimize_split_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w, \
                                            int h, const VmKParams &P, const uint32_t *tables, \
                                            int offx, int offy, int pass, uint32_t *flags,     \

@@ -875,10 +875,10 @@ __device__ __forceinline__ void taps32(const VmLevelView &L, const TapLane &t, c
     taps32_finish(t, texel, wgt, lx, ly);
 }
 
-// one lane's term of ssim_change (morph.cu:671-728): stored SSIM value - value with the pixel's lumas
-// replaced by lx, ly, for the window neighbour whose sums `nb` holds (0 where there is none)
+// sum over the window of (stored SSIM value - value with the pixel's lumas replaced by
+// lx, ly): ssim_change (morph.cu:671-728) on 32 lanes
 template <bool INTERIOR>
-__device__ __forceinline__ float change_term(const VmKParams &P, const Nb1 &nb, const PixelCtx &c, float lx, float ly)
+__device__ __forceinline__ float change32(const VmKParams &P, const Nb1 &nb, const PixelCtx &c, float lx, float ly)
 {
     const float dmx = lx - c.old_luma.x, dmy = ly - c.old_luma.y;
     const float dvx = lx * lx - c.old_luma.x * c.old_luma.x;
@@ -897,38 +897,7 @@ __device__ __forceinline__ float change_term(const VmKParams &P, const Nb1 &nb, 
                                     nb.X + dcross, n, P.ssim_clamp);
         acc = valid ? nb.VAL - val : 0.0f;
     }
-    return acc;
-}
-
-// sum over the window: ssim_change on 32 lanes, one neighbour per lane
-template <bool INTERIOR>
-__device__ __forceinline__ float change32(const VmKParams &P, const Nb1 &nb, const PixelCtx &c, float lx, float ly)
-{
-    return group_sum(change_term<INTERIOR>(P, nb, c, lx, ly), 32);
-}
-
-// ... on 16 lanes, two neighbours per lane (k and k + 16): the two 16-lane trees of group_sum(., 32)
-// side by side, then its last stage -- the same additions in the same order, bit for bit
-__device__ __forceinline__ float tree16(float x)
-{
-    x += dpp_xor1(x);
-    x += dpp_xor2(x);
-    x += dpp_half_mirror(x);
-    x += dpp_mirror(x);
-    return x;
-}
-template <bool INTERIOR>
-__device__ __forceinline__ float change16x2(const VmKParams &P, const Nb1 &lo, const Nb1 &hi, const PixelCtx &c, float lx,
-                                            float ly)
-{
-    const float s_lo = tree16(change_term<INTERIOR>(P, lo, c, lx, ly));
-    const float s_hi = tree16(change_term<INTERIOR>(P, hi, c, lx, ly));
-    return s_lo + s_hi;
-}
-
-__device__ __forceinline__ float bcast_lane(float v, int lane)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+    return group_sum(acc, 32);
 }
 
 // prevent_foldover (morph.cu:872-883): lane s < 16 tests segment s & 7 of ring s >> 3
@@ -1074,70 +1043,65 @@ __device__ __forceinline__ bool decide32(const VmLevelView &L, const VmKParams &
     return true;
 }
 
-// decide32 with a whole wave per pixel: the line search is a chain of dependent energy evaluations (the
-// only thing a launch-bound small level waits for), and the chip is idle there, so the wave's four
-// 16-lane rows evaluate FOUR points at once (round 4; rounds 2-3 took two, one per half):
-//   gradient: +eps / -eps of both axes side by side (one round instead of four),
-//   golden section, first round: its two initial points AND the two points its first step can ask for;
-//   then per round the point the search needs now, BOTH points the step after it can ask for (that
-//   step's position depends on one comparison only), and the point of a third step under the guess
-//   that the comparisons repeat (measured on the 120x68 level of a 1080p pair: they do for 99 % of the
-//   steps -- most accepted moves are small, the search keeps shrinking towards 0): two steps of the
-//   search per round for certain, three when the guess holds.
-// A row holds two window neighbours per lane (k and k + 16, fetched from the other half-row of the
-// 32-lane layout by one swizzle per sum); its taps, its 16 fold-over lanes and the two 16-lane trees
-// of the window sum are the 32-lane search's own instructions on the same values, and every
-// evaluation that is USED is the one decide32 makes at that step -- same point, same arithmetic -- so the
-// result is bit-identical to decide32's; n_eval counts the search's evaluations, not the speculative ones.
+// decide32 with a whole wave per pixel: the line search is a chain of dependent energy
+// evaluations (the only thing a launch-bound small level waits for), and the chip is idle there,
+// so the two halves of the wave evaluate two points at once --
+//   gradient: +eps and -eps of an axis side by side (2 rounds instead of 4),
+//   the two initial points of the golden section side by side,
+//   then per round the point the search needs now AND the point it will need next if the coming
+//   comparison goes the way the last one went (the next point's position depends only on that one
+//   bit).  When the guess holds the round completes two steps of the search.
+// Every evaluation that is USED is the one decide32 makes at that step (same point, same
+// arithmetic, same lanes' roles), so the result is bit-identical to decide32's; n_eval counts
+// the search's evaluations, not the speculative ones.
+// (Round 4 tried FOUR points per round -- the wave's four 16-lane rows, two window neighbours per lane, the two
+// 16-lane trees of the 32-lane sum side by side: the gradient in one round, two golden-section steps per round
+// for certain and a third under the same guess; bit-identical, all schedule-equality tests green.  Measured: no
+// gain -- PASS 11.37 vs 11.15 us per phase, STEP 14.5 vs 14.1 (tools/dev_pass.py).  A round then costs ~255
+// instructions (two SSIM terms, two trees, 12 v_readlane broadcasts, the bookkeeping of a three-step speculation)
+// against ~150 here for ~2.7 instead of ~1.9 steps: 94 against 79 instructions per step of the search.  Removed.)
 template <bool INTERIOR, class Ring>
 __device__ __forceinline__ bool decide64(const VmLevelView &L, const VmKParams &P, const Nb1 &nb, const Ring &ring,
-                                         const PixelCtx &c, int sub, bool, float2 &step, float2 &luma,
+                                         const PixelCtx &c, int sub, bool hi, float2 &step, float2 &luma,
                                          uint32_t &n_eval)
 {
     n_eval += 4;
     const bool has_temp = L.temp_mask != nullptr; // uniform in the launch
     const float WT = has_temp ? P.w_temp * c.tmask * L.factor_d * L.inv_wh : 0.0f;
     const TapLane tl = tap_lane_make(L, sub);
-    const int row = (threadIdx.x >> 4) & 3; // which of the round's four points this lane works on
-    // window neighbours sub & 15 and (sub & 15) + 16: one is the lane's own, the other its partner's
-    Nb1 lo, hi;
-    {
-        Nb1 o;
-        o.A = swz_xor16(nb.A);
-        o.B = swz_xor16(nb.B);
-        o.VX = swz_xor16(nb.VX);
-        o.VY = swz_xor16(nb.VY);
-        o.X = swz_xor16(nb.X);
-        o.VAL = swz_xor16(nb.VAL);
-        o.N = swz_xor16(nb.N);
-        const bool low = sub < 16;
-        lo.A = low ? nb.A : o.A; hi.A = low ? o.A : nb.A;
-        lo.B = low ? nb.B : o.B; hi.B = low ? o.B : nb.B;
-        lo.VX = low ? nb.VX : o.VX; hi.VX = low ? o.VX : nb.VX;
-        lo.VY = low ? nb.VY : o.VY; hi.VY = low ? o.VY : nb.VY;
-        lo.X = low ? nb.X : o.X; hi.X = low ? o.X : nb.X;
-        lo.VAL = low ? nb.VAL : o.VAL; hi.VAL = low ? o.VAL : nb.VAL;
-        lo.N = low ? nb.N : o.N; hi.N = low ? o.N : nb.N;
-    }
     float lx, ly;
     float gx = 0, gy = 0;
     {
-        // compute_gradient (morph.cu:763-778): row k takes evaluation k of decide32's loop
-        const float sgn = (row & 1) ? -1.0f : 1.0f;
-        const float dx = row < 2 ? sgn * P.eps : 0.0f, dy = row < 2 ? 0.0f : sgn * P.eps;
-        taps32(L, tl, c, c.v.x + dx, c.v.y + dy, lx, ly);
-        const float change = change16x2<INTERIOR>(P, lo, hi, c, lx, ly);
-        const float dd = dx * dx + dy * dy;
-        const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
-        const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
-        float e = (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
-        if (has_temp)
-            e = fmaf(WT, temp_change(c, dx, dy), e);
-        e *= sgn;
-        gx += bcast_lane(e, 0); // (0 + E+) + (-E-), as decide32
-        gx += bcast_lane(e, 16);
-        gy += bcast_lane(e, 32);
-        gy += bcast_lane(e, 48);
+        // compute_gradient (morph.cu:763-778): half 0 takes +eps (k = 0, 2), half 1 -eps (k = 1, 3)
+        const float sgn = hi ? -1.0f : 1.0f;
+        float g_tex[2], g_wgt[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float dx = r == 0 ? sgn * P.eps : 0.0f, dy = r == 0 ? 0.0f : sgn * P.eps;
+            taps32_issue(L, tl, c, c.v.x + dx, c.v.y + dy, g_tex[r], g_wgt[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float dx = r == 0 ? sgn * P.eps : 0.0f, dy = r == 0 ? 0.0f : sgn * P.eps;
+            taps32_finish(tl, g_tex[r], g_wgt[r], lx, ly);
+            const float change = change32<INTERIOR>(P, nb, c, lx, ly);
+            const float dd = dx * dx + dy * dy;
+            const float v_tps = fmaf(c.tps_axy, dd, fmaf(c.tps_b.x, dx, c.tps_b.y * dy));
+            const float v_ui = fmaf(c.ui_axy, dd, fmaf(c.ui_b.x, dx, c.ui_b.y * dy));
+            float e = (P.w_ui * v_ui + P.w_ssim * change) * L.inv_wh + P.w_tps * v_tps;
+            if (has_temp)
+                e = fmaf(WT, temp_change(c, dx, dy), e);
+            e *= sgn;
+            float e_lo, e_hi;
+            halves(e, e_lo, e_hi);
+            if (r == 0) {
+                gx += e_lo;
+                gx += e_hi;
+            } else {
+                gy += e_lo;
+                gy += e_hi;
+            }
+        }
     }
     gx = -gx;
     gy = -gy;
@@ -1152,120 +1116,74 @@ __device__ __forceinline__ bool decide64(const VmLevelView &L, const VmKParams &
     const float Q2 = (WU * c.ui_axy + P.w_tps * c.tps_axy) * gg;
     const float Q1 = WU * (c.ui_b.x * gx + c.ui_b.y * gy) + P.w_tps * (c.tps_b.x * gx + c.tps_b.y * gy);
     const float T0 = fabsf(c.v.x - c.tref.x) + fabsf(c.v.y - c.tref.y);
-    // the energy along the line at this row's t; f and the lumas of all four rows come back
-    float f4[4];
-    float2 l4[4];
-#define ELINE4(T_)                                                                     \
+    // the energy at t of this half; f and the lumas of both halves come back
+#define ELINE2(T_, FLO_, FHI_, LLO_, LHI_)                                              \
     {                                                                                  \
         const float nvx_ = fmaf(gx, (T_), c.v.x), nvy_ = fmaf(gy, (T_), c.v.y);        \
         taps32(L, tl, c, nvx_, nvy_, lx, ly);                                          \
-        float f_ = fmaf(WS, change16x2<INTERIOR>(P, lo, hi, c, lx, ly), (T_) * fmaf(Q2, (T_), Q1)); \
+        float f_ = fmaf(WS, change32<INTERIOR>(P, nb, c, lx, ly), (T_) * fmaf(Q2, (T_), Q1)); \
         if (has_temp)                                                                  \
             f_ = fmaf(WT, (fabsf(nvx_ - c.tref.x) + fabsf(nvy_ - c.tref.y)) - T0, f_); \
-        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                             \
-            f4[r_] = bcast_lane(f_, 16 * r_);                                          \
-            l4[r_] = make_float2(bcast_lane(lx, 16 * r_), bcast_lane(ly, 16 * r_));    \
-        }                                                                              \
+        halves(f_, (FLO_), (FHI_));                                                    \
+        halves(lx, (LLO_).x, (LHI_).x);                                                \
+        halves(ly, (LLO_).y, (LHI_).y);                                                \
     }
-    // golden_section_search, morph.cu:885-947.  One step of it, positions only: under the comparison `lt`
-    // [a, cc] <- [b, cc], b <- x  or  [a, cc] <- [a, x], x <- b, and one new point xn
+    // golden_section_search, morph.cu:885-947
     const float R = 0.618033989f, C = 1.0f - R;
-#define GS_POS(A_, B_, X_, CC_, LT_, A1_, B1_, X1_, CC1_, XN_)                         \
-    {                                                                                  \
-        const float p_ = (LT_) ? (X_) : (B_), q_ = (LT_) ? (CC_) : (A_);               \
-        (XN_) = p_ * R + q_ * C;                                                       \
-        (A1_) = (LT_) ? (B_) : (A_);                                                   \
-        (CC1_) = (LT_) ? (CC_) : (X_);                                                 \
-        (B1_) = (LT_) ? (X_) : (XN_);                                                  \
-        (X1_) = (LT_) ? (XN_) : (B_);                                                  \
-    }
-    // ... and its values: the new point's energy and lumas take the place decide32 gives them
-#define GS_VAL(LT_, F_, LF_)                                                           \
-    {                                                                                  \
-        const float ofb_ = fb;                                                         \
-        const float2 olb_ = lb;                                                        \
-        fb = (LT_) ? fx : (F_);                                                        \
-        fx = (LT_) ? (F_) : ofb_;                                                      \
-        lb = (LT_) ? lq : (LF_);                                                       \
-        lq = (LT_) ? (LF_) : olb_;                                                     \
-        ++n_eval;                                                                      \
-    }
     float a = 0;
     float b = cc * C, x = b * R + cc * C;
     float fb, fx;
     float2 lb, lq; // lumas at b and at x
-    {
-        // first round: b, x and both points the first step can ask for
-        float aT, bT, xT, ccT, nT, aF, bF, xF, ccF, nF;
-        GS_POS(a, b, x, cc, true, aT, bT, xT, ccT, nT);
-        GS_POS(a, b, x, cc, false, aF, bF, xF, ccF, nF);
-        const float t = row == 0 ? b : (row == 1 ? x : (row == 2 ? nT : nF));
-        ELINE4(t);
-        fb = f4[0];
-        fx = f4[1];
-        lb = l4[0];
-        lq = l4[1];
-        n_eval += 2;
-        if (cc - a > P.eps) {
-            const bool lt = fx < fb;
-            const float f = lt ? f4[2] : f4[3];
-            const float2 lf = lt ? l4[2] : l4[3];
-            a = lt ? aT : aF;
-            b = lt ? bT : bF;
-            x = lt ? xT : xF;
-            cc = lt ? ccT : ccF;
-            GS_VAL(lt, f, lf);
-        }
-    }
+    ELINE2(hi ? x : b, fb, fx, lb, lq);
+    n_eval += 2;
 #pragma unroll 1
     for (;;) {
         if (!(cc - a > P.eps))
             break;
-        // step 1 of the round: its comparison is known, its point A is not evaluated yet
         const bool lt = fx < fb;
-        float a1, b1, x1, cc1, nA;
-        GS_POS(a, b, x, cc, lt, a1, b1, x1, cc1, nA);
-        // step 2: both points it can ask for
-        float aT, bT, xT, ccT, nT, aF, bF, xF, ccF, nF;
-        GS_POS(a1, b1, x1, cc1, true, aT, bT, xT, ccT, nT);
-        GS_POS(a1, b1, x1, cc1, false, aF, bF, xF, ccF, nF);
-        // step 3 under the guess that both comparisons fall like this one
+        // this step: [a, cc] <- [b, cc], b <- x  or  [a, cc] <- [a, x], x <- b;  one new point xn
+        const float p = lt ? x : b, qv = lt ? cc : a;
+        const float a1 = lt ? b : a, cc1 = lt ? cc : x;
+        const float xn = p * R + qv * C;
+        const float b1 = lt ? x : xn, x1 = lt ? xn : b;
+        // the step after it, should its comparison fall like this one did
+        // The guess: the comparison repeats.  Measured on the 120x68 level of the 1080p pair it
+        // holds for 99 % of the steps (most accepted moves are small: the search keeps shrinking
+        // towards 0); a parabola through the three known points predicted no better and cost more.
         const bool G = lt;
-        float a3, b3, x3, cc3, nG;
+        const float p2 = G ? x1 : b1, q2 = G ? cc1 : a1;
+        const float xn2 = p2 * R + q2 * C;
+        float f1, f2;
+        float2 l1, l2;
+        ELINE2(hi ? xn2 : xn, f1, f2, l1, l2);
+        ++n_eval;
         {
-            const float ag = G ? aT : aF, bg = G ? bT : bF, xg = G ? xT : xF, ccg = G ? ccT : ccF;
-            GS_POS(ag, bg, xg, ccg, G, a3, b3, x3, cc3, nG);
+            const float nfb = lt ? fx : f1, nfx = lt ? f1 : fb;
+            const float2 nlb = lt ? lq : l1, nlq = lt ? l1 : lb;
+            a = a1;
+            cc = cc1;
+            b = b1;
+            x = x1;
+            fb = nfb;
+            fx = nfx;
+            lb = nlb;
+            lq = nlq;
         }
-        const float t = row == 0 ? nA : (row == 1 ? nT : (row == 2 ? nF : nG));
-        ELINE4(t);
-        a = a1;
-        b = b1;
-        x = x1;
-        cc = cc1;
-        GS_VAL(lt, f4[0], l4[0]);
-        if (!(cc - a > P.eps))
-            break;
-        const bool lt2 = fx < fb;
-        {
-            const float f = lt2 ? f4[1] : f4[2];
-            const float2 lf = lt2 ? l4[1] : l4[2];
-            a = lt2 ? aT : aF;
-            b = lt2 ? bT : bF;
-            x = lt2 ? xT : xF;
-            cc = lt2 ? ccT : ccF;
-            GS_VAL(lt2, f, lf);
-        }
-        if (lt2 == G && cc - a > P.eps && (fx < fb) == G) { // the guess held: row 3 evaluated the third step's point
-            a = a3;
-            b = b3;
-            x = x3;
-            cc = cc3;
-            GS_VAL(G, f4[3], l4[3]);
+        if (cc - a > P.eps && (fx < fb) == G) { // the guess held: f2 is the next step's evaluation
+            const float ob = b, ofb = fb;
+            const float2 olb = lb;
+            a = G ? b : a;
+            cc = G ? cc : x;
+            b = G ? x : xn2;
+            x = G ? xn2 : ob;
+            fb = G ? fx : f2;
+            fx = G ? f2 : ofb;
+            lb = G ? lq : l2;
+            lq = G ? l2 : olb;
+            ++n_eval;
         }
     }
-#undef ELINE4
-#undef GS_POS
-#undef GS_VAL
+#undef ELINE2
     const float tmin = fx < fb ? x : b, fmin = fx < fb ? fx : fb;
     if (!(fmin < 0))
         return false;
@@ -1523,10 +1441,13 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
 // DENSE = false (FAST only): the variant for pruned sweeps -- every phase runs the lean line
 // search, 16 candidates per round; without the dense path the kernel needs 134 instead of
 // 256 VGPRs (measured: pruned sweeps 5-8 % faster).
+// sp_list / sp_cnt / sp_cap (SPARSE kernel, list kept in LDS): the set words this tile owns are appended to
+// the pass's new word list as they are written back (entries past sp_cap are only counted: overflow).
 template <bool DENSE, int SMAX = VM_SMAX, int MINF = VM_MIN_FANOUT, bool INTV = true>
 __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, const VmKParams &P,
                                            const uint32_t *__restrict__ tables, bool tables_staged, int ox, int oy,
-                                           int tid, int T, bool &improving, uint32_t &st_cand, uint32_t &st_commit)
+                                           int tid, int T, bool &improving, uint32_t &st_cand, uint32_t &st_commit,
+                                           uint32_t *sp_list = nullptr, uint32_t *sp_cnt = nullptr, uint32_t sp_cap = 0)
 {
     VM_TTSF(0);
     // --- improving-mask words of the tile and its ring of neighbour blocks ---
@@ -1826,8 +1747,15 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
     if (tid < g.nbx * g.nby) {
         int mx = tid % g.nbx, my = tid / g.nbx;
         // words owned by this tile: blocks that contain one of its pixels
-        if (mx >= 1 && mx <= g.nbx - 2 && my >= 1 && my <= g.nby - 2)
-            L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)] = S.mask[my][mx];
+        if (mx >= 1 && mx <= g.nbx - 2 && my >= 1 && my <= g.nby - 2) {
+            const uint32_t wi = (uint32_t)((g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)), wv = S.mask[my][mx];
+            L.impmask[wi] = wv;
+            if (sp_list && wv) {
+                const uint32_t k = atomicAdd(sp_cnt, 1u);
+                if (k < sp_cap)
+                    sp_list[k] = wi;
+            }
+        }
     }
     improving = improving || tile_improving;
     VM_TTSF(3);
@@ -1897,11 +1825,13 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
 // the words those tiles own.  A converged level costs a few barriers per pass; pairs of a batch
 // advance independently.  Tiles of one pass touch disjoint state, so their order is free: the
 // results are bit-identical to the TILE schedule.
+#define VM_SPARSE_LDS_CAP 1024
 struct SparseLds {
     uint32_t tilebits[256]; // tiles of the current pass with a set mask word in their window
-    int done[128];          // tiles swept in this pass (for the list update)
+    int done[128];          // (list in memory) tiles swept in this pass, for the list update
     int ndone;
     uint32_t nnew;
+    uint32_t wl[2][VM_SPARSE_LDS_CAP]; // (list in LDS) the non-zero mask words: current list and the next pass's
 };
 
 // does the mask window of the tile at (ox, oy) hold block (bx, by)?  (mask_geom: the words
@@ -1924,10 +1854,18 @@ __global__ __launch_bounds__(256) void SUF(k_sparse_scan)(const VmLevelView *__r
     }
 }
 
+// The word list lives in LDS while it fits (lds_cap <= VM_SPARSE_LDS_CAP entries; round 4): building the
+// tile set of a pass, carrying the list over and adding the words of the swept tiles then touch no memory
+// at all.  (In memory the same steps were three chains of dependent loads -- list entry -> mask word ->
+// stamp -- per pass: ~10 us of the ~25 us a pass of a cycling level took.)  A word of the list can only
+// have changed if a swept tile owns it (at most one tile of a pass owns a word: the 5-pixel gaps are as
+// wide as a block); such entries are dropped and come back from tile_sweep, which appends the set words a
+// tile owns as it writes them back.  Should the list outgrow LDS, the kernel rescans the level into the
+// lists in memory and goes on there (lds_cap = 0 forces that path: tests).
 template <bool DENSE>
 __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1))) void SUF(k_sparse)(
     const VmLevelView *__restrict__ views, int cap, VmKParams P, const uint32_t *__restrict__ tables,
-    uint32_t *__restrict__ flags, uint32_t *__restrict__ stats, int it0, int nit, int fixed_work)
+    uint32_t *__restrict__ flags, uint32_t *__restrict__ stats, int it0, int nit, int fixed_work, int lds_cap)
 {
     __shared__ TileLds S;
     __shared__ SparseLds Q;
@@ -1945,8 +1883,13 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
     const int ntw = (gx * gy + 31) / 32; // <= 256 (the host checks)
     const int nwords = L.imp_rs * L.imp_rows;
     uint32_t *const lists[2] = {L.sp_wl, L.sp_wl + nwords};
+    const uint32_t lcap = (uint32_t)min(max(lds_cap, 0), VM_SPARSE_LDS_CAP);
     int cur = 0;
     uint32_t nw = L.sp_cnt[0]; // length of the current list (from k_sparse_scan); then carried in registers
+    bool in_lds = nw <= lcap;   // uniform
+    if (in_lds)
+        for (uint32_t k = tid; k < nw; k += T)
+            Q.wl[0][k] = L.sp_wl[k];
     __syncthreads();
     for (int it = it0; it < it0 + nit; ++it) {
         // no set mask word anywhere: no tile of any pass of any later iteration can be active --
@@ -1959,8 +1902,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
             S.n_eval = 0;
         for (int pass = 0; pass < 4; ++pass) {
             const int offx = (pass & 1) ? VM_TILE_W : 0, offy = (pass & 2) ? VM_TILE_H : 0; // morph.cu:1382-1385
-            const uint32_t *list = lists[cur];
-            uint32_t *nlist = lists[cur ^ 1];
+            const uint32_t *list = in_lds ? Q.wl[cur] : lists[cur];
             // ---- 1. the tiles of this pass whose mask window holds a listed word ----
             for (int k = tid; k < ntw; k += T)
                 Q.tilebits[k] = 0;
@@ -1988,7 +1930,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                     const int t = wd * 32 + __ffs(bits) - 1;
                     bits &= bits - 1;
                     const int ox = (t % gx) * VM_PITCH_X + offx, oy = (t / gx) * VM_PITCH_Y + offy;
-                    if (tile_sweep<DENSE>(S, L, P, tables, true, ox, oy, tid, T, improving, st_cand, st_commit)) {
+                    if (tile_sweep<DENSE>(S, L, P, tables, true, ox, oy, tid, T, improving, st_cand, st_commit,
+                                          in_lds ? Q.wl[cur ^ 1] : nullptr, &Q.nnew, lcap)) {
                         ++st_tiles;
                         if (tid == 0) {
                             if (Q.ndone < 128)
@@ -2001,6 +1944,52 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
             }
             // ---- 3. the list for the next pass: old entries that are still set, plus the set
             // words the swept tiles own (no other word can have changed) ----
+            if (in_lds) {
+                // an entry owned by a swept tile has been dealt with by that tile (appended again if still
+                // set); every other entry is unchanged, hence still set
+                uint32_t *nl = Q.wl[cur ^ 1];
+                for (uint32_t k = tid; k < nw; k += T) {
+                    const uint32_t wi = list[k];
+                    const int bx = (int)(wi % (uint32_t)L.imp_rs) - 1, by = (int)(wi / (uint32_t)L.imp_rs) - 1;
+                    // the tile of this pass that holds a pixel of block (bx, by), if any
+                    bool swept = false;
+                    const int nx = 5 * bx + 4 - offx, ny = 5 * by + 4 - offy;
+                    if (nx >= 0 && ny >= 0) {
+                        const int c = nx / VM_PITCH_X, r = ny / VM_PITCH_Y;
+                        const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
+                        if (c < gx && r < gy && ox < L.w && oy < L.h && 5 * bx <= min(ox + VM_TILE_W - 1, L.w - 1) &&
+                            5 * by <= min(oy + VM_TILE_H - 1, L.h - 1))
+                            swept = (Q.tilebits[(r * gx + c) >> 5] >> ((r * gx + c) & 31)) & 1u;
+                    }
+                    if (!swept) {
+                        const uint32_t q = atomicAdd(&Q.nnew, 1u);
+                        if (q < lcap)
+                            nl[q] = wi;
+                    }
+                }
+                __syncthreads();
+                nw = Q.nnew;
+                if (nw > lcap) {
+                    // outgrown: every set word of the level into list 0 in memory, and on from there
+                    __syncthreads();
+                    if (tid == 0)
+                        Q.nnew = 0;
+                    __syncthreads();
+                    for (int wi = tid; wi < nwords; wi += T)
+                        if (L.impmask[wi] != 0)
+                            lists[0][atomicAdd(&Q.nnew, 1u)] = (uint32_t)wi;
+                    __syncthreads();
+                    nw = Q.nnew;
+                    in_lds = false;
+                    cur = 1; // (flipped to 0 below)
+                    for (int wi = tid; wi < nwords; wi += T)
+                        L.sp_stamp[wi] = 0; // stamps are epochs of the passes walked in memory
+                }
+                cur ^= 1;
+                __syncthreads(); // Q.nnew is reset at the top of the next pass
+                continue;
+            }
+            uint32_t *nlist = lists[cur ^ 1];
             const uint32_t epoch = (uint32_t)(it * 4 + pass) + 1u;
             for (uint32_t k = tid; k < nw; k += T) {
                 const uint32_t wi = list[k];
@@ -3563,20 +3552,20 @@ void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int 
 // a batch of `nit` iterations of the SPARSE schedule: list scan + one workgroup per pair
 void SUF(vm_launch_optimize_sparse)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
                                     const uint32_t *tables, uint32_t *flags, uint32_t *stats, int it0, int nit,
-                                    int fixed_work, int threads, int dense, hipStream_t s)
+                                    int fixed_work, int threads, int dense, int lds_cap, hipStream_t s)
 {
     const int nwords = ((w + 4) / 5 + 2) * ((h + 4) / 5 + 2);
     hipLaunchKernelGGL(SUF(k_sparse_scan), dim3((nwords + 255) / 256, 1, nbatch), dim3(256), 0, s, views);
 #if !VM_EXACT
     if (!dense) {
         hipLaunchKernelGGL(SUF(k_sparse)<false>, dim3(1, 1, nbatch), dim3(threads), 0, s, views, cap, P, tables, flags,
-                           stats, it0, nit, fixed_work);
+                           stats, it0, nit, fixed_work, lds_cap);
         return;
     }
 #endif
     (void)dense;
     hipLaunchKernelGGL(SUF(k_sparse)<true>, dim3(1, 1, nbatch), dim3(threads), 0, s, views, cap, P, tables, flags, stats,
-                       it0, nit, fixed_work);
+                       it0, nit, fixed_work, lds_cap);
 }
 
 // the device iteration counter of graph-replayed sweeps: set it to, or advance it by, `value`
