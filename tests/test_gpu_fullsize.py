@@ -761,12 +761,14 @@ def test_config2_batch_of_8_pairs_at_1080p_equals_individual_solves(gpu_ctx, mod
         gpu_ctx.set_math_mode(capi.MATH_EXACT)
 
 
-@pytest.mark.parametrize("npairs", [1, 3])
-def test_sparse_schedule_equals_tile_at_1080p(gpu_ctx, npairs):
+@pytest.mark.parametrize("npairs,lds_cap", [(1, 0), (3, 0), (1, 1), (1, 24), (3, 40)])
+def test_sparse_schedule_equals_tile_at_1080p(gpu_ctx, npairs, lds_cap):
     """config[1] geometry, FAST, 60 sweeps per level, fixed work: the SPARSE schedule (pruned levels
     swept by one workgroup per pair, 1-2 launches per batch of iterations) ends bit-identical to
     the TILE schedule (4 launches per iteration), alone and as a batch whose pairs advance
-    independently inside the sparse kernel; and it needs fewer launches"""
+    independently inside the sparse kernel; and it needs fewer launches.  lds_cap: the capacity of the
+    kernel's LDS-resident word list (0: the built-in 1024) -- 1 keeps the list in memory from the start, 24 / 40
+    make it outgrow LDS in mid-run (rescan of the level into the lists in memory, then on from there)."""
     gpu_ctx.set_math_mode(capi.MATH_FAST)
     gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
     w, h = 1920, 1080
@@ -774,7 +776,7 @@ def test_sparse_schedule_equals_tile_at_1080p(gpu_ctx, npairs):
     out = {}
     try:
         for sched in (capi.SWEEP_TILE, capi.SWEEP_SPARSE):
-            gpu_ctx.set_tuning(sched, 0, 0)
+            gpu_ctx.set_tuning(sched, 0, lds_cap if sched == capi.SWEEP_SPARSE else 0)
             batch = []
             for k in range(npairs):
                 pyr = morph.Pyramid(gpu_ctx)

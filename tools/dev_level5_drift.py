@@ -53,6 +53,8 @@ for f in frames:
         l0, l1 = p[el].field("img0"), p[el].field("img1")
         ctx.set_math_mode(mode)
         ctx.set_commit_order(order)
+        if name == "fast" and os.environ.get("VM_DRIFT_SCHED"):
+            ctx.set_tuning(int(os.environ["VM_DRIFT_SCHED"]), 0, int(os.environ.get("VM_DRIFT_PARTS", "0")))
         if mode != capi.MATH_EXACT:
             capi.check(L.vm_init_level(p._h, el - 1, w, h, None, 0))      # the variant's own SSIM values
         done, snaps = 0, {}
@@ -62,6 +64,7 @@ for f in frames:
             done = k
             snaps[k] = p[el].v
         out[name] = snaps
+        ctx.set_tuning(0, 0, 0)
         p.clear()
     ctx.set_math_mode(capi.MATH_EXACT)
     ctx.set_commit_order(0)
@@ -78,3 +81,14 @@ for f in frames:
             e = energy(l0, l1, v)
             line += "  %s: rms %.5f ahead %+.4f dE %+.5f%%" % (name, np.sqrt((d ** 2).sum(-1).mean()), float((d * travel).sum()) / t2, 100 * (e[0] - e_ex[0]) / e_ex[0])
         print(line, flush=True)
+        if os.environ.get("VM_DRIFT_WHERE"):
+            for name, _, _ in VAR[1:]:
+                dd = np.sqrt(((out[name][k] - ve) ** 2).sum(-1))
+                hh, ww = dd.shape
+                yy, xx = np.mgrid[0:hh, 0:ww]
+                edge = np.minimum(np.minimum(xx, ww - 1 - xx), np.minimum(yy, hh - 1 - yy))
+                big = dd > 0.03
+                top = np.argsort(dd.ravel())[-5:][::-1]
+                print("      %-6s max %.3f  >0.03: %3d px (of them within 4 of the border: %3d)  share of sum sq from >0.03: %.2f  rms of the rest %.5f  top: %s" % (
+                    name, dd.max(), int(big.sum()), int((big & (edge < 4)).sum()), float((dd[big] ** 2).sum() / max((dd ** 2).sum(), 1e-30)),
+                    float(np.sqrt((dd[~big] ** 2).mean())), [(int(t % ww), int(t // ww), round(float(dd.ravel()[t]), 3)) for t in top]), flush=True)

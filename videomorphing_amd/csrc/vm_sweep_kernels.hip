@@ -232,11 +232,22 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
 #define VM_SMAX 13
 #define VM_MIN_FANOUT 2
 #endif
+// The mean of a window whose first-moment sum is `sum`, with the pixel's luma changed by d: (sum + d) / n, the SUM
+// rounded first -- exactly the sum a commit of that move leaves in memory (m += d), so that the energy a line search
+// predicts is the energy the level then has.  Rounds 1-3 kept pre-divided means and evaluated fma(d, 1/n, mean): a
+// finer-grained landscape than the stored one.  A move accepted for a predicted gain below the rounding of the sums
+// could then LOSE energy once committed, and the descent lost its monotonicity at the noise floor: on the 120x68
+// level of config[1] a patch of border pixels (x = 0..1, y ~ 50-56, window counts 15 and 20) crept 0.2-0.37 px away
+// over ~150 iterations, uphill in the oracle's energy (+2-3 % of the level's total) -- 5 px at full resolution, and
+// the whole of FAST's excess distance from the family of legal builds (r04: tools/dev_level5_drift.py,
+// profiles/r04_notes.md).  Costs one instruction per mean (add + mul instead of one fma).
+__device__ __forceinline__ float window_mean(float sum, float d, float inv_n) { return (sum + d) * inv_n; }
+
 // SMAX = neighbours a lane may own: 13 with a fan-out of >= 2 lanes per pixel (the 256-VGPR dense
 // kernel), 7 with >= 4 (the 128-VGPR one: two workgroups per CU)
 template <int SMAX>
 struct NbCacheT {
-    float A[SMAX], B[SMAX];                   // window means (sum / n)
+    float A[SMAX], B[SMAX];                   // raw first-moment sums (window_mean() forms the means)
     float VX[SMAX], VY[SMAX], X[SMAX];        // raw second-moment sums
     float VAL[SMAX];                          // current SSIM value (value - new is summed,
                                               // as the reference does: 1e-3..1e-6 of the values)
@@ -319,8 +330,9 @@ __device__ __forceinline__ void nb_load(NbCacheT<SMAX> &nb, const VmLevelView &L
             in = n == 25.0f ? 0.04f : __builtin_amdgcn_rcpf(n);
             nb.N[j] = ok ? n : 0.0f; // 1/count is recomputed per evaluation: registers are scarcer than v_rcp
         }
-        nb.A[j] = m.x * in;
-        nb.B[j] = m.y * in;
+        (void)in;
+        nb.A[j] = m.x;
+        nb.B[j] = m.y;
         nb.VX[j] = q.x;
         nb.VY[j] = q.y;
         nb.X[j] = cr;
@@ -358,7 +370,7 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
             if (INTERIOR) {
                 // the last slot of a lane may lie past the 25th neighbour: it then holds a copy
                 // of the centre neighbour and is masked by the k < 25 test below
-                const float val = ssim_core(fmaf(dmx, 0.04f, nb.A[j]), fmaf(dmy, 0.04f, nb.B[j]), nb.VX[j] + dvx,
+                const float val = ssim_core(window_mean(nb.A[j], dmx, 0.04f), window_mean(nb.B[j], dmy, 0.04f), nb.VX[j] + dvx,
                                             nb.VY[j] + dvy, nb.X[j] + dcross, 25.0f, P.ssim_clamp);
                 const float d = nb.VAL[j] - val;
                 acc += ((threadIdx.x & (Lf - 1)) + j * Lf < 25) ? d : 0.0f;
@@ -366,7 +378,7 @@ __device__ __forceinline__ float energy_change(const VmLevelView &L, const VmKPa
                 const bool valid = nb.N[j] != 0.0f;
                 const float n = valid ? nb.N[j] : 25.0f;
                 const float in = n == 25.0f ? 0.04f : __builtin_amdgcn_rcpf(n);
-                const float val = ssim_core(fmaf(dmx, in, nb.A[j]), fmaf(dmy, in, nb.B[j]), nb.VX[j] + dvx,
+                const float val = ssim_core(window_mean(nb.A[j], dmx, in), window_mean(nb.B[j], dmy, in), nb.VX[j] + dvx,
                                             nb.VY[j] + dvy, nb.X[j] + dcross, n, P.ssim_clamp);
                 acc += valid ? nb.VAL[j] - val : 0.0f;
             }
@@ -751,7 +763,7 @@ __device__ __forceinline__ bool decide_x64(const VmLevelView &L, const VmKParams
 // golden-section loop is branch-free.  Same arithmetic per SSIM term as the generic FAST
 // path (ssim_core); the tap sums and the energy along the search line are re-associated.
 struct Nb1 {
-    float A, B, VX, VY, X, VAL, N; // N = window count, 0: lane owns no in-image neighbour
+    float A, B, VX, VY, X, VAL, N; // A, B: raw first-moment sums; N = window count, 0: lane owns no in-image neighbour
 };
 
 __device__ __forceinline__ float group_min32(float x)
@@ -785,9 +797,10 @@ __device__ __forceinline__ void nb1_make(Nb1 &nb, const VmLevelView &L, bool ok,
         n = ok ? (float)(window_count(qy, L.h) * window_count(qx, L.w)) : 25.0f;
         in = n == 25.0f ? 0.04f : __builtin_amdgcn_rcpf(n);
     }
+    (void)in;
     nb.N = ok ? n : 0.0f;
-    nb.A = m.x * in;
-    nb.B = m.y * in;
+    nb.A = m.x; // RAW first-moment sums: see window_mean()
+    nb.B = m.y;
     nb.VX = q.x;
     nb.VY = q.y;
     nb.X = cr;
@@ -886,14 +899,14 @@ __device__ __forceinline__ float change32(const VmKParams &P, const Nb1 &nb, con
     const float dcross = lx * ly - c.old_luma.x * c.old_luma.y;
     float acc;
     if (INTERIOR) {
-        const float val = ssim_core(fmaf(dmx, 0.04f, nb.A), fmaf(dmy, 0.04f, nb.B), nb.VX + dvx, nb.VY + dvy,
+        const float val = ssim_core(window_mean(nb.A, dmx, 0.04f), window_mean(nb.B, dmy, 0.04f), nb.VX + dvx, nb.VY + dvy,
                                     nb.X + dcross, 25.0f, P.ssim_clamp);
         acc = nb.N != 0.0f ? nb.VAL - val : 0.0f;
     } else {
         const bool valid = nb.N != 0.0f;
         const float n = valid ? nb.N : 25.0f;
         const float in = n == 25.0f ? 0.04f : __builtin_amdgcn_rcpf(n);
-        const float val = ssim_core(fmaf(dmx, in, nb.A), fmaf(dmy, in, nb.B), nb.VX + dvx, nb.VY + dvy,
+        const float val = ssim_core(window_mean(nb.A, dmx, in), window_mean(nb.B, dmy, in), nb.VX + dvx, nb.VY + dvy,
                                     nb.X + dcross, n, P.ssim_clamp);
         acc = valid ? nb.VAL - val : 0.0f;
     }
