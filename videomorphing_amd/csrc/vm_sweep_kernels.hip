@@ -1265,6 +1265,31 @@ __device__ __forceinline__ bool mask_hit(const uint32_t (*mask)[16], const uint3
     return hit;
 }
 
+// bits of mask word (bx, by) whose pixels lie inside [x0, x1] x [y0, y1]
+__device__ __forceinline__ uint32_t block_bits_in(int bx, int by, int x0, int x1, int y0, int y1)
+{
+    uint32_t cols = 0, m = 0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+        if (5 * bx + r >= x0 && 5 * bx + r <= x1)
+            cols |= 1u << r;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+        if (5 * by + r >= y0 && 5 * by + r <= y1)
+            m |= cols << (5 * r);
+    return m;
+}
+
+// Can the tile at (ox, oy) have a candidate at all?  A pixel is one iff a set mask bit lies within +-2 of it
+// (get_improve_mask_idx), so only the bits of the positions inside the tile's rectangle + 2 count -- pixels of this
+// tile or of the gaps around it, which no other tile of the pass owns: a race-free test, the same in every
+// schedule.  (Positions past the right / bottom image edge count: init_improving_mask sets whole words and
+// nothing clears the bits of pixels that do not exist, see k_pass.)
+__device__ __forceinline__ uint32_t tile_reach_bits(const VmLevelView &L, int ox, int oy, int bx, int by)
+{
+    return block_bits_in(bx, by, ox - 2, min(ox + VM_TILE_W - 1, L.w - 1) + 2, oy - 2, min(oy + VM_TILE_H - 1, L.h - 1) + 2);
+}
+
 // ordered compaction of the (at most 256) flagged phase pixels of a workgroup into
 // list[]: slot order, hence identical in every workgroup that looks at the same tile.
 // Every thread of the workgroup calls it; returns the number of entries.
@@ -1460,7 +1485,8 @@ template <bool DENSE, int SMAX = VM_SMAX, int MINF = VM_MIN_FANOUT, bool INTV = 
 __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, const VmKParams &P,
                                            const uint32_t *__restrict__ tables, bool tables_staged, int ox, int oy,
                                            int tid, int T, bool &improving, uint32_t &st_cand, uint32_t &st_commit,
-                                           uint32_t *sp_list = nullptr, uint32_t *sp_cnt = nullptr, uint32_t sp_cap = 0)
+                                           uint32_t *sp_list = nullptr, uint32_t *sp_val = nullptr, uint32_t *sp_cnt = nullptr,
+                                           uint32_t sp_cap = 0)
 {
     VM_TTSF(0);
     // --- improving-mask words of the tile and its ring of neighbour blocks ---
@@ -1471,11 +1497,18 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
         mymask = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)];
         S.mask[my][mx] = mymask;
     }
-    // tile-level early out: no set bit anywhere near the tile means no pixel of it is a
-    // candidate in any phase, and re-deriving the SSIM values from unchanged sums
-    // reproduces them bit for bit
-    if (!__syncthreads_or(mymask != 0))
-        return false;
+    // tile-level early out: no set bit within +-2 of the tile means no pixel of it is a candidate in
+    // phase 0, hence no commit, hence none in the later phases; and re-deriving the SSIM values from
+    // unchanged sums reproduces them bit for bit.  (Rounds 1-3 tested whole words of the window: a tile
+    // beside an active one was staged and walked through four empty phases, ~5 us a time -- a third of a
+    // cycling level's iteration.)
+    {
+        uint32_t reach = 0;
+        if (tid < g.nbx * g.nby)
+            reach = mymask & tile_reach_bits(L, ox, oy, g.bx0 + tid % g.nbx, g.by0 + tid / g.nbx);
+        if (!__syncthreads_or(reach != 0))
+            return false;
+    }
 
     if (!tables_staged) { // TILE: per launch, after the early out; SPARSE: once per kernel
         for (int k = tid; k < 625; k += T)
@@ -1765,8 +1798,10 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
             L.impmask[wi] = wv;
             if (sp_list && wv) {
                 const uint32_t k = atomicAdd(sp_cnt, 1u);
-                if (k < sp_cap)
+                if (k < sp_cap) {
                     sp_list[k] = wi;
+                    sp_val[k] = wv;
+                }
             }
         }
     }
@@ -1845,6 +1880,7 @@ struct SparseLds {
     int ndone;
     uint32_t nnew;
     uint32_t wl[2][VM_SPARSE_LDS_CAP]; // (list in LDS) the non-zero mask words: current list and the next pass's
+    uint32_t wv[2][VM_SPARSE_LDS_CAP]; // ... and their values
 };
 
 // does the mask window of the tile at (ox, oy) hold block (bx, by)?  (mask_geom: the words
@@ -1901,8 +1937,11 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
     uint32_t nw = L.sp_cnt[0]; // length of the current list (from k_sparse_scan); then carried in registers
     bool in_lds = nw <= lcap;   // uniform
     if (in_lds)
-        for (uint32_t k = tid; k < nw; k += T)
-            Q.wl[0][k] = L.sp_wl[k];
+        for (uint32_t k = tid; k < nw; k += T) {
+            const uint32_t wi = L.sp_wl[k];
+            Q.wl[0][k] = wi;
+            Q.wv[0][k] = L.impmask[wi];
+        }
     __syncthreads();
     for (int it = it0; it < it0 + nit; ++it) {
         // no set mask word anywhere: no tile of any pass of any later iteration can be active --
@@ -1926,12 +1965,14 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
             __syncthreads();
             for (uint32_t k = tid; k < nw; k += T) {
                 const int wi = (int)list[k];
+                const uint32_t wv = in_lds ? Q.wv[cur][k] : L.impmask[wi];
                 const int bx = wi % L.imp_rs - 1, by = wi / L.imp_rs - 1;
                 const int ce = (5 * bx - offx) / VM_PITCH_X, re = (5 * by - offy) / VM_PITCH_Y;
                 for (int r = max(re - 1, 0); r <= re + 1 && r < gy; ++r)
                     for (int c = max(ce - 1, 0); c <= ce + 1 && c < gx; ++c) {
                         const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
-                        if (ox < L.w && oy < L.h && tile_window_has(L, ox, oy, bx, by))
+                        // (tile_sweep's early-out test: a set bit within +-2 of the tile)
+                        if (ox < L.w && oy < L.h && tile_window_has(L, ox, oy, bx, by) && (wv & tile_reach_bits(L, ox, oy, bx, by)))
                             atomicOr(&Q.tilebits[(r * gx + c) >> 5], 1u << ((r * gx + c) & 31));
                     }
             }
@@ -1944,7 +1985,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                     bits &= bits - 1;
                     const int ox = (t % gx) * VM_PITCH_X + offx, oy = (t / gx) * VM_PITCH_Y + offy;
                     if (tile_sweep<DENSE>(S, L, P, tables, true, ox, oy, tid, T, improving, st_cand, st_commit,
-                                          in_lds ? Q.wl[cur ^ 1] : nullptr, &Q.nnew, lcap)) {
+                                          in_lds ? Q.wl[cur ^ 1] : nullptr, Q.wv[cur ^ 1], &Q.nnew, lcap)) {
                         ++st_tiles;
                         if (tid == 0) {
                             if (Q.ndone < 128)
@@ -1976,8 +2017,10 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                     }
                     if (!swept) {
                         const uint32_t q = atomicAdd(&Q.nnew, 1u);
-                        if (q < lcap)
+                        if (q < lcap) {
                             nl[q] = wi;
+                            Q.wv[cur ^ 1][q] = Q.wv[cur][k];
+                        }
                     }
                 }
                 __syncthreads();
@@ -2891,21 +2934,6 @@ template <class T> __device__ __forceinline__ T ldo(const char *base, uint32_t b
 template <class T> __device__ __forceinline__ void sto(const char *base, uint32_t byte_off, T v, bool wt)
 {
     sth((T *)const_cast<char *>(base + byte_off), v, wt);
-}
-
-// bits of mask word (bx, by) whose pixels lie inside [x0, x1] x [y0, y1]
-__device__ __forceinline__ uint32_t block_bits_in(int bx, int by, int x0, int x1, int y0, int y1)
-{
-    uint32_t cols = 0, m = 0;
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-        if (5 * bx + r >= x0 && 5 * bx + r <= x1)
-            cols |= 1u << r;
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-        if (5 * by + r >= y0 && 5 * by + r <= y1)
-            m |= cols << (5 * r);
-    return m;
 }
 
 #define VM_PASS_PARTS 32
