@@ -2,7 +2,7 @@
 # dev: register / LDS / spill figures of the sweep kernels (device-only compile)
 # usage: tools/kres.sh [fast|exact] [extra -D flags]
 mode=${1:-fast}; shift
-if [ "$mode" = exact ]; then F="-DVM_EXACT=1 -ffp-contract=off"; else F="-DVM_EXACT=0 -ffp-contract=fast"; fi
+if [ "$mode" = exact ]; then F="-DVM_EXACT=1 -ffp-contract=off"; else F="-DVM_EXACT=0 -ffp-contract=off"; fi   # the flags of videomorphing_amd/build.py
 src=${SRC:-videomorphing_amd/csrc/vm_sweep_kernels.hip}
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --offload-device-only -Iinclude $F "$@" -c $src -o /tmp/kres_$$.co || exit 1
 python3 -c "import sys; d=open(sys.argv[1],'rb').read(); open(sys.argv[1],'wb').write(d[d.find(b'\x7fELF'):])" /tmp/kres_$$.co

@@ -109,6 +109,7 @@ struct TileLds {
     uint32_t imp[225];
     uint32_t mask[6][16];    // improving-mask words covering the tile +-1 block
     uint32_t n_eval;         // energy evaluations of the workgroup (one count per candidate)
+    uint32_t dirty[(VM_NCELL + 31) / 32]; // lean kernels: cells a commit of this visit reached (only those are written back)
 };
 
 // the LDS of the SPLIT kernels: no window sums
@@ -1510,6 +1511,8 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
             return false;
     }
 
+    if (!DENSE && tid < (VM_NCELL + 31) / 32)
+        S.dirty[tid] = 0; // (ordered before the first gather by the barriers below)
     if (!tables_staged) { // TILE: per launch, after the early out; SPARSE: once per kernel
         for (int k = tid; k < 625; k += T)
             S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
@@ -1760,6 +1763,8 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                     float2 m = S.mean[cell], q = S.var[cell], tb = S.tpsb[cell];
                     float cr = S.cross[cell];
                     gather_cell_bits(S, L, ox, oy, rx, ry, pi, pj, sy0, sx0, rowbits, m, q, cr, tb, P.rev_commit);
+                    if (!DENSE)
+                        atomicOr(&S.dirty[cell >> 5], 1u << (cell & 31));
                     {
                         S.mean[cell] = m;
                         S.var[cell] = q;
@@ -1777,8 +1782,11 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
     VM_TTSF(2);
 
     // ---- SaveSSIM (morph.cu:1236-1256), tps.b and the owned mask words ----
+    // (a pruned visit commits a pixel or two: only the cells those commits reached have changed)
     if (tile_improving) {
         for (int c = tid; c < VM_NCELL; c += T) {
+            if (!DENSE && !((S.dirty[c >> 5] >> (c & 31)) & 1u))
+                continue;
             int gx = ox - 2 + c % VM_HALO_W, gy = oy - 2 + c / VM_HALO_W;
             if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h)
                 continue;
@@ -1881,6 +1889,8 @@ struct SparseLds {
     uint32_t nnew;
     uint32_t wl[2][VM_SPARSE_LDS_CAP]; // (list in LDS) the non-zero mask words: current list and the next pass's
     uint32_t wv[2][VM_SPARSE_LDS_CAP]; // ... and their values
+    int tl[64];                        // the tiles selected for this pass, in the order they were found
+    uint32_t ntl;                      // how many (entries past 64 are only counted: the bitmap is walked instead)
 };
 
 // does the mask window of the tile at (ox, oy) hold block (bx, by)?  (mask_geom: the words
@@ -1955,12 +1965,14 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
         for (int pass = 0; pass < 4; ++pass) {
             const int offx = (pass & 1) ? VM_TILE_W : 0, offy = (pass & 2) ? VM_TILE_H : 0; // morph.cu:1382-1385
             const uint32_t *list = in_lds ? Q.wl[cur] : lists[cur];
+            VM_TTSF(4);
             // ---- 1. the tiles of this pass whose mask window holds a listed word ----
             for (int k = tid; k < ntw; k += T)
                 Q.tilebits[k] = 0;
             if (tid == 0) {
                 Q.ndone = 0;
                 Q.nnew = 0;
+                Q.ntl = 0;
             }
             __syncthreads();
             for (uint32_t k = tid; k < nw; k += T) {
@@ -1972,16 +1984,26 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                     for (int c = max(ce - 1, 0); c <= ce + 1 && c < gx; ++c) {
                         const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
                         // (tile_sweep's early-out test: a set bit within +-2 of the tile)
-                        if (ox < L.w && oy < L.h && tile_window_has(L, ox, oy, bx, by) && (wv & tile_reach_bits(L, ox, oy, bx, by)))
-                            atomicOr(&Q.tilebits[(r * gx + c) >> 5], 1u << ((r * gx + c) & 31));
+                        if (ox < L.w && oy < L.h && tile_window_has(L, ox, oy, bx, by) && (wv & tile_reach_bits(L, ox, oy, bx, by))) {
+                            const uint32_t bit = 1u << ((r * gx + c) & 31);
+                            if (!(atomicOr(&Q.tilebits[(r * gx + c) >> 5], bit) & bit)) { // first to name this tile
+                                const uint32_t q = atomicAdd(&Q.ntl, 1u);
+                                if (q < 64)
+                                    Q.tl[q] = r * gx + c;
+                            }
+                        }
                     }
             }
             __syncthreads();
-            // ---- 2. sweep them, one after the other ----
-            for (int wd = 0; wd < ntw; ++wd) {
-                uint32_t bits = Q.tilebits[wd];
+            VM_TTSF(5);
+            // ---- 2. sweep them, one after the other (tiles of a pass touch disjoint state: any order) ----
+            // (a few tiles: straight from the list; many: the bitmap, word by word -- walking all of its up to 46
+            // words for the one tile of a cycling level was ~3 us of every pass)
+            const int ntl = (int)Q.ntl;
+            for (int wd = 0; wd < (ntl <= 64 ? ntl : ntw); ++wd) {
+                uint32_t bits = ntl <= 64 ? 1u : Q.tilebits[wd];
                 while (bits) {
-                    const int t = wd * 32 + __ffs(bits) - 1;
+                    const int t = ntl <= 64 ? Q.tl[wd] : wd * 32 + __ffs(bits) - 1;
                     bits &= bits - 1;
                     const int ox = (t % gx) * VM_PITCH_X + offx, oy = (t / gx) * VM_PITCH_Y + offy;
                     if (tile_sweep<DENSE>(S, L, P, tables, true, ox, oy, tid, T, improving, st_cand, st_commit,
@@ -1996,6 +2018,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                     __syncthreads(); // the tile's state and mask words are out before anything reads them
                 }
             }
+            VM_TTSF(6);
             // ---- 3. the list for the next pass: old entries that are still set, plus the set
             // words the swept tiles own (no other word can have changed) ----
             if (in_lds) {
@@ -2043,6 +2066,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                 }
                 cur ^= 1;
                 __syncthreads(); // Q.nnew is reset at the top of the next pass
+                VM_TTSF(7);
                 continue;
             }
             uint32_t *nlist = lists[cur ^ 1];
