@@ -160,3 +160,35 @@ def test_bench_reads_the_counters_of_its_own_workload_shape(tmp_path):
     assert isinstance(tj.get("entries"), list) and tj["entries"]
     for e in tj["entries"]:
         assert isinstance(e["config"], int) and isinstance(e["pairs_per_launch"], int) and isinstance(e["per_kernel"], dict)
+
+
+def test_bench_config2_chunks_and_batches():
+    """bench.config2_setup / config2_step (no GPU: stand-in contexts and pyramids): a rank's pairs go to its contexts
+    in contiguous chunks, a chunk is solved in EVEN batches of at most max_batch pairs, every pair exactly once per
+    step, one host thread per context"""
+    class Ctx(object):
+        pass
+
+    class Pyr(object):
+        def __init__(self, ctx, img):
+            self._ctx, self.img = ctx, img
+    frames = lambda ids: [("f%d" % i,) * 2 for i in ids]
+    for npairs, nctx_in, max_batch, want_B, want_nctx in ((60, 2, 32, 30, 2), (8, 2, 32, 4, 2), (7, 2, 32, 4, 2), (60, 1, 32, 30, 1),
+                                                            (1, 2, 32, 1, 1), (15, 2, 4, 4, 2)):
+        ctxs = [Ctx() for _ in range(nctx_in)]
+        pyrs, B, nctx, distinct = bench.config2_setup(list(range(100, 100 + npairs)), ctxs, frames, lambda c, img: Pyr(c, img), max_batch)
+        assert (B, nctx) == (want_B, want_nctx), (npairs, nctx_in, max_batch, B, nctx)
+        assert len(pyrs) == npairs and distinct == min(npairs, 8)
+        owners = [ctxs.index(p._ctx) for p in pyrs]
+        assert owners == sorted(owners) and set(owners) == set(range(nctx))            # contiguous chunks, every context used
+        assert max(owners.count(k) for k in range(nctx)) - min(owners.count(k) for k in range(nctx)) <= 1
+        assert [p.img[0] for p in pyrs] == ["f%d" % (100 + k % distinct) for k in range(npairs)]   # frames reused cyclically
+        groups = []
+
+        def solve_group(ps):
+            groups.append(list(ps))
+            return [id(p) for p in ps]
+        res = bench.config2_step(pyrs, ctxs[:nctx], B, solve_group)
+        assert sorted(res) == sorted(id(p) for p in pyrs)
+        assert all(1 <= len(g) <= B and len(set(p._ctx for p in g)) == 1 for g in groups)
+        assert sum(len(g) for g in groups) == npairs
