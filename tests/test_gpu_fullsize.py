@@ -703,6 +703,22 @@ def test_fast_solve_sits_at_the_chaos_floor_of_config1(gpu_ctx):
     assert (dpx <= 2).mean() >= 0.98 and dpx.mean() < 0.6, ((dpx <= 2).mean(), dpx.mean())
 
 
+def test_fast_sits_inside_the_family_at_config3(gpu_ctx):
+    """The same per-frame comparison at config[3] (3840x2160, 7 levels, 500 iterations per level): one more level
+    between the never-converging small levels and the result doubles what separates two legal builds (measured,
+    r04: family range 0.35-0.42 px RMS, 65-66 % of the pixels within 0.25 px; energies of the members up to 2x
+    apart) -- and FAST lies inside that range (0.27-0.35 px, 71-74 % within 0.25 px, energy not above the
+    family's).  Two frames."""
+    res = chaos_floor_measure(gpu_ctx, frames=(0, 3), w=3840, h=2160)
+    for f, r in res.items():
+        msg = (f, chaos_round(r))
+        assert r["rms_floor"] > 0.05, msg
+        assert r["rms_fast0"] <= 1.25 * r["rms_floor"], msg
+        assert r["within_fast0"] >= r["within_floor"] - 0.03, msg
+        assert r["e_fast0"] <= max(0.005, 1.25 * r["e_floor"]), msg
+        assert r["E_fast"] <= 1.05 * max(r["E_family"]), msg
+
+
 def test_fast_does_not_drift_on_the_never_converging_level(gpu_ctx):
     """Regression test of round 4's finding.  The 120x68 level of config[1] never converges within its 500
     iterations, so the final field of a solve is wherever that slow descent stands -- and whatever separates two
