@@ -248,7 +248,7 @@ extern "C" int vm_set_commit_order(vm_ctx *c, int order)
 {
     if (!c) return vm_fail(VM_E_INVALID, "vm_set_commit_order: ctx is NULL");
     if (order < 0 || order > 3) return vm_fail(VM_E_INVALID, "vm_set_commit_order: order %d (0 row-major, 1 reversed, 2 column-major, 3 column-major reversed)", order);
-    c->commit_reversed = order;
+    c->commit_order = order;
     return VM_OK;
 }
 
@@ -717,7 +717,7 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, int math_mode, int n, int w, int h,
     if (!c->use_graphs) return nullptr;
     for (auto &g : c->graphs)
         if (g.math_mode == math_mode && g.n == n && g.w == w && g.h == h && g.cap == cap && g.fixed_work == fixed_work &&
-            g.threads == threads && g.dense == dense && g.rev == c->commit_reversed && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
+            g.threads == threads && g.dense == dense && g.order == c->commit_order && g.views == c->views && g.flags == c->flags && g.stats == c->stats &&
             memcmp(&g.kp, &c->kp, sizeof(c->kp)) == 0)
             return g.exec;
     if (!c->iter_dev && hipMalloc((void **)&c->iter_dev, sizeof(int)) != hipSuccess) {
@@ -749,7 +749,7 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, int math_mode, int n, int w, int h,
         for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
         c->graphs.clear();
     }
-    c->graphs.push_back({math_mode, n, w, h, cap, fixed_work, threads, dense, c->commit_reversed, c->views, c->flags, c->stats, c->kp, exec});
+    c->graphs.push_back({math_mode, n, w, h, cap, fixed_work, threads, dense, c->commit_order, c->views, c->flags, c->stats, c->kp, exec});
     return exec;
 }
 
@@ -853,7 +853,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
             return vm_fail(VM_E_INVALID, "batch: pages with and without the temporal term cannot share a launch");
     }
     VmKParams P = {c->kp.w_ui, c->kp.w_tps, c->kp.w_ssim, c->kp.ssim_clamp, c->kp.eps, c->kp.bcond, c->kp.w_temp,
-                   c->commit_reversed};
+                   c->commit_order};
     int cap = 1;
     int rc0 = vm_iteration_cap(max_iter, &cap);
     if (rc0 != VM_OK) return rc0;

@@ -94,13 +94,13 @@ struct vm_ctx {
     int *iter_dev = nullptr;         // device iteration counter read by the replayed kernels
     struct SweepGraph {
         int math_mode;
-        int n, w, h, cap, fixed_work, threads, dense, rev;
+        int n, w, h, cap, fixed_work, threads, dense, order;
         const void *views, *flags, *stats;
         vm_kern_params kp;
         hipGraphExec_t exec;
     };
     std::vector<SweepGraph> graphs;
-    int commit_reversed = 0;         // vm_set_commit_order (EXACT, diagnostic): order 0..3
+    int commit_order = 0;         // vm_set_commit_order (EXACT, diagnostic): order 0..3
     int use_graphs = -1;             // -1: not decided yet, 0: off (VM_NO_GRAPH or a failed capture), 1: on
 };
 

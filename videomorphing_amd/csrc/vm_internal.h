@@ -58,7 +58,7 @@ struct VmKParams {
     float w_ui, w_tps, w_ssim, ssim_clamp, eps;
     int bcond;
     float w_temp;
-    int rev_commit; // EXACT only, diagnostic (vm_set_commit_order): bit 0 = a phase's commits in reversed order, bit 1 = column-major
+    int commit_order; // EXACT only, diagnostic (vm_set_commit_order): bit 0 = a phase's commits in reversed order, bit 1 = column-major
 };
 
 // per-iteration activity counters of the sweep kernels (uint32 words per iteration):

@@ -1412,7 +1412,7 @@ __device__ __forceinline__ bool commit_own(LdsT &S, const VmLevelView &L, const 
 // (UpdateSSIM, :1258-1279).
 template <class LdsT>
 __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L, int ox, int oy, int rx, int ry,
-                                            int pi, int pj, float2 &m, float2 &q, float &cr, float2 &tb, int rev)
+                                            int pi, int pj, float2 &m, float2 &q, float &cr, float2 &tb, int order)
 {
     int ylo = max(ry - 2, 0), yhi = min(ry + 2, VM_TILE_H - 1);
     int xlo = max(rx - 2, 0), xhi = min(rx + 2, VM_TILE_W - 1);
@@ -1423,12 +1423,12 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
     // diagnostic (vm_set_commit_order): the same records in another order -- bit 0 = reversed, bit 1 =
     // column-major over the committing pixels; equally legal orders of the commits the reference
     // leaves to atomics
-    if (rev) {
+    if (order) {
         const int ny = yhi >= ylo ? ((yhi - ylo) >> 1) + 1 : 0, nx = xhi >= xlo ? ((xhi - xlo) >> 1) + 1 : 0;
         const int n = ny * nx;
         for (int k0 = 0; k0 < n; ++k0) {
-            const int k = (rev & 1) ? n - 1 - k0 : k0;
-            const int iy = (rev & 2) ? k % ny : k / nx, ix = (rev & 2) ? k / ny : k % nx;
+            const int k = (order & 1) ? n - 1 - k0 : k0;
+            const int iy = (order & 2) ? k % ny : k / nx, ix = (order & 2) ? k / ny : k % nx;
             const int y = ylo + 2 * iy, x = xlo + 2 * ix;
             const int rec = (y >> 1) * 32 + (x >> 1);
             if (S.d_ok[rec] != 1)
@@ -1448,7 +1448,7 @@ __device__ __forceinline__ bool gather_cell(const LdsT &S, const VmLevelView &L,
         return touched;
     }
 #else
-    (void)rev;
+    (void)order;
 #endif
     for (int y = ylo; y <= yhi; y += 2)
         for (int x = xlo; x <= xhi; x += 2) {
@@ -1762,7 +1762,7 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
                         continue;
                     float2 m = S.mean[cell], q = S.var[cell], tb = S.tpsb[cell];
                     float cr = S.cross[cell];
-                    gather_cell_bits(S, L, ox, oy, rx, ry, pi, pj, sy0, sx0, rowbits, m, q, cr, tb, P.rev_commit);
+                    gather_cell_bits(S, L, ox, oy, rx, ry, pi, pj, sy0, sx0, rowbits, m, q, cr, tb, P.commit_order);
                     if (!DENSE)
                         atomicOr(&S.dirty[cell >> 5], 1u << (cell & 31));
                     {
@@ -2348,7 +2348,7 @@ __global__ __launch_bounds__(1024) void SUF(k_commit)(const VmLevelView *__restr
             const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2;
             float2 m = cm[e], q = cq[e], tb = ctb[e];
             float cr = ccr[e];
-            if (!gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb, P.rev_commit))
+            if (!gather_cell(S, L, ox, oy, rx, ry, pi, pj, m, q, cr, tb, P.commit_order))
                 continue;
             const int gi = cgi[e];
             L.mean[gi] = m;
@@ -2449,10 +2449,10 @@ __device__ __forceinline__ uint32_t transpose5(uint32_t h)
 template <bool COH = false>
 __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__restrict__ r_a,
                                           const float4 *__restrict__ r_b, const float *s_tps, uint32_t hits, int qx,
-                                          int qy, float2 &m, float2 &q, float &cr, float2 &tb, int rev)
+                                          int qy, float2 &m, float2 &q, float &cr, float2 &tb, int order)
 {
 #if !VM_EXACT
-    (void)rev;
+    (void)order;
 #endif
     const bool touched = hits != 0;
 #pragma unroll
@@ -2468,15 +2468,15 @@ __device__ __forceinline__ bool fold_cell(const VmLevelView &L, const float4 *__
                 continue;
             }
 #if VM_EXACT
-            // rev (vm_set_commit_order): bit 0 = the last window position first, bit 1 = positions in
+            // order (vm_set_commit_order): bit 0 = the last window position first, bit 1 = positions in
             // column-major order (picked from the transposed 5 x 5 bit field)
             int b = -1;
             if (hits) {
-                if (!(rev & 2)) {
-                    b = (rev & 1) ? 31 - __clz(hits) : __ffs(hits) - 1;
+                if (!(order & 2)) {
+                    b = (order & 1) ? 31 - __clz(hits) : __ffs(hits) - 1;
                 } else {
                     const uint32_t ht = transpose5(hits);
-                    const int bt = (rev & 1) ? 31 - __clz(ht) : __ffs(ht) - 1;
+                    const int bt = (order & 1) ? 31 - __clz(ht) : __ffs(ht) - 1;
                     b = (bt % 5) * 5 + bt / 5;
                 }
                 hits &= ~(1u << b);
@@ -2626,7 +2626,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
             float2 m = cm[e], q = cq[e], tb = ctb[e];
             float cr = ccr[e], val = cval[e];
             const uint32_t hits = in ? cell_hits(S.bits, bx0, by0, qx, qy) : 0u;
-            const bool touched = fold_cell(L, r_a, r_b, S.tps, hits, in ? qx : 0, in ? qy : 0, m, q, cr, tb, P.rev_commit);
+            const bool touched = fold_cell(L, r_a, r_b, S.tps, hits, in ? qx : 0, in ? qy : 0, m, q, cr, tb, P.commit_order);
             if (!in)
                 continue;
             if (touched) {
@@ -2779,7 +2779,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 128))) vo
         float2 m = s_mean[gi], q = s_var[gi], tb = s_tpsb[gi];
         float cr = s_cross[gi], val = s_value[gi];
         const uint32_t hits = live && okc ? cell_hits(S.bits, bx0, by0, cx, cy) : 0u;
-        if (fold_cell(L, r_a, r_b, S.tps, hits, cx, cy, m, q, cr, tb, P.rev_commit)) {
+        if (fold_cell(L, r_a, r_b, S.tps, hits, cx, cy, m, q, cr, tb, P.commit_order)) {
             const float counter = (float)(window_count(cy, L.h) * window_count(cx, L.w));
             val = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
         }
@@ -3406,8 +3406,8 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
                 for (int k0 = 0; k0 < 9; ++k0) {
 #if VM_EXACT
                     // vm_set_commit_order: bit 0 = reversed, bit 1 = column-major (k = row * 3 + column)
-                    const int kr = (P.rev_commit & 1) ? 8 - k0 : k0;
-                    const int k = (P.rev_commit & 2) ? (kr % 3) * 3 + kr / 3 : kr;
+                    const int kr = (P.commit_order & 1) ? 8 - k0 : k0;
+                    const int k = (P.commit_order & 2) ? (kr % 3) * 3 + kr / 3 : kr;
 #else
                     const int k = k0;
 #endif

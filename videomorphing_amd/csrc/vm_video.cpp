@@ -528,7 +528,7 @@ static int ensure_lanes(vm_video *v, int n)
         ln.c->sweep_threads = p->sweep_threads;
         ln.c->sweep_mode = p->sweep_mode;
         ln.c->sweep_parts = p->sweep_parts;
-        ln.c->commit_reversed = p->commit_reversed;
+        ln.c->commit_order = p->commit_order;
     }
     return VM_OK;
 }
