@@ -2,7 +2,7 @@
 stopping rule): the family of equally legal runs (four commit orders in EXACT arithmetic, two of them with fused
 multiply-adds, tests/test_gpu_fullsize.py::CHAOS_FAMILY) and FAST under the automatic schedule, per frame; energies from the oracle's vmo_energy on the host.
 The measurement is tests/test_gpu_fullsize.py::chaos_floor_measure; this prints it as JSON lines.
-usage: tools/dev_chaos_floor.py [frame ...]"""
+usage: tools/dev_chaos_floor.py [--4k] [frame ...]      (--4k: config[3], 3840x2160, 7 levels)"""
 import json
 import os
 import sys
@@ -15,11 +15,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from videomorphing_amd import capi, morph  # noqa: E402
 import test_gpu_fullsize as T  # noqa: E402
 
-frames = [int(a) for a in sys.argv[1:]] or list(T.CHAOS_FRAMES)
+big = "--4k" in sys.argv
+frames = [int(a) for a in sys.argv[1:] if a != "--4k"] or (list(T.CHAOS_FRAMES) if not big else [0, 3, 6])
+size = dict(w=3840, h=2160) if big else {}
 ctx = morph.Context(0, capi.MATH_EXACT)
 signed = []
 for f in frames:
-    r = T.chaos_floor_measure(ctx, frames=(f,))[f]
+    r = T.chaos_floor_measure(ctx, frames=(f,), **size)[f]
     signed.append(r["e_fast_signed"])
     print(json.dumps({"frame": f, **T.chaos_round(r)}), flush=True)
 s = np.array(signed)
