@@ -10,12 +10,14 @@ done
 python3 - $O $G <<'PY'
 import json, sys, glob
 d, G = sys.argv[1], int(sys.argv[2])
-ms, pairs = [], []
+ms, pairs, ex = [], [], []
 for k in range(G):
     j = json.loads(open("%s/rank%d.json" % (d, k)).read().strip().splitlines()[-1])
-    ms.append(j["ms_per_step"]); pairs.append(j["as_rank"]["pairs"])
+    ms.append(j["ms_per_step"]); pairs.append(j["as_rank"]["pairs"]); ex.append(j["executed_pixel_iters"] / j["steps"])
 out = {"G": G, "pairs_per_rank": pairs, "ms_per_rank": ms, "max_over_mean": max(ms) / (sum(ms) / len(ms)),
-       "job_ms_static_partition": max(ms), "job_G_pixel_iters_per_s": 60 * 500 * (1920*1080 + 960*540 + 480*270 + 240*135 + 120*68) / max(ms) / 1e6}
+       "job_ms_static_partition": max(ms),
+       "job_executed_G_pixel_iters_per_s": sum(ex) / (max(ms) * 1e-3) / 1e9,
+       "job_nominal_G_pixel_iters_per_s": 60 * 500 * (1920*1080 + 960*540 + 480*270 + 240*135 + 120*68) / max(ms) / 1e6}
 print(json.dumps(out))
 open(d + "/summary.json", "w").write(json.dumps(out, indent=1))
 PY
