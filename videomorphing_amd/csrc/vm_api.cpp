@@ -39,6 +39,7 @@ static int vm_sparse_tiles()
 #include <cstring>
 #include <string>
 #include <vector>
+#include <cerrno>
 #include <fcntl.h>
 #include <sys/file.h>
 #include <unistd.h>
@@ -790,8 +791,12 @@ struct PassToken {
             if (d->fd < 0) d->fd = -1;
         }
         if (d->fd >= 0 && flock(d->fd, LOCK_EX | LOCK_NB) != 0) {
-            d->mu.unlock();
-            return false;
+            if (errno == EWOULDBLOCK) { // another process holds the device's token
+                d->mu.unlock();
+                return false;
+            }
+            close(d->fd); // a file system without flock(): the token is process-local from here on
+            d->fd = -1;
         }
         owns = true;
         return true;
