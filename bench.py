@@ -556,6 +556,16 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
             live = sum(float(pr[i].iters_live) * sizes[i][0] * sizes[i][1] for pr in progs[k * per:(k + 1) * per] for i in R)
             rates.append(live * world / (t_ms * 1e-3) / 1e6)
         out["value_median_step"] = round(statistics.median(rates), 2)
+        # a step whose finest level ran all of its sweeps (two or three border pixels trading rounding-level moves: about one
+        # solve in four, under any arithmetic) executes ~5x the units of one whose finest level converged, in ~1.4x the time:
+        # the two kinds of step, apart
+        if config != 2 and per == 1:
+            cyc = [int(progs[k][0].iters_live >= progs[k][0].iters and progs[k][0].iters > 1) for k in range(len(step_ms))]
+            for name, sel in (("steps_finest_level_cycling", 1), ("steps_finest_level_converging", 0)):
+                ks = [k for k in range(len(step_ms)) if cyc[k] == sel]
+                if ks:
+                    out[name] = {"count": len(ks), "ms_mean": round(sum(step_ms[k] for k in ks) / len(ks), 2),
+                                 "mpix_iters_per_s": round(sum(rates[k] for k in ks) / len(ks), 2)}
         out["step_executed_mpix_iters"] = [round(sum(float(pr[i].iters_live) * sizes[i][0] * sizes[i][1] for pr in progs[k * per:(k + 1) * per]
                                                      for i in R) / 1e6, 2) for k in range(len(step_ms))]
     return out
