@@ -163,6 +163,13 @@ int  vm_set_commit_order(vm_ctx *ctx, int order);
  * context has rerun with STEP. */
 int  vm_dbg_pass_force_timeout(vm_ctx *ctx, int on);
 int  vm_dbg_pass_fallbacks(vm_ctx *ctx);
+/* Test hook of the SPARSE schedule's resident visits (FAST arithmetic): while the set bits
+ * of a pruned level's improving mask fit one tile, k_sparse keeps the window sums around them in LDS across passes
+ * and iterations instead of staging and writing back a tile per pass (kernel_optimize_level's LoadSSIM / SaveSSIM,
+ * morph.cu:1214-1256, once per residency instead of once per visit) -- the same bits as list-driven visits.
+ * mode 0 = automatic (default), 1 = never, 2 = the LDS copy is re-centred after every commit, 3 = residency is given
+ * up at the first commit (the two exits a growing active region takes, forced).  Other values: VM_E_INVALID. */
+int  vm_dbg_sparse_resident(vm_ctx *ctx, int mode);
 /* Diagnostic of the PASS schedule: on which XCD (0..7) each of the first `n` (<= 2048)
  * workgroups of the most recent PASS launch ran (workgroup b belongs to tile group
  * (b / 256) * 8 + b % 8; a group whose 32 workgroups report one XCD keeps its tile in one

@@ -104,6 +104,9 @@ def test_sparse_schedule_equals_tile_on_random_levels(gpu_ctx, oracle, mode, see
                 rng.set_state(st)
                 pyr = _pruned_level(gpu_ctx, oracle, rng, w, h, kw, cons, trial)
                 gpu_ctx.set_tuning(sched, 0, 0)
+                # (FAST, the lean kernel's resident visits: automatic; the LDS copy re-centred after every commit;
+                # residency given up at the first commit)
+                gpu_ctx.set_sparse_resident((0, 2, 3)[trial % 3])
                 pr = capi.Progress()
                 capi.check(pyr._L.vm_optimize_level(pyr._h, 0, iters, None, fixed, C.byref(pr)))
                 res.append(([pyr[1].field(n).copy() for n in STATE], (pr.iters, pr.improving, pr.commits, pr.candidates, pr.evaluations),
@@ -119,5 +122,6 @@ def test_sparse_schedule_equals_tile_on_random_levels(gpu_ctx, oracle, mode, see
             used += res[1][2] > 0
     finally:
         gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_sparse_resident(0)
         gpu_ctx.set_math_mode(capi.MATH_EXACT)
     assert used >= 2, used          # the sparse kernel really ran (the 1080p tests exercise it at length)

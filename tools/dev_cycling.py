@@ -51,8 +51,13 @@ for f in frames:
                 st = buf[:32].reshape(4, 8).astype(np.int64)
                 sf = buf[8192 + 512:8192 + 512 + 16].astype(np.int64)
                 us = lambda a, b: (b - a) / 100.0
-                print("   last tile visit: entry -> LDS %.2f us; phases %s; save %.2f; total %.2f" % (
-                    us(sf[0], sf[1]), ["%.2f (search %.2f)" % (us(st[k][0], st[k][5]), us(st[k][1], st[k][2])) for k in range(4)], us(sf[2], sf[3]), us(sf[0], sf[3])))
+                print("   last tile visit: entry -> LDS %.2f us; save %.2f; total %.2f" % (us(sf[0], sf[1]), us(sf[2], sf[3]), us(sf[0], sf[3])))
+                # stamps of a phase: 0 start, 1 candidates compacted, 6 pixel context + window loaded (lean pieces only), 2 search
+                # done (wave 0), 3 barrier, 4 commits counted, 5 gather done + barrier
+                for k in range(4):
+                    print("     phase %d: total %.2f = candidates %.2f + context %.2f + search %.2f + barrier %.2f + commits %.2f + gather %.2f" % (
+                        k, us(st[k][0], st[k][5]), us(st[k][0], st[k][1]), us(st[k][1], st[k][6]) if st[k][6] > st[k][1] else float("nan"),
+                        us(max(st[k][6], st[k][1]), st[k][2]), us(st[k][2], st[k][3]), us(st[k][3], st[k][4]), us(st[k][4], st[k][5])))
                 print("   last pass of the kernel: tile selection %.2f us, sweeps %.2f, list update %.2f" % (us(sf[4], sf[5]), us(sf[5], sf[6]), us(sf[6], sf[7])))
         except AttributeError:
             pass

@@ -31,12 +31,14 @@ for trial in range(trials):
     iters = float(rng.randint(10, 90))
     fixed = int(rng.randint(0, 2))
     cap = int(rng.choice([0, 0, 1, 5, 17, 64]))
+    resm = int(rng.choice([0, 0, 2, 3]))      # resident visits: automatic, re-centred at every commit, given up at the first
     st = rng.get_state()
     res = []
     for sched in (capi.SWEEP_TILE, capi.SWEEP_SPARSE):
         rng.set_state(st)
         pyr = F._pruned_level(ctx, O, rng, w, h, kw, cons, trial)
         ctx.set_tuning(sched, 0, cap if sched == capi.SWEEP_SPARSE else 0)
+        ctx.set_sparse_resident(resm)
         pr = capi.Progress()
         capi.check(pyr._L.vm_optimize_level(pyr._h, 0, iters, None, fixed, C.byref(pr)))
         res.append(([pyr[1].field(n).copy() for n in F.STATE], (pr.iters, pr.improving, pr.commits, pr.candidates, pr.evaluations, pr.active_tiles),
@@ -45,6 +47,7 @@ for trial in range(trials):
     used += res[1][2] > 0
     if not ok:
         bad += 1
-        print("MISMATCH trial %d mode %d %dx%d iters %g fixed %d cap %d: counters %s vs %s" % (trial, mode, w, h, iters, fixed, cap, res[0][1], res[1][1]), flush=True)
+        print("MISMATCH trial %d mode %d %dx%d iters %g fixed %d cap %d resident %d: counters %s vs %s" % (trial, mode, w, h, iters, fixed, cap, resm, res[0][1], res[1][1]), flush=True)
 ctx.set_tuning(0, 0, 0)
+ctx.set_sparse_resident(0)
 print("fuzz seed %d: %d trials, sparse kernel used in %d, mismatches %d" % (seed, trials, used, bad))

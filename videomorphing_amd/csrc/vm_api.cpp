@@ -253,6 +253,14 @@ extern "C" int vm_set_commit_order(vm_ctx *c, int order)
     return VM_OK;
 }
 
+extern "C" int vm_dbg_sparse_resident(vm_ctx *c, int mode)
+{
+    if (!c) return vm_fail(VM_E_INVALID, "vm_dbg_sparse_resident: ctx is NULL");
+    if (mode < 0 || mode > 3) return vm_fail(VM_E_INVALID, "vm_dbg_sparse_resident: mode %d (0 automatic, 1 never, 2 re-centre at every commit, 3 give up at the first commit)", mode);
+    c->sparse_resident = mode;
+    return VM_OK;
+}
+
 extern "C" int vm_dbg_pass_force_timeout(vm_ctx *c, int on)
 {
     if (!c) return vm_fail(VM_E_INVALID, "vm_dbg_pass_force_timeout: ctx is NULL");
@@ -1088,7 +1096,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
             // "as good as none": the list then lives in memory from the first pass it holds two words -- tests)
             SL.sparse(
                 c->views, n, cap, l0.w, l0.h, P, c->tables, c->flags, c->stats, done, nb, fixed_work, threads, dense,
-                c->sweep_mode == VM_SWEEP_SPARSE && c->sweep_parts > 0 ? c->sweep_parts : 1 << 20, s);
+                c->sweep_mode == VM_SWEEP_SPARSE && c->sweep_parts > 0 ? c->sweep_parts : 1 << 20, c->sparse_resident, s);
             launches += 2;
             it0 = done + nb;
         }

@@ -91,7 +91,7 @@ struct VmKParams {
                                             int h, const VmKParams &P, const uint32_t *tables, \
                                             uint32_t *flags, uint32_t *stats, int it0, int nit, \
                                             int fixed_work, int threads, int dense, int lds_cap,   \
-                                            hipStream_t s);                                    \
+                                            int res_mode, hipStream_t s);                      \
     void vm_launch_optimize_split_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w, \
                                            int h, const VmKParams &P, const uint32_t *tables, \
                                            int offx, int offy, int pass, uint32_t *flags,     \

@@ -1891,6 +1891,11 @@ struct SparseLds {
     uint32_t wv[2][VM_SPARSE_LDS_CAP]; // ... and their values
     int tl[64];                        // the tiles selected for this pass, in the order they were found
     uint32_t ntl;                      // how many (entries past 64 are only counted: the bitmap is walked instead)
+    // resident visits (lean kernel): bounding box of the set mask bits (x0, x1, y0, y1), which of the <= 4 real
+    // tiles of a pass a set bit reaches (bit 4: any set bit at all), a commit left the safe rectangle
+    int bb[4];
+    uint32_t rw[2];
+    uint32_t unsafe;
 };
 
 // does the mask window of the tile at (ox, oy) hold block (bx, by)?  (mask_geom: the words
@@ -1913,6 +1918,317 @@ __global__ __launch_bounds__(256) void SUF(k_sparse_scan)(const VmLevelView *__r
     }
 }
 
+#if !VM_EXACT
+// ---------------------------------------------------------------------------
+// The lean tile visit of the SPARSE schedule in pieces (round 4): load, four phases, store -- tile_sweep<false>
+// taken apart so that the window sums of a small active region can STAY in LDS across the four passes of an
+// iteration and across iterations (a RESIDENT visit).  A finest level that never converges is two or three
+// pixels of one border row trading rounding-level moves (profiles/r04_notes.md): every pass has one tile over them,
+// and each visit staged 1360 cells, walked four phases and wrote back, 2000 times.
+//
+// The LDS copy is a VIRTUAL tile: VM_TILE_W x VM_TILE_H pixels + halo at an origin (vx, vy) that is not on any
+// pass's tile grid, placed around the bounding box of the set mask bits.  A real tile (ox, oy) of a pass is then
+// swept inside it: its candidates are the mask hits of the virtual tile's slots that lie in the real tile's
+// rectangle, its phase (pi, pj) is the virtual tile's phase (pi ^ (oy - vy) & 1, pj ^ (ox - vx) & 1), and everything
+// a phase does -- line searches on the pre-phase sums, own-pixel commits, the per-cell gather in row-major
+// order of the committing pixels, the mask bits -- is position-relative, so the bits are those of the real
+// tile's own visit.  What makes it legal: (1) every candidate of any real tile (a pixel within +-2 of a set bit)
+// lies inside the virtual tile -- all set bits sit in a SAFE rectangle, two pixels inside the virtual tile's edges
+// (or at the level's edge), checked on entry and after every commit (a commit sets the bit of its pixel); a
+// commit outside re-centres the virtual tile (store, load) before the next phase, and if the bits no longer fit
+// one tile the visit goes on in the real tile's own frame and the kernel returns to list-driven visits;
+// (2) nothing else touches the level meanwhile (one workgroup per pair).
+struct SvTile {
+    int vx, vy;
+    MaskGeom g;
+};
+
+__device__ __forceinline__ void sv_load_mask(TileLds &S, const VmLevelView &L, const MaskGeom &g, int tid)
+{
+    if (tid < g.nbx * g.nby) {
+        const int mx = tid % g.nbx, my = tid / g.nbx;
+        S.mask[my][mx] = L.impmask[(g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)];
+    }
+}
+
+// LoadSSIM (morph.cu:1214-1234) + the tile's tps.b, as in tile_sweep; ends with a barrier
+__device__ __forceinline__ void sv_load_state(TileLds &S, const VmLevelView &L, int vx, int vy, int tid, int T)
+{
+    if (tid < (VM_NCELL + 31) / 32)
+        S.dirty[tid] = 0;
+    for (int c0 = tid; c0 < VM_NCELL; c0 += 3 * T) {
+        float2 m[3], q[3], tb[3];
+        float cr[3], val[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int c = c0 + e * T;
+            const int gx = vx - 2 + c % VM_HALO_W, gy = vy - 2 + c / VM_HALO_W;
+            const bool in = c < VM_NCELL && gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
+            const int gi = in ? gy * L.rs + gx : 0;
+            m[e] = L.mean[gi];
+            q[e] = L.var[gi];
+            tb[e] = L.tps_b[gi];
+            cr[e] = L.cross[gi];
+            val[e] = L.value[gi];
+            if (!in) {
+                m[e] = q[e] = tb[e] = make_float2(0, 0);
+                cr[e] = val[e] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int c = c0 + e * T;
+            if (c < VM_NCELL) {
+                S.mean[c] = m[e];
+                S.var[c] = q[e];
+                S.tpsb[c] = tb[e];
+                S.cross[c] = cr[e];
+                S.value[c] = val[e];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// SaveSSIM (morph.cu:1236-1256) of the cells a commit reached, tps.b, and the mask words the tile owns (blocks
+// that contain one of its pixels); set words are appended to the pass's new word list when one is given
+__device__ __forceinline__ void sv_store(const TileLds &S, const VmLevelView &L, const MaskGeom &g, int vx, int vy, int tid,
+                                         int T, uint32_t *sp_list, uint32_t *sp_val, uint32_t *sp_cnt, uint32_t sp_cap)
+{
+    for (int c = tid; c < VM_NCELL; c += T) {
+        if (!((S.dirty[c >> 5] >> (c & 31)) & 1u))
+            continue;
+        const int gx = vx - 2 + c % VM_HALO_W, gy = vy - 2 + c / VM_HALO_W;
+        if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h)
+            continue;
+        const int gi = gy * L.rs + gx;
+        L.mean[gi] = S.mean[c];
+        L.var[gi] = S.var[c];
+        L.tps_b[gi] = S.tpsb[c];
+        L.cross[gi] = S.cross[c];
+        L.value[gi] = S.value[c];
+    }
+    if (tid < g.nbx * g.nby) {
+        const int mx = tid % g.nbx, my = tid / g.nbx;
+        if (mx >= 1 && mx <= g.nbx - 2 && my >= 1 && my <= g.nby - 2) {
+            const uint32_t wi = (uint32_t)((g.by0 + my + 1) * L.imp_rs + (g.bx0 + mx + 1)), wv = S.mask[my][mx];
+            L.impmask[wi] = wv;
+            if (sp_list && wv) {
+                const uint32_t k = atomicAdd(sp_cnt, 1u);
+                if (k < sp_cap) {
+                    sp_list[k] = wi;
+                    sp_val[k] = wv;
+                }
+            }
+        }
+    }
+}
+
+// where a virtual tile goes for set bits in [x0, x1] x [y0, y1]: false if they do not fit one (every pixel within
+// +-2 of a bit must be a pixel of the tile).  Margins are split evenly; the tile is kept inside the level, whose
+// edges need no margin.
+__device__ __forceinline__ bool sv_place(const VmLevelView &L, int x0, int x1, int y0, int y1, int &vx, int &vy)
+{
+    const int sx = VM_TILE_W - 5 - (x1 - x0), sy = VM_TILE_H - 5 - (y1 - y0);
+    if (x0 > x1 || y0 > y1 || sx < 0 || sy < 0)
+        return false;
+    vx = min(max(x0 - 2 - sx / 2, 0), max(L.w - VM_TILE_W, 0));
+    vy = min(max(y0 - 2 - sy / 2, 0), max(L.h - VM_TILE_H, 0));
+    return true;
+}
+
+// is a set bit at (px, py) inside the safe rectangle of the virtual tile?
+__device__ __forceinline__ bool sv_safe(const VmLevelView &L, const SvTile &V, int px, int py)
+{
+    return max(px - 2, 0) >= V.vx && min(px + 2, L.w - 1) <= min(V.vx + VM_TILE_W - 1, L.w - 1) && max(py - 2, 0) >= V.vy &&
+           min(py + 2, L.h - 1) <= min(V.vy + VM_TILE_H - 1, L.h - 1);
+}
+
+// bounding box of the set bits of mask word `w` of block (bx, by) into Q.bb (LDS atomics)
+__device__ __forceinline__ void sv_bbox_add(SparseLds &Q, uint32_t w, int bx, int by)
+{
+    if (!w)
+        return;
+    const uint32_t cols = (w | (w >> 5) | (w >> 10) | (w >> 15) | (w >> 20)) & 31u;
+    uint32_t rows = 0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+        rows |= ((w >> (5 * r)) & 31u) ? 1u << r : 0u;
+    atomicMin(&Q.bb[0], 5 * bx + __ffs(cols) - 1);
+    atomicMax(&Q.bb[1], 5 * bx + 31 - __clz(cols));
+    atomicMin(&Q.bb[2], 5 * by + __ffs(rows) - 1);
+    atomicMax(&Q.bb[3], 5 * by + 31 - __clz(rows));
+}
+
+// The four Jacobi phases of the real tile (ox, oy) inside the LDS copy at V (V = the real tile itself: a plain
+// visit).  res: 0 = plain visit; 1 = resident; 2, 3 = resident, tests: every commit counts as unsafe, and (3) no
+// re-centred tile is accepted.  Returns whether a pixel committed; `left` = the virtual tile was given up
+// (V is now the real tile's own frame, stored by the caller like a plain visit).
+__device__ __forceinline__ bool sv_phases(TileLds &S, SparseLds &Q, const VmLevelView &L, const VmKParams &P, SvTile &V,
+                                          int ox, int oy, int tid, int T, uint32_t &st_cand, uint32_t &st_commit, int res,
+                                          bool &left)
+{
+    const int rx1 = min(ox + VM_TILE_W - 1, L.w - 1), ry1 = min(oy + VM_TILE_H - 1, L.h - 1);
+    bool tile_improving = false;
+    for (int pi = 0; pi < 2; ++pi) {
+        for (int pj = 0; pj < 2; ++pj) {
+            const int vx = V.vx, vy = V.vy;
+            const int vpi = pi ^ ((oy - vy) & 1), vpj = pj ^ ((ox - vx) & 1);
+            VM_TTS(pi * 2 + pj, 0);
+            // ---- 1. candidates of this phase ----
+            bool cand = false, hit = false;
+            if (tid < 256) {
+                const int px = vx + (tid & 31) * 2 + vpj, py = vy + (tid >> 5) * 2 + vpi;
+                int state = 0;
+                if (px >= ox && px <= rx1 && py >= oy && py <= ry1 && mask_hit(S.mask, S.imp, V.g, px, py)) {
+                    state = 2; // in the mask: its bit is cleared unless it commits
+                    hit = true;
+                    cand = !pixel_locked(L, P.bcond, px, py);
+                }
+                S.d_ok[tid] = state;
+            }
+            bool any_hit;
+            const int n_act = compact256(cand, tid, S.list, S.wave_cnt, hit, &any_hit);
+            if (!any_hit)
+                continue;
+            VM_TTS(pi * 2 + pj, 1);
+            if (n_act > 0) {
+                st_cand += n_act;
+                // ---- 2. line searches on the pre-phase state: the lean search, a whole wave per candidate
+                // (two points of the search per round) while the workgroup has that many waves ----
+                const bool wide = n_act * 64 <= T;
+                for (int base = 0; base < n_act; base += wide ? T / 64 : T / 32) {
+                    const int li = base + (wide ? tid >> 6 : tid >> 5), sub = tid & 31;
+                    const bool writer = wide ? (tid & 63) == 0 : sub == 0;
+                    const int slot = S.list[min(li, n_act - 1)];
+                    const int tx = slot & 31, ty = slot >> 5;
+                    const int px = vx + tx * 2 + vpj, py = vy + ty * 2 + vpi;
+                    const bool wave_interior = __all(li >= n_act || is_interior(L, px, py));
+                    if (li < n_act) {
+                        PixelCtx c;
+                        ctx_load(c, L, S.tps, px, py);
+                        LdsSrc src{&S, (ty * 2 + vpi) * VM_HALO_W + (tx * 2 + vpj)};
+                        c.tps_b = S.tpsb[src.hc + 2 * VM_HALO_W + 2];
+                        VM_TTS(pi * 2 + pj, 6);
+                        float2 step, luma;
+#ifdef VM_PROF
+                        unsigned long long ts[16];
+#endif
+                        Nb1 nb;
+                        bool ok;
+                        uint32_t n_eval = 0;
+                        if (wave_interior) {
+                            nb1_load<true>(nb, L, src, c, sub);
+                            ok = wide ? decide64<true>(L, P, nb, RingGlobal{L.v}, c, sub, (tid & 32) != 0, step, luma, n_eval)
+                                      : decide32<true>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
+                        } else {
+                            nb1_load<false>(nb, L, src, c, sub);
+                            ok = wide ? decide64<false>(L, P, nb, RingGlobal{L.v}, c, sub, (tid & 32) != 0, step, luma, n_eval)
+                                      : decide32<false>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
+                        }
+                        if (writer)
+                            atomicAdd(&S.n_eval, n_eval);
+                        if (ok && writer) {
+                            // commit_pixel_motion (morph.cu:990-1026), the pixel's own part, at once
+                            const float2 ol = c.old_luma;
+                            S.d_step[slot] = step;
+                            S.d_mean[slot] = make_float2(luma.x - ol.x, luma.y - ol.y);
+                            S.d_var[slot] = make_float2(luma.x * luma.x - ol.x * ol.x, luma.y * luma.y - ol.y * ol.y);
+                            S.d_cross[slot] = luma.x * luma.y - ol.x * ol.y;
+                            L.luma[c.idx] = luma;
+                            L.ui_b[c.idx] = make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy);
+                            L.v[c.idx] = make_float2(c.v.x + step.x, c.v.y + step.y);
+                            S.d_ok[slot] = 3;
+                            if (res && (res > 1 || !sv_safe(L, V, px, py)))
+                                Q.unsafe = 1u;
+                        }
+                    }
+                }
+            }
+            VM_TTS(pi * 2 + pj, 2);
+            __syncthreads();
+            VM_TTS(pi * 2 + pj, 3);
+
+            // ---- 3. commits ----
+            const bool ok = tid < 256 && commit_own(S, L, V.g, tid, vx, vy, vpi, vpj);
+            {
+                const unsigned long long cb = __ballot(ok);
+                if (tid < 256 && (tid & 63) == 0) {
+                    S.cbits[(tid >> 6) * 2] = (uint32_t)cb;
+                    S.cbits[(tid >> 6) * 2 + 1] = (uint32_t)(cb >> 32);
+                }
+            }
+            const int ncommit = __syncthreads_count(ok);
+            VM_TTS(pi * 2 + pj, 4);
+            if (ncommit) {
+                tile_improving = true;
+                st_commit += ncommit;
+                for (int cell = tid; cell < VM_NCELL; cell += T) {
+                    const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2; // tile-relative
+                    const int qx = vx + rx, qy = vy + ry;
+                    if (qx < 0 || qx >= L.w || qy < 0 || qy >= L.h)
+                        continue;
+                    int ylo = max(ry - 2, 0), xlo = max(rx - 2, 0);
+                    const int yhi = min(ry + 2, VM_TILE_H - 1), xhi = min(rx + 2, VM_TILE_W - 1);
+                    ylo += (ylo & 1) ^ vpi;
+                    xlo += (xlo & 1) ^ vpj;
+                    if (ylo > yhi || xlo > xhi)
+                        continue;
+                    const int sx0 = xlo >> 1, nx = ((xhi - xlo) >> 1) + 1, sy0 = ylo >> 1, ny = ((yhi - ylo) >> 1) + 1;
+                    const uint32_t colmask = ((1u << nx) - 1u) << sx0; // nx <= 3
+                    uint32_t rowbits[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        rowbits[t] = t < ny ? S.cbits[sy0 + t] & colmask : 0u;
+                    if (!(rowbits[0] | rowbits[1] | rowbits[2]))
+                        continue;
+                    float2 m = S.mean[cell], q = S.var[cell], tb = S.tpsb[cell];
+                    float cr = S.cross[cell];
+                    gather_cell_bits(S, L, vx, vy, rx, ry, vpi, vpj, sy0, sx0, rowbits, m, q, cr, tb, P.commit_order);
+                    atomicOr(&S.dirty[cell >> 5], 1u << (cell & 31));
+                    S.mean[cell] = m;
+                    S.var[cell] = q;
+                    S.cross[cell] = cr;
+                    S.tpsb[cell] = tb;
+                    const float counter = (float)(window_count(qy, L.h) * window_count(qx, L.w));
+                    S.value[cell] = ssim_value(m.x, m.y, q.x, q.y, cr, counter, P.ssim_clamp);
+                }
+            }
+            __syncthreads();
+            VM_TTS(pi * 2 + pj, 5);
+            if (!res || !(Q.unsafe & 1u)) // (uniform: written before the barrier above)
+                continue;
+            // ---- a commit left the safe rectangle: move the virtual tile before the next phase ----
+            sv_store(S, L, V.g, vx, vy, tid, T, nullptr, nullptr, nullptr, 0);
+            if (tid == 0) {
+                Q.bb[0] = Q.bb[2] = 0x7fffffff;
+                Q.bb[1] = Q.bb[3] = -0x7fffffff;
+            }
+            __syncthreads(); // the cells and words are out; nobody still reads Q.unsafe
+            if (tid < V.g.nbx * V.g.nby)
+                sv_bbox_add(Q, S.mask[tid / V.g.nbx][tid % V.g.nbx], V.g.bx0 + tid % V.g.nbx, V.g.by0 + tid / V.g.nbx);
+            if (tid == 0)
+                Q.unsafe = 0;
+            __syncthreads();
+            int nvx, nvy;
+            if (res == 3 || !sv_place(L, Q.bb[0], Q.bb[1], Q.bb[2], Q.bb[3], nvx, nvy)) {
+                nvx = ox; // the rest of this visit in the real tile's own frame, then back to list-driven visits
+                nvy = oy;
+                left = true;
+                res = 0;
+            }
+            V.vx = nvx;
+            V.vy = nvy;
+            V.g = mask_geom(L, nvx, nvy);
+            __syncthreads(); // S.mask and Q.bb are read before they are overwritten
+            sv_load_mask(S, L, V.g, tid);
+            sv_load_state(S, L, nvx, nvy, tid, T);
+        }
+    }
+    return tile_improving;
+}
+#endif // !VM_EXACT
+
 // The word list lives in LDS while it fits (lds_cap <= VM_SPARSE_LDS_CAP entries; round 4): building the
 // tile set of a pass, carrying the list over and adding the words of the swept tiles then touch no memory
 // at all.  (In memory the same steps were three chains of dependent loads -- list entry -> mask word ->
@@ -1921,11 +2237,17 @@ __global__ __launch_bounds__(256) void SUF(k_sparse_scan)(const VmLevelView *__r
 // wide as a block); such entries are dropped and come back from tile_sweep, which appends the set words a
 // tile owns as it writes them back.  Should the list outgrow LDS, the kernel rescans the level into the
 // lists in memory and goes on there (lds_cap = 0 forces that path: tests).
+// res_mode (lean kernel): 0 = resident visits where the set bits fit one tile, 1 = never; 2, 3 = tests (sv_phases)
 template <bool DENSE>
 __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1))) void SUF(k_sparse)(
     const VmLevelView *__restrict__ views, int cap, VmKParams P, const uint32_t *__restrict__ tables,
-    uint32_t *__restrict__ flags, uint32_t *__restrict__ stats, int it0, int nit, int fixed_work, int lds_cap)
+    uint32_t *__restrict__ flags, uint32_t *__restrict__ stats, int it0, int nit, int fixed_work, int lds_cap, int res_mode)
 {
+#if VM_EXACT
+    constexpr bool LEAN = false;
+#else
+    constexpr bool LEAN = !DENSE; // the visit from its pieces (sv_*): plain or resident
+#endif
     __shared__ TileLds S;
     __shared__ SparseLds Q;
     const int tid = threadIdx.x, T = blockDim.x;
@@ -1953,20 +2275,67 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
             Q.wv[0][k] = L.impmask[wi];
         }
     __syncthreads();
+    // every set word of the level into list 0 in memory, and on from there (the LDS list has been outgrown, or
+    // resident visits were given up)
+    auto rescan_into_memory = [&]() {
+        __syncthreads();
+        if (tid == 0)
+            Q.nnew = 0;
+        __syncthreads();
+        for (int wi = tid; wi < nwords; wi += T)
+            if (L.impmask[wi] != 0)
+                lists[0][atomicAdd(&Q.nnew, 1u)] = (uint32_t)wi;
+        __syncthreads();
+        nw = Q.nnew;
+        in_lds = false;
+        for (int wi = tid; wi < nwords; wi += T)
+            L.sp_stamp[wi] = 0; // stamps are epochs of the passes walked in memory
+    };
+#if !VM_EXACT
+    bool resident = false; // the window sums around the set bits stay in LDS (sv_phases); the word list rests
+    SvTile V{0, 0, MaskGeom{0, 0, 0, 0}};
+#else
+    constexpr bool resident = false;
+#endif
     for (int it = it0; it < it0 + nit; ++it) {
         // no set mask word anywhere: no tile of any pass of any later iteration can be active --
         // every remaining sweep of this batch is a no-op (its flags and counters stay zero)
         if (nw == 0)
             break;
-        bool improving = false;
+        bool improving = false, emptied = false;
         uint32_t st_cand = 0, st_commit = 0, st_tiles = 0;
         if (tid == 0)
             S.n_eval = 0;
+#if !VM_EXACT
+        if constexpr (LEAN) {
+            // a few set words whose bits fit one tile: go resident
+            if (!resident && in_lds && res_mode != 1 && nw <= 64) {
+                if (tid == 0) {
+                    Q.bb[0] = Q.bb[2] = 0x7fffffff;
+                    Q.bb[1] = Q.bb[3] = -0x7fffffff;
+                    Q.unsafe = 0;
+                }
+                __syncthreads();
+                if ((uint32_t)tid < nw) {
+                    const uint32_t wi = Q.wl[cur][tid];
+                    sv_bbox_add(Q, Q.wv[cur][tid], (int)(wi % (uint32_t)L.imp_rs) - 1, (int)(wi / (uint32_t)L.imp_rs) - 1);
+                }
+                __syncthreads();
+                if (sv_place(L, Q.bb[0], Q.bb[1], Q.bb[2], Q.bb[3], V.vx, V.vy)) {
+                    V.g = mask_geom(L, V.vx, V.vy);
+                    sv_load_mask(S, L, V.g, tid);
+                    sv_load_state(S, L, V.vx, V.vy, tid, T);
+                    resident = true;
+                }
+            }
+        }
+#endif
         for (int pass = 0; pass < 4; ++pass) {
             const int offx = (pass & 1) ? VM_TILE_W : 0, offy = (pass & 2) ? VM_TILE_H : 0; // morph.cu:1382-1385
             const uint32_t *list = in_lds ? Q.wl[cur] : lists[cur];
+            const bool pass_resident = resident; // (residency can end inside a pass, never begin)
             VM_TTSF(4);
-            // ---- 1. the tiles of this pass whose mask window holds a listed word ----
+            // ---- 1. the tiles of this pass that a set mask bit reaches ----
             for (int k = tid; k < ntw; k += T)
                 Q.tilebits[k] = 0;
             if (tid == 0) {
@@ -1975,26 +2344,70 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                 Q.ntl = 0;
             }
             __syncthreads();
-            for (uint32_t k = tid; k < nw; k += T) {
-                const int wi = (int)list[k];
-                const uint32_t wv = in_lds ? Q.wv[cur][k] : L.impmask[wi];
-                const int bx = wi % L.imp_rs - 1, by = wi / L.imp_rs - 1;
-                const int ce = (5 * bx - offx) / VM_PITCH_X, re = (5 * by - offy) / VM_PITCH_Y;
-                for (int r = max(re - 1, 0); r <= re + 1 && r < gy; ++r)
-                    for (int c = max(ce - 1, 0); c <= ce + 1 && c < gx; ++c) {
-                        const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
-                        // (tile_sweep's early-out test: a set bit within +-2 of the tile)
-                        if (ox < L.w && oy < L.h && tile_window_has(L, ox, oy, bx, by) && (wv & tile_reach_bits(L, ox, oy, bx, by))) {
-                            const uint32_t bit = 1u << ((r * gx + c) & 31);
-                            if (!(atomicOr(&Q.tilebits[(r * gx + c) >> 5], bit) & bit)) { // first to name this tile
-                                const uint32_t q = atomicAdd(&Q.ntl, 1u);
-                                if (q < 64)
-                                    Q.tl[q] = r * gx + c;
+#if !VM_EXACT
+            if (LEAN && pass_resident) {
+                // every set bit of the level is in the LDS copy of the words: the <= 2 x 2 tiles of this pass whose
+                // rectangle + 2 meets the virtual tile, tested as tile_sweep's early out tests them
+                const int ax = V.vx - (VM_TILE_W + 1) - offx, bx = V.vx + (VM_TILE_W + 1) - offx;
+                const int ay = V.vy - (VM_TILE_H + 1) - offy, by = V.vy + (VM_TILE_H + 1) - offy;
+                const int c_lo = ax > 0 ? (ax + VM_PITCH_X - 1) / VM_PITCH_X : 0, r_lo = ay > 0 ? (ay + VM_PITCH_Y - 1) / VM_PITCH_Y : 0;
+                const int c_hi = bx >= 0 ? min(bx / VM_PITCH_X, gx - 1) : -1, r_hi = by >= 0 ? min(by / VM_PITCH_Y, gy - 1) : -1;
+                if (tid < V.g.nbx * V.g.nby) {
+                    const int mx = tid % V.g.nbx, my = tid / V.g.nbx;
+                    const uint32_t w = S.mask[my][mx];
+                    if (w) {
+                        Q.unsafe = 2u; // (bit 1: a set bit exists; bit 0 is sv_phases')
+                        for (int r = r_lo; r <= r_hi; ++r)
+                            for (int c = c_lo; c <= c_hi; ++c) {
+                                const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
+                                if (ox < L.w && oy < L.h && (w & tile_reach_bits(L, ox, oy, V.g.bx0 + mx, V.g.by0 + my))) {
+                                    const uint32_t bit = 1u << ((r * gx + c) & 31);
+                                    if (!(atomicOr(&Q.tilebits[(r * gx + c) >> 5], bit) & bit))
+                                        Q.tl[atomicAdd(&Q.ntl, 1u)] = r * gx + c; // <= 4
+                                }
+                            }
+                    }
+                }
+                __syncthreads();
+                if (!(Q.unsafe & 2u)) {
+                    // no set bit left: the level has converged (what `nw == 0` says to list-driven visits)
+                    if (pass == 0) {
+                        sv_store(S, L, V.g, V.vx, V.vy, tid, T, nullptr, nullptr, nullptr, 0);
+                        resident = false;
+                        nw = 0;
+                        emptied = true;
+                        break;
+                    }
+                    continue;
+                }
+                __syncthreads();
+                if (tid == 0)
+                    Q.unsafe = 0;
+                // (ordered before its next use by the barriers of the first phase)
+            } else
+#endif
+            {
+                for (uint32_t k = tid; k < nw; k += T) {
+                    const int wi = (int)list[k];
+                    const uint32_t wv = in_lds ? Q.wv[cur][k] : L.impmask[wi];
+                    const int bx = wi % L.imp_rs - 1, by = wi / L.imp_rs - 1;
+                    const int ce = (5 * bx - offx) / VM_PITCH_X, re = (5 * by - offy) / VM_PITCH_Y;
+                    for (int r = max(re - 1, 0); r <= re + 1 && r < gy; ++r)
+                        for (int c = max(ce - 1, 0); c <= ce + 1 && c < gx; ++c) {
+                            const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
+                            // (tile_sweep's early-out test: a set bit within +-2 of the tile)
+                            if (ox < L.w && oy < L.h && tile_window_has(L, ox, oy, bx, by) && (wv & tile_reach_bits(L, ox, oy, bx, by))) {
+                                const uint32_t bit = 1u << ((r * gx + c) & 31);
+                                if (!(atomicOr(&Q.tilebits[(r * gx + c) >> 5], bit) & bit)) { // first to name this tile
+                                    const uint32_t q = atomicAdd(&Q.ntl, 1u);
+                                    if (q < 64)
+                                        Q.tl[q] = r * gx + c;
+                                }
                             }
                         }
-                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
             VM_TTSF(5);
             // ---- 2. sweep them, one after the other (tiles of a pass touch disjoint state: any order) ----
             // (a few tiles: straight from the list; many: the bitmap, word by word -- walking all of its up to 46
@@ -2006,8 +2419,39 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                     const int t = ntl <= 64 ? Q.tl[wd] : wd * 32 + __ffs(bits) - 1;
                     bits &= bits - 1;
                     const int ox = (t % gx) * VM_PITCH_X + offx, oy = (t / gx) * VM_PITCH_Y + offy;
-                    if (tile_sweep<DENSE>(S, L, P, tables, true, ox, oy, tid, T, improving, st_cand, st_commit,
-                                          in_lds ? Q.wl[cur ^ 1] : nullptr, Q.wv[cur ^ 1], &Q.nnew, lcap)) {
+                    bool visited;
+#if !VM_EXACT
+                    if constexpr (LEAN) {
+                        // plain visit: tile_sweep from its pieces; resident visit: the phases only
+                        visited = true;
+                        if (!resident) {
+                            V = SvTile{ox, oy, mask_geom(L, ox, oy)};
+                            uint32_t reach = 0;
+                            if (tid < V.g.nbx * V.g.nby) {
+                                const int mx = tid % V.g.nbx, my = tid / V.g.nbx;
+                                const uint32_t w = L.impmask[(V.g.by0 + my + 1) * L.imp_rs + (V.g.bx0 + mx + 1)];
+                                S.mask[my][mx] = w;
+                                reach = w & tile_reach_bits(L, ox, oy, V.g.bx0 + mx, V.g.by0 + my);
+                            }
+                            visited = __syncthreads_or(reach != 0); // tile_sweep's early out
+                            if (visited)
+                                sv_load_state(S, L, ox, oy, tid, T);
+                        }
+                        if (visited) {
+                            bool left = false;
+                            if (sv_phases(S, Q, L, P, V, ox, oy, tid, T, st_cand, st_commit, resident ? (res_mode ? res_mode : 1) : 0, left))
+                                improving = true;
+                            if (!resident || left) {
+                                const bool listed = !pass_resident && in_lds;
+                                sv_store(S, L, V.g, V.vx, V.vy, tid, T, listed ? Q.wl[cur ^ 1] : nullptr, Q.wv[cur ^ 1], &Q.nnew, lcap);
+                                resident = false;
+                            }
+                        }
+                    } else
+#endif
+                        visited = tile_sweep<DENSE>(S, L, P, tables, true, ox, oy, tid, T, improving, st_cand, st_commit,
+                                                    in_lds ? Q.wl[cur ^ 1] : nullptr, Q.wv[cur ^ 1], &Q.nnew, lcap);
+                    if (visited) {
                         ++st_tiles;
                         if (tid == 0) {
                             if (Q.ndone < 128)
@@ -2019,6 +2463,15 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                 }
             }
             VM_TTSF(6);
+            if (resident)
+                continue; // the LDS copy of the words is the list
+            if (pass_resident) {
+                // residency was given up in this pass: the list again, from a scan of the level
+                rescan_into_memory();
+                cur = 0;
+                __syncthreads();
+                continue;
+            }
             // ---- 3. the list for the next pass: old entries that are still set, plus the set
             // words the swept tiles own (no other word can have changed) ----
             if (in_lds) {
@@ -2048,21 +2501,9 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                 }
                 __syncthreads();
                 nw = Q.nnew;
-                if (nw > lcap) {
-                    // outgrown: every set word of the level into list 0 in memory, and on from there
-                    __syncthreads();
-                    if (tid == 0)
-                        Q.nnew = 0;
-                    __syncthreads();
-                    for (int wi = tid; wi < nwords; wi += T)
-                        if (L.impmask[wi] != 0)
-                            lists[0][atomicAdd(&Q.nnew, 1u)] = (uint32_t)wi;
-                    __syncthreads();
-                    nw = Q.nnew;
-                    in_lds = false;
+                if (nw > lcap) { // outgrown
+                    rescan_into_memory();
                     cur = 1; // (flipped to 0 below)
-                    for (int wi = tid; wi < nwords; wi += T)
-                        L.sp_stamp[wi] = 0; // stamps are epochs of the passes walked in memory
                 }
                 cur ^= 1;
                 __syncthreads(); // Q.nnew is reset at the top of the next pass
@@ -2108,6 +2549,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
             cur ^= 1;
             __syncthreads(); // Q.nnew is reset at the top of the next pass
         }
+        if (emptied)
+            break;
         if (tid == 0) { // one writer per pair and iteration; the host zeroed the arrays
             flags[it] = improving ? 1u : 0u;
             stats[it * VM_STAT_WORDS + 0] = st_tiles;
@@ -2119,6 +2562,10 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
             break; // reference semantics: the level stops here (the following flags stay 0)
         __syncthreads();
     }
+#if !VM_EXACT
+    if (LEAN && resident)
+        sv_store(S, L, V.g, V.vx, V.vy, tid, T, nullptr, nullptr, nullptr, 0);
+#endif
 }
 
 // ===========================================================================
@@ -3617,20 +4064,20 @@ void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int 
 // a batch of `nit` iterations of the SPARSE schedule: list scan + one workgroup per pair
 void SUF(vm_launch_optimize_sparse)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
                                     const uint32_t *tables, uint32_t *flags, uint32_t *stats, int it0, int nit,
-                                    int fixed_work, int threads, int dense, int lds_cap, hipStream_t s)
+                                    int fixed_work, int threads, int dense, int lds_cap, int res_mode, hipStream_t s)
 {
     const int nwords = ((w + 4) / 5 + 2) * ((h + 4) / 5 + 2);
     hipLaunchKernelGGL(SUF(k_sparse_scan), dim3((nwords + 255) / 256, 1, nbatch), dim3(256), 0, s, views);
 #if !VM_EXACT
     if (!dense) {
         hipLaunchKernelGGL(SUF(k_sparse)<false>, dim3(1, 1, nbatch), dim3(threads), 0, s, views, cap, P, tables, flags,
-                           stats, it0, nit, fixed_work, lds_cap);
+                           stats, it0, nit, fixed_work, lds_cap, res_mode);
         return;
     }
 #endif
     (void)dense;
     hipLaunchKernelGGL(SUF(k_sparse)<true>, dim3(1, 1, nbatch), dim3(threads), 0, s, views, cap, P, tables, flags, stats,
-                       it0, nit, fixed_work, lds_cap);
+                       it0, nit, fixed_work, lds_cap, res_mode);
 }
 
 // the device iteration counter of graph-replayed sweeps: set it to, or advance it by, `value`

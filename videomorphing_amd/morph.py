@@ -114,6 +114,11 @@ class Context(object):
         1 reversed, 2 column-major, 3 column-major reversed (vm_set_commit_order)"""
         capi.check(self._L.vm_set_commit_order(self._h, int(order)))
 
+    def set_sparse_resident(self, mode=0):
+        """test hook of the SPARSE schedule's resident visits (FAST): 0 automatic, 1 never, 2 re-centre the LDS copy
+        after every commit, 3 give residency up at the first commit (vm_dbg_sparse_resident)"""
+        capi.check(self._L.vm_dbg_sparse_resident(self._h, int(mode)))
+
     def sync(self):
         capi.check(self._L.vm_ctx_sync(self._h))
 
