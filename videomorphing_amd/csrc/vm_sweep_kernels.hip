@@ -44,6 +44,7 @@
 // Commits are applied by a per-cell gather of the committed pixels' records in a
 // fixed order: deterministic, one owner per cell, no float atomics (the reference
 // uses 75 shared + 25 global float atomics per accepted pixel, morph.cu:951-1015).
+#include <type_traits>
 #include "vm_morph_common.h"
 
 // Pointers in the level views come from memory, so the compiler knows them as generic and emits
@@ -1894,7 +1895,7 @@ struct SparseLds {
     // resident visits (lean kernel): bounding box of the set mask bits (x0, x1, y0, y1), which of the <= 4 real
     // tiles of a pass a set bit reaches (bit 4: any set bit at all), a commit left the safe rectangle
     int bb[4];
-    uint32_t rw[2];
+    uint32_t rw[2][2];
     uint32_t unsafe;
 };
 
@@ -1942,6 +1943,26 @@ struct SvTile {
     int vx, vy;
     MaskGeom g;
 };
+// the pixels' own state beside the window sums (tile + halo, as TileLds): a line search reads its pixel's v,
+// lumas and UI terms and the v of its 8 ring neighbours from here, a commit writes here, and sv_store takes the
+// committed pixels to memory -- no global load ahead of a search, no store acknowledgement ahead of a phase's
+// barrier (measured on a cycling 1080p level: ~0.4 us and, in phases with a commit, ~1.4 us of every phase)
+struct SvPix {
+    float2 v[VM_NCELL], luma[VM_NCELL], uib[VM_NCELL];
+    float uiaxy[VM_NCELL];
+    uint32_t dirty[(VM_NCELL + 31) / 32];
+};
+struct SvNone {};
+struct RingLds {
+    const float2 *v;
+    int pc; // the pixel's cell
+    __device__ __forceinline__ float2 operator()(int k, int) const
+    {
+        // ring offsets (-1,-1) (0,-1) (1,-1) (1,0) (1,1) (0,1) (-1,1) (-1,0), two bits each (fover32)
+        const int rx = ((0x06A4 >> (2 * k)) & 3) - 1, ry = ((0x6A40 >> (2 * k)) & 3) - 1;
+        return v[pc + ry * VM_HALO_W + rx];
+    }
+};
 
 __device__ __forceinline__ void sv_load_mask(TileLds &S, const VmLevelView &L, const MaskGeom &g, int tid)
 {
@@ -1951,16 +1972,18 @@ __device__ __forceinline__ void sv_load_mask(TileLds &S, const VmLevelView &L, c
     }
 }
 
-// LoadSSIM (morph.cu:1214-1234) + the tile's tps.b, as in tile_sweep; ends with a barrier
-__device__ __forceinline__ void sv_load_state(TileLds &S, const VmLevelView &L, int vx, int vy, int tid, int T)
+// LoadSSIM (morph.cu:1214-1234) + the tile's tps.b, as in tile_sweep, + the pixels' own state; ends with a barrier
+__device__ __forceinline__ void sv_load_state(TileLds &S, SvPix &X, const VmLevelView &L, int vx, int vy, int tid, int T)
 {
-    if (tid < (VM_NCELL + 31) / 32)
+    if (tid < (VM_NCELL + 31) / 32) {
         S.dirty[tid] = 0;
-    for (int c0 = tid; c0 < VM_NCELL; c0 += 3 * T) {
-        float2 m[3], q[3], tb[3];
-        float cr[3], val[3];
+        X.dirty[tid] = 0;
+    }
+    for (int c0 = tid; c0 < VM_NCELL; c0 += 2 * T) {
+        float2 m[2], q[2], tb[2], pv[2], pl[2], pu[2];
+        float cr[2], val[2], pa[2];
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
+        for (int e = 0; e < 2; ++e) {
             const int c = c0 + e * T;
             const int gx = vx - 2 + c % VM_HALO_W, gy = vy - 2 + c / VM_HALO_W;
             const bool in = c < VM_NCELL && gx >= 0 && gx < L.w && gy >= 0 && gy < L.h;
@@ -1970,13 +1993,17 @@ __device__ __forceinline__ void sv_load_state(TileLds &S, const VmLevelView &L, 
             tb[e] = L.tps_b[gi];
             cr[e] = L.cross[gi];
             val[e] = L.value[gi];
+            pv[e] = L.v[gi];
+            pl[e] = L.luma[gi];
+            pu[e] = L.ui_b[gi];
+            pa[e] = L.ui_axy[gi];
             if (!in) {
                 m[e] = q[e] = tb[e] = make_float2(0, 0);
                 cr[e] = val[e] = 0.0f;
             }
         }
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
+        for (int e = 0; e < 2; ++e) {
             const int c = c0 + e * T;
             if (c < VM_NCELL) {
                 S.mean[c] = m[e];
@@ -1984,6 +2011,10 @@ __device__ __forceinline__ void sv_load_state(TileLds &S, const VmLevelView &L, 
                 S.tpsb[c] = tb[e];
                 S.cross[c] = cr[e];
                 S.value[c] = val[e];
+                X.v[c] = pv[e];
+                X.luma[c] = pl[e];
+                X.uib[c] = pu[e];
+                X.uiaxy[c] = pa[e];
             }
         }
     }
@@ -1992,21 +2023,29 @@ __device__ __forceinline__ void sv_load_state(TileLds &S, const VmLevelView &L, 
 
 // SaveSSIM (morph.cu:1236-1256) of the cells a commit reached, tps.b, and the mask words the tile owns (blocks
 // that contain one of its pixels); set words are appended to the pass's new word list when one is given
-__device__ __forceinline__ void sv_store(const TileLds &S, const VmLevelView &L, const MaskGeom &g, int vx, int vy, int tid,
-                                         int T, uint32_t *sp_list, uint32_t *sp_val, uint32_t *sp_cnt, uint32_t sp_cap)
+__device__ __forceinline__ void sv_store(const TileLds &S, const SvPix &X, const VmLevelView &L, const MaskGeom &g, int vx, int vy,
+                                         int tid, int T, uint32_t *sp_list, uint32_t *sp_val, uint32_t *sp_cnt, uint32_t sp_cap)
 {
     for (int c = tid; c < VM_NCELL; c += T) {
-        if (!((S.dirty[c >> 5] >> (c & 31)) & 1u))
+        const bool dc = (S.dirty[c >> 5] >> (c & 31)) & 1u, dp = (X.dirty[c >> 5] >> (c & 31)) & 1u;
+        if (!dc && !dp)
             continue;
         const int gx = vx - 2 + c % VM_HALO_W, gy = vy - 2 + c / VM_HALO_W;
         if (gx < 0 || gx >= L.w || gy < 0 || gy >= L.h)
             continue;
         const int gi = gy * L.rs + gx;
-        L.mean[gi] = S.mean[c];
-        L.var[gi] = S.var[c];
-        L.tps_b[gi] = S.tpsb[c];
-        L.cross[gi] = S.cross[c];
-        L.value[gi] = S.value[c];
+        if (dc) {
+            L.mean[gi] = S.mean[c];
+            L.var[gi] = S.var[c];
+            L.tps_b[gi] = S.tpsb[c];
+            L.cross[gi] = S.cross[c];
+            L.value[gi] = S.value[c];
+        }
+        if (dp) { // a committed pixel: commit_pixel_motion's own-pixel part (morph.cu:990-1026)
+            L.v[gi] = X.v[c];
+            L.luma[gi] = X.luma[c];
+            L.ui_b[gi] = X.uib[c];
+        }
     }
     if (tid < g.nbx * g.nby) {
         const int mx = tid % g.nbx, my = tid / g.nbx;
@@ -2060,11 +2099,39 @@ __device__ __forceinline__ void sv_bbox_add(SparseLds &Q, uint32_t w, int bx, in
     atomicMax(&Q.bb[3], 5 * by + 31 - __clz(rows));
 }
 
+// slot number of the k-th set bit (k from 0; it exists) of the phase's candidate bitmap: bit tx of word ty
+__device__ __forceinline__ int sv_kth_slot(const uint32_t *cb, int k)
+{
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        w[i] = cb[i]; // (one round trip)
+    int sel = 0;
+    uint32_t x = w[0];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int c = __popc(w[i]);
+        if (k >= c && sel == i) {
+            k -= c;
+            sel = i + 1;
+            x = w[i + 1];
+        }
+    }
+    for (; k > 0; --k)
+        x &= x - 1;
+    return sel * 32 + __ffs(x) - 1;
+}
+
 // The four Jacobi phases of the real tile (ox, oy) inside the LDS copy at V (V = the real tile itself: a plain
 // visit).  res: 0 = plain visit; 1 = resident; 2, 3 = resident, tests: every commit counts as unsafe, and (3) no
 // re-centred tile is accepted.  Returns whether a pixel committed; `left` = the virtual tile was given up
 // (V is now the real tile's own frame, stored by the caller like a plain visit).
-__device__ __forceinline__ bool sv_phases(TileLds &S, SparseLds &Q, const VmLevelView &L, const VmKParams &P, SvTile &V,
+// Three barriers per phase with a mask hit, one without (tile_sweep: five and two): the candidates are a
+// bitmap (the four ballots of the slot threads; a searching wave picks its k-th set bit -- no compacted list),
+// and the wave that decides a pixel also does its commit bookkeeping (mask bit, commit bitmap), so the cells
+// gather right after the searches' barrier.  All mask reads of a phase (candidates) come before its first
+// barrier, all mask writes after it.
+__device__ __forceinline__ bool sv_phases(TileLds &S, SvPix &X, SparseLds &Q, const VmLevelView &L, const VmKParams &P, SvTile &V,
                                           int ox, int oy, int tid, int T, uint32_t &st_cand, uint32_t &st_commit, int res,
                                           bool &left)
 {
@@ -2077,20 +2144,33 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SparseLds &Q, const VmLeve
             VM_TTS(pi * 2 + pj, 0);
             // ---- 1. candidates of this phase ----
             bool cand = false, hit = false;
+            uint32_t *mword = nullptr;
+            uint32_t mbit = 0;
             if (tid < 256) {
                 const int px = vx + (tid & 31) * 2 + vpj, py = vy + (tid >> 5) * 2 + vpi;
-                int state = 0;
                 if (px >= ox && px <= rx1 && py >= oy && py <= ry1 && mask_hit(S.mask, S.imp, V.g, px, py)) {
-                    state = 2; // in the mask: its bit is cleared unless it commits
-                    hit = true;
+                    hit = true; // in the mask: its bit is cleared unless it commits
                     cand = !pixel_locked(L, P.bcond, px, py);
+                    mword = &S.mask[py / 5 - V.g.by0][px / 5 - V.g.bx0];
+                    mbit = 1u << ((px % 5) + (py % 5) * 5);
                 }
-                S.d_ok[tid] = state;
+                const unsigned long long bc = __ballot(cand), bh = __ballot(hit);
+                if ((tid & 63) == 0) {
+                    S.list[(tid >> 6) * 2] = (int)(uint32_t)bc; // the candidate bitmap: bit tx of word ty
+                    S.list[(tid >> 6) * 2 + 1] = (int)(uint32_t)(bc >> 32);
+                    S.wave_cnt[tid >> 6] = __popcll(bc) | (bh ? 1 << 16 : 0);
+                    S.cbits[(tid >> 6) * 2] = 0; // the commit bitmap of this phase
+                    S.cbits[(tid >> 6) * 2 + 1] = 0;
+                }
             }
-            bool any_hit;
-            const int n_act = compact256(cand, tid, S.list, S.wave_cnt, hit, &any_hit);
-            if (!any_hit)
+            __syncthreads();
+            const int w0 = S.wave_cnt[0], w1 = S.wave_cnt[1], w2 = S.wave_cnt[2], w3 = S.wave_cnt[3];
+            // no pixel of this phase in the mask: nothing to search, nothing to commit, no bit to clear
+            if (!((w0 | w1 | w2 | w3) >> 16))
                 continue;
+            const int n_act = (w0 & 0xFFFF) + (w1 & 0xFFFF) + (w2 & 0xFFFF) + (w3 & 0xFFFF);
+            if (hit && !cand)
+                atomicAnd(mword, ~mbit); // a locked pixel in the mask
             VM_TTS(pi * 2 + pj, 1);
             if (n_act > 0) {
                 st_cand += n_act;
@@ -2100,15 +2180,30 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SparseLds &Q, const VmLeve
                 for (int base = 0; base < n_act; base += wide ? T / 64 : T / 32) {
                     const int li = base + (wide ? tid >> 6 : tid >> 5), sub = tid & 31;
                     const bool writer = wide ? (tid & 63) == 0 : sub == 0;
-                    const int slot = S.list[min(li, n_act - 1)];
+                    const int slot = sv_kth_slot((const uint32_t *)S.list, min(li, n_act - 1));
                     const int tx = slot & 31, ty = slot >> 5;
                     const int px = vx + tx * 2 + vpj, py = vy + ty * 2 + vpi;
                     const bool wave_interior = __all(li >= n_act || is_interior(L, px, py));
                     if (li < n_act) {
-                        PixelCtx c;
-                        ctx_load(c, L, S.tps, px, py);
                         LdsSrc src{&S, (ty * 2 + vpi) * VM_HALO_W + (tx * 2 + vpj)};
-                        c.tps_b = S.tpsb[src.hc + 2 * VM_HALO_W + 2];
+                        const int pc = src.hc + 2 * VM_HALO_W + 2; // the pixel's own cell
+                        PixelCtx c; // (ctx_load, from the LDS copy)
+                        c.px = px;
+                        c.py = py;
+                        c.idx = py * L.rs + px;
+                        c.v = X.v[pc];
+                        c.old_luma = X.luma[pc];
+                        c.ui_axy = X.uiaxy[pc];
+                        c.ui_b = X.uib[pc];
+                        c.tps_axy = S.tps[(border_class(py, L.h) * 5 + border_class(px, L.w)) * 25 + 12] / 2;
+                        c.tref = make_float2(0, 0);
+                        c.tmask = 0.0f;
+                        if (L.temp_mask) { // uniform in the launch
+                            c.tref = L.temp_ref[c.idx];
+                            c.tmask = L.temp_mask[c.idx];
+                        }
+                        c.tps_b = S.tpsb[pc];
+                        const RingLds ring{X.v, pc};
                         VM_TTS(pi * 2 + pj, 6);
                         float2 step, luma;
 #ifdef VM_PROF
@@ -2119,28 +2214,36 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SparseLds &Q, const VmLeve
                         uint32_t n_eval = 0;
                         if (wave_interior) {
                             nb1_load<true>(nb, L, src, c, sub);
-                            ok = wide ? decide64<true>(L, P, nb, RingGlobal{L.v}, c, sub, (tid & 32) != 0, step, luma, n_eval)
-                                      : decide32<true>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
+                            ok = wide ? decide64<true>(L, P, nb, ring, c, sub, (tid & 32) != 0, step, luma, n_eval)
+                                      : decide32<true>(L, P, nb, ring, c, sub, step, luma, n_eval VM_TS_PASS);
                         } else {
                             nb1_load<false>(nb, L, src, c, sub);
-                            ok = wide ? decide64<false>(L, P, nb, RingGlobal{L.v}, c, sub, (tid & 32) != 0, step, luma, n_eval)
-                                      : decide32<false>(L, P, nb, RingGlobal{L.v}, c, sub, step, luma, n_eval VM_TS_PASS);
+                            ok = wide ? decide64<false>(L, P, nb, ring, c, sub, (tid & 32) != 0, step, luma, n_eval)
+                                      : decide32<false>(L, P, nb, ring, c, sub, step, luma, n_eval VM_TS_PASS);
                         }
-                        if (writer)
+                        if (writer) {
                             atomicAdd(&S.n_eval, n_eval);
-                        if (ok && writer) {
-                            // commit_pixel_motion (morph.cu:990-1026), the pixel's own part, at once
-                            const float2 ol = c.old_luma;
-                            S.d_step[slot] = step;
-                            S.d_mean[slot] = make_float2(luma.x - ol.x, luma.y - ol.y);
-                            S.d_var[slot] = make_float2(luma.x * luma.x - ol.x * ol.x, luma.y * luma.y - ol.y * ol.y);
-                            S.d_cross[slot] = luma.x * luma.y - ol.x * ol.y;
-                            L.luma[c.idx] = luma;
-                            L.ui_b[c.idx] = make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy);
-                            L.v[c.idx] = make_float2(c.v.x + step.x, c.v.y + step.y);
-                            S.d_ok[slot] = 3;
-                            if (res && (res > 1 || !sv_safe(L, V, px, py)))
-                                Q.unsafe = 1u;
+                            uint32_t *const mw = &S.mask[py / 5 - V.g.by0][px / 5 - V.g.bx0];
+                            const uint32_t mb = 1u << ((px % 5) + (py % 5) * 5);
+                            if (ok) {
+                                // commit_pixel_motion (morph.cu:990-1026), the pixel's own part, at once: nothing
+                                // else of this phase reads its v, luma or ui.b; its record for the cells' gather;
+                                // its mask bit
+                                const float2 ol = c.old_luma;
+                                S.d_step[slot] = step;
+                                S.d_mean[slot] = make_float2(luma.x - ol.x, luma.y - ol.y);
+                                S.d_var[slot] = make_float2(luma.x * luma.x - ol.x * ol.x, luma.y * luma.y - ol.y * ol.y);
+                                S.d_cross[slot] = luma.x * luma.y - ol.x * ol.y;
+                                X.luma[pc] = luma;
+                                X.uib[pc] = make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy);
+                                X.v[pc] = make_float2(c.v.x + step.x, c.v.y + step.y);
+                                atomicOr(&X.dirty[pc >> 5], 1u << (pc & 31));
+                                atomicOr(&S.cbits[ty], 1u << tx);
+                                atomicOr(mw, mb);
+                                if (res && (res > 1 || !sv_safe(L, V, px, py)))
+                                    Q.unsafe = 1u;
+                            } else
+                                atomicAnd(mw, ~mb);
                         }
                     }
                 }
@@ -2149,21 +2252,24 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SparseLds &Q, const VmLeve
             __syncthreads();
             VM_TTS(pi * 2 + pj, 3);
 
-            // ---- 3. commits ----
-            const bool ok = tid < 256 && commit_own(S, L, V.g, tid, vx, vy, vpi, vpj);
-            {
-                const unsigned long long cb = __ballot(ok);
-                if (tid < 256 && (tid & 63) == 0) {
-                    S.cbits[(tid >> 6) * 2] = (uint32_t)cb;
-                    S.cbits[(tid >> 6) * 2 + 1] = (uint32_t)(cb >> 32);
+            // ---- 3. the cells gather the commits of the phase ----
+            uint32_t cb[8];
+            int ncommit = 0, ty0 = 8, ty1 = -1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                cb[k] = S.cbits[k];
+                ncommit += __popc(cb[k]);
+                if (cb[k]) {
+                    ty0 = min(ty0, k);
+                    ty1 = k;
                 }
             }
-            const int ncommit = __syncthreads_count(ok);
             VM_TTS(pi * 2 + pj, 4);
             if (ncommit) {
                 tile_improving = true;
                 st_commit += ncommit;
-                for (int cell = tid; cell < VM_NCELL; cell += T) {
+                // (rows of the halo grid within +-2 of a committing pixel: 2 ty + vpi - 2 ... + 2, shifted by the halo's 2)
+                for (int cell = (2 * ty0 + vpi) * VM_HALO_W + tid; cell < (2 * ty1 + vpi + 5) * VM_HALO_W; cell += T) {
                     const int ry = cell / VM_HALO_W - 2, rx = cell % VM_HALO_W - 2; // tile-relative
                     const int qx = vx + rx, qy = vy + ry;
                     if (qx < 0 || qx >= L.w || qy < 0 || qy >= L.h)
@@ -2199,7 +2305,7 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SparseLds &Q, const VmLeve
             if (!res || !(Q.unsafe & 1u)) // (uniform: written before the barrier above)
                 continue;
             // ---- a commit left the safe rectangle: move the virtual tile before the next phase ----
-            sv_store(S, L, V.g, vx, vy, tid, T, nullptr, nullptr, nullptr, 0);
+            sv_store(S, X, L, V.g, vx, vy, tid, T, nullptr, nullptr, nullptr, 0);
             if (tid == 0) {
                 Q.bb[0] = Q.bb[2] = 0x7fffffff;
                 Q.bb[1] = Q.bb[3] = -0x7fffffff;
@@ -2222,7 +2328,7 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SparseLds &Q, const VmLeve
             V.g = mask_geom(L, nvx, nvy);
             __syncthreads(); // S.mask and Q.bb are read before they are overwritten
             sv_load_mask(S, L, V.g, tid);
-            sv_load_state(S, L, nvx, nvy, tid, T);
+            sv_load_state(S, X, L, nvx, nvy, tid, T);
         }
     }
     return tile_improving;
@@ -2250,6 +2356,9 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
 #endif
     __shared__ TileLds S;
     __shared__ SparseLds Q;
+#if !VM_EXACT
+    __shared__ typename std::conditional<LEAN, SvPix, SvNone>::type X;
+#endif
     const int tid = threadIdx.x, T = blockDim.x;
     const VmLevelView L = views[blockIdx.z];
     flags += (size_t)blockIdx.z * cap;
@@ -2324,7 +2433,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                 if (sv_place(L, Q.bb[0], Q.bb[1], Q.bb[2], Q.bb[3], V.vx, V.vy)) {
                     V.g = mask_geom(L, V.vx, V.vy);
                     sv_load_mask(S, L, V.g, tid);
-                    sv_load_state(S, L, V.vx, V.vy, tid, T);
+                    sv_load_state(S, X, L, V.vx, V.vy, tid, T);
                     resident = true;
                 }
             }
@@ -2336,43 +2445,46 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
             const bool pass_resident = resident; // (residency can end inside a pass, never begin)
             VM_TTSF(4);
             // ---- 1. the tiles of this pass that a set mask bit reaches ----
-            for (int k = tid; k < ntw; k += T)
-                Q.tilebits[k] = 0;
-            if (tid == 0) {
-                Q.ndone = 0;
-                Q.nnew = 0;
-                Q.ntl = 0;
-            }
-            __syncthreads();
+            int ntl = 0;
+            unsigned long long rtl = 0; // (resident) the <= 4 tiles, 16 bits each
+            bool selected = false;
 #if !VM_EXACT
-            if (LEAN && pass_resident) {
+            if constexpr (LEAN) if (pass_resident) {
+                selected = true;
                 // every set bit of the level is in the LDS copy of the words: the <= 2 x 2 tiles of this pass whose
                 // rectangle + 2 meets the virtual tile, tested as tile_sweep's early out tests them
                 const int ax = V.vx - (VM_TILE_W + 1) - offx, bx = V.vx + (VM_TILE_W + 1) - offx;
                 const int ay = V.vy - (VM_TILE_H + 1) - offy, by = V.vy + (VM_TILE_H + 1) - offy;
                 const int c_lo = ax > 0 ? (ax + VM_PITCH_X - 1) / VM_PITCH_X : 0, r_lo = ay > 0 ? (ay + VM_PITCH_Y - 1) / VM_PITCH_Y : 0;
                 const int c_hi = bx >= 0 ? min(bx / VM_PITCH_X, gx - 1) : -1, r_hi = by >= 0 ? min(by / VM_PITCH_Y, gy - 1) : -1;
-                if (tid < V.g.nbx * V.g.nby) {
-                    const int mx = tid % V.g.nbx, my = tid / V.g.nbx;
-                    const uint32_t w = S.mask[my][mx];
-                    if (w) {
-                        Q.unsafe = 2u; // (bit 1: a set bit exists; bit 0 is sv_phases')
-                        for (int r = r_lo; r <= r_hi; ++r)
-                            for (int c = c_lo; c <= c_hi; ++c) {
-                                const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
-                                if (ox < L.w && oy < L.h && (w & tile_reach_bits(L, ox, oy, V.g.bx0 + mx, V.g.by0 + my))) {
-                                    const uint32_t bit = 1u << ((r * gx + c) & 31);
-                                    if (!(atomicOr(&Q.tilebits[(r * gx + c) >> 5], bit) & bit))
-                                        Q.tl[atomicAdd(&Q.ntl, 1u)] = r * gx + c; // <= 4
+                if (tid < 128) { // the <= 96 words of a window sit in waves 0 and 1
+                    uint32_t mine = 0;
+                    if (tid < V.g.nbx * V.g.nby) {
+                        const int mx = tid % V.g.nbx, my = tid / V.g.nbx;
+                        const uint32_t w = S.mask[my][mx];
+                        if (w) {
+                            mine = 16u; // a set bit exists
+                            for (int r = r_lo; r <= r_hi; ++r)
+                                for (int c = c_lo; c <= c_hi; ++c) {
+                                    const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
+                                    if (ox < L.w && oy < L.h && (w & tile_reach_bits(L, ox, oy, V.g.bx0 + mx, V.g.by0 + my)))
+                                        mine |= 1u << ((r - r_lo) * 2 + (c - c_lo));
                                 }
-                            }
+                        }
                     }
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int bnum = 0; bnum < 5; ++bnum)
+                        m |= __ballot((mine >> bnum) & 1u) ? 1u << bnum : 0u;
+                    if ((tid & 63) == 0)
+                        Q.rw[pass & 1][tid >> 6] = m; // (two buffers: a pass without a visit has no barrier after its read)
                 }
                 __syncthreads();
-                if (!(Q.unsafe & 2u)) {
+                const uint32_t reach = Q.rw[pass & 1][0] | Q.rw[pass & 1][1];
+                if (!(reach & 16u)) {
                     // no set bit left: the level has converged (what `nw == 0` says to list-driven visits)
                     if (pass == 0) {
-                        sv_store(S, L, V.g, V.vx, V.vy, tid, T, nullptr, nullptr, nullptr, 0);
+                        sv_store(S, X, L, V.g, V.vx, V.vy, tid, T, nullptr, nullptr, nullptr, 0);
                         resident = false;
                         nw = 0;
                         emptied = true;
@@ -2380,13 +2492,22 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                     }
                     continue;
                 }
-                __syncthreads();
-                if (tid == 0)
-                    Q.unsafe = 0;
-                // (ordered before its next use by the barriers of the first phase)
-            } else
+                ntl = 0;
+                for (int r = r_lo; r <= r_hi; ++r)
+                    for (int c = c_lo; c <= c_hi; ++c)
+                        if ((reach >> ((r - r_lo) * 2 + (c - c_lo))) & 1u)
+                            rtl |= (unsigned long long)(r * gx + c) << (16 * ntl++);
+            }
 #endif
-            {
+            if (!selected) {
+                for (int k = tid; k < ntw; k += T)
+                    Q.tilebits[k] = 0;
+                if (tid == 0) {
+                    Q.ndone = 0;
+                    Q.nnew = 0;
+                    Q.ntl = 0;
+                }
+                __syncthreads();
                 for (uint32_t k = tid; k < nw; k += T) {
                     const int wi = (int)list[k];
                     const uint32_t wv = in_lds ? Q.wv[cur][k] : L.impmask[wi];
@@ -2407,16 +2528,16 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                         }
                 }
                 __syncthreads();
+                ntl = (int)Q.ntl;
             }
             VM_TTSF(5);
             // ---- 2. sweep them, one after the other (tiles of a pass touch disjoint state: any order) ----
             // (a few tiles: straight from the list; many: the bitmap, word by word -- walking all of its up to 46
             // words for the one tile of a cycling level was ~3 us of every pass)
-            const int ntl = (int)Q.ntl;
             for (int wd = 0; wd < (ntl <= 64 ? ntl : ntw); ++wd) {
                 uint32_t bits = ntl <= 64 ? 1u : Q.tilebits[wd];
                 while (bits) {
-                    const int t = ntl <= 64 ? Q.tl[wd] : wd * 32 + __ffs(bits) - 1;
+                    const int t = pass_resident ? (int)((rtl >> (16 * wd)) & 0xFFFFu) : (ntl <= 64 ? Q.tl[wd] : wd * 32 + __ffs(bits) - 1);
                     bits &= bits - 1;
                     const int ox = (t % gx) * VM_PITCH_X + offx, oy = (t / gx) * VM_PITCH_Y + offy;
                     bool visited;
@@ -2435,15 +2556,15 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                             }
                             visited = __syncthreads_or(reach != 0); // tile_sweep's early out
                             if (visited)
-                                sv_load_state(S, L, ox, oy, tid, T);
+                                sv_load_state(S, X, L, ox, oy, tid, T);
                         }
                         if (visited) {
                             bool left = false;
-                            if (sv_phases(S, Q, L, P, V, ox, oy, tid, T, st_cand, st_commit, resident ? (res_mode ? res_mode : 1) : 0, left))
+                            if (sv_phases(S, X, Q, L, P, V, ox, oy, tid, T, st_cand, st_commit, resident ? (res_mode ? res_mode : 1) : 0, left))
                                 improving = true;
                             if (!resident || left) {
                                 const bool listed = !pass_resident && in_lds;
-                                sv_store(S, L, V.g, V.vx, V.vy, tid, T, listed ? Q.wl[cur ^ 1] : nullptr, Q.wv[cur ^ 1], &Q.nnew, lcap);
+                                sv_store(S, X, L, V.g, V.vx, V.vy, tid, T, listed ? Q.wl[cur ^ 1] : nullptr, Q.wv[cur ^ 1], &Q.nnew, lcap);
                                 resident = false;
                             }
                         }
@@ -2453,7 +2574,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                                                     in_lds ? Q.wl[cur ^ 1] : nullptr, Q.wv[cur ^ 1], &Q.nnew, lcap);
                     if (visited) {
                         ++st_tiles;
-                        if (tid == 0) {
+                        if (tid == 0 && !pass_resident) {
                             if (Q.ndone < 128)
                                 Q.done[Q.ndone] = t;
                             ++Q.ndone;
@@ -2563,8 +2684,8 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
         __syncthreads();
     }
 #if !VM_EXACT
-    if (LEAN && resident)
-        sv_store(S, L, V.g, V.vx, V.vy, tid, T, nullptr, nullptr, nullptr, 0);
+    if constexpr (LEAN) if (resident)
+        sv_store(S, X, L, V.g, V.vx, V.vy, tid, T, nullptr, nullptr, nullptr, 0);
 #endif
 }
 
