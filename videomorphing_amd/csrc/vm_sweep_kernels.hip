@@ -1892,8 +1892,9 @@ struct SparseLds {
     uint32_t wv[2][VM_SPARSE_LDS_CAP]; // ... and their values
     int tl[64];                        // the tiles selected for this pass, in the order they were found
     uint32_t ntl;                      // how many (entries past 64 are only counted: the bitmap is walked instead)
-    // resident visits (lean kernel): bounding box of the set mask bits (x0, x1, y0, y1), which of the <= 4 real
-    // tiles of a pass a set bit reaches (bit 4: any set bit at all), a commit left the safe rectangle
+    // resident visits (lean kernel): bounding box of the set mask bits (x0, x1, y0, y1); per pass parity and per
+    // wave 0 / 1, which of the <= 4 real tiles of the pass a set bit reaches (bit 4: any set bit at all); 1 = a
+    // commit left the safe rectangle
     int bb[4];
     uint32_t rw[2][2];
     uint32_t unsafe;
