@@ -36,7 +36,9 @@
 //  see the comment at k_step.  Bit-identical to SPLIT.
 //
 //  SPARSE schedule (k_sparse, one launch per batch of iterations of a pruned level): one
-//  workgroup per pair walks the iterations, sweeping only the tiles whose mask words are set.
+//  workgroup per pair walks the iterations, sweeping only the tiles whose mask words are set;
+//  while the set bits fit one tile (FAST) the window sums around them stay in LDS across passes
+//  and iterations (resident visits, see the comment at SvTile).
 //
 //  PASS schedule (k_pass, one launch per pass): a tile = a group of 32 workgroups on one XCD,
 //  the four phases behind a tile-local barrier; see the comment at PassLds.
