@@ -99,6 +99,7 @@ def parse_args(argv=None):
                     help="N = 1, config 1: skip `scale_reference` (config[2]'s job -- the workload an N > 1 run shards -- on this one GPU)")
     ap.add_argument("--scale-ref-pairs", type=int, default=60, help="frame pairs of the scale_reference job")
     ap.add_argument("--size", default=None, help="WxH override (development only)")
+    ap.add_argument("--sweep-threads", type=int, default=0, help="threads per sweep workgroup, 0 = the library's choice (development only)")
     ap.add_argument("--as-rank", type=int, default=-1,
                     help="config 2 on ONE GPU: solve the shard rank K of an --of G-rank job would get (static partition "
                          "study: per-rank load without the G GPUs)")
@@ -164,6 +165,8 @@ def main():
     ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(nctx)]
     for c in ctxs:
         c.set_params(blk.kp)
+        if args.sweep_threads:
+            c.set_tuning(capi.SWEEP_AUTO, args.sweep_threads, 0)
     ctx = ctxs[0]
     L = capi.load()
     nlev = synth.num_levels(w, h, blk.start_res)

@@ -914,6 +914,38 @@ def test_resident_sparse_visits_equal_list_driven_ones_on_a_cycling_level(gpu_ct
     assert cycling >= 1 or w != 1920, cycling        # at 1080p at least one of the two frames does cycle
 
 
+@pytest.mark.parametrize("w,h", [(120, 68), (240, 135), (150, 97)])
+def test_dense_sweeps_do_not_depend_on_the_workgroup_size(gpu_ctx, w, h):
+    """FAST, dense TILE sweeps of a small level from a rough start (every pixel searched for the first sweeps) with
+    256- and with 512-thread workgroups: the same bits in every state array and the same counters -- the lane
+    fan-out per candidate, which orders the FAST sums, is a constant of the kernel; a 256-thread workgroup takes
+    a full phase in two rounds.  (The library picks 256 for such levels when enough of their workgroups are in
+    flight on the device to pair up on the CUs: vm_api.cpp, SmallDensePresence.)"""
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+    i0, i1 = synth.make_pair(w, h)
+    v0 = (0.9 * synth.displacement(w, h)).astype(np.float32)
+    out = []
+    try:
+        for threads in (512, 256):
+            gpu_ctx.set_tuning(capi.SWEEP_TILE, threads, 0)
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build_levels([(w, h), ((w + 1) // 2, (h + 1) // 2)])
+            pyr.upload_luma(1, i0, i1)
+            pyr[1].v = v0
+            capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+            pr = capi.Progress()
+            capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 24.0, None, 1, C.byref(pr)))
+            out.append(([pyr[1].field(n).copy() for n in _STATE], (pr.iters, pr.commits, pr.candidates, pr.evaluations, pr.active_tiles)))
+            del pyr
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    assert out[0][1] == out[1][1] and out[0][1][1] > 1000, (out[0][1], out[1][1])
+    for n, a, b in zip(_STATE, out[0][0], out[1][0]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), n
+
+
 _FORM_SCRIPT = r"""
 import sys, ctypes as C
 import numpy as np

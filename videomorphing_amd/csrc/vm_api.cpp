@@ -3,6 +3,7 @@
 // coarse-to-fine driver.  Kernels live in vm_morph_kernels.hip (optimizer),
 // vm_render.hip (compositor) and vm_poisson.hip (boundary extension).
 #include "vm_internal.h"
+#include <atomic>
 #include "vm_host.h"
 
 #ifndef VM_STEP_MAX_TILES
@@ -18,6 +19,10 @@ static int vm_step_max_tiles()
 #ifndef VM_STEP_BIG_PARTS
 #define VM_STEP_BIG_PARTS 8
 #endif
+#ifndef VM_CORUN_MIN_WGS
+#define VM_CORUN_MIN_WGS 384 // small-level dense workgroups in flight on a device from which 256-thread workgroups pay (1.5 per CU)
+#endif
+#define VM_MAX_DEVICES_TRACKED 64
 #ifndef VM_PASS_MAX_GROUPS
 #define VM_PASS_MAX_GROUPS 8 // AUTO: PASS instead of STEP while a pass has at most this many tiles (x pairs): one 256-workgroup chunk
 #endif
@@ -682,6 +687,33 @@ int vm_level_init(vm_ctx *c, vm_level &l, int w0, int h0, const vm_constraint *c
     return VM_OK;
 }
 
+// How many workgroups the dense sweeps of SMALL levels (<= 32 tiles per pass: the 256-VGPR kernel without the
+// interior form, one 512-thread workgroup = 8 waves = all of a CU's registers) have in flight on a device, summed
+// over the contexts of this process that are sweeping such a level right now.  A batch of 30 pairs x 8 tiles
+// = 240 workgroups fills the chip one per CU; a second stream's 240 then wait for them.  As 256-thread
+// workgroups (4 waves: a tile's ~127 candidates of a phase at two lanes each; a full phase in two rounds) two
+// fit a CU -- 2 x 75 KB of LDS, 2 x 4 waves x 256 VGPRs -- and the two streams' tiles run side by side, each SIMD
+// with two searching waves instead of one: config[2]'s 60 pairs on one GPU 968 -> 890 ms.  It only pays when the
+// workgroups in flight exceed the CUs by enough (measured: 2 x 240 and 1 x 840 yes; 1 x 240, 2 x 120 no: -16 %),
+// so the rule counts them.  Results do not depend on the workgroup size (the lane fan-out per candidate, which
+// orders the FAST sums, is a compile-time constant of the kernel).
+static std::atomic<int> g_small_dense_wgs[VM_MAX_DEVICES_TRACKED];
+struct SmallDensePresence {
+    int dev = -1, wgs = 0;
+    void enter(int device, int n_wgs)
+    {
+        if (device < 0 || device >= VM_MAX_DEVICES_TRACKED) return;
+        dev = device;
+        wgs = n_wgs;
+        g_small_dense_wgs[dev].fetch_add(wgs);
+    }
+    int in_flight() const { return dev < 0 ? wgs : g_small_dense_wgs[dev].load(); }
+    ~SmallDensePresence()
+    {
+        if (dev >= 0) g_small_dense_wgs[dev].fetch_sub(wgs);
+    }
+};
+
 // the sweep launchers of one arithmetic build of vm_sweep_kernels.hip
 struct SweepLaunchers {
     decltype(&vm_launch_optimize_exact) optimize;
@@ -923,6 +955,11 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     // window sums must not spill), EXACT ones for up to 1024
     const int threads = std::min(c->sweep_threads ? c->sweep_threads : 512, exact ? 1024 : 512);
     const int tiles_per_pass = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
+    // (see SmallDensePresence) this call's share of the small-level dense workgroups on the device, while it lasts
+    SmallDensePresence small_dense;
+    static const bool no_corun = getenv("VM_NO_CORUN") != nullptr; // dev switch
+    if (!exact && !no_corun && tiles_per_pass <= 32 && c->sweep_threads == 0)
+        small_dense.enter(c->device, tiles_per_pass * n);
     // SPLIT / STEP schedules: workgroups per tile (every candidate gets 32 lanes, 16 candidates
     // per 512-thread workgroup)
     // (16 workgroups of 16 candidates per tile while the chip has room for them; 8 of 32 when a
@@ -1100,9 +1137,12 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
             launches += 2;
             it0 = done + nb;
         }
+        // dense TILE sweeps of a small level as 256-thread workgroups when enough of them are in flight on the
+        // device to pair up on the CUs (SmallDensePresence)
+        const int tile_threads = (small_dense.dev >= 0 && dense == 1 && small_dense.in_flight() >= VM_CORUN_MIN_WGS) ? 256 : threads;
         if (!split && !sparse && nb >= VM_GRAPH_ITERS) {
             // TILE batch: whole groups of VM_GRAPH_ITERS iterations are graph replays
-            if (hipGraphExec_t ge = sweep_graph(c, c->math_mode, n, l0.w, l0.h, cap, fixed_work, threads, dense, P)) {
+            if (hipGraphExec_t ge = sweep_graph(c, c->math_mode, n, l0.w, l0.h, cap, fixed_work, tile_threads, dense, P)) {
                 SL.next_iter(c->iter_dev, 1, done, s);
                 for (; it0 + VM_GRAPH_ITERS <= done + nb; it0 += VM_GRAPH_ITERS) {
                     VM_HIP(hipGraphLaunch(ge, s));
@@ -1138,7 +1178,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
                     SL.split(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], k, c->flags, c->stats, it, fixed_work, threads, parts, s);
                     launches += 8;
                 } else {
-                    SL.optimize(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, threads, nullptr, dense, s);
+                    SL.optimize(c->views, n, cap, l0.w, l0.h, P, c->tables, offs[k][0], offs[k][1], c->flags, c->stats, it, fixed_work, tile_threads, nullptr, dense, s);
                     ++launches;
                 }
             }
