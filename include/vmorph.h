@@ -170,6 +170,8 @@ int  vm_dbg_pass_fallbacks(vm_ctx *ctx);
  * mode 0 = automatic (default), 1 = never, 2 = the LDS copy is re-centred after every commit, 3 = residency is given
  * up at the first commit (the two exits a growing active region takes, forced).  Other values: VM_E_INVALID. */
 int  vm_dbg_sparse_resident(vm_ctx *ctx, int mode);
+/* ... and how many tile visits of this context's solves were served from that LDS copy so far (saturating). */
+int  vm_dbg_sparse_resident_visits(vm_ctx *ctx);
 /* Diagnostic of the PASS schedule: on which XCD (0..7) each of the first `n` (<= 2048)
  * workgroups of the most recent PASS launch ran (workgroup b belongs to tile group
  * (b / 256) * 8 + b % 8; a group whose 32 workgroups report one XCD keeps its tile in one
@@ -202,6 +204,11 @@ int  vm_level_get_v(vm_pyr *pyr, int lvl, float *v_xy, int pitch);
 int  vm_level_get_field(vm_pyr *pyr, int lvl, int field, void *host);
 /* Morph::clear_level, Algorithm/morph.cu:392-414 */
 int  vm_level_clear(vm_pyr *pyr, int lvl);
+/* Test hook: overwrite the improving mask of an initialised level (init_improving_mask's array, morph.cu:203-260; the
+ * layout vm_level_get_field(VM_F_IMPMASK) returns: ((h + 4) / 5 + 2) rows of (w + 4) / 5 + 2 words, bit x % 5 + 5 (y % 5) of
+ * word (y / 5 + 1, x / 5 + 1)).  Any mask is a legal state -- it only says which pixels the next sweep searches -- so tests
+ * plant small clusters of set bits to drive the schedules through their pruned regimes. */
+int  vm_dbg_level_set_mask(vm_pyr *pyr, int lvl, const uint32_t *words);
 
 /* ---- solver -------------------------------------------------------------- */
 /* Morph::cpu_optimize_level, Algorithm/morph.cu:419-590 (host banded solve of

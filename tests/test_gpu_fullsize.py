@@ -897,7 +897,14 @@ def test_resident_sparse_visits_equal_list_driven_ones_on_a_cycling_level(gpu_ct
                 pyr.build(i0, i1, 32)
                 assert pyr.size() == nlev + 1
                 prog = (capi.Progress * (nlev - 1))()
+                served = gpu_ctx.sparse_resident_visits()
                 capi.check(pyr._L.vm_solve(pyr._h, 500.0, 1.0, None, 0, None, 0, prog))
+                served = gpu_ctx.sparse_resident_visits() - served
+                # never: none; automatic on a cycling level: most of its ~2000 visits
+                if mode == 1:
+                    assert served == 0, (frame, served)
+                elif prog[0].iters == 500:
+                    assert served > (1000 if mode == 0 else 0), (frame, mode, served)
                 got = ([pyr[1].field(n).copy() for n in _STATE],
                        [(p.iters, p.improving, p.commits, p.candidates, p.evaluations, p.active_tiles) for p in prog])
                 del pyr

@@ -32,11 +32,18 @@ for trial in range(trials):
     fixed = int(rng.randint(0, 2))
     cap = int(rng.choice([0, 0, 1, 5, 17, 64]))
     resm = int(rng.choice([0, 0, 2, 3]))      # resident visits: automatic, re-centred at every commit, given up at the first
+    extra = float(rng.choice([0, 150, 400]))  # more TILE sweeps before the comparison: down to a few clusters (what goes resident)
+    words = F._plant_clusters(rng, w, h) if trial % 2 else None   # ... or a planted mask of a few clusters,
+    sweeps = float(rng.choice([6, 12, 25, 80])) if trial % 2 else 80.0   # on a level that is more or less settled
     st = rng.get_state()
     res = []
     for sched in (capi.SWEEP_TILE, capi.SWEEP_SPARSE):
         rng.set_state(st)
-        pyr = F._pruned_level(ctx, O, rng, w, h, kw, cons, trial)
+        pyr = F._pruned_level(ctx, O, rng, w, h, kw, cons, trial, sweeps)
+        if extra:
+            capi.check(pyr._L.vm_optimize_level(pyr._h, 0, extra, None, 1, None))     # (the TILE schedule is still set)
+        if words is not None:
+            pyr[1].set_impmask(words)
         ctx.set_tuning(sched, 0, cap if sched == capi.SWEEP_SPARSE else 0)
         ctx.set_sparse_resident(resm)
         pr = capi.Progress()
@@ -50,4 +57,4 @@ for trial in range(trials):
         print("MISMATCH trial %d mode %d %dx%d iters %g fixed %d cap %d resident %d: counters %s vs %s" % (trial, mode, w, h, iters, fixed, cap, resm, res[0][1], res[1][1]), flush=True)
 ctx.set_tuning(0, 0, 0)
 ctx.set_sparse_resident(0)
-print("fuzz seed %d: %d trials, sparse kernel used in %d, mismatches %d" % (seed, trials, used, bad))
+print("fuzz seed %d: %d trials, sparse kernel used in %d, mismatches %d; tile visits served from the resident LDS copy: %d" % (seed, trials, used, bad, ctx.sparse_resident_visits()))

@@ -27,7 +27,7 @@ FIELDS = {  # name -> (id, channels)
 SYMBOLS = [
     "vm_last_error", "vm_version", "vm_ctx_create", "vm_ctx_destroy", "vm_ctx_sync",
     "vm_set_params", "vm_get_params", "vm_set_math_mode", "vm_set_tuning", "vm_set_commit_order", "vm_dbg_pass_placement", "vm_dbg_pass_force_timeout",
-    "vm_dbg_pass_fallbacks", "vm_dbg_sparse_resident", "vm_device_info",
+    "vm_dbg_pass_fallbacks", "vm_dbg_level_set_mask", "vm_dbg_sparse_resident", "vm_dbg_sparse_resident_visits", "vm_device_info",
     "vm_pyramid_create", "vm_pyramid_destroy", "vm_pyramid_levels", "vm_level_dims",
     "vm_level_upload_luma", "vm_pyramid_build_rgb", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
@@ -117,6 +117,7 @@ def load():
         "vm_dbg_pass_force_timeout": [vp, i],
         "vm_dbg_pass_fallbacks": [vp],
         "vm_dbg_sparse_resident": [vp, C.c_int],
+        "vm_dbg_sparse_resident_visits": [vp],
         "vm_device_info": [vp, C.c_char_p, C.POINTER(i), C.POINTER(C.c_uint64)],
         "vm_pyramid_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(vp)],
         "vm_pyramid_levels": [vp],
@@ -127,6 +128,7 @@ def load():
         "vm_level_get_v": [vp, i, vp, i],
         "vm_level_get_field": [vp, i, i, vp],
         "vm_level_clear": [vp, i],
+        "vm_dbg_level_set_mask": [vp, i, vp],
         "vm_coarse_solve": [vp, i, i, i, vp, i],
         "vm_upsample_v": [vp, i, i],
         "vm_init_level": [vp, i, i, i, vp, i],

@@ -266,6 +266,12 @@ extern "C" int vm_dbg_sparse_resident(vm_ctx *c, int mode)
     return VM_OK;
 }
 
+extern "C" int vm_dbg_sparse_resident_visits(vm_ctx *c)
+{
+    if (!c) return vm_fail(VM_E_INVALID, "vm_dbg_sparse_resident_visits: ctx is NULL");
+    return (int)std::min<unsigned long long>(c->sparse_resident_visits, 0x7fffffffull);
+}
+
 extern "C" int vm_dbg_pass_force_timeout(vm_ctx *c, int on)
 {
     if (!c) return vm_fail(VM_E_INVALID, "vm_dbg_pass_force_timeout: ctx is NULL");
@@ -604,6 +610,18 @@ int vm_level_read_field(vm_ctx *c, vm_level &l, int field, void *host)
     }
     if (!src) return vm_fail(VM_E_STATE, "vm_level_get_field: the level has no such array");
     VM_HIP(hipMemcpy2DAsync(host, (size_t)l.w * elem, src, (size_t)l.rs * elem, (size_t)l.w * elem, l.h, hipMemcpyDeviceToHost, s));
+    VM_HIP(hipStreamSynchronize(s));
+    return VM_OK;
+}
+
+extern "C" int vm_dbg_level_set_mask(vm_pyr *p, int lvl, const uint32_t *words)
+{
+    CHECK_LVL(p, lvl);
+    vm_level &l = p->lv[lvl];
+    if (!words) return vm_fail(VM_E_INVALID, "vm_dbg_level_set_mask: NULL");
+    if (!l.has_state || !l.view.impmask) return vm_fail(VM_E_STATE, "vm_dbg_level_set_mask: level not initialised");
+    hipStream_t s = p->ctx->stream;
+    VM_HIP(hipMemcpyAsync(l.view.impmask, words, (size_t)l.imp_rs * l.imp_rows * 4, hipMemcpyHostToDevice, s));
     VM_HIP(hipStreamSynchronize(s));
     return VM_OK;
 }
@@ -1244,6 +1262,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
                 b_cand += st[VM_STAT_WORDS * it + 1];
                 st_commit[i] += st[VM_STAT_WORDS * it + 2];
                 st_eval[i] += st[VM_STAT_WORDS * it + 4];
+                c->sparse_resident_visits += st[VM_STAT_WORDS * it + 5];
                 improving[i] = fl[it] != 0;
                 if (!improving[i] && live[i] < 0) live[i] = it + 1; // the reference's loop ends here (morph.cu:1390)
                 if (!improving[i] && !fixed_work) { executed[i] = it + 1; stopped[i] = 1; }

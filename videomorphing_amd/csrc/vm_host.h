@@ -102,6 +102,7 @@ struct vm_ctx {
     std::vector<SweepGraph> graphs;
     int commit_order = 0;         // vm_set_commit_order (EXACT, diagnostic): order 0..3
     int sparse_resident = 0;      // vm_dbg_sparse_resident: 0 = automatic, 1 = never, 2 / 3 = tests (k_sparse, sv_phases)
+    unsigned long long sparse_resident_visits = 0; // vm_dbg_sparse_resident_visits: tile visits served from the resident LDS copy
     int use_graphs = -1;             // -1: not decided yet, 0: off (VM_NO_GRAPH or a failed capture), 1: on
 };
 

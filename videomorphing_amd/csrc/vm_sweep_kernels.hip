@@ -2415,7 +2415,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
         if (nw == 0)
             break;
         bool improving = false, emptied = false;
-        uint32_t st_cand = 0, st_commit = 0, st_tiles = 0;
+        uint32_t st_cand = 0, st_commit = 0, st_tiles = 0, st_res = 0;
         if (tid == 0)
             S.n_eval = 0;
 #if !VM_EXACT
@@ -2563,6 +2563,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
                         }
                         if (visited) {
                             bool left = false;
+                            st_res += resident ? 1u : 0u;
                             if (sv_phases(S, X, Q, L, P, V, ox, oy, tid, T, st_cand, st_commit, resident ? (res_mode ? res_mode : 1) : 0, left))
                                 improving = true;
                             if (!resident || left) {
@@ -2681,6 +2682,7 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(1)))
             stats[it * VM_STAT_WORDS + 1] = st_cand;
             stats[it * VM_STAT_WORDS + 2] = st_commit;
             stats[it * VM_STAT_WORDS + 4] = S.n_eval;
+            stats[it * VM_STAT_WORDS + 5] = st_res; // tile visits served from the resident LDS copy (diagnostic)
         }
         if (!fixed_work && !improving)
             break; // reference semantics: the level stops here (the following flags stay 0)

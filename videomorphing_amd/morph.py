@@ -119,6 +119,10 @@ class Context(object):
         after every commit, 3 give residency up at the first commit (vm_dbg_sparse_resident)"""
         capi.check(self._L.vm_dbg_sparse_resident(self._h, int(mode)))
 
+    def sparse_resident_visits(self):
+        """tile visits of this context's solves served from the resident LDS copy so far (vm_dbg_sparse_resident_visits)"""
+        return int(self._L.vm_dbg_sparse_resident_visits(self._h))
+
     def sync(self):
         capi.check(self._L.vm_ctx_sync(self._h))
 
@@ -181,6 +185,12 @@ class PyramidLevel(object):
             out = np.zeros((self.height, self.width), dtype=np.float32)
         capi.check(L.vm_level_get_field(self._pyr._h, self._lvl(), fid, out.ctypes.data))
         return out
+
+    def set_impmask(self, words):
+        """test hook: overwrite the improving mask (the array field("impmask") returns), vm_dbg_level_set_mask"""
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        assert words.shape == ((self.height + 4) // 5 + 2, self.impmask_rowstride)
+        capi.check(self._pyr._L.vm_dbg_level_set_mask(self._pyr._h, self._lvl(), words.ctypes.data))
 
     @property
     def v(self):
