@@ -1900,6 +1900,11 @@ struct SparseLds {
     int bb[4];
     uint32_t rw[2][2];
     uint32_t unsafe;
+    // sv_phases, per phase and in two buffers (phases alternate: a phase without a mask hit has ONE barrier, so the
+    // next phase's writers must not touch what a slow wave may still be reading): candidates and hits per slot wave,
+    // the candidate bitmap and the commit bitmap (bit tx of word ty)
+    int ph_cnt[2][4];
+    uint32_t ph_cand[2][8], ph_commit[2][8];
 };
 
 // does the mask window of the tile at (ox, oy) hold block (bx, by)?  (mask_geom: the words
@@ -2133,7 +2138,9 @@ __device__ __forceinline__ int sv_kth_slot(const uint32_t *cb, int k)
 // bitmap (the four ballots of the slot threads; a searching wave picks its k-th set bit -- no compacted list),
 // and the wave that decides a pixel also does its commit bookkeeping (mask bit, commit bitmap), so the cells
 // gather right after the searches' barrier.  All mask reads of a phase (candidates) come before its first
-// barrier, all mask writes after it.
+// barrier, all mask writes after it.  The per-phase words (counts, candidate and commit bitmaps) exist twice and
+// phases alternate between them: a phase without a mask hit is a single barrier, and the next phase's
+// writers must not run into a wave that has not read this phase's counts yet.
 __device__ __forceinline__ bool sv_phases(TileLds &S, SvPix &X, SparseLds &Q, const VmLevelView &L, const VmKParams &P, SvTile &V,
                                           int ox, int oy, int tid, int T, uint32_t &st_cand, uint32_t &st_commit, int res,
                                           bool &left)
@@ -2144,6 +2151,8 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SvPix &X, SparseLds &Q, co
         for (int pj = 0; pj < 2; ++pj) {
             const int vx = V.vx, vy = V.vy;
             const int vpi = pi ^ ((oy - vy) & 1), vpj = pj ^ ((ox - vx) & 1);
+            int *const ph_cnt = Q.ph_cnt[pj];
+            uint32_t *const ph_cand = Q.ph_cand[pj], *const ph_commit = Q.ph_commit[pj];
             VM_TTS(pi * 2 + pj, 0);
             // ---- 1. candidates of this phase ----
             bool cand = false, hit = false;
@@ -2159,15 +2168,15 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SvPix &X, SparseLds &Q, co
                 }
                 const unsigned long long bc = __ballot(cand), bh = __ballot(hit);
                 if ((tid & 63) == 0) {
-                    S.list[(tid >> 6) * 2] = (int)(uint32_t)bc; // the candidate bitmap: bit tx of word ty
-                    S.list[(tid >> 6) * 2 + 1] = (int)(uint32_t)(bc >> 32);
-                    S.wave_cnt[tid >> 6] = __popcll(bc) | (bh ? 1 << 16 : 0);
-                    S.cbits[(tid >> 6) * 2] = 0; // the commit bitmap of this phase
-                    S.cbits[(tid >> 6) * 2 + 1] = 0;
+                    ph_cand[(tid >> 6) * 2] = (uint32_t)bc; // the candidate bitmap: bit tx of word ty
+                    ph_cand[(tid >> 6) * 2 + 1] = (uint32_t)(bc >> 32);
+                    ph_cnt[tid >> 6] = __popcll(bc) | (bh ? 1 << 16 : 0);
+                    ph_commit[(tid >> 6) * 2] = 0; // the commit bitmap of this phase
+                    ph_commit[(tid >> 6) * 2 + 1] = 0;
                 }
             }
             __syncthreads();
-            const int w0 = S.wave_cnt[0], w1 = S.wave_cnt[1], w2 = S.wave_cnt[2], w3 = S.wave_cnt[3];
+            const int w0 = ph_cnt[0], w1 = ph_cnt[1], w2 = ph_cnt[2], w3 = ph_cnt[3];
             // no pixel of this phase in the mask: nothing to search, nothing to commit, no bit to clear
             if (!((w0 | w1 | w2 | w3) >> 16))
                 continue;
@@ -2183,7 +2192,7 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SvPix &X, SparseLds &Q, co
                 for (int base = 0; base < n_act; base += wide ? T / 64 : T / 32) {
                     const int li = base + (wide ? tid >> 6 : tid >> 5), sub = tid & 31;
                     const bool writer = wide ? (tid & 63) == 0 : sub == 0;
-                    const int slot = sv_kth_slot((const uint32_t *)S.list, min(li, n_act - 1));
+                    const int slot = sv_kth_slot(ph_cand, min(li, n_act - 1));
                     const int tx = slot & 31, ty = slot >> 5;
                     const int px = vx + tx * 2 + vpj, py = vy + ty * 2 + vpi;
                     const bool wave_interior = __all(li >= n_act || is_interior(L, px, py));
@@ -2241,7 +2250,7 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SvPix &X, SparseLds &Q, co
                                 X.uib[pc] = make_float2(c.ui_b.x + 2 * step.x * c.ui_axy, c.ui_b.y + 2 * step.y * c.ui_axy);
                                 X.v[pc] = make_float2(c.v.x + step.x, c.v.y + step.y);
                                 atomicOr(&X.dirty[pc >> 5], 1u << (pc & 31));
-                                atomicOr(&S.cbits[ty], 1u << tx);
+                                atomicOr(&ph_commit[ty], 1u << tx);
                                 atomicOr(mw, mb);
                                 if (res && (res > 1 || !sv_safe(L, V, px, py)))
                                     Q.unsafe = 1u;
@@ -2260,7 +2269,7 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SvPix &X, SparseLds &Q, co
             int ncommit = 0, ty0 = 8, ty1 = -1;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                cb[k] = S.cbits[k];
+                cb[k] = ph_commit[k];
                 ncommit += __popc(cb[k]);
                 if (cb[k]) {
                     ty0 = min(ty0, k);
@@ -2288,7 +2297,7 @@ __device__ __forceinline__ bool sv_phases(TileLds &S, SvPix &X, SparseLds &Q, co
                     uint32_t rowbits[3];
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
-                        rowbits[t] = t < ny ? S.cbits[sy0 + t] & colmask : 0u;
+                        rowbits[t] = t < ny ? ph_commit[sy0 + t] & colmask : 0u;
                     if (!(rowbits[0] | rowbits[1] | rowbits[2]))
                         continue;
                     float2 m = S.mean[cell], q = S.var[cell], tb = S.tpsb[cell];
