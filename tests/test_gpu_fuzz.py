@@ -201,3 +201,38 @@ def test_resident_sparse_visits_on_planted_clusters(gpu_ctx, oracle):
     served = gpu_ctx.sparse_resident_visits() - served0
     print("tile visits served from the resident copy:", served)
     assert served > 100, served
+
+
+@pytest.mark.parametrize("seed", [61, 62])
+def test_listed_tile_passes_equal_direct_ones(gpu_ctx, oracle, seed):
+    """FAST, the TILE schedule on pruned levels: a pass launched as tiles x pairs workgroups (direct) against the listed
+    form big batches take -- a scan lists the tiles of the pass a set mask bit reaches, a fixed grid of workgroups walks the
+    list (vm_set_tuning(VM_SWEEP_TILE, 0, parts = 1) lowers the threshold to one workgroup).  Bit-identical state,
+    iteration counts and activity counters, fixed work and reference stopping rule, graph replays included (>= 8
+    iterations)."""
+    rng = np.random.RandomState(seed)
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    try:
+        for trial in range(8):
+            w, h, kw, cons = _draw(rng, 420, 200)
+            w, h = max(w, 40), max(h, 40)
+            if trial % 3:
+                kw = dict(bcond=kw["bcond"], eps=kw["eps"], ssim_clamp=kw["ssim_clamp"])
+            iters = float(rng.randint(4, 70))
+            fixed = int(rng.randint(0, 2))
+            st = rng.get_state()
+            res = []
+            for listed in (0, 1):
+                rng.set_state(st)
+                pyr = _pruned_level(gpu_ctx, oracle, rng, w, h, kw, cons, trial, 40.0)
+                gpu_ctx.set_tuning(capi.SWEEP_TILE, 0, listed)
+                pr = capi.Progress()
+                capi.check(pyr._L.vm_optimize_level(pyr._h, 0, iters, None, fixed, C.byref(pr)))
+                res.append(([pyr[1].field(n).copy() for n in STATE],
+                            (pr.iters, pr.improving, pr.commits, pr.candidates, pr.evaluations, pr.active_tiles)))
+            assert res[0][1] == res[1][1], (trial, w, h, kw, iters, fixed, res[0][1], res[1][1])
+            for n, a, b in zip(STATE, res[0][0], res[1][0]):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (trial, n, w, h, kw, iters, fixed)
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)

@@ -95,7 +95,7 @@ struct vm_ctx {
     struct SweepGraph {
         int math_mode;
         int n, w, h, cap, fixed_work, threads, dense, order;
-        const void *views, *flags, *stats;
+        const void *views, *flags, *stats, *tile_list;
         vm_kern_params kp;
         hipGraphExec_t exec;
     };
@@ -103,6 +103,8 @@ struct vm_ctx {
     int commit_order = 0;         // vm_set_commit_order (EXACT, diagnostic): order 0..3
     int sparse_resident = 0;      // vm_dbg_sparse_resident: 0 = automatic, 1 = never, 2 / 3 = tests (k_sparse, sv_phases)
     unsigned long long sparse_resident_visits = 0; // vm_dbg_sparse_resident_visits: tile visits served from the resident LDS copy
+    uint32_t *tile_list = nullptr;   // the listed form of pruned TILE passes over big batches (k_tile_scan): counters, stamps, entries
+    size_t tile_list_words = 0;
     int use_graphs = -1;             // -1: not decided yet, 0: off (VM_NO_GRAPH or a failed capture), 1: on
 };
 

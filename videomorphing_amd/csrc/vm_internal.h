@@ -65,6 +65,8 @@ struct VmKParams {
 // [0] tile visits that were not skipped (TILE), [1] line searches, [2] commits,
 // [3] tile-phases with records (SPLIT / STEP), [4] energy evaluations
 #define VM_STAT_WORDS 8
+// the listed form of a pruned TILE pass (vm_sweep_kernels.hip, k_tile_scan): workgroups of the sweep
+#define VM_TILE_LIST_GRID 1024 // (what the chip holds of the lean kernel at once: a longer list is walked in turns)
 
 // constant tables living in one device buffer: 625 floats (thin-plate stencil
 // per border class) followed by 225 uint32 (improving-mask window bits)
@@ -85,7 +87,7 @@ struct VmKParams {
                                      const VmKParams &P, const uint32_t *tables, int offx,    \
                                      int offy, uint32_t *flags, uint32_t *stats, int iter_idx,\
                                      int fixed_work, int threads, const int *iter_dev,        \
-                                     int dense, hipStream_t s);                               \
+                                     int dense, uint32_t *tile_list, hipStream_t s);          \
     void vm_launch_next_iter_##SUFFIX(int *iter_dev, int set, int value, hipStream_t s);      \
     void vm_launch_optimize_sparse_##SUFFIX(const VmLevelView *views, int nbatch, int cap, int w, \
                                             int h, const VmKParams &P, const uint32_t *tables, \

@@ -46,6 +46,7 @@
 // Commits are applied by a per-cell gather of the committed pixels' records in a
 // fixed order: deterministic, one owner per cell, no float atomics (the reference
 // uses 75 shared + 25 global float atomics per accepted pixel, morph.cu:951-1015).
+#include <algorithm>
 #include <type_traits>
 #include "vm_morph_common.h"
 
@@ -1872,6 +1873,103 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
     }
 }
 
+// does the mask window of the tile at (ox, oy) hold block (bx, by)?  (mask_geom: the words
+// k_optimize / tile_sweep test before doing anything)
+__device__ __forceinline__ bool tile_window_has(const VmLevelView &L, int ox, int oy, int bx, int by)
+{
+    const MaskGeom g = mask_geom(L, ox, oy);
+    return bx >= g.bx0 && bx < g.bx0 + g.nbx && by >= g.by0 && by < g.by0 + g.nby;
+}
+
+// ---------------------------------------------------------------------------
+// The LISTED form of a pruned TILE pass (FAST, lean kernel, big batches).  A pass over a pruned level of a batch
+// launches tiles x pairs workgroups of which a handful find a set mask bit near their tile; the rest cost nothing
+// but their dispatch -- and that is the cost: measured ~4.7 ns per empty 512-thread workgroup, whatever it does
+// before it returns (the chip starts about one wave per cycle): 30 pairs x 832 tiles of the 1080p level = 118 us
+// per pass, 30 us at 960x540 (tools/dev_empty_tile_cost.py).  Here a scan (a few thousand waves) walks the mask
+// words of every pair, marks the tiles of this pass a set bit reaches -- tile_sweep's own early-out test, which
+// depends on nothing a tile of the same pass writes -- and appends each once to a list; the sweep then runs as a
+// fixed grid of workgroups that take list entries in turn.  Same tiles, same state, any order: bit-identical.
+// tl: [0 .. 4 cap) entry counters, one per iteration and pass of the call, then the stamps (one per pair and tile: the
+// epoch of the scan that listed it last), then the entries (pair << 16 | tile); the host zeroes counters and stamps
+// before every call (epochs restart there).
+__global__ __launch_bounds__(256) void SUF(k_tile_scan)(const VmLevelView *__restrict__ views, int cap, int offx, int offy,
+                                                        const uint32_t *__restrict__ flags, int iter_idx, int fixed_work,
+                                                        const int *__restrict__ iter_dev, uint32_t *__restrict__ tl,
+                                                        int tiles_stride)
+{
+    if (iter_dev)
+        iter_idx += *iter_dev;
+    const int pass = (offx ? 1 : 0) + (offy ? 2 : 0);
+    const uint32_t epoch = (uint32_t)(iter_idx * 4 + pass) + 1u;
+    const int slot = iter_idx * 4 + pass;
+    const int z = blockIdx.z;
+    if (!fixed_work && iter_idx > 0 && flags[(size_t)z * cap + iter_idx - 1] == 0)
+        return; // converged in the previous iteration (sticky)
+    const VmLevelView L = views[z];
+    const int gx = (L.w + VM_PITCH_X - 1) / VM_PITCH_X, gy = (L.h + VM_PITCH_Y - 1) / VM_PITCH_Y;
+    const int nwords = L.imp_rs * L.imp_rows;
+    uint32_t *const stamp = tl + 4 * (size_t)cap + (size_t)z * tiles_stride;
+    uint32_t *const entries = tl + 4 * (size_t)cap + (size_t)gridDim.z * tiles_stride;
+    for (int wi = blockIdx.x * 256 + threadIdx.x; wi < nwords; wi += gridDim.x * 256) {
+        const uint32_t wv = L.impmask[wi];
+        if (!wv)
+            continue;
+        const int bx = wi % L.imp_rs - 1, by = wi / L.imp_rs - 1;
+        const int ce = (5 * bx - offx) / VM_PITCH_X, re = (5 * by - offy) / VM_PITCH_Y;
+        for (int r = max(re - 1, 0); r <= re + 1 && r < gy; ++r)
+            for (int c = max(ce - 1, 0); c <= ce + 1 && c < gx; ++c) {
+                const int ox = c * VM_PITCH_X + offx, oy = r * VM_PITCH_Y + offy;
+                if (ox < L.w && oy < L.h && tile_window_has(L, ox, oy, bx, by) && (wv & tile_reach_bits(L, ox, oy, bx, by)) &&
+                    atomicExch(&stamp[r * gx + c], epoch) != epoch) // first to name this tile
+                    entries[atomicAdd(&tl[slot], 1u)] = (uint32_t)z << 16 | (uint32_t)(r * gx + c);
+            }
+    }
+}
+
+#if !VM_EXACT
+__global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(4))) void SUF(k_optimize_listed)(
+    const VmLevelView *__restrict__ views, int cap, VmKParams P, const uint32_t *__restrict__ tables, int offx, int offy,
+    uint32_t *__restrict__ flags, uint32_t *__restrict__ stats, int iter_idx, const int *__restrict__ iter_dev,
+    const uint32_t *__restrict__ tl, int tiles_stride, int nbatch)
+{
+    __shared__ TileLds S;
+    if (iter_dev)
+        iter_idx += *iter_dev;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int pass = (offx ? 1 : 0) + (offy ? 2 : 0);
+    const uint32_t cnt = tl[iter_idx * 4 + pass];
+    if (blockIdx.x >= cnt)
+        return;
+    const uint32_t *const entries = tl + 4 * (size_t)cap + (size_t)nbatch * tiles_stride;
+    for (int k = tid; k < 625; k += T)
+        S.tps[k] = __uint_as_float(tables[VM_TAB_TPS + k]);
+    for (int k = tid; k < 225; k += T)
+        S.imp[k] = tables[VM_TAB_IMP + k];
+    for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const uint32_t ent = entries[e];
+        const int z = (int)(ent >> 16), t = (int)(ent & 0xFFFFu);
+        const VmLevelView L = views[z];
+        const int gx = (L.w + VM_PITCH_X - 1) / VM_PITCH_X;
+        const int ox = (t % gx) * VM_PITCH_X + offx, oy = (t / gx) * VM_PITCH_Y + offy;
+        if (tid == 0)
+            S.n_eval = 0; // ordered before its first use by the barriers of tile_sweep
+        bool improving = false;
+        uint32_t st_cand = 0, st_commit = 0;
+        if (tile_sweep<false>(S, L, P, tables, true, ox, oy, tid, T, improving, st_cand, st_commit) && tid == 0) {
+            uint32_t *const st = stats + ((size_t)z * cap + iter_idx) * VM_STAT_WORDS;
+            if (improving)
+                flags[(size_t)z * cap + iter_idx] = 1u; // every writer stores the same 1
+            atomicAdd(&st[0], 1u);
+            atomicAdd(&st[1], st_cand);
+            atomicAdd(&st[2], st_commit);
+            atomicAdd(&st[4], S.n_eval);
+        }
+        __syncthreads(); // the tile's LDS is done with before the next entry stages its own
+    }
+}
+#endif
+
 // ===========================================================================
 // SPARSE schedule: the pruned regime without kernel boundaries.  After the first sweeps of a
 // level the improving mask leaves a handful of active tiles (none once the level has
@@ -1906,14 +2004,6 @@ struct SparseLds {
     int ph_cnt[2][4];
     uint32_t ph_cand[2][8], ph_commit[2][8];
 };
-
-// does the mask window of the tile at (ox, oy) hold block (bx, by)?  (mask_geom: the words
-// k_optimize / tile_sweep test before doing anything)
-__device__ __forceinline__ bool tile_window_has(const VmLevelView &L, int ox, int oy, int bx, int by)
-{
-    const MaskGeom g = mask_geom(L, ox, oy);
-    return bx >= g.bx0 && bx < g.bx0 + g.nbx && by >= g.by0 && by < g.by0 + g.nby;
-}
 
 // every non-zero mask word of the level into the pair's list 0
 __global__ __launch_bounds__(256) void SUF(k_sparse_scan)(const VmLevelView *__restrict__ views)
@@ -4160,10 +4250,18 @@ extern "C" int vm_dbg_prof_read(void *dst, size_t bytes)
 void SUF(vm_launch_optimize)(const VmLevelView *views, int nbatch, int cap, int w, int h, const VmKParams &P,
                              const uint32_t *tables, int offx, int offy, uint32_t *flags, uint32_t *stats,
                              int iter_idx, int fixed_work, int threads, const int *iter_dev, int dense,
-                             hipStream_t s)
+                             uint32_t *tile_list, hipStream_t s)
 {
     dim3 b(threads), g((w + VM_PITCH_X - 1) / VM_PITCH_X, (h + VM_PITCH_Y - 1) / VM_PITCH_Y, nbatch);
 #if !VM_EXACT
+    if (!dense && tile_list) { // the listed form of a pruned pass (k_tile_scan)
+        const int nwords = ((w + 4) / 5 + 2) * ((h + 4) / 5 + 2), tiles = (int)(g.x * g.y);
+        hipLaunchKernelGGL(SUF(k_tile_scan), dim3(std::min((nwords + 255) / 256, 32), 1, nbatch), dim3(256), 0, s, views, cap, offx,
+                           offy, flags, iter_idx, fixed_work, iter_dev, tile_list, tiles);
+        hipLaunchKernelGGL(SUF(k_optimize_listed), dim3(std::min(tiles * nbatch, VM_TILE_LIST_GRID)), b, 0, s, views, cap, P, tables,
+                           offx, offy, flags, stats, iter_idx, iter_dev, tile_list, tiles, nbatch);
+        return;
+    }
     if (!dense) {
         hipLaunchKernelGGL(SUF(k_optimize)<false>, g, b, 0, s, views, cap, P, tables, offx, offy, flags, stats,
                            iter_idx, fixed_work, iter_dev);
