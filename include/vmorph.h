@@ -143,7 +143,10 @@ int  vm_set_math_mode(vm_ctx *ctx, int mode);
  * pass for small levels: a tile's four phases stay inside the launch, its 32 workgroups (one
  * wave per phase pixel) meet at a tile-local barrier between phases; VM_SWEEP_AUTO picks per
  * batch of iterations.
- * threads/parts: 0 = automatic. */
+ * threads/parts: 0 = automatic.  `parts` of a FORCED schedule (tests): SPLIT / STEP = workgroups per tile; SPARSE = the
+ * LDS capacity of the kernel's word list; PASS = 1: write-through stores from the start, 2: tile groups spread over
+ * the XCDs; TILE (FAST) = from how many workgroups per pass (tiles x pairs) a pruned pass takes its listed form -- a
+ * scan of the mask lists the tiles a set bit reaches, a fixed grid of workgroups walks the list; 0 = 4096. */
 enum { VM_SWEEP_AUTO = 0, VM_SWEEP_TILE = 1, VM_SWEEP_SPLIT = 2, VM_SWEEP_STEP = 3, VM_SWEEP_SPARSE = 4, VM_SWEEP_PASS = 5 };
 int  vm_set_tuning(vm_ctx *ctx, int sweep_mode, int threads, int parts);
 /* Diagnostic, EXACT arithmetic only: the order in which the commits of one Jacobi phase are
