@@ -33,6 +33,13 @@ import statistics
 import sys
 import time
 
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4): a
+# fifth stream shares a queue with another and their kernels serialise.  This script holds the context of its config[1]
+# steps AND the three of `scale_reference` (plus torch's own stream): measured, 60 pairs on three streams 1312 ms with
+# the default against 838 with 8 queues.  Set before anything initialises HIP; a host that runs more than three solver
+# contexts per process should do the same.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
@@ -158,9 +165,12 @@ def main():
 
     # config 2: two streams per GPU by default -- measured on MI355X (tools/dev_inflight.sh, 8 / 60 pairs
     # on one GPU): 1 stream 21.3 / 38.2, 2 streams 25.3 / 47.9, 4 streams 20.2 / 46.2 G pixel*iters/s
-    # (beyond two the host's launch rate, ~3.5 us per eager launch under the runtime's lock, binds)
+    # (beyond two the host's launch rate, ~3.5 us per eager launch under the runtime's lock, binds) --,
+    # three from 24 pairs per GPU on (r04, ms per job, 2 -> 3 streams: 60 pairs 859 -> 838, 30 pairs 569 -> 558,
+    # 15 pairs 466 -> 479)
     if config == 2 and args.inflight == 0:
-        args.inflight = 2
+        my_pairs = len(vdist.shard_pairs(args.pairs, world, rank) if args.as_rank < 0 else vdist.shard_pairs(args.pairs, args.of, args.as_rank))
+        args.inflight = default_streams(my_pairs)
     nctx = max(1, args.inflight)
     ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(nctx)]
     for c in ctxs:
@@ -284,12 +294,17 @@ def main():
     else:
         el_max, pix_total, pix_live_total = el, pix_iters, pix_live
 
+    # (scale_reference first: measured after the other extras -- the same job, fresh contexts -- it takes 970 instead of
+    # 838 ms; not the clocks, not the hardware queues: what the allocator hands out after 60 pyramids, a video and the
+    # compositor's canvases have come and gone)
     extras = {}
+    scale_ref = None
+    if rank == 0 and world == 1 and config == 1 and not args.size and not (args.no_extras or args.no_scale_ref):
+        scale_ref = scale_reference(args, morph, blk, local_rank, frames, solve_group, sizes, nlev, FIXED)
     if rank == 0 and not (args.no_extras or args.no_extras_but_scale_ref) and config != 2:
         extras = run_extras(args, np, capi, morph, synth, L, blk, ctx, pyrs[0], w, h, nlev, FIXED, B, solve, solve_group)
-
-    if rank == 0 and world == 1 and config == 1 and not args.size and not (args.no_extras or args.no_scale_ref):
-        extras["scale_reference"] = scale_reference(args, morph, blk, local_rank, frames, solve_group, sizes, nlev, FIXED)
+    if scale_ref is not None:
+        extras["scale_reference"] = scale_ref
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -340,11 +355,16 @@ def config2_step(ps, ctxs, B, solve_group):
         return [r for res in ex.map(work, chunks) for r in res]
 
 
+def default_streams(pairs_on_this_gpu):
+    """streams (contexts, each driven by its own host thread) for config[2]'s job on one GPU"""
+    return 3 if pairs_on_this_gpu >= 24 else 2
+
+
 def scale_reference(args, morph, blk, local_rank, frames, solve_group, sizes, nlev, fixed):
     """The workload an N > 1 run of this script shards (config[2]: --scale-ref-pairs independent 1080p
-    pairs, two streams, batches of <= --max-batch pairs per launch) on THIS one GPU: the same-workload
+    pairs, the streams of default_streams(), batches of <= --max-batch pairs per launch) on THIS one GPU: the same-workload
     denominator of a scaling curve whose N = 1 point is config[1]."""
-    ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(2)]
+    ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(default_streams(args.scale_ref_pairs))]
     for c in ctxs:
         c.set_params(blk.kp)
 
