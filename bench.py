@@ -295,8 +295,7 @@ def main():
         el_max, pix_total, pix_live_total = el, pix_iters, pix_live
 
     # (scale_reference first: measured after the other extras -- the same job, fresh contexts -- it takes 970 instead of
-    # 838 ms; not the clocks, not the hardware queues: what the allocator hands out after 60 pyramids, a video and the
-    # compositor's canvases have come and gone)
+    # 838 ms; not the clocks, not the hardware queues, not the churn of pyramids (tools/dev_alloc_history.py): unexplained)
     extras = {}
     scale_ref = None
     if rank == 0 and world == 1 and config == 1 and not args.size and not (args.no_extras or args.no_scale_ref):
