@@ -1,4 +1,6 @@
 """Host-side logic of the mirror API and the bench accounting (CPU only)."""
+import os
+
 import numpy as np
 
 import bench
@@ -173,8 +175,11 @@ def test_bench_config2_chunks_and_batches():
         def __init__(self, ctx, img):
             self._ctx, self.img = ctx, img
     frames = lambda ids: [("f%d" % i,) * 2 for i in ids]
+    # (streams as bench.default_streams() picks them: three from 24 pairs per GPU on, two below)
+    assert [bench.default_streams(n) for n in (60, 30, 24, 23, 15, 8, 7, 1)] == [3, 3, 3, 2, 2, 2, 2, 2]
+    assert os.environ.get("GPU_MAX_HW_QUEUES")          # importing bench.py asks for more hardware queues than HIP's four
     for npairs, nctx_in, max_batch, want_B, want_nctx in ((60, 2, 32, 30, 2), (8, 2, 32, 4, 2), (7, 2, 32, 4, 2), (60, 1, 32, 30, 1),
-                                                            (1, 2, 32, 1, 1), (15, 2, 4, 4, 2)):
+                                                            (1, 2, 32, 1, 1), (15, 2, 4, 4, 2), (60, 3, 32, 20, 3), (30, 3, 32, 10, 3)):
         ctxs = [Ctx() for _ in range(nctx_in)]
         pyrs, B, nctx, distinct = bench.config2_setup(list(range(100, 100 + npairs)), ctxs, frames, lambda c, img: Pyr(c, img), max_batch)
         assert (B, nctx) == (want_B, want_nctx), (npairs, nctx_in, max_batch, B, nctx)
