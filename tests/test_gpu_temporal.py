@@ -148,6 +148,40 @@ def test_sweeps_with_the_temporal_term_exact(gpu_ctx, oracle, sched):
     assert vid.pages[0][0].field("temp_mask").max() > 0
 
 
+@pytest.mark.parametrize("resident", [0, 2, 3])
+def test_sparse_sweeps_with_the_temporal_term_fast(gpu_ctx, oracle, resident):
+    """flag == true, FAST, a long run into the pruned regime: the SPARSE schedule (its lean kernel reads the temporal
+    reference and weight beside the LDS copy of the pixel's own state; resident visits automatic / re-centred at every
+    commit / given up at the first) ends bit-identical to the TILE schedule, both pages"""
+    gpu_ctx.set_math_mode(capi.MATH_FAST)
+    _kp(gpu_ctx, oracle, w_temp=25.0)
+    levels = [(210, 118, 2), (105, 59, 2)]
+    rng = np.random.RandomState(17)
+    v0 = [(0.7 * synth.displacement(210, 118, amp=1.0) + 0.1 * rng.randn(118, 210, 2)).astype(np.float32) for t in range(2)]
+    out = {}
+    try:
+        for sched in (capi.SWEEP_TILE, capi.SWEEP_SPARSE):
+            vid, dev = _make(oracle, gpu_ctx, levels, seed=11)
+            gpu_ctx.set_tuning(sched, 0, 0)
+            gpu_ctx.set_sparse_resident(resident)
+            for t in range(2):
+                dev.pages[0][t].v = v0[t]
+            capi.check(dev._L.vm_video_init_level(dev._h, 0, None, 0))
+            prog = (capi.Progress * 2)()
+            capi.check(dev._L.vm_video_optimize_level(dev._h, 0, 160.0, None, 1, prog))
+            out[sched] = ([[dev.pages[0][t].field(f) for f in ("v", "mean", "var", "cross", "value", "tps_b", "luma")] for t in range(2)],
+                          [(prog[t].iters, prog[t].commits, prog[t].candidates, prog[t].active_tiles) for t in range(2)])
+    finally:
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_sparse_resident(0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    assert out[capi.SWEEP_TILE][1] == out[capi.SWEEP_SPARSE][1], (out[capi.SWEEP_TILE][1], out[capi.SWEEP_SPARSE][1])
+    assert out[capi.SWEEP_TILE][1][0][1] > 1000
+    for t in range(2):
+        for a, b in zip(out[capi.SWEEP_TILE][0][t], out[capi.SWEEP_SPARSE][0][t]):
+            assert np.array_equal(_bits(a), _bits(b)), t
+
+
 def test_video_solve_exact(gpu_ctx, oracle):
     """Morph::calculate_halfway_parametrization over a temporal pyramid (5 -> 3 pages), with
     point constraints on two frames and a locked border: level by level and in one
