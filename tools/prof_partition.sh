@@ -1,7 +1,7 @@
 #!/bin/bash
 # static partition study: every rank's shard of config[2] (60 pairs over G ranks), each run
 # alone on this one GPU; per-rank ms, max / mean.  usage: bash tools/prof_partition.sh <G> [inflight]
-G=${1:-8}; INF=${2:-2}
+G=${1:-8}; INF=${2:-0}   # 0 = bench.default_streams()
 O=gpurun_out/partition_G$G
 mkdir -p $O
 for k in $(seq 0 $((G-1))); do
