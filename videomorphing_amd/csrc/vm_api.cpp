@@ -1242,11 +1242,12 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         VM_HIP(hipGetLastError());
         if (pass)
             VM_HIP(hipMemcpyAsync(c->pass_err_host, c->pass_err, 4, hipMemcpyDeviceToHost, s));
-        // this batch's flags and counters of every pair: rows of nb iterations out of arrays of `cap` per pair -- one strided
-        // copy each (a batch of 30 pairs made 60 copies of a few hundred bytes per batch of iterations)
-        VM_HIP(hipMemcpy2DAsync(c->flags_host + done, (size_t)cap * 4, c->flags + done, (size_t)cap * 4, (size_t)nb * 4, n, hipMemcpyDeviceToHost, s));
-        VM_HIP(hipMemcpy2DAsync(c->stats_host + (size_t)done * VM_STAT_WORDS, (size_t)cap * 4 * VM_STAT_WORDS, c->stats + (size_t)done * VM_STAT_WORDS,
-                                (size_t)cap * 4 * VM_STAT_WORDS, (size_t)nb * 4 * VM_STAT_WORDS, n, hipMemcpyDeviceToHost, s));
+        // (one strided copy per array instead of 2 n small ones was measured: 60 pairs 838 -> 836 ms, 8 pairs 328 -> 332: not kept)
+        for (int i = 0; i < n; ++i) {
+            VM_HIP(hipMemcpyAsync(c->flags_host + (size_t)i * cap + done, c->flags + (size_t)i * cap + done, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+            VM_HIP(hipMemcpyAsync(c->stats_host + ((size_t)i * cap + done) * VM_STAT_WORDS, c->stats + ((size_t)i * cap + done) * VM_STAT_WORDS,
+                                  (size_t)nb * 4 * VM_STAT_WORDS, hipMemcpyDeviceToHost, s));
+        }
         VM_HIP(hipStreamSynchronize(s));
         if (pass && c->pass_err_host[0]) {
             VM_HIP(hipMemsetAsync(c->pass_err, 0, 4, s));
