@@ -107,6 +107,7 @@ def parse_args(argv=None):
     ap.add_argument("--scale-ref-pairs", type=int, default=60, help="frame pairs of the scale_reference job")
     ap.add_argument("--size", default=None, help="WxH override (development only)")
     ap.add_argument("--sweep-threads", type=int, default=0, help="threads per sweep workgroup, 0 = the library's choice (development only)")
+    ap.add_argument("--sweep-parts", type=int, default=0, help="workgroups per tile of the STEP schedule, 0 = the library's choice (development only)")
     ap.add_argument("--as-rank", type=int, default=-1,
                     help="config 2 on ONE GPU: solve the shard rank K of an --of G-rank job would get (static partition "
                          "study: per-rank load without the G GPUs)")
@@ -175,8 +176,8 @@ def main():
     ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(nctx)]
     for c in ctxs:
         c.set_params(blk.kp)
-        if args.sweep_threads:
-            c.set_tuning(capi.SWEEP_AUTO, args.sweep_threads, 0)
+        if args.sweep_threads or args.sweep_parts:
+            c.set_tuning(capi.SWEEP_AUTO, args.sweep_threads, args.sweep_parts)
     ctx = ctxs[0]
     L = capi.load()
     nlev = synth.num_levels(w, h, blk.start_res)
