@@ -79,11 +79,21 @@ enum {
                            the same algorithm (sweep kernels only; not bit-comparable to the
                            oracle), used to measure the reproducibility floor FAST is judged
                            against (tests/test_gpu_fullsize.py) */
-    VM_MATH_REF_FASTMATH = 3 /* diagnostic: the EXACT source as the reference's project file compiles
+    VM_MATH_REF_FASTMATH = 3, /* diagnostic: the EXACT source as the reference's project file compiles
                            it -- --use_fast_math (MdiEditor.vcxproj:208-213): contraction plus
                            approximate division (x * rcp(y), CUDA's __fdividef) and square root.  The
                            reference's own expressions in the reference's own arithmetic: the third
                            member of the family of legal builds */
+    VM_MATH_REF_TEX8 = 4,  /* diagnostic: the EXACT source (IEEE, no contraction) with every texture
+                           fetch -- both images, Algorithm/morph.cu:29-30, 316-322 (taps at :212-213,
+                           680-681, 960-961), and the inter-level upsample, include/util/
+                           imgop_upsample.cu:17-31 -- filtered with CUDA's 9-bit fixed-point bilinear
+                           weights (8 fractional bits, rounded to nearest): the one piece of the
+                           reference BINARY's arithmetic no other mode has; the finite-difference
+                           step eps = 0.01 px is 2.56 weight quanta.  The CPU checker under tests/ has
+                           the same switch; the two agree bit for bit */
+    VM_MATH_REF_TEX8_TRUNC = 5 /* the same with truncated weights (the CUDA guide does not state the
+                           rounding rule): sensitivity check */
 };
 
 /* progress of one optimize_level call; mirrors the public progress members of
@@ -350,6 +360,14 @@ int  vm_render_halfway_dev(vm_frame *f, float color_fa, float geo_fa, int color_
  * multigrid-preconditioned CG instead of MKL DSS.  iters/rel_res may be NULL. */
 int  vm_poisson_extend(vm_frame *f, int side, float tol, int max_it,
                        int *iters, float *rel_res, float *elapsed_ms);
+/* The body of CPoissonExt::run's frame loop (Algorithm/PoissonExt.cpp:24-36: prepare + poissonExtend of
+ * side 1, then of side 2) for n frames of one context and one size AT ONCE: side 1 samples the original
+ * image 2 and side 2 the original image 1 (the copies taken at :26-27, here at vm_frame_upload), so the
+ * 2 n systems are independent and share every kernel launch (blockIdx.z = system).  Same results per system
+ * as vm_poisson_extend.  iters / rel_res (may be NULL): 2 n entries, [2 i] = side 1 of frames[i], [2 i + 1] =
+ * side 2.  n <= 32. */
+int  vm_poisson_extend_frames(vm_frame *const *frames, int n, float tol, int max_it,
+                              int *iters, float *rel_res, float *elapsed_ms);
 /* CQuadraticPath::optimize for one frame, Algorithm/QuadraticPath.cpp:24-223
  * (QuadraticPath.h:14-24): from the frame's halfway field v the per-pixel optimal
  * Jacobian blend and the Neumann Poisson solve for the quadratic motion path u,

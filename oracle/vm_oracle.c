@@ -61,14 +61,34 @@ float vmo_ssim(float mx, float my, float vx, float vy, float cross,
 
 /* CUDA tex2D, linear filter, clamp addressing, unnormalised coordinates
  * (set up at morph.cu:316-322): texel centres sit at i+0.5.  Exact float
- * weights (the 1.8 fixed-point weights of the hardware are not emulated). */
+ * weights by default (the 1.8 fixed-point weights of the
+ * hardware are not emulated).
+ *
+ * vmo_set_tex_filter(1 | 2): DIAGNOSTIC -- the weights quantised as CUDA's
+ * linear filter does, "9-bit fixed point format with 8 bits of fractional
+ * value (so 1.0 is exactly represented)" (CUDA C Programming Guide, Texture
+ * Fetching / Linear Filtering).  The guide does not state the rounding rule:
+ * 1 = round to nearest, floor(256 a + 0.5) / 256 (the only reading under which
+ * the fraction can reach the 1.0 the format represents), 2 = truncation.
+ * Mirrors VM_MATH_REF_TEX8 / _TRUNC of the HIP path (vm_morph_common.h:
+ * tex8_weight) bit for bit; used to measure how far the reference BINARY's
+ * arithmetic sits from the exact-weight runs. */
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static int g_tex_filter = 0;
+void vmo_set_tex_filter(int mode) { g_tex_filter = (mode == 1 || mode == 2) ? mode : 0; }
+int  vmo_get_tex_filter(void) { return g_tex_filter; }
+static inline float texw(float a)
+{
+    if (g_tex_filter == 1) return floorf(a * 256.0f + 0.5f) * 0.00390625f;
+    if (g_tex_filter == 2) return floorf(a * 256.0f) * 0.00390625f;
+    return a;
+}
 
 float vmo_tex2d(const float *img, int w, int h, float x, float y)
 {
     float xb = x - 0.5f, yb = y - 0.5f;
     float fi = floorf(xb), fj = floorf(yb);
-    float a = xb - fi, b = yb - fj;
+    float a = texw(xb - fi), b = texw(yb - fj);
     fi = fminf(fmaxf(fi, -1.0f), (float)w);
     fj = fminf(fmaxf(fj, -1.0f), (float)h);
     int i0 = clampi((int)fi, 0, w - 1), i1 = clampi((int)fi + 1, 0, w - 1);
@@ -83,7 +103,7 @@ void vmo_tex2d_f2(const float *img, int w, int h, float x, float y, float *out2)
 {
     float xb = x - 0.5f, yb = y - 0.5f;
     float fi = floorf(xb), fj = floorf(yb);
-    float a = xb - fi, b = yb - fj;
+    float a = texw(xb - fi), b = texw(yb - fj);
     fi = fminf(fmaxf(fi, -1.0f), (float)w);
     fj = fminf(fmaxf(fj, -1.0f), (float)h);
     int i0 = clampi((int)fi, 0, w - 1), i1 = clampi((int)fi + 1, 0, w - 1);

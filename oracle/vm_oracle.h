@@ -90,6 +90,9 @@ float vmo_ssim(float mx, float my, float vx, float vy, float cross,
                float counter, float clamp);                  /* morph.cu:85-118 */
 float vmo_tex2d(const float *img, int w, int h, float x, float y);
 void  vmo_tex2d_f2(const float *img, int w, int h, float x, float y, float *out2);
+/* diagnostic: 0 = exact float weights (default), 1 / 2 = CUDA's 8-bit filter weights, rounded / truncated */
+void  vmo_set_tex_filter(int mode);
+int   vmo_get_tex_filter(void);
 void  vmo_tps_stencil(float *out625);                        /* stencils.cpp:156-261 */
 void  vmo_tps_rows_from_dense(float *out625);                /* morph.cu:439-469 */
 void  vmo_io_stencil(int *out625);                           /* stencils.cpp:10-71 */

@@ -1,0 +1,66 @@
+"""Generates tests/golden/full_solve_hashes.json: the ORACLE's whole coarse-to-fine solves at
+BASELINE.json's full sizes, fingerprinted.
+
+  config[1]: 1920x1080 pair, 6 levels (start_res 32), max_iter 500, drop 1, the reference's stopping
+             rule (morph.cu:150-168, 1353-1391) -- synthetic frames 0, 1, 2, 6, 9 (6 and 9: frames whose
+             finest level keeps exchanging moves until iteration 500);
+  config[3]: 3840x2160 pair, 7 levels, same settings -- frame 0.
+
+Per solve: the per-level iteration counts (coarse to fine), SHA-256 of every state array of the finest
+level (tests/fullsize_hash.py) and a fingerprint of the synthetic inputs.  CPU only (runs in the build
+container, minutes per 1080p solve on 8 cores, tens of minutes for 4K); the GPU test
+test_full_solve_exact_matches_oracle_hashes then needs seconds per solve on the GPU box instead of the
+5-12 minutes the oracle takes there.
+
+usage: python tests/golden/make_full_solve_hashes.py [--only 1080p|4k] [--frames 0,1,...]   (merges into the JSON)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from videomorphing_amd import synth  # noqa: E402  (host-side input generator only)
+import oracle  # noqa: E402
+import fullsize_hash as FH  # noqa: E402
+
+OUT = os.path.join(HERE, "full_solve_hashes.json")
+CASES = {"1080p": (1920, 1080, 6, (0, 1, 2, 6, 9)), "4k": (3840, 2160, 7, (0,))}
+
+
+def main():
+    args = sys.argv[1:]
+    only = args[args.index("--only") + 1] if "--only" in args else None
+    frames_arg = [int(x) for x in args[args.index("--frames") + 1].split(",")] if "--frames" in args else None
+    try:
+        doc = json.load(open(OUT))
+    except Exception:
+        doc = {"settings": {"max_iter": 500, "drop": 1.0, "start_res": 32, "semantics": "reference (stop at the first sweep without an accepted move)",
+                            "params": "oracle.default_params() = UI/MdiEditor.cpp:131-140", "arithmetic": "oracle: IEEE f32, no contraction, row-major commits"},
+               "solves": {}}
+    threads = len(os.sched_getaffinity(0))
+    for name, (w, h, nlev, frames) in CASES.items():
+        if only and name != only:
+            continue
+        for f in (frames_arg or frames):
+            key = "%s/frame%d" % (name, f)
+            i0, i1 = synth.make_pair(w, h, frame=f)
+            t0 = time.time()
+            per = []
+            lo = oracle.solve(synth.build_pyramid(i0, i1, nlev), oracle.default_params(), 500, 1.0, threads=threads, per_level=per)
+            doc["solves"][key] = {"size": [w, h], "levels": nlev, "frame": f, "inputs": FH.input_hash(i0, i1),
+                                  "iters_coarse_to_fine": [int(p[1]) for p in per],
+                                  "max_abs_v": float(np.abs(lo.field("v")).max()),
+                                  "sha256": FH.state_hashes(lo), "oracle_s": round(time.time() - t0, 1), "oracle_threads": threads}
+            print(key, doc["solves"][key]["iters_coarse_to_fine"], doc["solves"][key]["oracle_s"], "s", flush=True)
+            json.dump(doc, open(OUT, "w"), indent=1, sort_keys=True)
+            del lo
+
+
+if __name__ == "__main__":
+    main()

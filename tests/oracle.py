@@ -136,6 +136,9 @@ def lib():
     L.vmo_flow_concat.restype = None
     L.vmo_set_commit_order.argtypes = [C.c_int]
     L.vmo_set_commit_order.restype = None
+    L.vmo_set_tex_filter.argtypes = [C.c_int]
+    L.vmo_set_tex_filter.restype = None
+    L.vmo_get_tex_filter.restype = C.c_int
     L.vmo_set_threads.argtypes = [C.c_int]
     L.vmo_set_threads.restype = None
     L.vmo_get_threads.restype = C.c_int

@@ -1,5 +1,9 @@
 """BASELINE.json's full sizes (config[1] 1080p, config[3] 4K) on the GPU.
 
+Against the oracle's own whole solves through fixtures (tests/golden/full_solve_hashes.json: per-level
+iteration counts + SHA-256 of the finest level's state, written by the oracle in the build container):
+  * config[1] on five synthetic frames and config[3] (4K, 7 levels) on one
+    (test_full_solve_exact_matches_oracle_hashes).
 Against the oracle itself, bit for bit (EXACT arithmetic; the oracle needs ~10-20 s of the
 box's host cores for each):
   * config[1] as stated -- one 1920x1080 pair, 6 levels, max_iter 500 per level, the
@@ -79,6 +83,53 @@ def test_full_solve_exact_1080p(gpu_ctx, oracle):
     assert per[0][1] == 500                    # the 120x68 level uses all of its 500 iterations
     _assert_level_equals_oracle(lo, pyr[1], "1080p solve")
     assert np.abs(pyr[1].v).max() > 5.0        # ~19 px of displacement were found
+
+
+def _full_solve_cases():
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "full_solve_hashes.json")
+    doc = json.load(open(path))
+    return sorted(doc["solves"].items())
+
+
+@pytest.mark.parametrize("key,fix", _full_solve_cases(), ids=[k for k, _ in _full_solve_cases()])
+def test_full_solve_exact_matches_oracle_hashes(gpu_ctx, key, fix):
+    """Whole coarse-to-fine EXACT solves at BASELINE.json's full sizes against the ORACLE's, through fixtures: the
+    oracle solved config[1] (1920x1080, 6 levels, max_iter 500, the reference's stopping rule, morph.cu:150-168,
+    1353-1391) on synthetic frames 0, 1, 2, 6, 9 and config[3] (3840x2160, 7 levels) on frame 0 in the build
+    container (tests/golden/make_full_solve_hashes.py; 17-36 s per 1080p solve, minutes for 4K) and left the
+    per-level iteration counts and SHA-256 of every state array of the finest level in
+    tests/golden/full_solve_hashes.json.  The HIP path must reproduce every count and every hash: bit-identical
+    fields without running the oracle on the GPU box.  The fixture also fingerprints the synthetic inputs (numpy's
+    float64 sin / cos need not round alike on every host CPU); if this host generates other inputs the 1080p cases
+    fall back to running the oracle here (as test_full_solve_exact_1080p does), the 4K case is skipped with that
+    reason -- neither is a parity failure."""
+    import fullsize_hash as FH
+    w, h = fix["size"]
+    nlev, frame = fix["levels"], fix["frame"]
+    i0, i1 = synth.make_pair(w, h, frame=frame)
+    want_iters, want = fix["iters_coarse_to_fine"], fix["sha256"]
+    if FH.input_hash(i0, i1) != fix["inputs"]:
+        if w > 1920:
+            pytest.skip("this host's numpy generates other synthetic inputs than the fixture's; the 4K oracle run takes minutes")
+        import oracle as O
+        per = []
+        lo = O.solve(synth.build_pyramid(i0, i1, nlev), O.default_params(), 500, 1.0, threads=_all_cpus(), per_level=per)
+        want_iters, want = [int(p[1]) for p in per], FH.state_hashes(lo)
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 500, 1.0, 32
+    gpu_ctx.set_params(morph.KernParameters(prm))
+    pyr = morph.Pyramid(gpu_ctx)
+    pyr.build(i0, i1, 32)
+    assert pyr.size() == nlev + 1
+    prog = (capi.Progress * (nlev - 1))()
+    capi.check(pyr._L.vm_solve(pyr._h, 500.0, 1.0, None, 0, None, 0, prog))
+    assert [int(prog[el].iters) for el in range(nlev - 2, -1, -1)] == want_iters
+    got = FH.state_hashes(pyr[1])
+    assert got == want, {f: (got[f] == want[f]) for f in want}
+    assert abs(float(np.abs(pyr[1].v).max()) - fix["max_abs_v"]) < 1e-6 or FH.input_hash(i0, i1) != fix["inputs"]
+    pyr.clear()
 
 
 def test_dense_sweep_exact_4k(gpu_ctx, oracle):
@@ -596,10 +647,16 @@ CHAOS_FRAMES = (0, 3, 6, 9, 12, 15)      # r03's bench: frames 6 and 12 are the 
 # (row-major = the oracle, reversed, column-major, c.-m. reversed: the reference leaves the order to float atomics,
 # morph.cu:951-1015); with fused multiply-adds (VM_MATH_EXACT_FMA: nvcc's default --fmad=true); and as the reference's
 # project file really compiles it, --use_fast_math (VM_MATH_REF_FASTMATH: contraction + approximate division and
-# square root, MdiEditor.vcxproj:208-213), each under two of the orders
+# square root, MdiEditor.vcxproj:208-213), each under two of the orders; and (round 5) with every texture fetch filtered
+# the way the reference BINARY's tex2D(linear) fetches are -- CUDA's 9-bit fixed-point bilinear weights, 8 fractional
+# bits, against a finite-difference step of eps = 0.01 px = 2.56 quanta (VM_MATH_REF_TEX8: morph.cu:316-322, 680-681,
+# 763-778; bit-identical to the oracle with vmo_set_tex_filter(1), tests/test_gpu_parity.py), two orders
 CHAOS_FAMILY = (("x0", capi.MATH_EXACT, 0), ("x1", capi.MATH_EXACT, 1), ("x2", capi.MATH_EXACT, 2), ("x3", capi.MATH_EXACT, 3),
                 ("f0", capi.MATH_EXACT_FMA, 0), ("f2", capi.MATH_EXACT_FMA, 2),
-                ("r0", capi.MATH_REF_FASTMATH, 0), ("r2", capi.MATH_REF_FASTMATH, 2))
+                ("r0", capi.MATH_REF_FASTMATH, 0), ("r2", capi.MATH_REF_FASTMATH, 2),
+                ("t0", capi.MATH_REF_TEX8, 0), ("t2", capi.MATH_REF_TEX8, 2))
+# (names starting with "t" / "u" are the texture-quantised members: chaos_floor_measure keeps them OUT of the floors
+# FAST is judged against -- what rounds 3-4 called the family -- and reports them beside it)
 
 
 def chaos_floor_measure(ctx, frames=CHAOS_FRAMES, family=CHAOS_FAMILY, w=1920, h=1080, keep_fields_of=None):
@@ -626,7 +683,9 @@ def chaos_floor_measure(ctx, frames=CHAOS_FRAMES, family=CHAOS_FAMILY, w=1920, h
                 del pyr
             rms = lambda a, b: float(np.sqrt(((out[a] - out[b]) ** 2).sum(-1).mean()))
             within = lambda a, b: float((np.sqrt(((out[a] - out[b]) ** 2).sum(-1)) < 0.25).mean())
-            ex = [f[0] for f in family]
+            names = [f[0] for f in family]
+            tex = [a for a in names if a[0] in "tu"]         # 8-bit texture weights (the reference BINARY's sampling) ...
+            ex = [a for a in names if a[0] not in "tu"]      # ... and the exact-weight members: the family FAST is judged against
             pairs = [(a, b) for k, a in enumerate(ex) for b in ex[k + 1:]]
             opairs = [(a, b) for a, b in pairs if a[0] == "x" and b[0] == "x"]      # commit orders only
             rpairs = [(a, b) for a, b in pairs if (a[0] == "r") != (b[0] == "r")]    # --use_fast_math against IEEE builds
@@ -646,6 +705,14 @@ def chaos_floor_measure(ctx, frames=CHAOS_FRAMES, family=CHAOS_FAMILY, w=1920, h
                 "within_floor": min(within(a, b) for a, b in pairs), "within_fast0": within("fast", ex[0]),
                 "e_floor": (max(Ex) - min(Ex)) / Ex[0], "e_fast0": abs(E["fast"] - Ex[0]) / Ex[0],
                 "e_fast_signed": (E["fast"] - float(np.mean(Ex))) / float(np.mean(Ex)),
+                # round 5: where the reference binary's texture arithmetic lands -- every TEX8 member against every
+                # exact-weight member, the TEX8 members among themselves, FAST against them, their energies (oracle, exact weights)
+                "rms_tex8_vs_exact": [rms(a, b) for a in tex for b in ex] if tex else None,
+                "rms_tex8_pairs": {a + b: rms(a, b) for k, a in enumerate(tex) for b in tex[k + 1:]} if len(tex) > 1 else None,
+                "rms_fast_vs_tex8": [rms("fast", a) for a in tex] if tex else None,
+                "within_tex8_vs_exact": [within(a, b) for a in tex for b in ex] if tex else None,
+                "E_tex8": [E[a] for a in tex] if tex else None,
+                "e_tex8_signed": (float(np.mean([E[a] for a in tex])) - float(np.mean(Ex))) / float(np.mean(Ex)) if tex else None,
             }
             if keep_fields_of is not None and frame == keep_fields_of:
                 r["fields"] = (out[ex[0]], out["fast"])
@@ -690,6 +757,20 @@ def test_fast_solve_sits_at_the_chaos_floor_of_config1(gpu_ctx):
     signed = np.array([r["e_fast_signed"] for r in res.values()])
     sem = signed.std(ddof=1) / np.sqrt(len(signed))
     assert signed.mean() <= 2.0 * sem, (signed.tolist(), float(signed.mean()), float(sem))
+    # Round 5 -- the reference BINARY's texture arithmetic (TEX8 members: CUDA's 8-bit bilinear weights, eps = 2.56
+    # weight quanta) does NOT lie inside that family: measured 1.75-1.93 px RMS from every exact-weight member (ten
+    # times the family's range), with an energy (oracle, exact weights) 54-63 % above theirs -- the quantised
+    # landscape stalls the descent on the small levels (the 240x135 level stops after 17-40 sweeps instead of
+    # 100-216).  So no exact-weight build, the oracle of SURVEY appendix A included, can be held to 0.05 px -- or to
+    # the family's 0.19 px -- of the reference binary; what CAN be stated and is asserted: (i) the gap is there and it
+    # is large, (ii) FAST is no further from the TEX8 runs than the exact-weight legal builds are, (iii) the TEX8 runs
+    # never reach a lower energy than the exact-weight family.
+    for f, r in res.items():
+        msg = (f, table[f])
+        lo, hi = min(r["rms_tex8_vs_exact"]), max(r["rms_tex8_vs_exact"])
+        assert lo > 3.0 * r["rms_floor"], msg
+        assert max(r["rms_fast_vs_tex8"]) <= 1.1 * hi and min(r["rms_fast_vs_tex8"]) >= 0.9 * lo, msg
+        assert min(r["E_tex8"]) > max(r["E_family"]), msg
     # the rendered halfway frame from either field: >= 99 % of the bytes within 2 levels
     w, h = 1920, 1080
     ex = int(0.1 * max(w, h))
@@ -712,6 +793,9 @@ def test_fast_sits_inside_the_family_at_config3(gpu_ctx):
     res = chaos_floor_measure(gpu_ctx, frames=(0, 3), w=3840, h=2160)
     for f, r in res.items():
         msg = (f, chaos_round(r))
+        # the TEX8 members (round 5): 3.7-3.95 px RMS from every exact-weight member at this size, FAST among the latter
+        assert min(r["rms_tex8_vs_exact"]) > 3.0 * r["rms_floor"], msg
+        assert max(r["rms_fast_vs_tex8"]) <= 1.1 * max(r["rms_tex8_vs_exact"]), msg
         assert r["rms_floor"] > 0.05, msg
         assert r["rms_fast0"] <= 1.25 * r["rms_floor"], msg
         assert r["within_fast0"] >= r["within_floor"] - 0.03, msg

@@ -712,3 +712,86 @@ def test_legal_arithmetic_variants_are_rounding_level_variants_of_exact(gpu_ctx,
     assert abs(a[1] - b[1]) <= 0.03 * a[1] and abs(a[2] - b[2]) <= 0.03 * a[2], (a[1:], b[1:])
     assert not np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
     assert np.abs(b[0] - v0).max() > 0
+
+
+_TEX8 = [(capi.MATH_REF_TEX8, 1), (capi.MATH_REF_TEX8_TRUNC, 2)]
+
+
+@pytest.mark.parametrize("mode,rule", _TEX8)
+@pytest.mark.parametrize("sched", [capi.SWEEP_TILE, capi.SWEEP_STEP, capi.SWEEP_PASS])
+def test_tex8_build_equals_the_oracle_with_the_same_filter(gpu_ctx, oracle, sched, mode, rule):
+    """VM_MATH_REF_TEX8 / _TRUNC -- the EXACT source with CUDA's 8-bit bilinear filter weights in every
+    texture fetch (the reference: morph.cu:316-322, taps at :212-213, 680-681, 960-961) -- against the oracle
+    with vmo_set_tex_filter(rule): init_level and four sweeps bit-identical under every schedule, and
+    different from the exact-weight run (the switch does something)."""
+    w, h = 138, 84
+    i0, i1 = synth.make_pair(w, h)
+    v0 = (0.8 * synth.displacement(w, h)).astype(np.float32)
+    P = oracle.default_params()
+    gpu_ctx.set_params(_kp(P))
+    try:
+        oracle.lib().vmo_set_tex_filter(rule)
+        gpu_ctx.set_math_mode(mode)
+        gpu_ctx.set_tuning(sched, 0, 0)
+        lo = oracle.Level(w, h)
+        lo.set_images(i0, i1)
+        lo.field("v")[...] = v0
+        lo.init(0.0)
+        pyr = morph.Pyramid(gpu_ctx)
+        pyr.build_levels([(w, h), (69, 42)])
+        pyr.upload_luma(1, i0, i1)
+        pyr[1].v = v0
+        capi.check(pyr._L.vm_init_level(pyr._h, 0, w, h, None, 0))
+        for f in ("luma", "mean", "var", "cross", "value", "tps_b"):
+            assert np.array_equal(lo.field(f).view(np.uint32), pyr[1].field(f).view(np.uint32)), ("init", f)
+        luma_q = pyr[1].field("luma").copy()
+        for _ in range(4):
+            lo.optimize_iter(P)
+        pr = capi.Progress()
+        capi.check(pyr._L.vm_optimize_level(pyr._h, 0, 4.0, None, 1, C.byref(pr)))
+        assert pr.commits > 1000
+        for f in ("v", "luma", "mean", "var", "cross", "tps_b", "value"):
+            assert np.array_equal(lo.field(f).view(np.uint32), pyr[1].field(f).view(np.uint32)), ("sweeps", f)
+        # the exact-weight init differs: the lumas are filtered with other weights
+        oracle.lib().vmo_set_tex_filter(0)
+        lx = oracle.Level(w, h)
+        lx.set_images(i0, i1)
+        lx.field("v")[...] = v0
+        lx.init(0.0)
+        d = np.abs(lx.field("luma") - luma_q)
+        assert 0 < d.max() < 1.0 and (d > 0).mean() > 0.5, (d.max(), (d > 0).mean())
+    finally:
+        oracle.lib().vmo_set_tex_filter(0)
+        gpu_ctx.set_tuning(capi.SWEEP_AUTO, 0, 0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+
+
+@pytest.mark.parametrize("mode,rule", _TEX8)
+def test_tex8_full_solve_equals_the_oracle_with_the_same_filter(gpu_ctx, oracle, mode, rule):
+    """a whole coarse-to-fine solve (150x97, 3 levels: the inter-level upsample samples the coarser field at
+    fractions that 8 bits do not hold -- include/util/imgop_upsample.cu:17-31 fetches through a linear-filtered
+    texture too) in the TEX8 build = the oracle with the same filter, bit for bit incl. iteration counts"""
+    w, h = 150, 97
+    i0, i1 = synth.make_pair(w, h)
+    P = _params(oracle)
+    try:
+        oracle.lib().vmo_set_tex_filter(rule)
+        per = []
+        lo = oracle.solve(synth.build_pyramid(i0, i1, 3), P, 40, 1.0, threads=8, per_level=per)
+        oracle.lib().vmo_set_tex_filter(0)
+        lx = oracle.solve(synth.build_pyramid(i0, i1, 3), P, 40, 1.0, threads=8)
+        gpu_ctx.set_math_mode(mode)
+        prm = morph.Parameters()
+        prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 40, 1.0, 32
+        pyr = morph.Pyramid(gpu_ctx)
+        pyr.build(i0, i1, 32)
+        assert pyr.size() == 4
+        m = morph.Morph(prm, pyr)
+        assert m.calculate_halfway_parametrization() is True
+        assert [m.progress[el]["iters"] for el in (2, 1)] == [p[1] for p in per]
+        a, b = lo.field("v"), pyr[1].v
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "max |dv| = %g" % np.abs(a - b).max()
+        assert not np.array_equal(lx.field("v"), b)
+    finally:
+        oracle.lib().vmo_set_tex_filter(0)
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)

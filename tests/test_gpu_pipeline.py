@@ -97,3 +97,77 @@ def test_config4_pipeline_at_1080p(gpu_ctx):
         assert np.abs(f1.astype(int) - rgb1.astype(int)).mean() < 6.0
     finally:
         gpu_ctx.set_math_mode(capi.MATH_EXACT)
+
+
+def _frame_pair(w, h, ex, seed):
+    rng = np.random.RandomState(seed)
+    rgb0, rgb1 = synth.make_rgb_pair(w, h, frame=seed)
+    v = (0.6 * synth.displacement(w, h) + 0.2 * rng.randn(h, w, 2)).astype(np.float32)
+    return morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), v
+
+
+@pytest.mark.parametrize("w,h,ex", [(160, 110, 16), (333, 47, 33), (20, 12, 3), (40, 30, 6), (96, 64, 10)])
+def test_poisson_batch_of_both_sides_and_frames_equals_one_side_at_a_time(gpu_ctx, oracle, w, h, ex):
+    """vm_poisson_extend_frames: the 2 n systems of n frames in one batch (blockIdx.z = system) give what n x 2 calls of
+    vm_poisson_extend give -- same iteration counts, colours within one level (the double-precision dot products are
+    accumulated by atomics, whose order differs from run to run) -- and side 1 of the first frame agrees with the
+    oracle's CG like the single call does.  Sizes: hierarchies of one level (26 x 18 canvas), two levels, odd
+    canvases, ex > the block width."""
+    frames = [_frame_pair(w, h, ex, s) for s in (0, 3, 7)]
+    single, batch = [], []
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    for e0, e1, v in frames:
+        fr.upload(e0, e1, v, None)
+        r1, r2 = fr.poisson_extend(1, tol=1e-6), fr.poisson_extend(2, tol=1e-6)
+        single.append((r1[0], r2[0], fr.download_ext(1), fr.download_ext(2)))
+    fr.close()
+    frs = [morph.Frame(gpu_ctx, w, h, ex) for _ in frames]
+    for f, (e0, e1, v) in zip(frs, frames):
+        f.upload(e0, e1, v, None)
+    res, ms = morph.poisson_extend_frames(frs, tol=1e-6)
+    assert ms > 0
+    for f, r, s in zip(frs, res, single):
+        assert (r[0][0], r[1][0]) == (s[0], s[1]), (r, s[:2])
+        assert r[0][1] <= 1e-6 and r[1][1] <= 1e-6
+        for side in (1, 2):
+            a, b = f.download_ext(side).astype(int), s[1 + side].astype(int)
+            assert np.array_equal(a[..., 3], b[..., 3]) and np.abs(a - b).max() <= 1, (side, np.abs(a - b).max())
+    e0, e1, v = frames[0]
+    ref, _, _ = oracle.poisson_extend(e0, w, h, ex, e1[ex:ex + h, ex:ex + w].copy(), v, 1, tol=1e-9)
+    d = np.abs(frs[0].download_ext(1)[..., :3].astype(int) - ref[..., :3].astype(int))
+    assert d.max() <= 1, (d.max(), (d > 0).mean())
+    # both sides of one frame through the frame's own method
+    (i1, rr1), (i2, rr2), _ = frs[1].poisson_extend_both(tol=1e-6)          # already extended: alpha is 0 everywhere now
+    assert (i1, i2) == (0, 0) and rr1 == 0 and rr2 == 0
+    for f in frs:
+        f.close()
+
+
+def test_poisson_batch_with_an_irregular_outside_region(gpu_ctx, oracle):
+    """the block lists are built from the canvas' alpha, not from the frame rectangle: holes of alpha > 0 INSIDE the
+    image (unknowns in otherwise interior blocks) and an image region that is not a rectangle are solved like the
+    oracle solves them"""
+    w, h, ex = 200, 90, 20
+    e0, e1, v = _frame_pair(w, h, ex, 5)
+    e0 = e0.copy()
+    e0[ex + 30:ex + 41, ex + 100:ex + 131, 3] = 255          # a hole in the middle of image 0
+    e0[ex:ex + 12, ex:ex + 70, 3] = 255                       # a bite out of its corner
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(e0, e1, v, None)
+    ref, _, _ = oracle.poisson_extend(e0, w, h, ex, e1[ex:ex + h, ex:ex + w].copy(), v, 1, tol=1e-9)
+    (i1, rr1), (i2, rr2), _ = fr.poisson_extend_both(tol=1e-6)
+    out = fr.download_ext(1)
+    assert i1 > 0 and rr1 <= 1e-6 and out[..., 3].max() == 0
+    d = np.abs(out[..., :3].astype(int) - ref[..., :3].astype(int))
+    assert d.max() <= 1, (d.max(), (d > 0).mean())
+    fr.close()
+
+
+def test_poisson_batch_refuses_mixed_frames(gpu_ctx):
+    a, b = morph.Frame(gpu_ctx, 64, 40, 8), morph.Frame(gpu_ctx, 48, 40, 8)
+    with pytest.raises(capi.VmError):
+        morph.poisson_extend_frames([a, b])
+    with pytest.raises(capi.VmError):
+        morph.poisson_extend_frames([a, a])
+    a.close()
+    b.close()

@@ -429,3 +429,52 @@ def test_commit_orders_are_legal_reorderings(oracle):
                 assert np.abs(one[a][0] - one[b][0]).max() < 0.05, (a, b)
     finally:
         L.vmo_set_commit_order(0)
+
+
+def test_tex8_filter_switch(oracle):
+    """vmo_set_tex_filter: the diagnostic restatement of CUDA's linear filter -- bilinear weights in 9-bit
+    fixed point, 8 fractional bits (CUDA C Programming Guide, Texture Fetching / Linear Filtering; the
+    reference samples through it at morph.cu:212-213, 680-681, 960-961).  Mode 1 rounds the fraction to the
+    nearest 1/256 (ties up; 1.0 reachable), mode 2 truncates, mode 0 (default) keeps exact float weights.
+    A ramp image makes the filter's output the quantised coordinate itself."""
+    L = oracle.lib()
+    w, h = 8, 4
+    img = np.tile(np.arange(w, dtype=np.float32), (h, 1)).copy()         # T[i, j] = i
+    t = lambda x, y=1.5: L.vmo_tex2d(img.ctypes.data, w, h, x, y)
+    q = 1.0 / 256
+    try:
+        assert L.vmo_get_tex_filter() == 0
+        assert abs(t(2.5 + 0.3 * q) - (2.0 + 0.3 * q)) < 1e-6              # exact float weights: no staircase
+        L.vmo_set_tex_filter(1)
+        assert t(2.5) == 2.0 and t(2.5 + q) == 2.0 + q                   # representable fractions are untouched
+        assert t(2.5 + 0.3 * q) == 2.0 and t(2.5 + 0.7 * q) == 2.0 + q   # nearest
+        assert t(2.5 + 255.6 * q) == 3.0                                 # the fraction reaches 1.0: the next texel exactly
+        assert t(2.5 + 0.01) == 2.0 + 3 * q and t(2.5 - 0.01) == 2.0 - 3 * q     # eps = 0.01 px = 2.56 quanta -> 3
+        assert t(2.5 + 0.005) == 2.0 + q                                 # 1.28 quanta -> 1
+        # both axes: weights quantised independently, products exact
+        img2 = (np.arange(h, dtype=np.float32)[:, None] * 16 + np.arange(w, dtype=np.float32)[None, :]).copy()
+        t2 = lambda x, y: L.vmo_tex2d(img2.ctypes.data, w, h, x, y)
+        assert t2(2.5 + 0.3 * q, 1.5 + 1.6 * q) == 16 * (1 + 2 * q) + 2.0
+        L.vmo_set_tex_filter(2)
+        assert t(2.5 + 0.7 * q) == 2.0 and t(2.5 + 1.2 * q) == 2.0 + q   # truncation
+        assert t(2.5 + 255.6 * q) == 2.0 + 255 * q
+        # a short solve under either rule stays close to the exact-weight one and differs from it
+        P = oracle.default_params()
+        ww, hh = 96, 40
+        i0, i1 = synth.make_pair(ww, hh)
+        v0 = (0.8 * synth.displacement(ww, hh)).astype(np.float32)
+
+        def run(mode):
+            L.vmo_set_tex_filter(mode)
+            lv = oracle.Level(ww, hh)
+            lv.set_images(i0, i1)
+            lv.field("v")[...] = v0
+            lv.init(0.0)
+            for _ in range(3):
+                lv.optimize_iter(P)
+            return lv.field("v").copy()
+        a, b, c = run(0), run(1), run(2)
+        assert not np.array_equal(a, b) and not np.array_equal(b, c)
+        assert np.sqrt(((a - b) ** 2).sum(-1).mean()) < 0.1 and np.sqrt(((a - c) ** 2).sum(-1).mean()) < 0.1
+    finally:
+        L.vmo_set_tex_filter(0)

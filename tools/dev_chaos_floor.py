@@ -2,7 +2,9 @@
 stopping rule): the family of equally legal runs (four commit orders in EXACT arithmetic, two of them with fused
 multiply-adds, tests/test_gpu_fullsize.py::CHAOS_FAMILY) and FAST under the automatic schedule, per frame; energies from the oracle's vmo_energy on the host.
 The measurement is tests/test_gpu_fullsize.py::chaos_floor_measure; this prints it as JSON lines.
-usage: tools/dev_chaos_floor.py [--4k] [frame ...]      (--4k: config[3], 3840x2160, 7 levels)"""
+Round 5: the family holds two runs with CUDA's 8-bit texture filter weights (VM_MATH_REF_TEX8); --trunc adds one
+with truncated weights (member "u0": sensitivity to the rounding rule the CUDA guide leaves open).
+usage: tools/dev_chaos_floor.py [--4k] [--trunc] [frame ...]      (--4k: config[3], 3840x2160, 7 levels)"""
 import json
 import os
 import sys
@@ -16,12 +18,14 @@ from videomorphing_amd import capi, morph  # noqa: E402
 import test_gpu_fullsize as T  # noqa: E402
 
 big = "--4k" in sys.argv
-frames = [int(a) for a in sys.argv[1:] if a != "--4k"] or (list(T.CHAOS_FRAMES) if not big else [0, 3, 6])
+trunc = "--trunc" in sys.argv
+family = T.CHAOS_FAMILY + ((("u0", capi.MATH_REF_TEX8_TRUNC, 0),) if trunc else ())
+frames = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or (list(T.CHAOS_FRAMES) if not big else [0, 3, 6])
 size = dict(w=3840, h=2160) if big else {}
 ctx = morph.Context(0, capi.MATH_EXACT)
 signed = []
 for f in frames:
-    r = T.chaos_floor_measure(ctx, frames=(f,), **size)[f]
+    r = T.chaos_floor_measure(ctx, frames=(f,), family=family, **size)[f]
     signed.append(r["e_fast_signed"])
     print(json.dumps({"frame": f, **T.chaos_round(r)}), flush=True)
 s = np.array(signed)

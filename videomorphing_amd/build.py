@@ -30,6 +30,13 @@ UNITS = [
     # VM_MATH_REF_FASTMATH (diagnostic): the same source as the reference's project compiles it -- --use_fast_math:
     # contraction, approximate division and square root
     ("vm_sweep_kernels.hip", "vm_sweep_kernels_reffm.o", ["-DVM_EXACT=3", "-ffp-contract=fast"]),
+    # VM_MATH_REF_TEX8 / _TRUNC (diagnostic): the EXACT source, IEEE, with CUDA's 8-bit bilinear filter weights in
+    # every texture fetch (images and the inter-level upsample): what separates the reference BINARY's arithmetic
+    # from every other member of the family of legal builds (vm_morph_common.h: tex8_weight)
+    ("vm_sweep_kernels.hip", "vm_sweep_kernels_tex8.o", ["-DVM_EXACT=4", "-ffp-contract=off"]),
+    ("vm_sweep_kernels.hip", "vm_sweep_kernels_tex8t.o", ["-DVM_EXACT=5", "-ffp-contract=off"]),
+    ("vm_morph_kernels.hip", "vm_morph_kernels_tex8.o", ["-DVM_EXACT=4", "-ffp-contract=off"]),
+    ("vm_morph_kernels.hip", "vm_morph_kernels_tex8t.o", ["-DVM_EXACT=5", "-ffp-contract=off"]),
     # FAST fuses multiply-adds where the source says fmaf(), nowhere else: with -ffp-contract=fast
     # two inlined copies of one expression (a*b + c*d) may be contracted differently, and the
     # schedules would agree bit for bit only while their code is laid out alike (measured cost of
@@ -38,6 +45,7 @@ UNITS = [
     ("vm_render.hip", "vm_render.o", ["-ffp-contract=off"]),
     ("vm_poisson.hip", "vm_poisson.o", ["-ffp-contract=off"]),
     ("vm_mg.hip", "vm_mg.o", ["-ffp-contract=fast"]),
+    ("vm_mgb.hip", "vm_mgb.o", ["-ffp-contract=fast"]),
     ("vm_pyramid.hip", "vm_pyramid.o", ["-ffp-contract=off"]),
     ("vm_temporal.hip", "vm_temporal.o", ["-ffp-contract=off"]),
     ("vm_sync.hip", "vm_sync_kernels.o", ["-ffp-contract=off"]),

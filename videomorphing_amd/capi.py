@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvmorph_hip.so")
 VM_OK = 0
 VM_E_INVALID, VM_E_DEVICE, VM_E_STATE, VM_E_NUMERIC, VM_E_CANCELLED = -1, -2, -3, -4, -5
 BCOND_NONE, BCOND_CORNER, BCOND_BORDER = 0, 1, 2
-MATH_EXACT, MATH_FAST, MATH_EXACT_FMA, MATH_REF_FASTMATH = 0, 1, 2, 3
+MATH_EXACT, MATH_FAST, MATH_EXACT_FMA, MATH_REF_FASTMATH, MATH_REF_TEX8, MATH_REF_TEX8_TRUNC = 0, 1, 2, 3, 4, 5
 SWEEP_AUTO, SWEEP_TILE, SWEEP_SPLIT, SWEEP_STEP, SWEEP_SPARSE, SWEEP_PASS = 0, 1, 2, 3, 4, 5
 
 FIELDS = {  # name -> (id, channels)
@@ -33,7 +33,7 @@ SYMBOLS = [
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
     "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
     "vm_frame_download_ext", "vm_frame_set_v_from_level", "vm_render_halfway",
-    "vm_render_halfway_dev", "vm_poisson_extend", "vm_frame_quadratic_path", "vm_frame_download_qpath", "vm_frame_download_v",
+    "vm_render_halfway_dev", "vm_poisson_extend", "vm_poisson_extend_frames", "vm_frame_quadratic_path", "vm_frame_download_qpath", "vm_frame_download_v",
     "vm_rccl_bcast",
     "vm_video_create", "vm_video_destroy", "vm_video_levels", "vm_video_level_dims", "vm_video_upload_luma",
     "vm_video_upload_flows", "vm_video_build_rgb", "vm_video_build_flows", "vm_video_set_v", "vm_video_get_v",
@@ -144,6 +144,7 @@ def load():
         "vm_render_halfway": [vp, f, f, i, vp, i],
         "vm_render_halfway_dev": [vp, f, f, i, C.POINTER(f)],
         "vm_poisson_extend": [vp, i, f, i, C.POINTER(i), C.POINTER(f), C.POINTER(f)],
+        "vm_poisson_extend_frames": [C.POINTER(vp), i, f, i, C.POINTER(i), C.POINTER(f), C.POINTER(f)],
         "vm_frame_quadratic_path": [vp, f, i, C.POINTER(i), C.POINTER(f), C.POINTER(f)],
         "vm_frame_download_qpath": [vp, vp],
         "vm_frame_download_v": [vp, vp],

@@ -202,6 +202,7 @@ static void ctx_free(vm_ctx *c)
     hipFree(c->views);
     hipFree(c->iter_dev);
     hipFree(c->tile_list);
+    hipFree(c->mgb_sys);
     for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -248,7 +249,7 @@ extern "C" int vm_get_params(vm_ctx *c, vm_kern_params *p)
 
 extern "C" int vm_set_math_mode(vm_ctx *c, int mode)
 {
-    if (!c || mode < VM_MATH_EXACT || mode > VM_MATH_REF_FASTMATH)
+    if (!c || mode < VM_MATH_EXACT || mode > VM_MATH_REF_TEX8_TRUNC)
         return vm_fail(VM_E_INVALID, "vm_set_math_mode: bad argument");
     c->math_mode = mode;
     return VM_OK;
@@ -669,7 +670,11 @@ extern "C" int vm_coarse_solve(vm_pyr *p, int lvl, int w0, int h0, const vm_cons
 // upsample(PyramidLevel&dest, PyramidLevel&orig) for one page, upsample.cu:260-286
 int vm_level_upsample(vm_ctx *c, vm_level &d, const vm_level &s)
 {
-    if (c->math_mode != VM_MATH_FAST)
+    if (c->math_mode == VM_MATH_REF_TEX8)          // the reference upsamples through a linear-filtered texture too
+        vm_launch_upsample_tex8(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, c->stream);
+    else if (c->math_mode == VM_MATH_REF_TEX8_TRUNC)
+        vm_launch_upsample_tex8t(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, c->stream);
+    else if (c->math_mode != VM_MATH_FAST)
         vm_launch_upsample_exact(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, c->stream);
     else
         vm_launch_upsample_fast(d.view.v, d.w, d.h, d.rs, s.view.v, s.w, s.h, s.rs, c->stream);
@@ -697,7 +702,13 @@ int vm_level_init(vm_ctx *c, vm_level &l, int w0, int h0, const vm_constraint *c
     if (n < 0 || (n > 0 && !cons)) return vm_fail(VM_E_INVALID, "vm_init_level: constraints");
     int rc = upload_constraints(c, cons, n);
     if (rc != VM_OK) return rc;
-    if (c->math_mode != VM_MATH_FAST) {
+    if (c->math_mode == VM_MATH_REF_TEX8) {
+        vm_launch_init_level_tex8(l.view, c->kp.ssim_clamp, c->tables, c->stream);
+        if (n > 0) vm_launch_splat_exact(l.view, w0, h0, c->cons_dev, n, c->stream);
+    } else if (c->math_mode == VM_MATH_REF_TEX8_TRUNC) {
+        vm_launch_init_level_tex8t(l.view, c->kp.ssim_clamp, c->tables, c->stream);
+        if (n > 0) vm_launch_splat_exact(l.view, w0, h0, c->cons_dev, n, c->stream);
+    } else if (c->math_mode != VM_MATH_FAST) {
         vm_launch_init_level_exact(l.view, c->kp.ssim_clamp, c->tables, c->stream);
         if (n > 0) vm_launch_splat_exact(l.view, w0, h0, c->cons_dev, n, c->stream);
     } else {
@@ -763,7 +774,21 @@ static const SweepLaunchers &sweep_launchers(int math_mode)
     static const SweepLaunchers reffm = {vm_launch_optimize_reffm, vm_launch_next_iter_reffm, vm_launch_optimize_sparse_reffm,
                                          vm_launch_optimize_split_reffm, vm_launch_optimize_step_reffm, vm_launch_optimize_pass_reffm,
                                          vm_pass_resident_blocks_reffm};
-    return math_mode == VM_MATH_FAST ? fast : (math_mode == VM_MATH_EXACT_FMA ? exactf : (math_mode == VM_MATH_REF_FASTMATH ? reffm : exact));
+    // VM_MATH_REF_TEX8 / _TRUNC: that source, IEEE, with the 8-bit bilinear weights of CUDA's texture filter
+    static const SweepLaunchers tex8 = {vm_launch_optimize_tex8, vm_launch_next_iter_tex8, vm_launch_optimize_sparse_tex8,
+                                        vm_launch_optimize_split_tex8, vm_launch_optimize_step_tex8, vm_launch_optimize_pass_tex8,
+                                        vm_pass_resident_blocks_tex8};
+    static const SweepLaunchers tex8t = {vm_launch_optimize_tex8t, vm_launch_next_iter_tex8t, vm_launch_optimize_sparse_tex8t,
+                                         vm_launch_optimize_split_tex8t, vm_launch_optimize_step_tex8t, vm_launch_optimize_pass_tex8t,
+                                         vm_pass_resident_blocks_tex8t};
+    switch (math_mode) {
+    case VM_MATH_FAST: return fast;
+    case VM_MATH_EXACT_FMA: return exactf;
+    case VM_MATH_REF_FASTMATH: return reffm;
+    case VM_MATH_REF_TEX8: return tex8;
+    case VM_MATH_REF_TEX8_TRUNC: return tex8t;
+    default: return exact;
+    }
 }
 
 // A hipGraph of VM_GRAPH_ITERS TILE-schedule iterations (4 pass launches each, one counter bump)
@@ -1050,7 +1075,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         want_pass = false;
     }
     if (want_pass) { // a 256-workgroup chunk of the launch must fit the device at once
-        int &res = c->pass_resident[c->math_mode & 3];
+        int &res = c->pass_resident[c->math_mode & 7];
         if (res < 0) res = SL.pass_resident(c->device);
         if (res < 256) {
             if (c->sweep_mode == VM_SWEEP_PASS)

@@ -44,7 +44,7 @@ extern "C" void vm_frame_destroy(vm_frame *f)
         else hipDeviceSynchronize();
         hipFree(f->ext[0]); hipFree(f->ext[1]);
         hipFree(f->crop[0]); hipFree(f->crop[1]);
-        hipFree(f->v); hipFree(f->u); hipFree(f->out); hipFree(f->pws);
+        hipFree(f->v); hipFree(f->u); hipFree(f->out); hipFree(f->pws); hipFree(f->pws2[0]); hipFree(f->pws2[1]);
         (void)hipGetLastError();
     }
     delete f;

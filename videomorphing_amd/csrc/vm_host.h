@@ -75,7 +75,7 @@ struct vm_ctx {
     uint32_t *pass_bar = nullptr;
     size_t pass_bar_words = 0;
     uint32_t *pass_err = nullptr, *pass_err_host = nullptr;
-    int pass_resident[4] = {-1, -1, -1, -1}; // co-resident k_pass workgroups on this device, per arithmetic build (math_mode); -1: not asked yet
+    int pass_resident[8] = {-1, -1, -1, -1, -1, -1, -1, -1}; // co-resident k_pass workgroups on this device, per arithmetic build (math_mode); -1: not asked yet
     uint32_t *pass_dbg = nullptr;    // vm_dbg_pass_xcd: 256 words, XCC id per workgroup of the last launch
     void *pass_snap = nullptr;       // AUTO: the levels' slabs as they stood before the current PASS batch
     size_t pass_snap_bytes = 0;
@@ -106,6 +106,7 @@ struct vm_ctx {
     uint32_t *tile_list = nullptr;   // the listed form of pruned TILE passes over big batches (k_tile_scan): counters, stamps, entries
     size_t tile_list_words = 0;
     int use_graphs = -1;             // -1: not decided yet, 0: off (VM_NO_GRAPH or a failed capture), 1: on
+    void *mgb_sys = nullptr;         // device descriptors of the systems of the current Poisson batch (vm_poisson_api.cpp)
 };
 
 struct vm_level {
@@ -175,9 +176,12 @@ struct vm_frame {
     uchar4 *crop[2] = {nullptr, nullptr}; // w x h originals (CPoissonExt::_image1/_image2, PoissonExt.cpp:26-27)
     float2 *v = nullptr, *u = nullptr;    // h x rs
     uint8_t *out = nullptr;               // h x w x 3
-    // Poisson workspace (allocated on first use)
+    // Poisson workspace (allocated on first use): pws = the quadratic path's and the A/B solvers', pws2[side - 1] =
+    // one per side for the batched solver (both sides of a frame are in flight together)
     void *pws = nullptr;
     size_t pws_bytes = 0;
+    void *pws2[2] = {nullptr, nullptr};
+    size_t pws2_bytes[2] = {0, 0};
 };
 
 // level-wise pieces of the solver shared by the frame-pair API (vm_api.cpp) and the video

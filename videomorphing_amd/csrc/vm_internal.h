@@ -125,6 +125,8 @@ VM_DECL_LAUNCHERS(exact)
 VM_DECL_LAUNCHERS(fast)
 VM_DECL_LAUNCHERS(exactf) // sweeps only (vm_sweep_kernels.hip with -DVM_EXACT=2 -ffp-contract=fast): VM_MATH_EXACT_FMA
 VM_DECL_LAUNCHERS(reffm)  // sweeps only (-DVM_EXACT=3 -ffp-contract=fast): VM_MATH_REF_FASTMATH
+VM_DECL_LAUNCHERS(tex8)   // sweeps, init_level, upsample (-DVM_EXACT=4 -ffp-contract=off): VM_MATH_REF_TEX8
+VM_DECL_LAUNCHERS(tex8t)  // the same with truncated weights (-DVM_EXACT=5): VM_MATH_REF_TEX8_TRUNC
 
 // compositor / result delivery (single arithmetic mode)
 void vm_launch_upscale(float2 *dst, int w0, int h0, int dpitch, const float2 *v, int w, int h,

@@ -8,10 +8,19 @@
 #include "vm_internal.h"
 
 #ifndef VM_EXACT
-#error "define VM_EXACT to 0 or 1"
+#error "define VM_EXACT to 0 (FAST), 1 (EXACT) or 2-5 (diagnostic builds of the EXACT source)"
 #endif
 
-#if VM_EXACT == 3
+#if VM_EXACT == 4
+// VM_MATH_REF_TEX8: the EXACT source, IEEE arithmetic, with the texture fetches quantised the way the
+// reference's tex2D(linear) fetches are on CUDA hardware (tex8_weight below)
+#define SUF(name) name##_tex8
+#define VM_TEX8 1
+#elif VM_EXACT == 5
+// VM_MATH_REF_TEX8_TRUNC: the same with the weights truncated instead of rounded (sensitivity to the rule)
+#define SUF(name) name##_tex8t
+#define VM_TEX8 2
+#elif VM_EXACT == 3
 // VM_MATH_REF_FASTMATH (sweeps only): the EXACT source -- the reference's own expressions in its own order --
 // with what its project file compiles it with, --use_fast_math (MdiEditor.vcxproj:208-213): fused
 // multiply-adds, approximate division (x * rcp(y), CUDA: __fdividef) and approximate square root
@@ -118,14 +127,38 @@ __device__ __forceinline__ float ssim_value(float mx, float my, float vx, float 
 }
 #endif
 
+#ifdef VM_TEX8
+// CUDA's linear filter (the reference samples both images and the coarser level's field through it:
+// morph.cu:29-30, 316-322; taps at :212-213, 680-681, 960-961; imgop_upsample.cu:17-31) evaluates
+//   (1-a)(1-b) T[i,j] + a(1-b) T[i+1,j] + (1-a) b T[i,j+1] + a b T[i+1,j+1],  a = frac(x - 0.5), b = frac(y - 0.5)
+// with a and b "stored in 9-bit fixed point format with 8 bits of fractional value (so 1.0 is exactly
+// represented)" (CUDA C Programming Guide, appendix Texture Fetching, Linear Filtering).  The guide does not
+// say how the fraction is brought to 8 bits.  Rule taken here (VM_TEX8 == 1): round to nearest,
+// a_q = floor(256 a + 0.5) / 256 -- the only reading under which a_q can reach the 1.0 the format is said
+// to represent exactly (a truncated fraction never exceeds 255/256); a_q = 1 gives T[i+1] exactly, i.e. what
+// rounding the COORDINATE to 1/256 would give.  VM_TEX8 == 2 truncates instead (sensitivity check).  The
+// four products and three sums stay f32 in the order tap() has them: the hardware's internal order and
+// width are not documented either, and with 8-bit weights the weight products are exact.
+__device__ __forceinline__ float tex8_weight(float a)
+{
+#if VM_TEX8 == 1
+    return floorf(a * 256.0f + 0.5f) * 0.00390625f;
+#else
+    return floorf(a * 256.0f) * 0.00390625f;
+#endif
+}
+#else
+__device__ __forceinline__ float tex8_weight(float a) { return a; }
+#endif
+
 // tex2D(linear, clamp, unnormalised) on a pitched f32 image: texel centres at
-// i+0.5 (morph.cu:316-322); exact float weights
+// i+0.5 (morph.cu:316-322); exact float weights (the TEX8 diagnostic builds: 8-bit ones, above)
 __device__ __forceinline__ float tap(const float *__restrict__ img, int w, int h, int rs, float x,
                                      float y)
 {
     float xb = x - 0.5f, yb = y - 0.5f;
     float fi = floorf(xb), fj = floorf(yb);
-    float a = xb - fi, b = yb - fj;
+    float a = tex8_weight(xb - fi), b = tex8_weight(yb - fj);
     fi = fminf(fmaxf(fi, -1.0f), (float)w);
     fj = fminf(fmaxf(fj, -1.0f), (float)h);
     int i0 = (int)fi, j0 = (int)fj;
@@ -142,7 +175,7 @@ __device__ __forceinline__ float2 tap2(const float2 *__restrict__ img, int w, in
 {
     float xb = x - 0.5f, yb = y - 0.5f;
     float fi = floorf(xb), fj = floorf(yb);
-    float a = xb - fi, b = yb - fj;
+    float a = tex8_weight(xb - fi), b = tex8_weight(yb - fj);
     fi = fminf(fmaxf(fi, -1.0f), (float)w);
     fj = fminf(fmaxf(fj, -1.0f), (float)h);
     int i0 = (int)fi, j0 = (int)fj;

@@ -3,6 +3,7 @@
 // RCCL broadcast helper.
 #include "vm_host.h"
 #include "vm_mg.h"
+#include "vm_mgb.h"
 #include "vm_poisson.h"
 
 #include <cmath>
@@ -258,7 +259,8 @@ static int poisson_solve_nested(vm_frame *f, int side, float tol, int max_it, in
     return VM_OK;
 }
 
-// multigrid-preconditioned CG on the reference's system (the default)
+// multigrid-preconditioned CG on the reference's system, one system at a time over the whole canvas: round 4's
+// form, kept for A/B measurements (VM_POISSON_SOLVER=mg1)
 static int poisson_solve_mg(vm_frame *f, int side, float tol, int max_it, int *total_it, double *rel_out)
 {
     vm_ctx *c = f->ctx;
@@ -292,6 +294,211 @@ static int poisson_solve_mg(vm_frame *f, int side, float tol, int max_it, int *t
     return VM_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The default solver (round 5): the same multigrid-preconditioned CG, batched over systems (a system = one side of
+// one frame), swept over the ring of unknowns only, with the fused kernels of vm_mgb.hip.
+
+namespace {
+
+struct MgbWork {          // one system's device workspace, carved from f->pws2[side - 1]
+    VmMgbSys S;           // host copy of the device descriptor
+    uint8_t *type;
+    float4 *Xbest;
+    char *xcoarse;        // the x arrays of levels >= 1, contiguous (cleared per extension)
+    size_t xcoarse_bytes;
+    int *counts;          // nblocks per level (device)
+};
+
+size_t mgb_bytes(int w, int h)
+{
+    const auto sz = mg_sizes(w, h);
+    const size_t N0 = (size_t)w * h;
+    size_t need = al256(N0) + al256(sizeof(VmMgbScalars)) + al256(VM_MGB_MAXLEV * sizeof(int)) + 5 * al256(N0 * 16);
+    for (size_t l = 0; l < sz.size(); ++l) {
+        const size_t N = (size_t)sz[l].first * sz[l].second;
+        const size_t nb = (size_t)((sz[l].first + 63) / 64) * ((sz[l].second + 3) / 4);
+        need += 3 * al256(N * 4) + 2 * al256(N * 16) + 2 * al256(nb * 4);
+    }
+    return need;
+}
+
+void mgb_carve(MgbWork &W, int w, int h, char *b)
+{
+    const auto sz = mg_sizes(w, h);
+    const size_t N0 = (size_t)w * h;
+    W.type = (uint8_t *)b; b += al256(N0);
+    W.S.type = W.type;
+    W.S.sc = (VmMgbScalars *)b; b += al256(sizeof(VmMgbScalars));
+    W.counts = (int *)b; b += al256(VM_MGB_MAXLEV * sizeof(int));
+    W.S.X = (float4 *)b; b += al256(N0 * 16);
+    W.S.P[0] = (float4 *)b; b += al256(N0 * 16);
+    W.S.P[1] = (float4 *)b; b += al256(N0 * 16);
+    W.S.Q = (float4 *)b; b += al256(N0 * 16);
+    W.Xbest = (float4 *)b; b += al256(N0 * 16);
+    W.S.nlev = (int)sz.size();
+    for (size_t l = 0; l < sz.size(); ++l) {
+        VmMgbLevel &L = W.S.lv[l];
+        L.w = sz[l].first; L.h = sz[l].second;
+        L.gx = (L.w + 63) / 64; L.gy = (L.h + 3) / 4;
+        const size_t N = (size_t)L.w * L.h, nb = (size_t)L.gx * L.gy;
+        L.we = (float *)b; b += al256(N * 4);
+        L.ws = (float *)b; b += al256(N * 4);
+        L.dg = (float *)b; b += al256(N * 4);
+        L.b = (float4 *)b; b += al256(N * 16);
+        L.flags = (uint32_t *)b; b += al256(nb * 4);
+        L.blocks = (uint32_t *)b; b += al256(nb * 4);
+        L.nblocks = W.counts + l;
+    }
+    // the x arrays last and together: level 0's (z), then the coarse ones, which are cleared per extension (a
+    // fine cell may read the correction of a coarse cell that is no unknown and sits in a block nobody sweeps)
+    W.S.lv[0].x = (float4 *)b; b += al256(N0 * 16);
+    W.xcoarse = b;
+    for (size_t l = 1; l < sz.size(); ++l) {
+        W.S.lv[l].x = (float4 *)b;
+        b += al256((size_t)sz[l].first * sz[l].second * 16);
+    }
+    W.xcoarse_bytes = (size_t)(b - W.xcoarse);
+}
+
+// z = M^-1 r of every active system: one V(1,1) cycle; iteration k's r.z lands in rz[k & 1]
+void mgb_vcycle(const VmMgbSys *dev, int nsys, const MgbWork &W0, const std::vector<int> &nb, int k, uint64_t active, hipStream_t s)
+{
+    const int nlev = W0.S.nlev;
+    if (nlev == 1) {
+        vm_mgb_launch_coarsest(dev, nsys, 0, kMgOmega, kMgCoarseSweeps, active, s);
+        vm_mgb_launch_dot_rz(dev, nsys, nb[0], k, active, s);
+        return;
+    }
+    const int tail = nlev - 2;      // levels tail, tail + 1 run in one workgroup
+    for (int l = 0; l < tail; ++l)
+        vm_mgb_launch_restrict(dev, nsys, l, nb[l + 1], kMgOmega, active, s);
+    vm_mgb_launch_tail(dev, nsys, tail, kMgOmega, kMgCoarseSweeps, active, s);
+    if (tail == 0)
+        vm_mgb_launch_dot_rz(dev, nsys, nb[0], k, active, s);
+    for (int l = tail - 1; l >= 0; --l)
+        vm_mgb_launch_prolong(dev, nsys, l, nb[l], kMgOmega, k, active, s);
+}
+
+double mgb_rel(const VmMgbScalars &h, int par)
+{
+    double worst = 0;
+    for (int c = 0; c < 3; ++c) {
+        double bb = 0, rr = 0;
+        for (int k = 0; k < VM_MGB_SLOTS; ++k) { bb += h.bb[k][c]; rr += h.rr[par][k][c]; }
+        if (!(bb == bb) || !(rr == rr) || std::isinf(bb) || std::isinf(rr)) return -1;
+        if (bb > 0) worst = std::max(worst, std::sqrt(rr / bb));
+    }
+    return worst;
+}
+
+} // namespace
+
+// Poisson extension of nsys systems (frames[i], sides[i]) of one context and one canvas size as ONE batch
+static int poisson_solve_batch(vm_ctx *c, vm_frame *const *frames, const int *sides, int nsys, float tol, int max_it,
+                               int *iters, double *rels)
+{
+    hipStream_t s = c->stream;
+    const int cw = frames[0]->cw, ch = frames[0]->ch;
+    const size_t N0 = (size_t)cw * ch, need = mgb_bytes(cw, ch);
+    std::vector<MgbWork> W(nsys);
+    for (int i = 0; i < nsys; ++i) {
+        vm_frame *f = frames[i];
+        const int sd = sides[i] - 1;
+        if (f->pws2_bytes[sd] < need) {
+            hipFree(f->pws2[sd]);
+            f->pws2[sd] = nullptr;
+            f->pws2_bytes[sd] = 0;
+            VM_HIP(hipMalloc(&f->pws2[sd], need));
+            f->pws2_bytes[sd] = need;
+        }
+        mgb_carve(W[i], cw, ch, (char *)f->pws2[sd]);
+    }
+    if (!c->mgb_sys) VM_HIP(hipMalloc((void **)&c->mgb_sys, VM_MGB_MAXSYS * sizeof(VmMgbSys)));
+    VmMgbSys *dev = (VmMgbSys *)c->mgb_sys;
+    std::vector<VmMgbSys> hs(nsys);
+    for (int i = 0; i < nsys; ++i) hs[i] = W[i].S;
+    VM_HIP(hipMemcpyAsync(dev, hs.data(), nsys * sizeof(VmMgbSys), hipMemcpyHostToDevice, s));
+    const int nlev = W[0].S.nlev;
+    // classify, fill, right-hand side + initial guess (per system), then the hierarchy and its block lists (batched)
+    for (int i = 0; i < nsys; ++i) {
+        vm_frame *f = frames[i];
+        const int side = sides[i];
+        uchar4 *ext = f->ext[side - 1];
+        const uchar4 *other = f->crop[side == 1 ? 1 : 0]; // PoissonExt.cpp:54-57
+        vm_poisson_launch_prepare(ext, W[i].type, other, f->v, f->w, f->h, f->rs, f->ex, side == 1 ? 1 : -1, s);
+        vm_poisson_launch_setup(ext, W[i].type, W[i].S.lv[0].b, W[i].S.X, cw, ch, s);
+        VM_HIP(hipMemsetAsync(W[i].S.sc, 0, sizeof(VmMgbScalars), s));
+        if (W[i].xcoarse_bytes) VM_HIP(hipMemsetAsync(W[i].xcoarse, 0, W[i].xcoarse_bytes, s));
+    }
+    vm_mgb_launch_level0(dev, nsys, W[0].S.lv[0].gx, W[0].S.lv[0].gy, s);
+    for (int l = 1; l < nlev; ++l)
+        vm_mgb_launch_coarsen(dev, nsys, l, W[0].S.lv[l].gx, W[0].S.lv[l].gy, s);
+    vm_mgb_launch_compact(dev, nsys, nlev, s);
+    VM_HIP(hipGetLastError());
+    std::vector<int> cnt((size_t)nsys * VM_MGB_MAXLEV), nb(nlev, 0);
+    for (int i = 0; i < nsys; ++i)
+        VM_HIP(hipMemcpyAsync(&cnt[(size_t)i * VM_MGB_MAXLEV], W[i].counts, nlev * sizeof(int), hipMemcpyDeviceToHost, s));
+    VM_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < nsys; ++i)
+        for (int l = 0; l < nlev; ++l) nb[l] = std::max(nb[l], cnt[(size_t)i * VM_MGB_MAXLEV + l]);
+    if (nb[0] == 0) {                       // no unknown anywhere: nothing to extend
+        for (int i = 0; i < nsys; ++i) { iters[i] = 0; rels[i] = 0; }
+        return VM_OK;
+    }
+    uint64_t active = nsys == 64 ? ~0ull : ((1ull << nsys) - 1);
+    vm_mgb_launch_init(dev, nsys, nb[0], active, s);
+    std::vector<VmMgbScalars> h(nsys);
+    std::vector<double> best(nsys, 1e300);
+    std::vector<int> best_it(nsys, 0), stale(nsys, 0), saved(nsys, 0);
+    int it = 0;
+    const int check = 4;
+    while (true) {
+        for (int i = 0; i < nsys; ++i)
+            if ((active >> i) & 1) VM_HIP(hipMemcpyAsync(&h[i], W[i].S.sc, sizeof(VmMgbScalars), hipMemcpyDeviceToHost, s));
+        VM_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < nsys; ++i) {
+            if (!((active >> i) & 1)) continue;
+            const double worst = mgb_rel(h[i], (it - 1) & 1);   // it == 0: parity 1, where k_mgb_init left r.r
+            if (worst < 0)
+                return vm_fail(VM_E_NUMERIC, it == 0 ? "multigrid PCG: the right-hand side is not finite" : "multigrid PCG broke down (NaN)");
+            if (worst < best[i]) {
+                best[i] = worst;
+                best_it[i] = it;
+                stale[i] = 0;
+                // the recursively updated residual can pass below what the stored iterate attains and the iteration
+                // then drifts: near the tolerance the best iterate seen at a check is kept
+                if (worst <= 30.0 * tol) {
+                    VM_HIP(hipMemcpyAsync(W[i].Xbest, W[i].S.X, N0 * sizeof(float4), hipMemcpyDeviceToDevice, s));
+                    saved[i] = 1;
+                }
+            } else {
+                ++stale[i];
+            }
+            if (worst <= tol || it >= max_it || stale[i] >= 3 || worst > 1e3 * best[i]) {
+                active &= ~(1ull << i);
+                if (saved[i] && best_it[i] != it)
+                    VM_HIP(hipMemcpyAsync(W[i].S.X, W[i].Xbest, N0 * sizeof(float4), hipMemcpyDeviceToDevice, s));
+                else if (!saved[i]) { best[i] = worst; best_it[i] = it; }     // what X holds
+            }
+        }
+        if (!active) break;
+        const int nbt = std::min(check, max_it - it);
+        for (int k = 0; k < nbt; ++k, ++it) {
+            mgb_vcycle(dev, nsys, W[0], nb, it, active, s);
+            vm_mgb_launch_dirspmv(dev, nsys, nb[0], it, active, s);
+            vm_mgb_launch_update(dev, nsys, nb[0], it, active, s);
+        }
+        VM_HIP(hipGetLastError());
+    }
+    for (int i = 0; i < nsys; ++i) {
+        vm_poisson_launch_paste(frames[i]->ext[sides[i] - 1], W[i].type, W[i].S.X, cw, ch, s);
+        iters[i] = best_it[i];
+        rels[i] = best[i];
+    }
+    VM_HIP(hipGetLastError());
+    return VM_OK;
+}
+
 extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, int *iters,
                                  float *rel_res, float *elapsed_ms)
 {
@@ -301,12 +508,14 @@ extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, i
     VM_ON_DEVICE(c);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipStream_t s = c->stream;
-    static const bool jacobi = getenv("VM_POISSON_SOLVER") && !strcmp(getenv("VM_POISSON_SOLVER"), "jacobi");
+    static const char *solver = getenv("VM_POISSON_SOLVER");
+    static const bool jacobi = solver && !strcmp(solver, "jacobi"), mg1 = solver && !strcmp(solver, "mg1");
     VM_HIP(hipEventRecord(c->ev0, s));
     int total_it = 0;
     double rel = 0;
     int rc = jacobi ? poisson_solve_nested(f, side, tol, max_it, &total_it, &rel)
-                    : poisson_solve_mg(f, side, tol, max_it, &total_it, &rel);
+             : mg1  ? poisson_solve_mg(f, side, tol, max_it, &total_it, &rel)
+                    : poisson_solve_batch(c, &f, &side, 1, tol, max_it, &total_it, &rel);
     if (rc != VM_OK) return rc;
     VM_HIP(hipGetLastError());
     VM_HIP(hipEventRecord(c->ev1, s));
@@ -318,6 +527,52 @@ extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, i
     if (elapsed_ms) *elapsed_ms = ms;
     if (rel > tol)
         return vm_fail(VM_E_NUMERIC, "vm_poisson_extend: residual %.3g after %d iterations (tol %.3g)", rel, total_it, (double)tol);
+    return VM_OK;
+}
+
+// Both sides of n frames in one batch: CPoissonExt::run's loop body (PoissonExt.cpp:24-36) for n frames at once --
+// side 1 samples the ORIGINAL image 2 and side 2 the original image 1 (the crops taken at upload), so the 2 n
+// systems are independent.  iters / rel_res: 2 n entries, [2 i] = side 1 of frame i, [2 i + 1] = side 2.
+extern "C" int vm_poisson_extend_frames(vm_frame *const *frames, int n, float tol, int max_it, int *iters,
+                                        float *rel_res, float *elapsed_ms)
+{
+    if (!frames || n < 1 || 2 * n > VM_MGB_MAXSYS || !(tol > 0) || max_it < 1)
+        return vm_fail(VM_E_INVALID, "vm_poisson_extend_frames: bad argument (1 <= n <= %d)", VM_MGB_MAXSYS / 2);
+    for (int i = 0; i < n; ++i) {
+        if (!frames[i]) return vm_fail(VM_E_INVALID, "vm_poisson_extend_frames: frame %d is NULL", i);
+        if (frames[i]->ctx != frames[0]->ctx) return vm_fail(VM_E_INVALID, "vm_poisson_extend_frames: the frames belong to different contexts");
+        if (frames[i]->cw != frames[0]->cw || frames[i]->ch != frames[0]->ch)
+            return vm_fail(VM_E_INVALID, "vm_poisson_extend_frames: the frames differ in size");
+        for (int j = 0; j < i; ++j)
+            if (frames[j] == frames[i]) return vm_fail(VM_E_INVALID, "vm_poisson_extend_frames: frame %d listed twice", i);
+    }
+    vm_ctx *c = frames[0]->ctx;
+    if (!vm_ctx_alive(c)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__);
+    VM_ON_DEVICE(c);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    hipStream_t s = c->stream;
+    std::vector<vm_frame *> fr(2 * n);
+    std::vector<int> sd(2 * n), its(2 * n, 0);
+    std::vector<double> rel(2 * n, 0.0);
+    for (int i = 0; i < n; ++i) { fr[2 * i] = fr[2 * i + 1] = frames[i]; sd[2 * i] = 1; sd[2 * i + 1] = 2; }
+    VM_HIP(hipEventRecord(c->ev0, s));
+    int rc = poisson_solve_batch(c, fr.data(), sd.data(), 2 * n, tol, max_it, its.data(), rel.data());
+    if (rc != VM_OK) return rc;
+    VM_HIP(hipEventRecord(c->ev1, s));
+    VM_HIP(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    VM_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (elapsed_ms) *elapsed_ms = ms;
+    double worst = 0;
+    int at = 0;
+    for (int i = 0; i < 2 * n; ++i) {
+        if (iters) iters[i] = its[i];
+        if (rel_res) rel_res[i] = (float)rel[i];
+        if (rel[i] > worst) { worst = rel[i]; at = i; }
+    }
+    if (worst > tol)
+        return vm_fail(VM_E_NUMERIC, "vm_poisson_extend_frames: residual %.3g after %d iterations on side %d of frame %d (tol %.3g)",
+                       worst, its[at], at % 2 + 1, at / 2, (double)tol);
     return VM_OK;
 }
 

@@ -520,6 +520,22 @@ class Frame(object):
                                              C.byref(rr), C.byref(ms)))
         return it.value, rr.value, ms.value
 
+    def poisson_extend_both(self, tol=1e-5, max_it=20000):
+        """both sides of this frame as one batch: ((iters1, rel1), (iters2, rel2), ms)"""
+        r = poisson_extend_frames([self], tol, max_it)
+        return r[0][0], r[0][1], r[1]
+
+
+def poisson_extend_frames(frames, tol=1e-5, max_it=20000):
+    """CPoissonExt::run's loop body (PoissonExt.cpp:24-36) for several frames of one context at once: both sides of
+    every frame are independent systems and share every launch.  Returns ([((iters, rel) side 1, (iters, rel) side 2)
+    per frame], elapsed ms)."""
+    n = len(frames)
+    arr = (C.c_void_p * n)(*[f._h for f in frames])
+    it, rr, ms = (C.c_int * (2 * n))(), (C.c_float * (2 * n))(), C.c_float(0)
+    capi.check(frames[0]._L.vm_poisson_extend_frames(arr, n, tol, max_it, it, rr, C.byref(ms)))
+    return [((it[2 * i], rr[2 * i]), (it[2 * i + 1], rr[2 * i + 1])) for i in range(n)], ms.value
+
 
 def make_extended(rgb, ex):
     """Extended RGBA8 canvas of Pyramid::build, pyramid.cu:186-200: filled with
