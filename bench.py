@@ -105,6 +105,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-scale-ref", action="store_true",
                     help="N = 1, config 1: skip `scale_reference` (config[2]'s job -- the workload an N > 1 run shards -- on this one GPU)")
     ap.add_argument("--scale-ref-pairs", type=int, default=60, help="frame pairs of the scale_reference job")
+    ap.add_argument("--extras", default="", help="development: comma-separated names of the extras to run (default: all): semantics, "
+                                                 "math, batched, temporal, sync, render, poisson, qpath, pipeline8, pipeline30, config3")
+    ap.add_argument("--scale-ref-last", action="store_true", help="development: run scale_reference AFTER the other extras (the order "
+                                                                    "rounds 3-4 found 16 %% slower; tools/dev_scale_ref_bisect.sh)")
     ap.add_argument("--size", default=None, help="WxH override (development only)")
     ap.add_argument("--sweep-threads", type=int, default=0, help="threads per sweep workgroup, 0 = the library's choice (development only)")
     ap.add_argument("--sweep-parts", type=int, default=0, help="workgroups per tile of the STEP schedule, 0 = the library's choice (development only)")
@@ -299,10 +303,13 @@ def main():
     # 838 ms; not the clocks, not the hardware queues, not the churn of pyramids (tools/dev_alloc_history.py): unexplained)
     extras = {}
     scale_ref = None
-    if rank == 0 and world == 1 and config == 1 and not args.size and not (args.no_extras or args.no_scale_ref):
+    want_scale_ref = rank == 0 and world == 1 and config == 1 and not args.size and not (args.no_extras or args.no_scale_ref)
+    if want_scale_ref and not args.scale_ref_last:
         scale_ref = scale_reference(args, morph, blk, local_rank, frames, solve_group, sizes, nlev, FIXED)
     if rank == 0 and not (args.no_extras or args.no_extras_but_scale_ref) and config != 2:
-        extras = run_extras(args, np, capi, morph, synth, L, blk, ctx, pyrs[0], w, h, nlev, FIXED, B, solve, solve_group)
+        extras = run_extras(args, np, capi, morph, synth, L, blk, ctx, pyrs[0], w, h, nlev, FIXED, B, solve, solve_group, local_rank)
+    if want_scale_ref and args.scale_ref_last:
+        scale_ref = scale_reference(args, morph, blk, local_rank, frames, solve_group, sizes, nlev, FIXED)
     if scale_ref is not None:
         extras["scale_reference"] = scale_ref
 
@@ -312,7 +319,8 @@ def main():
 
     if rank == 0:
         out = report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, progs, step_ms, el_max, pix_total,
-                     cpu, distinct_frames, len(pyrs) if config == 2 else None, pix_live_total)
+                     cpu, distinct_frames, len(pyrs) if config == 2 else None, pix_live_total,
+                     frame_ids=ids[args.warmup * B:] if config != 2 else None)
         out.update(extras)
         if args.as_rank >= 0:
             out["as_rank"] = {"rank": args.as_rank, "of": args.of, "pairs": len(pyrs),
@@ -360,40 +368,75 @@ def default_streams(pairs_on_this_gpu):
     return 3 if pairs_on_this_gpu >= 24 else 2
 
 
+def clock_mhz(progs, R, which):
+    """shader clock held inside a sweep kernel: the in-kernel probe's sum of s_memtime differences / sum of
+    s_memrealtime differences x 100 MHz over every launch of the run (vm_progress.clk_*: [0] dense TILE kernel, [1] k_pass)"""
+    c = sum(pr[i].clk_shader_ticks[which] for pr in progs for i in R)
+    t = sum(pr[i].clk_wall_ticks[which] for pr in progs for i in R)
+    return round(c / t * 100.0, 1) if t > 0 else None
+
+
+def activity(progs, R, seconds, kern_ms):
+    """energy evaluations / line searches per second of wall time and the VALU fraction SURVEY 8(d) defines
+    (evaluations x 1185 flop-equivalents / HIP-event time of the sweep kernels / 157 TFLOP/s)"""
+    evals = sum(pr[i].evaluations for pr in progs for i in R)
+    ls = sum(pr[i].candidates for pr in progs for i in R)
+    return {"evals_per_s": round(evals / seconds), "line_searches_per_s": round(ls / seconds),
+            "valu_frac": round(evals * FLOP_PER_EVAL / (kern_ms * 1e-3) / VALU_PEAK_FLOPS, 5) if kern_ms > 0 else None}
+
+
 def scale_reference(args, morph, blk, local_rank, frames, solve_group, sizes, nlev, fixed):
     """The workload an N > 1 run of this script shards (config[2]: --scale-ref-pairs independent 1080p
     pairs, the streams of default_streams(), batches of <= --max-batch pairs per launch) on THIS one GPU: the same-workload
-    denominator of a scaling curve whose N = 1 point is config[1]."""
-    ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(default_streams(args.scale_ref_pairs))]
-    for c in ctxs:
-        c.set_params(blk.kp)
+    denominator of a scaling curve whose N = 1 point is config[1].  Never fatal: a failure (a smaller or shared GPU
+    running out of memory, say) is reported in place of the figures and the headline line is printed all the same."""
+    ctxs, pyrs = [], []
+    try:
+        ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(default_streams(args.scale_ref_pairs))]
+        for c in ctxs:
+            c.set_params(blk.kp)
 
-    def pyramid(c, imgs):
-        p = morph.Pyramid(c)
-        p.build(imgs[0], imgs[1], blk.start_res, nlevels=nlev)
-        return p
-    mine = list(range(args.scale_ref_pairs))
-    pyrs, B, nctx, distinct = config2_setup(mine, ctxs, frames, pyramid, args.max_batch)
-    config2_step(pyrs, ctxs[:nctx], B, solve_group)                    # warm-up (workspaces, graphs)
-    for c in ctxs:
-        c.sync()
-    t0 = time.perf_counter()
-    progs = config2_step(pyrs, ctxs[:nctx], B, solve_group)
-    for c in ctxs:
-        c.sync()
-    dt = time.perf_counter() - t0
-    R = range(nlev - 1)
-    nominal = sum(pr[i].pixel_iters for pr in progs for i in R)
-    live = sum(float(pr[i].iters_live) * sizes[i][0] * sizes[i][1] for pr in progs for i in R)
-    for p in pyrs:
-        p.clear()
-    for c in ctxs:
-        c.close()
-    return {"workload": "config[2] on this one GPU: %d independent 1080p pairs (%d distinct frames), %d stream(s) x batches of %d pairs per "
-                        "launch, one step" % (len(mine), distinct, nctx, B),
-            "value": round(live / dt / 1e6, 2), "value_nominal": round(nominal / dt / 1e6, 2), "unit": "Mpixel*iters/s",
-            "ms_per_step": round(dt * 1e3, 2), "executed_pixel_iters": round(live),
-            "note": "`python bench.py --gpus N` (N > 1) shards exactly this job over N ranks: divide its value by this one"}
+        def pyramid(c, imgs):
+            p = morph.Pyramid(c)
+            p.build(imgs[0], imgs[1], blk.start_res, nlevels=nlev)
+            return p
+        mine = list(range(args.scale_ref_pairs))
+        pyrs, B, nctx, distinct = config2_setup(mine, ctxs, frames, pyramid, args.max_batch)
+        config2_step(pyrs, ctxs[:nctx], B, solve_group)                    # warm-up (workspaces, graphs)
+        for c in ctxs:
+            c.sync()
+        t0 = time.perf_counter()
+        progs = config2_step(pyrs, ctxs[:nctx], B, solve_group)
+        for c in ctxs:
+            c.sync()
+        dt = time.perf_counter() - t0
+        R = range(nlev - 1)
+        nominal = sum(pr[i].pixel_iters for pr in progs for i in R)
+        live = sum(float(pr[i].iters_live) * sizes[i][0] * sizes[i][1] for pr in progs for i in R)
+        # sweep-kernel time summed over the streams: they overlap, so the VALU fraction is quoted against the WALL time
+        kern_ms = sum(pr[i].elapsed_ms for pr in progs for i in R)
+        out = {"workload": "config[2] on this one GPU: %d independent 1080p pairs (%d distinct frames), %d stream(s) x batches of %d pairs per "
+                           "launch, one step" % (len(mine), distinct, nctx, B),
+               "value": round(live / dt / 1e6, 2), "value_nominal": round(nominal / dt / 1e6, 2), "unit": "Mpixel*iters/s",
+               "ms_per_step": round(dt * 1e3, 2), "executed_pixel_iters": round(live),
+               "sclk_mhz_observed": {"dense_tile_kernel": clock_mhz(progs, R, 0), "k_pass": clock_mhz(progs, R, 1)},
+               "sweep_kernel_ms_summed_over_streams": round(kern_ms, 1),
+               "note": "`python bench.py --gpus N` (N > 1) shards exactly this job over N ranks: divide its value by this one"}
+        out.update(activity(progs, R, dt, dt * 1e3))          # valu_frac against wall time (streams overlap)
+        return out
+    except Exception as e:                                     # noqa: BLE001 -- reported, never fatal
+        return {"error": str(e)[-300:]}
+    finally:
+        for p in pyrs:
+            try:
+                p.clear()
+            except Exception:
+                pass
+        for c in ctxs:
+            try:
+                c.close()
+            except Exception:
+                pass
 
 
 def load_pmc(config, pairs_per_launch, path=None):
@@ -444,7 +487,7 @@ def pmc_bytes(pmc_k, pmc_n, prefix):
 
 
 def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, progs, step_ms, el_max, pix_total, cpu,
-           distinct_frames, pairs_this_rank, pix_live_total):
+           distinct_frames, pairs_this_rank, pix_live_total, frame_ids=None):
     R = range(nlev - 1)
     nsolve = max(len(progs), 1)
     kern_ms = sum(pr[i].elapsed_ms for pr in progs for i in R)
@@ -530,6 +573,13 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
         "executed_pixel_iters": round(pix_live_total),
         # max_iter sweeps credited for every level whether they ran or not (rounds 1-3 quoted this one)
         "value_nominal": round(pix_total / el_max / 1e6, 2),
+        # what the chip did per second of wall time (rank 0's share x ranks), whatever the units credited: energy evaluations
+        # (each 2 bilinear taps + 25 SSIM terms), line searches, and SURVEY 8(d)'s VALU fraction of the sweep kernels
+        "evals_per_s": round(evals * world / el_max), "line_searches_per_s": round(line_searches * world / el_max),
+        "valu_frac": round(evals * FLOP_PER_EVAL / (kern_ms * 1e-3) / VALU_PEAK_FLOPS, 5) if kern_ms > 0 else None,
+        # the shader clock actually held INSIDE the two chain-bound kernels (in-kernel probe: s_memtime / s_memrealtime of
+        # their first workgroup, every launch of the timed region); the VALU peak above assumes 2400 MHz
+        "sclk_mhz_observed": {"k_pass": clock_mhz(progs, R, 1), "dense_tile_kernel": clock_mhz(progs, R, 0), "assumed_by_valu_peak": 2400},
         "roofline": {"bound": "hbm",
                      # the dominant sweep kernel (largest share of sweep time): ALGORITHMIC bytes of one
                      # launch (100 B per pixel-visit x the visits one launch covers) / its
@@ -588,7 +638,18 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
                 ks = [k for k in range(len(step_ms)) if cyc[k] == sel]
                 if ks:
                     out[name] = {"count": len(ks), "ms_mean": round(sum(step_ms[k] for k in ks) / len(ks), 2),
-                                 "mpix_iters_per_s": round(sum(rates[k] for k in ks) / len(ks), 2)}
+                                 "mpix_iters_per_s": round(sum(rates[k] for k in ks) / len(ks), 2),
+                                 "executed_mpix_iters_mean": round(sum(rates[k] * step_ms[k] * 1e-3 for k in ks) / len(ks), 1)}
+            # which frames they are: `value` moves with the NUMBER of cycling frames (a cycling step executes ~5x the units
+            # in ~1.4x the time), so a round that changes that number cannot move the headline unnoticed; the two
+            # comparable figures are ms_converging_steps and ms_cycling_steps
+            if frame_ids is not None and len(frame_ids) == len(step_ms):
+                out["config"]["frame_ids"] = list(frame_ids)
+                out["config"]["cycling_frame_ids"] = [frame_ids[k] for k in range(len(step_ms)) if cyc[k]]
+            conv = [step_ms[k] for k in range(len(step_ms)) if not cyc[k]]
+            cycl = [step_ms[k] for k in range(len(step_ms)) if cyc[k]]
+            out["ms_converging_steps"] = round(statistics.median(conv), 2) if conv else None
+            out["ms_cycling_steps"] = round(statistics.median(cycl), 2) if cycl else None
         out["step_executed_mpix_iters"] = [round(sum(float(pr[i].iters_live) * sizes[i][0] * sizes[i][1] for pr in progs[k * per:(k + 1) * per]
                                                      for i in R) / 1e6, 2) for k in range(len(step_ms))]
     return out
@@ -603,33 +664,38 @@ def workload_name(config, w, h, nlev, blk, B, args, world, pairs_this_rank):
     return "config[%d]: %s, %s per step per GPU" % (config, base, "one pair" if B == 1 else "a batch of %d independent pairs" % B)
 
 
-def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, B, solve, solve_group):
+def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, B, solve, solve_group, local_rank=0):
     """context numbers beside the headline (rank 0, one GPU): the other stopping rule, the other
-    arithmetic, batched throughput, compositor stages"""
+    arithmetic, batched throughput, compositor stages, config[3] and config[4] in one step each.
+    --extras a,b,... (development) runs only the named ones."""
+    only = set(x for x in args.extras.split(",") if x)
+    want = lambda name: not only or name in only
     saved_kp = capi.KernParams()      # extras that bring their own Parameters put these back
     capi.check(L.vm_get_params(ctx._h, C.byref(saved_kp)))
     extras = {}
     R = range(nlev - 1)
     sz = [(p[el].width, p[el].height) for el in range(1, nlev)]
     executed = lambda prs: sum(float(q[i].iters_live) * sz[i][0] * sz[i][1] for q in prs for i in R)
-    ctx.sync(); t1 = time.perf_counter(); pr = solve(p, fixed=1 - FIXED); ctx.sync(); dt = time.perf_counter() - t1
-    extras["%s_semantics" % ("reference" if FIXED else "fixed")] = {
-        "mpix_iters_per_s": round(executed([pr]) / dt / 1e6, 2),
-        "ms_per_solve": round(dt * 1e3, 2),
-        "iters_per_level_fine_to_coarse": [pr[i].iters for i in R]}
-    other = capi.MATH_EXACT if blk.math_mode == capi.MATH_FAST else capi.MATH_FAST
-    ctx.set_math_mode(other)
-    ctx.sync(); t1 = time.perf_counter(); pr = solve(p); ctx.sync(); dt = time.perf_counter() - t1
-    extras["%s_math" % ("exact" if other == capi.MATH_EXACT else "fast")] = {
-        "mpix_iters_per_s": round(executed([pr]) / dt / 1e6, 2), "ms_per_solve": round(dt * 1e3, 2),
-        "iters_executed_per_level_fine_to_coarse": [pr[i].iters_live for i in R]}
-    ctx.set_math_mode(blk.math_mode)
+    if want("semantics"):
+        ctx.sync(); t1 = time.perf_counter(); pr = solve(p, fixed=1 - FIXED); ctx.sync(); dt = time.perf_counter() - t1
+        extras["%s_semantics" % ("reference" if FIXED else "fixed")] = {
+            "mpix_iters_per_s": round(executed([pr]) / dt / 1e6, 2),
+            "ms_per_solve": round(dt * 1e3, 2),
+            "iters_per_level_fine_to_coarse": [pr[i].iters for i in R]}
+    if want("math"):
+        other = capi.MATH_EXACT if blk.math_mode == capi.MATH_FAST else capi.MATH_FAST
+        ctx.set_math_mode(other)
+        ctx.sync(); t1 = time.perf_counter(); pr = solve(p); ctx.sync(); dt = time.perf_counter() - t1
+        extras["%s_math" % ("exact" if other == capi.MATH_EXACT else "fast")] = {
+            "mpix_iters_per_s": round(executed([pr]) / dt / 1e6, 2), "ms_per_solve": round(dt * 1e3, 2),
+            "iters_executed_per_level_fine_to_coarse": [pr[i].iters_live for i in R]}
+        ctx.set_math_mode(blk.math_mode)
     if w * h > 1920 * 1080:
         return extras
     # batched throughput: B independent pairs relaxed by the same launches (the per-GPU workload
     # of config[2]); 4 distinct frames reused cyclically
     base_frames = [synth.make_pair(w, h, frame=1000 + k) for k in range(4)]
-    if B == 1:
+    if B == 1 and want("batched"):
         bt = {}
         for nb in (8, 32):
             group = []
@@ -649,117 +715,126 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
     # the temporally coupled path: a 5-frame 1080p video pair with analytic
     # flows, every frame tied to its solved neighbour (middle page, then both chains, two pages
     # per launch); the device-side flow pyramid included, lumas uploaded per page
-    try:
-        d = 5
-        levels, ft = synth.video_levels(w, h, d, blk.start_res)
-        vid = morph.VideoPyramid(ctx)
-        vid.build_levels(levels, ft, d)
-        pages = synth.page_frames(levels, ft)
-        vf = [synth.make_video_pair(w, h, t) for t in range(d)]
-        vp = [synth.build_pyramid(a, b2, len(levels)) for a, b2 in vf]
-        for l in range(len(levels) - 1):
-            for t in range(levels[l][2]):
-                vid.upload_luma(l, t, *vp[pages[l][t]][l])
-        flows = synth.constant_flows(w, h, d)
-        vid.build_flows(*flows)                         # warm-up (scratch planes are allocated on first use)
-        ctx.sync(); t1 = time.perf_counter()
-        vid.build_flows(*flows)
-        ctx.sync(); t_flow = time.perf_counter() - t1
-        prm = morph.Parameters()
-        prm.max_iter, prm.max_iter_drop_factor, prm.start_res = int(blk.max_iter), blk.max_iter_drop_factor, blk.start_res
-        vm = morph.VideoMorph(prm, vid, fixed_work=bool(FIXED))
-        vm.calculate_halfway_parametrization()          # warm-up (workspaces)
-        ctx.sync(); t1 = time.perf_counter()
-        vm.calculate_halfway_parametrization()
-        ctx.sync(); dt = time.perf_counter() - t1
-        units = sum(l[0] * l[1] * pr["iters_live"] for (lv, t), pr in vm.progress.items() for l in [levels[lv]])
-        nominal = sum(l[0] * l[1] * pr["iters"] for (lv, t), pr in vm.progress.items() for l in [levels[lv]])
-        extras["temporal_video_%d_frames" % d] = {"mpix_iters_per_s": round(units / dt / 1e6, 1), "nominal_mpix_iters_per_s": round(nominal / dt / 1e6, 1),
-                                                  "ms_per_video": round(dt * 1e3, 1),
-                                                  "flow_pyramid_ms": round(t_flow * 1e3, 1),
-                                                  "depth_per_level": [l[2] for l in levels]}
-        # ... and on to the screen (CMatchingThread::update_result for a video, then the compositor):
-        # per frame of the video its full-resolution field straight into a device-resident frame
-        # (vm_frame_set_v_from_video), Poisson extension of both sides, 9 rendered in-between frames;
-        # canvases uploaded once per frame (PCIe included)
-        exv = int(0.1 * max(w, h))
-        rv0, rv1 = synth.make_rgb_pair(w, h)
-        ev0, ev1 = morph.make_extended(rv0, exv), morph.make_extended(rv1, exv)
-        frv = morph.Frame(ctx, w, h, exv)
-        frv.upload(ev0, ev1, None, None)
-        frv.set_v_from_video(vid, 0, 0)
-        frv.poisson_extend(1, tol=1e-5)            # workspaces
-        ctx.sync(); t1 = time.perf_counter()
-        for fidx in range(d):
+    if want("temporal"):
+        try:
+            d = 5
+            levels, ft = synth.video_levels(w, h, d, blk.start_res)
+            vid = morph.VideoPyramid(ctx)
+            vid.build_levels(levels, ft, d)
+            pages = synth.page_frames(levels, ft)
+            vf = [synth.make_video_pair(w, h, t) for t in range(d)]
+            vp = [synth.build_pyramid(a, b2, len(levels)) for a, b2 in vf]
+            for l in range(len(levels) - 1):
+                for t in range(levels[l][2]):
+                    vid.upload_luma(l, t, *vp[pages[l][t]][l])
+            flows = synth.constant_flows(w, h, d)
+            vid.build_flows(*flows)                         # warm-up (scratch planes are allocated on first use)
+            ctx.sync(); t1 = time.perf_counter()
+            vid.build_flows(*flows)
+            ctx.sync(); t_flow = time.perf_counter() - t1
+            prm = morph.Parameters()
+            prm.max_iter, prm.max_iter_drop_factor, prm.start_res = int(blk.max_iter), blk.max_iter_drop_factor, blk.start_res
+            vm = morph.VideoMorph(prm, vid, fixed_work=bool(FIXED))
+            vm.calculate_halfway_parametrization()          # warm-up (workspaces)
+            ctx.sync(); t1 = time.perf_counter()
+            vm.calculate_halfway_parametrization()
+            ctx.sync(); dt = time.perf_counter() - t1
+            units = sum(l[0] * l[1] * pr["iters_live"] for (lv, t), pr in vm.progress.items() for l in [levels[lv]])
+            nominal = sum(l[0] * l[1] * pr["iters"] for (lv, t), pr in vm.progress.items() for l in [levels[lv]])
+            extras["temporal_video_%d_frames" % d] = {"mpix_iters_per_s": round(units / dt / 1e6, 1), "nominal_mpix_iters_per_s": round(nominal / dt / 1e6, 1),
+                                                      "ms_per_video": round(dt * 1e3, 1),
+                                                      "flow_pyramid_ms": round(t_flow * 1e3, 1),
+                                                      "depth_per_level": [l[2] for l in levels]}
+            # ... and on to the screen (CMatchingThread::update_result for a video, then the compositor):
+            # per frame of the video its full-resolution field straight into a device-resident frame
+            # (vm_frame_set_v_from_video), Poisson extension of both sides (one batch), 9 rendered in-between
+            # frames; canvases uploaded once per frame (PCIe included)
+            exv = int(0.1 * max(w, h))
+            rv0, rv1 = synth.make_rgb_pair(w, h)
+            ev0, ev1 = morph.make_extended(rv0, exv), morph.make_extended(rv1, exv)
+            frv = morph.Frame(ctx, w, h, exv)
             frv.upload(ev0, ev1, None, None)
-            frv.set_v_from_video(vid, 0, fidx)
-            frv.poisson_extend(1, tol=1e-5)
-            frv.poisson_extend(2, tol=1e-5)
-            for k in range(1, 10):
-                frv.render_halfway_dev(0.1 * k, 0.1 * k, 1)
-        ctx.sync(); dtv = time.perf_counter() - t1
-        frv.close()
-        extras["video_pipeline_%d_frames" % d] = {"compositor_ms_per_video_frame": round(dtv * 1e3 / d, 1),
-                                                  "rendered_frames_per_s": round(d * 9 / dtv, 1),
-                                                  "solve_plus_compositor_ms_per_video": round((dt + dtv) * 1e3, 1)}
-        del vid
-    except capi.VmError as e:
-        extras["temporal_video_5_frames"] = {"error": str(e)[-160:]}
-    finally:
-        ctx.set_params(saved_kp)
+            frv.set_v_from_video(vid, 0, 0)
+            frv.poisson_extend_both(tol=1e-5)          # workspaces
+            ctx.sync(); t1 = time.perf_counter()
+            for fidx in range(d):
+                frv.upload(ev0, ev1, None, None)
+                frv.set_v_from_video(vid, 0, fidx)
+                frv.poisson_extend_both(tol=1e-5)
+                for k in range(1, 10):
+                    frv.render_halfway_dev(0.1 * k, 0.1 * k, 1)
+            ctx.sync(); dtv = time.perf_counter() - t1
+            frv.close()
+            extras["video_pipeline_%d_frames" % d] = {"compositor_ms_per_video_frame": round(dtv * 1e3 / d, 1),
+                                                      "rendered_frames_per_s": round(d * 9 / dtv, 1),
+                                                      "solve_plus_compositor_ms_per_video": round((dt + dtv) * 1e3, 1)}
+            del vid
+        except capi.VmError as e:
+            extras["temporal_video_5_frames"] = {"error": str(e)[-160:]}
+        finally:
+            ctx.set_params(saved_kp)
     # the synchronisation stage that precedes the morph in the reference's app (CSyncThread +
     # render_resample_image, SURVEY 8(f) "(later)"): a 1080p x 60-frame pair, 24 constraints across
     # frames, the reference's iteration schedule (max_iter * 10 at the coarsest level, halved per
     # level).  HBM-bound: 124 algorithmic bytes per voxel and CG iteration.
-    try:
-        extras["sync_stage_1080p_x60"] = sync_stage_extra(np, morph, ctx, w, h, 60, blk)
-    except capi.VmError as e:
-        extras["sync_stage_1080p_x60"] = {"error": str(e)[-160:]}
-    finally:
-        ctx.set_params(saved_kp)        # the sync stage runs with its own w_ui / w_tps
-    # compositor: frames/s of render_halfway with device-resident inputs
+    if want("sync"):
+        try:
+            extras["sync_stage_1080p_x60"] = sync_stage_extra(np, morph, ctx, w, h, 60, blk)
+        except capi.VmError as e:
+            extras["sync_stage_1080p_x60"] = {"error": str(e)[-160:]}
+        finally:
+            ctx.set_params(saved_kp)        # the sync stage runs with its own w_ui / w_tps
+    # compositor: frames/s of render_halfway with device-resident inputs (Metric 2, render only)
     ex = int(0.1 * max(w, h))
     rgb0, rgb1 = synth.make_rgb_pair(w, h)
     fr = morph.Frame(ctx, w, h, ex)
-    fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
+    e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
+    fr.upload(e0, e1, None, None)
     fr.set_v_from_level(p, 1)
-    fr.render_halfway_dev(0.5, 0.5, 1)
-    ms = [fr.render_halfway_dev(0.5, 0.1 * k, 1) for k in range(1, 10)]
-    extras["render_frames_per_s"] = round(1000.0 / (sum(ms) / len(ms)), 1)
-    # Poisson boundary extension of both sides of that frame (config[4]'s other stage)
-    pe = {}
-    fr.poisson_extend(1, tol=1e-3)      # the workspace is allocated on first use: not timed
-    for tol in (1e-4, 1e-5):
-        fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), None, None)
-        r1, r2 = fr.poisson_extend(1, tol=tol), fr.poisson_extend(2, tol=tol)
-        pe["tol_%g" % tol] = {"ms_per_frame": round(r1[2] + r2[2], 1), "cg_iterations": [r1[0], r2[0]]}
-    extras["poisson_extend_1080p_ex%d" % ex] = pe
+    render_ms = None
+    if want("render") or want("pipeline30"):
+        fr.render_halfway_dev(0.5, 0.5, 1)
+        ms = [fr.render_halfway_dev(0.5, 0.1 * k, 1) for k in range(1, 10)]
+        render_ms = sum(ms) / len(ms)
+        extras["render_frames_per_s"] = round(1000.0 / render_ms, 1)
+    # Poisson boundary extension of both sides of that frame (config[4]'s other stage): the two sides as one batch
+    # (vm_poisson_extend_frames), and -- for the record of what batching buys -- one side at a time
+    if want("poisson"):
+        pe = {}
+        fr.poisson_extend_both(tol=1e-3)      # the workspaces are allocated on first use: not timed
+        for tol in (1e-4, 1e-5):
+            fr.upload(e0, e1, None, None)
+            (i1, _), (i2, _), ms_both = fr.poisson_extend_both(tol=tol)
+            pe["tol_%g" % tol] = {"ms_per_frame": round(ms_both, 2), "cg_iterations": [i1, i2]}
+        fr.upload(e0, e1, None, None)
+        r1, r2 = fr.poisson_extend(1, tol=1e-5), fr.poisson_extend(2, tol=1e-5)
+        pe["tol_1e-05_one_side_at_a_time"] = {"ms_per_frame": round(r1[2] + r2[2], 2), "cg_iterations": [r1[0], r2[0]]}
+        extras["poisson_extend_1080p_ex%d" % ex] = pe
     # quadratic motion path of that frame (QuadraticPath.cpp), SURVEY 8(f) rank 4
-    fr.set_v_from_level(p, 1)
-    try:
-        qp = fr.quadratic_path(tol=1e-4)
-        extras["quadratic_path_1080p"] = {"ms_per_frame": round(qp[2], 1), "pcg_iterations": qp[0], "tol": 1e-4,
-                                          "residual": float("%.3g" % qp[1])}
-    except capi.VmError as e:        # e.g. a folded v: the blend of the Jacobians is 0/0 there
-        extras["quadratic_path_1080p"] = {"error": str(e)[-120:]}
+    if want("qpath"):
+        fr.set_v_from_level(p, 1)
+        try:
+            qp = fr.quadratic_path(tol=1e-4)
+            extras["quadratic_path_1080p"] = {"ms_per_frame": round(qp[2], 1), "pcg_iterations": qp[0], "tol": 1e-4,
+                                              "residual": float("%.3g" % qp[1])}
+        except capi.VmError as e:        # e.g. a folded v: the blend of the Jacobians is 0/0 there
+            extras["quadratic_path_1080p"] = {"error": str(e)[-120:]}
     # config[4]'s whole pipeline on one GPU: 8 frame pairs solved as a batch (reference
     # semantics), then per frame v upscale -> Poisson extension of both sides -> 9 rendered
     # in-between frames; canvases uploaded once per frame (PCIe included)
-    if B == 1:
+    if B == 1 and want("pipeline8"):
         group = []
         for k in range(8):
             q = morph.Pyramid(ctx)
             q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
             group.append(q)
-        e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
         ctx.sync(); t1 = time.perf_counter()
         morph.solve_batch(group, blk.max_iter, blk.max_iter_drop_factor, fixed_work=False)
         t_solve = time.perf_counter() - t1
         for q in group:
             fr.upload(e0, e1, None, None)
             fr.set_v_from_level(q, 1)
-            fr.poisson_extend(1, tol=1e-5)
-            fr.poisson_extend(2, tol=1e-5)
+            fr.poisson_extend_both(tol=1e-5)
             for k in range(1, 10):
                 fr.render_halfway_dev(0.1 * k, 0.1 * k, 1)
         ctx.sync(); dt = time.perf_counter() - t1
@@ -767,7 +842,105 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
                                               "rendered_frames_per_s": round(8 * 9 / dt, 1)}
         del group
     fr.close()
+    # config[4] as BASELINE.json states it, on this one GPU: THIRTY 1080p frame pairs with 8 point constraints each and
+    # BCOND_BORDER, solved in batches (reference semantics); then the compositor over all thirty frames: canvases
+    # uploaded once per frame (PCIe included), v upscaled on the device, Poisson extension of both sides of FOUR frames
+    # per batch (8 systems per launch), 9 rendered in-between frames per pair
+    if B == 1 and want("pipeline30"):
+        try:
+            extras["pipeline_config4_30_frames"] = pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, base_frames, e0, e1, ex, render_ms)
+        except capi.VmError as e:
+            extras["pipeline_config4_30_frames"] = {"error": str(e)[-200:]}
+        finally:
+            ctx.set_params(saved_kp)
+    # config[3] (3840x2160, 7 levels) in one step, for the driver's record (`--config 3` runs it as the headline)
+    if B == 1 and want("config3"):
+        try:
+            w3, h3 = CONFIG_SIZE[3]
+            nl3 = synth.num_levels(w3, h3, blk.start_res)
+            i0, i1 = synth.make_pair(w3, h3, frame=0)
+            q = morph.Pyramid(ctx)
+            q.build(i0, i1, blk.start_res, nlevels=nl3)
+            sz3 = [(q[el].width, q[el].height) for el in range(1, nl3)]
+            best = None
+            for rep in range(2):                         # the first solve allocates the schedule workspaces
+                prog = (capi.Progress * (nl3 - 1))()
+                ctx.sync(); t1 = time.perf_counter()
+                capi.check(L.vm_solve(q._h, blk.max_iter, blk.max_iter_drop_factor, None, 0, None, FIXED, prog))
+                ctx.sync(); best = time.perf_counter() - t1
+            live3 = sum(float(prog[i].iters_live) * sz3[i][0] * sz3[i][1] for i in range(nl3 - 1))
+            extras["config3_4k"] = {"workload": "config[3]: one %dx%d pair, %d-level pyramid, max_iter %d/level, frame 0, one step" % (w3, h3, nl3, int(blk.max_iter)),
+                                    "ms_per_step": round(best * 1e3, 2), "executed_pixel_iters": round(live3),
+                                    "value": round(live3 / best / 1e6, 2), "unit": "Mpixel*iters/s",
+                                    "value_nominal": round(sum(prog[i].pixel_iters for i in range(nl3 - 1)) / best / 1e6, 2),
+                                    "iters_executed_per_level_fine_to_coarse": [prog[i].iters_live for i in range(nl3 - 1)],
+                                    "evals_per_s": round(sum(prog[i].evaluations for i in range(nl3 - 1)) / best)}
+            q.clear()
+            del q
+        except capi.VmError as e:
+            extras["config3_4k"] = {"error": str(e)[-200:]}
     return extras
+
+
+def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, base_frames, e0, e1, ex, render_ms, nframes=30, per_batch=4):
+    """config[4] on one GPU (see run_extras): returns the extras entry"""
+    cons = synth.make_constraints(w, h, 8)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res, prm.bcond = int(blk.max_iter), blk.max_iter_drop_factor, blk.start_res, capi.BCOND_BORDER
+    for c in cons:
+        prm.add_point_pair(*c[:4], weight=float(c[4]))
+    ctx.set_params(morph.KernParameters(prm))
+    ca, nc = morph._cons_array(cons)
+    group = []
+    for k in range(nframes):
+        q = morph.Pyramid(ctx)
+        q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
+        group.append(q)
+    frs = [morph.Frame(ctx, w, h, ex) for _ in range(per_batch)]
+    for f in frs:                                           # workspaces
+        f.upload(e0, e1, None, None)
+        f.set_v_from_level(group[0], 1)
+    morph.poisson_extend_frames(frs, tol=1e-3)
+    ctx.sync(); t1 = time.perf_counter()
+    for g0 in range(0, nframes, 15):
+        morph.solve_batch(group[g0:g0 + 15], blk.max_iter, blk.max_iter_drop_factor, fixed_work=False, constraints=cons)
+    ctx.sync(); t_solve = time.perf_counter() - t1
+    t_up = t_po = t_re = 0.0
+    its = []
+    for g0 in range(0, nframes, per_batch):
+        qs = group[g0:g0 + per_batch]
+        t2 = time.perf_counter()
+        for f, q in zip(frs, qs):
+            f.upload(e0, e1, None, None)
+            f.set_v_from_level(q, 1)
+        ctx.sync(); t3 = time.perf_counter()
+        res, _ = morph.poisson_extend_frames(frs[:len(qs)], tol=1e-5)
+        ctx.sync(); t4 = time.perf_counter()
+        for f in frs[:len(qs)]:
+            for k in range(1, 10):
+                f.render_halfway_dev(0.1 * k, 0.1 * k, 1)
+        ctx.sync(); t5 = time.perf_counter()
+        t_up += t3 - t2; t_po += t4 - t3; t_re += t5 - t4
+        its += [s[0] for r in res for s in r]
+    dt = time.perf_counter() - t1
+    for f in frs:
+        f.close()
+    for q in group:
+        q.clear()
+    comp = (t_up + t_po + t_re) / nframes * 1e3
+    return {"workload": "config[4] on one GPU: %d 1080p pairs, 8 point constraints each, BCOND_BORDER, solved in 2 batches of 15 (reference "
+                        "semantics); per frame: canvases uploaded (PCIe), v upscaled on the device, Poisson extension (ex = %d, tol 1e-5) of "
+                        "both sides, %d frames = %d systems per batch; 9 rendered in-between frames per pair" % (nframes, ex, per_batch, 2 * per_batch),
+            "ms_per_pair": round(dt * 1e3 / nframes, 1), "solve_ms_per_pair": round(t_solve * 1e3 / nframes, 1),
+            "compositor_ms_per_frame": round(comp, 2),
+            "compositor_split_ms_per_frame": {"upload_pcie_and_v_upscale": round(t_up / nframes * 1e3, 2), "poisson_both_sides": round(t_po / nframes * 1e3, 2),
+                                              "render_9_frames": round(t_re / nframes * 1e3, 2)},
+            "pcg_iterations_min_max": [min(its), max(its)],
+            # Metric 2 (SURVEY 8(d)): frames/s of render_halfway, device-resident inputs -- render only, and with the
+            # Poisson extension (and the canvas upload) of the pair amortised over its 9 rendered frames
+            "render_frames_per_s": {"render_only": round(1000.0 / render_ms, 1) if render_ms else None,
+                                    "with_poisson_amortised": round(nframes * 9 / (t_up + t_po + t_re), 1),
+                                    "whole_pipeline_incl_solve": round(nframes * 9 / dt, 1)}}
 
 
 def sync_stage_extra(np, morph, ctx, w, h, d, blk):

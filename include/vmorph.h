@@ -119,6 +119,12 @@ typedef struct {
      * iters - iters_live sweeps past convergence are provable no-ops (every mask bit is clear)
      * and are skipped on the device. */
     int    iters_live;
+    /* in-kernel clock probe: the first workgroup of every launch of the dense TILE kernel ([0]) and of the PASS
+     * kernel ([1]) brackets its sweep with s_memtime (shader cycles) and s_memrealtime (constant 100 MHz); the
+     * sums over the call's launches.  clk_shader_ticks / clk_wall_ticks x 100 MHz = the shader clock the chip
+     * actually held inside that kernel (0 / 0: the schedule did not run). */
+    double clk_shader_ticks[2];
+    double clk_wall_ticks[2];
 } vm_progress;
 
 /* device-state arrays a test or a UI may read back (vm_level_get_field) */
@@ -253,6 +259,11 @@ int  vm_optimize_level_batch(vm_pyr **pyrs, int n, int lvl, float max_iter,
                              volatile const int *run_flag, int fixed_work, vm_progress *out);
 int  vm_solve_batch(vm_pyr **pyrs, int n, float max_iter, float max_iter_drop_factor,
                     volatile const int *run_flag, int fixed_work, vm_progress *per_level);
+/* the same with every pair's own user constraints (Parameters::lp/rp/cnt of its frame, resolved as for
+ * vm_solve: Algorithm/morph.cu:345-388, 471-505): cons[i] / ncons[i], cons == NULL = none anywhere */
+int  vm_solve_batch_cons(vm_pyr **pyrs, int n, float max_iter, float max_iter_drop_factor,
+                         const vm_constraint *const *cons, const int *ncons,
+                         volatile const int *run_flag, int fixed_work, vm_progress *per_level);
 /* CMatchingThread::update_result + Resize, Algorithm/MatchingThread.cpp:22-100:
  * v of level `lvl` scaled by (W0/W, H0/H) and bilinearly resized to w0 x h0 */
 int  vm_upscale_result(vm_pyr *pyr, int lvl, int w0, int h0, float *v_xy_out, int pitch);
@@ -458,6 +469,18 @@ typedef struct {
 /* in-place RCCL broadcast of `bytes` at device pointer `dev_buf` from rank
  * `root` on communicator `nccl_comm` (an ncclComm_t), on the context's stream */
 int  vm_rccl_bcast(vm_ctx *ctx, void *nccl_comm, void *dev_buf, uint64_t bytes, int root);
+/* One PROCESS driving n devices (SURVEY 7 step 9, 8(b) `vm_bcast_params`; the reference is single-GPU,
+ * UI/MdiEditor.cpp:54-75 picks one device): ncclCommInitAll over `devices` (n distinct ordinals) -> comms_out[n];
+ * vm_rccl_comm_destroy frees one. */
+int  vm_rccl_comm_init_all(int n, const int *devices, void **comms_out);
+void vm_rccl_comm_destroy(void *nccl_comm);
+/* The shared parameter block from ctxs[root] to all n contexts over RCCL (one ncclBroadcast per communicator
+ * inside one ncclGroup, each on its context's stream); every context then sets its kernel parameters and
+ * arithmetic mode from the copy IT received.  blocks_out: n entries (may be NULL), the block as received.
+ * comms == NULL is a TEST MODE for contexts sharing one device (RCCL wants one rank per device): the copies go
+ * device-to-device on that device instead. */
+int  vm_bcast_params(vm_ctx *const *ctxs, void *const *nccl_comms, int n, int root,
+                     const vm_param_block *blk, vm_param_block *blocks_out);
 
 #ifdef __cplusplus
 }

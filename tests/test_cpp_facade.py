@@ -174,3 +174,85 @@ def test_sync_facade_matches_python_mirror(solve_sync, gpu_ctx, tmp_path):
         for side in range(2):
             assert np.array_equal(frames[t, side], pyr.render_resample(float(side), t)), (t, side)
     assert np.abs(X).max() > 0.01 and np.abs(Z).max() > 0.001
+
+
+@pytest.fixture(scope="module")
+def solve_shard(tmp_path_factory, vmlib):
+    exe = str(tmp_path_factory.mktemp("cppm") / "solve_shard")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "solve_shard.cpp"), "-o", exe,
+                           "-L", libdir, "-lvmorph_hip", "-Wl,-rpath," + libdir, "-lpthread"])
+    return exe
+
+
+def test_cpp_shard_plan_equals_the_python_partition(solve_shard):
+    """the C++ multi-device driver partitions the pairs like videomorphing_amd.dist.shard_pairs (what bench.py's
+    N-process form uses): pair k -> rank floor(k G / N)"""
+    from videomorphing_amd import dist as vdist
+    for G, N in [(8, 60), (4, 30), (2, 5), (3, 2), (8, 8), (1, 7)]:
+        out = subprocess.check_output([solve_shard, "--plan", str(G), str(N)]).decode().splitlines()
+        got = [[int(x) for x in ln.split(":")[1].split()] for ln in out]
+        assert got == [vdist.shard_pairs(N, G, r) for r in range(G)], (G, N)
+
+
+@pytest.mark.gpu
+def test_cpp_multi_device_driver_matches_python(solve_shard, gpu_ctx, tmp_path):
+    """examples/solve_shard.cpp -- one C++ process, G host threads x G contexts, the parameter block handed from
+    rank 0 to every context (vm_bcast_params; here its one-device test mode: this box has one GPU and RCCL wants one
+    rank per device), static block partition, vm_solve_batch per context, results gathered on the host -- with
+    G = 2 contexts on device 0 and 5 pairs: every field bit-identical to the Python path (one vm_solve per pair),
+    and the non-default parameters really travelled (max_iter 18, start_res 16)."""
+    from videomorphing_amd import morph
+    w, h, N = 150, 100, 5
+    frames = [synth.make_pair(w, h, frame=k, amp=0.4 + 0.2 * k) for k in range(N)]
+    np.concatenate([np.stack([a, b]).ravel() for a, b in frames]).astype(np.float32).tofile(str(tmp_path / "fr.f32"))
+    out = tmp_path / "v.f32"
+    r = subprocess.run([solve_shard, "2", str(w), str(h), str(N), str(tmp_path / "fr.f32"), str(out), "18", "16", "exact", "--one-device"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "rank 0 on device 0: 3 pairs" in r.stdout and "rank 1 on device 0: 2 pairs" in r.stdout
+    assert r.stdout.count("max_iter 18 start_res 16 math 0") == 2, r.stdout
+    v_cpp = np.fromfile(str(out), np.float32).reshape(N, h, w, 2)
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 18, 1.0, 16
+    for k, (i0, i1) in enumerate(frames):
+        pyr = morph.Pyramid(gpu_ctx)
+        pyr.build(i0, i1, 16)
+        t = morph.MatchingThread(prm, pyr)
+        t.start()
+        t.wait()
+        assert np.array_equal(v_cpp[k].view(np.uint32), pyr._vector[0].view(np.uint32)), k
+    assert np.abs(v_cpp).max() > 0.1
+
+
+@pytest.mark.gpu
+def test_bcast_params_over_rccl_on_one_device(gpu_ctx):
+    """vm_rccl_comm_init_all + vm_bcast_params with a real communicator (one rank: this box's one GPU): the block goes
+    through ncclBroadcast inside an ncclGroup and the context adopts it; two contexts on one device are refused by
+    vm_rccl_comm_init_all with the pointer to the test mode"""
+    import ctypes as C
+    from videomorphing_amd import morph
+    L = capi.load()
+    ctx = morph.Context(0, capi.MATH_EXACT)
+    comm = (C.c_void_p * 1)()
+    dev = (C.c_int * 1)(0)
+    capi.check(L.vm_rccl_comm_init_all(1, dev, comm))
+    blk = capi.ParamBlock()
+    prm = morph.Parameters()
+    prm.w_tps, prm.eps = 0.07, 0.02
+    blk.kp = morph.KernParameters(prm)
+    blk.max_iter, blk.max_iter_drop_factor, blk.start_res, blk.math_mode = 77.0, 2.0, 24, capi.MATH_FAST
+    got = (capi.ParamBlock * 1)()
+    hs = (C.c_void_p * 1)(ctx._h)
+    capi.check(L.vm_bcast_params(hs, comm, 1, 0, C.byref(blk), got))
+    L.vm_rccl_comm_destroy(comm[0])
+    assert bytes(got[0]) == bytes(blk)
+    kp = capi.KernParams()
+    capi.check(L.vm_get_params(ctx._h, C.byref(kp)))
+    assert abs(kp.w_tps - 0.07) < 1e-7 and abs(kp.eps - 0.02) < 1e-7
+    two = (C.c_int * 2)(0, 0)
+    comms2 = (C.c_void_p * 2)()
+    assert L.vm_rccl_comm_init_all(2, two, comms2) != capi.VM_OK and "listed twice" in L.vm_last_error().decode()
+    ctx.close()

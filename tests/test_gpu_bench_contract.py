@@ -68,6 +68,15 @@ def test_bench_json_line():
     # ... and the EXACT arithmetic on that sample is the oracle's result bit for bit
     assert cb["parity_same_sample"]["bit_identical"] is True and cb["parity_same_sample"]["max_abs_dv"] == 0.0
     assert d["value"] > 50 * cb["value"] / cb["cores"]      # sanity: the GPU path is not the CPU path
+    # round 5: what the chip did per second whatever units are credited, the clock it held inside the chain-bound
+    # kernels (in-kernel probe), and the two kinds of step apart with the frames they are
+    assert d["evals_per_s"] > d["line_searches_per_s"] > 1e6 and 0 < d["valu_frac"] < 1 and d["valu_frac"] == rf["valu_frac"]
+    sclk = d["sclk_mhz_observed"]
+    assert 500 < sclk["k_pass"] <= 2600 and 500 < sclk["dense_tile_kernel"] <= 2600 and sclk["assumed_by_valu_peak"] == 2400
+    assert d["config"]["frame_ids"] == [1, 2] and set(d["config"]["cycling_frame_ids"]) <= {1, 2}
+    assert "ms_converging_steps" in d and "ms_cycling_steps" in d
+    n_cyc = len(d["config"]["cycling_frame_ids"])
+    assert (d["ms_cycling_steps"] is None) == (n_cyc == 0) and (d["ms_converging_steps"] is None) == (n_cyc == 2)
 
 
 def test_bench_scale_reference_in_the_n1_line():
@@ -81,6 +90,34 @@ def test_bench_scale_reference_in_the_n1_line():
     assert 0 < sr["value"] <= sr["value_nominal"] and sr["unit"] == d["unit"]
     assert abs(sr["value"] * 1e6 * sr["ms_per_step"] * 1e-3 / sr["executed_pixel_iters"] - 1.0) < 0.01
     assert abs(sr["value_nominal"] * 1e6 * sr["ms_per_step"] * 1e-3 / (6 * 500 * sum(w * h for w, h in SIZES)) - 1.0) < 0.01
+    # the dense regime's figures belong in the driver's record too (round 5)
+    assert sr["evals_per_s"] > sr["line_searches_per_s"] > 1e6 and 0 < sr["valu_frac"] < 1
+    assert 500 < sr["sclk_mhz_observed"]["dense_tile_kernel"] <= 2600
+
+
+def test_bench_extras_of_round_5():
+    """the driver's default line carries config[3] in one step, config[4] as stated (30 frames: solve with constraints,
+    batched Poisson extension, render) with Metric 2 both ways, and the Poisson extension's own figures; here with the
+    development switch that runs only those extras"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--no-scale-ref", "--extras", "render,poisson,pipeline30,config3"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+    c3 = d["config3_4k"]
+    assert "3840x2160" in c3["workload"] and len(c3["iters_executed_per_level_fine_to_coarse"]) == 6 and c3["ms_per_step"] > 0
+    assert abs(c3["value"] * 1e6 * c3["ms_per_step"] * 1e-3 / c3["executed_pixel_iters"] - 1.0) < 0.01
+    p30 = d["pipeline_config4_30_frames"]
+    assert "30 1080p pairs" in p30["workload"] and "BCOND_BORDER" in p30["workload"]
+    split = p30["compositor_split_ms_per_frame"]
+    assert abs(sum(split.values()) - p30["compositor_ms_per_frame"]) < 0.05
+    assert abs(p30["solve_ms_per_pair"] + p30["compositor_ms_per_frame"] - p30["ms_per_pair"]) < 0.15 * p30["ms_per_pair"]
+    lo, hi = p30["pcg_iterations_min_max"]
+    assert 8 <= lo <= hi <= 40                                     # tol 1e-5: 20 iterations on the synthetic frames
+    m2 = p30["render_frames_per_s"]
+    assert m2["render_only"] > m2["with_poisson_amortised"] > m2["whole_pipeline_incl_solve"] > 0
+    pe = d["poisson_extend_1080p_ex192"]
+    assert pe["tol_1e-05"]["cg_iterations"] == pe["tol_1e-05_one_side_at_a_time"]["cg_iterations"]
+    assert pe["tol_1e-05"]["ms_per_frame"] < pe["tol_1e-05_one_side_at_a_time"]["ms_per_frame"]
 
 
 def test_bench_gpus_2_self_launches_two_ranks():

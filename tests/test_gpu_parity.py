@@ -795,3 +795,53 @@ def test_tex8_full_solve_equals_the_oracle_with_the_same_filter(gpu_ctx, oracle,
     finally:
         oracle.lib().vmo_set_tex_filter(0)
         gpu_ctx.set_math_mode(capi.MATH_EXACT)
+
+
+def test_batched_solve_with_per_pair_constraints_equals_individual_solves(gpu_ctx):
+    """vm_solve_batch_cons: config[4]'s solve -- every pair of the batch with its OWN user point constraints
+    (morph.cu:345-388 splat, :471-505 coarse-level terms) and BCOND_BORDER -- ends bit-identical to the pairs
+    solved one at a time by vm_solve with the same constraints"""
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    w, h = 150, 100
+    frames = [synth.make_pair(w, h, frame=k, amp=0.3 + 0.3 * k) for k in range(3)]
+    cons = [synth.make_constraints(w, h, 4 + 2 * k, amp=0.3 + 0.3 * k) for k in range(3)]
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res, prm.bcond = 20, 1.0, 32, capi.BCOND_BORDER
+    gpu_ctx.set_params(morph.KernParameters(prm))
+    try:
+        single = []
+        for (i0, i1), c in zip(frames, cons):
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build(i0, i1, 32)
+            ca, n = morph._cons_array(c)
+            nl = pyr.size() - 2
+            prog = (capi.Progress * nl)()
+            capi.check(pyr._L.vm_solve(pyr._h, 20.0, 1.0, ca, n, None, 0, prog))
+            single.append((pyr[1].v, [prog[k].iters for k in range(nl)]))
+        batch = []
+        for i0, i1 in frames:
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build(i0, i1, 32)
+            batch.append(pyr)
+        prog = morph.solve_batch(batch, 20, 1.0, constraints=cons)
+        for k in range(3):
+            assert [p["iters"] for p in prog[k]] == single[k][1]
+            assert np.array_equal(single[k][0].view(np.uint32), batch[k][1].v.view(np.uint32)), k
+        # the constraints did something: the same pairs without them end elsewhere
+        free = []
+        for i0, i1 in frames:
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build(i0, i1, 32)
+            free.append(pyr)
+        morph.solve_batch(free, 20, 1.0)
+        assert not np.array_equal(free[2][1].v, batch[2][1].v)
+        # one shared constraint set for all pairs
+        shared = []
+        for i0, i1 in frames:
+            pyr = morph.Pyramid(gpu_ctx)
+            pyr.build(i0, i1, 32)
+            shared.append(pyr)
+        morph.solve_batch(shared, 20, 1.0, constraints=cons[0])
+        assert np.array_equal(shared[0][1].v.view(np.uint32), single[0][0].view(np.uint32))
+    finally:
+        gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))

@@ -9,14 +9,21 @@ import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
 
+import hashlib
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIBDIR = os.path.join(HERE, "lib")
+# A variant build (VM_DEFS = extra compiler flags, development: tools/gpu_variant.sh) gets object and library
+# directories of its own, named after the flags: its objects can never be linked into the product library by a
+# later incremental build, and nothing has to be restored afterwards.  Load it with VM_LIB_PATH=<printed path>.
+_VARIANT = os.environ.get("VM_DEFS", "").strip()
+_TAG = ("_" + hashlib.sha1(_VARIANT.encode()).hexdigest()[:10]) if _VARIANT else ""
+OBJ = os.path.join(HERE, "build" + _TAG)
+LIBDIR = os.path.join(HERE, "lib" + _TAG)
 LIB = os.path.join(LIBDIR, "libvmorph_hip.so")
 ARCH = "gfx950"
 
-COMMON = os.environ.get("VM_DEFS", "").split() + ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+COMMON = _VARIANT.split() + ["-O3", "-fPIC", "-std=c++17", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
           "-I" + os.path.join(HERE, "..", "include")]
 
 # (source, object, extra flags)

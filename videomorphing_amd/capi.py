@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvmorph_hip.so")
+# (VM_LIB_PATH: a variant build of the same library, development only -- tools/gpu_variant.sh)
+LIB_PATH = os.environ.get("VM_LIB_PATH") or os.path.join(_HERE, "lib", "libvmorph_hip.so")
 
 VM_OK = 0
 VM_E_INVALID, VM_E_DEVICE, VM_E_STATE, VM_E_NUMERIC, VM_E_CANCELLED = -1, -2, -3, -4, -5
@@ -31,10 +32,10 @@ SYMBOLS = [
     "vm_pyramid_create", "vm_pyramid_destroy", "vm_pyramid_levels", "vm_level_dims",
     "vm_level_upload_luma", "vm_pyramid_build_rgb", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
-    "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
+    "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_solve_batch_cons", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
     "vm_frame_download_ext", "vm_frame_set_v_from_level", "vm_render_halfway",
     "vm_render_halfway_dev", "vm_poisson_extend", "vm_poisson_extend_frames", "vm_frame_quadratic_path", "vm_frame_download_qpath", "vm_frame_download_v",
-    "vm_rccl_bcast",
+    "vm_rccl_bcast", "vm_rccl_comm_init_all", "vm_rccl_comm_destroy", "vm_bcast_params",
     "vm_video_create", "vm_video_destroy", "vm_video_levels", "vm_video_level_dims", "vm_video_upload_luma",
     "vm_video_upload_flows", "vm_video_build_rgb", "vm_video_build_flows", "vm_video_set_v", "vm_video_get_v",
     "vm_video_get_field", "vm_video_coarse_solve", "vm_video_upsample", "vm_video_init_level",
@@ -67,7 +68,7 @@ class Progress(C.Structure):
                 ("elapsed_ms", C.c_float), ("launches", C.c_int),
                 ("active_tiles", C.c_double), ("candidates", C.c_double), ("commits", C.c_double),
                 ("evaluations", C.c_double), ("sched_ms", C.c_float * 5), ("sched_launches", C.c_int * 5),
-                ("iters_live", C.c_int)]
+                ("iters_live", C.c_int), ("clk_shader_ticks", C.c_double * 2), ("clk_wall_ticks", C.c_double * 2)]
 
 
 class SyncConstraint(C.Structure):
@@ -136,6 +137,7 @@ def load():
         "vm_solve": [vp, f, f, vp, i, vp, i, vp],
         "vm_optimize_level_batch": [vp, i, i, f, vp, i, vp],
         "vm_solve_batch": [vp, i, f, f, vp, i, vp],
+        "vm_solve_batch_cons": [vp, i, f, f, vp, vp, vp, i, vp],
         "vm_upscale_result": [vp, i, i, i, vp, i],
         "vm_frame_create": [vp, i, i, i, C.POINTER(vp)],
         "vm_frame_upload": [vp, vp, vp, vp, vp],
@@ -149,6 +151,8 @@ def load():
         "vm_frame_download_qpath": [vp, vp],
         "vm_frame_download_v": [vp, vp],
         "vm_rccl_bcast": [vp, vp, vp, C.c_uint64, i],
+        "vm_rccl_comm_init_all": [i, C.POINTER(i), C.POINTER(vp)],
+        "vm_bcast_params": [C.POINTER(vp), C.POINTER(vp), i, i, C.POINTER(ParamBlock), C.POINTER(ParamBlock)],
         "vm_video_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i), i, C.POINTER(vp)],
         "vm_video_levels": [vp],
         "vm_video_level_dims": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(f)],
@@ -186,7 +190,7 @@ def load():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = i
-    for name in ("vm_ctx_destroy", "vm_pyramid_destroy", "vm_frame_destroy", "vm_video_destroy", "vm_sync_destroy"):
+    for name in ("vm_ctx_destroy", "vm_pyramid_destroy", "vm_frame_destroy", "vm_video_destroy", "vm_sync_destroy", "vm_rccl_comm_destroy"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = None
     _lib = L

@@ -50,6 +50,7 @@ static int vm_sparse_tiles()
 #include <cerrno>
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 static thread_local std::string g_err;
@@ -281,7 +282,12 @@ extern "C" int vm_dbg_pass_force_timeout(vm_ctx *c, int on)
 {
     if (!c) return vm_fail(VM_E_INVALID, "vm_dbg_pass_force_timeout: ctx is NULL");
     c->pass_test_timeout = on ? 1 : 0;
-    if (!on) c->pass_latched_off = false;
+    // switching the hook off re-admits the context to PASS only if the HOOK latched it off: a latch set by a
+    // genuine barrier timeout (masked or shared compute units) stays
+    if (!on && c->pass_latched_by_test) {
+        c->pass_latched_off = false;
+        c->pass_latched_by_test = false;
+    }
     return VM_OK;
 }
 
@@ -735,16 +741,18 @@ struct SmallDensePresence {
     int dev = -1, wgs = 0;
     void enter(int device, int n_wgs)
     {
-        if (device < 0 || device >= VM_MAX_DEVICES_TRACKED) return;
+        if (dev >= 0 || device < 0 || device >= VM_MAX_DEVICES_TRACKED) return;
         dev = device;
         wgs = n_wgs;
         g_small_dense_wgs[dev].fetch_add(wgs);
     }
-    int in_flight() const { return dev < 0 ? wgs : g_small_dense_wgs[dev].load(); }
-    ~SmallDensePresence()
+    void leave()
     {
         if (dev >= 0) g_small_dense_wgs[dev].fetch_sub(wgs);
+        dev = -1;
     }
+    int in_flight() const { return dev < 0 ? 0 : g_small_dense_wgs[dev].load(); }
+    ~SmallDensePresence() { leave(); }
 };
 
 // the sweep launchers of one arithmetic build of vm_sweep_kernels.hip
@@ -848,12 +856,12 @@ static hipGraphExec_t sweep_graph(vm_ctx *c, int math_mode, int n, int w, int h,
 // file named after the device's PCI bus id (so that HIP_VISIBLE_DEVICES renumbering cannot split it);
 // whoever does not get the token runs STEP for that call.  Kernels that do not spin (every other
 // schedule, any other program) only delay a PASS launch: they finish and free their compute units.
-// VM_LOCK_DIR (default /tmp) holds the files; if one cannot be opened the token is process-local and the
-// bounded barrier wait + the STEP rerun below remain the safety net.
+// VM_LOCK_DIR (default /tmp) holds the files; if one cannot be opened or locked the PASS schedule stays off in this
+// process (STEP instead); the bounded barrier wait + the STEP rerun below remain the safety net for everything else.
 namespace {
 struct PassDevice {
     std::mutex mu;
-    int fd = -2; // -2: not opened yet, -1: no lock file (process-local token)
+    int fd = -2; // -2: not opened yet, -3: no usable lock file (PASS stays off in this process), >= 0: the lock file
 };
 PassDevice g_pass_dev[64];
 
@@ -874,16 +882,45 @@ struct PassToken {
                 if (*q == ':' || *q == '/' || *q == '.') *q = '_';
             const char *dir = getenv("VM_LOCK_DIR");
             const std::string path = std::string(dir && *dir ? dir : "/tmp") + "/vmorph-pass-" + bus + ".lock";
-            d->fd = open(path.c_str(), O_RDONLY | O_CREAT | O_CLOEXEC, 0666);
-            if (d->fd < 0) d->fd = -1;
+            // Open an existing file first: with fs.protected_regular (the default of many distributions) another
+            // user's O_CREAT open of an existing file in a sticky directory fails with EACCES although a plain open
+            // succeeds.  Create it only if it is not there (world-readable is all flock() needs).
+            d->fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+            if (d->fd < 0 && errno == ENOENT) {
+                const mode_t um = umask(0);
+                d->fd = open(path.c_str(), O_RDONLY | O_CREAT | O_CLOEXEC, 0666);
+                umask(um);
+            }
+            if (d->fd < 0) {
+                // no lock file: exclusivity across processes cannot be had.  Refuse PASS rather than run it on a
+                // process-local token -- two processes in PASS at once time out against each other (STEP is the
+                // schedule of whoever does not hold the token anyway).  Said once.
+                d->fd = -3;
+                fprintf(stderr, "vmorph: cannot open %s (%s): the PASS schedule stays off on this device in this process; "
+                                "set VM_LOCK_DIR to a directory every user of the device can read\n", path.c_str(), strerror(errno));
+            }
         }
-        if (d->fd >= 0 && flock(d->fd, LOCK_EX | LOCK_NB) != 0) {
-            if (errno == EWOULDBLOCK) { // another process holds the device's token
+        if (d->fd == -3) {
+            d->mu.unlock();
+            return false;
+        }
+        if (d->fd >= 0) {
+            int rc;
+            do rc = flock(d->fd, LOCK_EX | LOCK_NB); while (rc != 0 && errno == EINTR);
+            if (rc != 0) {
+                if (errno != EWOULDBLOCK && errno != ENOLCK && errno != EOPNOTSUPP && errno != EINVAL) {
+                    d->mu.unlock();                 // an error that says nothing about the holder: not this time
+                    return false;
+                }
+                if (errno == EWOULDBLOCK) {         // another process holds the device's token
+                    d->mu.unlock();
+                    return false;
+                }
+                close(d->fd);                       // a file system without flock(): same as no lock file
+                d->fd = -3;
                 d->mu.unlock();
                 return false;
             }
-            close(d->fd); // a file system without flock(): the token is process-local from here on
-            d->fd = -1;
         }
         owns = true;
         return true;
@@ -1003,10 +1040,12 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     const int threads = std::min(c->sweep_threads ? c->sweep_threads : 512, exact ? 1024 : 512);
     const int tiles_per_pass = ((l0.w + VM_PITCH_X - 1) / VM_PITCH_X) * ((l0.h + VM_PITCH_Y - 1) / VM_PITCH_Y);
     // (see SmallDensePresence) this call's share of the small-level dense workgroups on the device, while it lasts
+    // -- registered only while the call's CURRENT batch launches such workgroups (dense TILE sweeps): a call that
+    // runs PASS, STEP, SPARSE or pruned lean batches has none in flight and must not make another context believe
+    // it has company (measured there: 256-thread workgroups without a partner cost 16 %)
     SmallDensePresence small_dense;
     static const bool no_corun = getenv("VM_NO_CORUN") != nullptr; // dev switch
-    if (!exact && !no_corun && tiles_per_pass <= 32 && c->sweep_threads == 0)
-        small_dense.enter(c->device, tiles_per_pass * n);
+    const bool small_dense_ok = !exact && !no_corun && tiles_per_pass <= 32 && c->sweep_threads == 0;
     // (k_tile_scan) the listed form of pruned TILE passes: from VM_TILE_LIST_MIN workgroups per pass on, tiles that fit the
     // entries' 16 bits; counters and stamps start from zero in every call (the epochs do)
     static const bool no_list = getenv("VM_NO_TILE_LIST") != nullptr; // dev switch
@@ -1114,6 +1153,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     bool cancelled = false;
     float ms = 0;
     float sched_ms[5] = {0, 0, 0, 0, 0}; // [0] TILE dense kernel, [1] TILE lean kernel, [2] STEP / SPLIT, [3] SPARSE, [4] PASS
+    double clk_shader[2] = {0, 0}, clk_wall[2] = {0, 0}; // in-kernel clock probe: [0] dense TILE kernel, [1] k_pass
     int sched_launches[5] = {0, 0, 0, 0, 0};
     static const bool force_dense = getenv("VM_TILE_DENSE") != nullptr; // dev switch
     // Iterations are enqueued in batches; each sweep kernel of iteration i exits at once (per
@@ -1204,7 +1244,11 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         }
         // dense TILE sweeps of a small level as 256-thread workgroups when enough of them are in flight on the
         // device to pair up on the CUs (SmallDensePresence)
-        const int tile_threads = (small_dense.dev >= 0 && dense == 1 && small_dense.in_flight() >= VM_CORUN_MIN_WGS) ? 256 : threads;
+        if (small_dense_ok && dense == 1 && !split && !sparse)
+            small_dense.enter(c->device, tiles_per_pass * n);
+        else
+            small_dense.leave();
+        const int tile_threads = small_dense.in_flight() >= VM_CORUN_MIN_WGS ? 256 : threads;
         // pruned TILE passes of a big batch: the listed form (k_tile_scan) -- dispatching tiles x pairs workgroups that
         // find nothing costs ~4.7 ns each, 118 us per pass over 30 1080p pairs
         uint32_t *const tile_list = (listed_ok && dense == 0 && !split && !sparse) ? c->tile_list : nullptr;
@@ -1291,6 +1335,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
             }
             launches = launches_before;
             may_pass = false;
+            if (!c->pass_latched_off) c->pass_latched_by_test = c->pass_test_timeout != 0;
             c->pass_latched_off = true;
             ++c->pass_fallbacks;
             pass_token.release();
@@ -1314,6 +1359,10 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
                 st_commit[i] += st[VM_STAT_WORDS * it + 2];
                 st_eval[i] += st[VM_STAT_WORDS * it + 4];
                 c->sparse_resident_visits += st[VM_STAT_WORDS * it + 5];
+                if (i == 0 && (sched == 0 || sched == 4)) { // in-kernel clock probe of the dense TILE kernel / of k_pass (pair 0 only)
+                    clk_shader[sched == 4] += st[VM_STAT_WORDS * it + 6];
+                    clk_wall[sched == 4] += st[VM_STAT_WORDS * it + 7];
+                }
                 improving[i] = fl[it] != 0;
                 if (!improving[i] && live[i] < 0) live[i] = it + 1; // the reference's loop ends here (morph.cu:1390)
                 if (!improving[i] && !fixed_work) { executed[i] = it + 1; stopped[i] = 1; }
@@ -1346,6 +1395,10 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
             out[i].sched_ms[k] = sched_ms[k];
             out[i].sched_launches[k] = sched_launches[k];
         }
+        for (int k = 0; k < 2; ++k) {
+            out[i].clk_shader_ticks[k] = clk_shader[k];
+            out[i].clk_wall_ticks[k] = clk_wall[k];
+        }
     }
     return cancelled ? vm_fail(VM_E_CANCELLED, "vm_optimize_level: cancelled by run_flag") : VM_OK;
 }
@@ -1364,19 +1417,22 @@ extern "C" int vm_optimize_level_batch(vm_pyr **pyrs, int n, int lvl, float max_
     return optimize_level_batch(pyrs, n, lvl, max_iter, run_flag, fixed_work, out);
 }
 
-// Morph::calculate_halfway_parametrization for a batch of pairs in lockstep
-extern "C" int vm_solve_batch(vm_pyr **pyrs, int n, float max_iter, float drop, volatile const int *run_flag,
-                              int fixed_work, vm_progress *per_level)
+// Morph::calculate_halfway_parametrization for a batch of pairs in lockstep; cons[i] / ncons[i] = pair i's own
+// user constraints (cons == NULL: none anywhere)
+extern "C" int vm_solve_batch_cons(vm_pyr **pyrs, int n, float max_iter, float drop, const vm_constraint *const *cons,
+                                   const int *ncons, volatile const int *run_flag, int fixed_work, vm_progress *per_level)
 {
     if (!pyrs || n < 1 || !pyrs[0]) return vm_fail(VM_E_INVALID, "vm_solve_batch: empty batch");
     if (!(drop > 0)) return vm_fail(VM_E_INVALID, "vm_solve_batch: max_iter_drop_factor must be > 0");
+    if (cons && !ncons) return vm_fail(VM_E_INVALID, "vm_solve_batch_cons: constraints without their counts");
     std::lock_guard<std::recursive_mutex> lock(pyrs[0]->ctx->mu);
     const int L = (int)pyrs[0]->lv.size();
     const int w0 = pyrs[0]->lv[0].w, h0 = pyrs[0]->lv[0].h;
     int rc;
     for (int i = 0; i < n; ++i) {
         if (!pyrs[i] || (int)pyrs[i]->lv.size() != L) return vm_fail(VM_E_INVALID, "vm_solve_batch: pyramids must share their geometry");
-        if ((rc = vm_coarse_solve(pyrs[i], L - 1, w0, h0, nullptr, 0)) != VM_OK) return rc;
+        if (cons && (ncons[i] < 0 || (ncons[i] > 0 && !cons[i]))) return vm_fail(VM_E_INVALID, "vm_solve_batch_cons: constraints of pair %d", i);
+        if ((rc = vm_coarse_solve(pyrs[i], L - 1, w0, h0, cons ? cons[i] : nullptr, cons ? ncons[i] : 0)) != VM_OK) return rc;
     }
     float mi = max_iter;
     std::vector<vm_progress> pr(n);
@@ -1384,7 +1440,7 @@ extern "C" int vm_solve_batch(vm_pyr **pyrs, int n, float max_iter, float drop, 
         if (run_flag && !*run_flag) return vm_fail(VM_E_CANCELLED, "vm_solve_batch: cancelled by run_flag");
         for (int i = 0; i < n; ++i) {
             if ((rc = vm_upsample_v(pyrs[i], el, el + 1)) != VM_OK) return rc;
-            if ((rc = vm_init_level(pyrs[i], el, w0, h0, nullptr, 0)) != VM_OK) return rc;
+            if ((rc = vm_init_level(pyrs[i], el, w0, h0, cons ? cons[i] : nullptr, cons ? ncons[i] : 0)) != VM_OK) return rc;
         }
         if ((rc = optimize_level_batch(pyrs, n, el, mi, run_flag, fixed_work, pr.data())) != VM_OK) return rc;
         if (per_level)
@@ -1392,6 +1448,12 @@ extern "C" int vm_solve_batch(vm_pyr **pyrs, int n, float max_iter, float drop, 
         mi /= drop;
     }
     return VM_OK;
+}
+
+extern "C" int vm_solve_batch(vm_pyr **pyrs, int n, float max_iter, float drop, volatile const int *run_flag,
+                              int fixed_work, vm_progress *per_level)
+{
+    return vm_solve_batch_cons(pyrs, n, max_iter, drop, nullptr, nullptr, run_flag, fixed_work, per_level);
 }
 
 extern "C" int vm_solve(vm_pyr *p, float max_iter, float drop, const vm_constraint *cons, int n,

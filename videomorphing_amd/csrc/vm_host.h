@@ -80,6 +80,7 @@ struct vm_ctx {
     void *pass_snap = nullptr;       // AUTO: the levels' slabs as they stood before the current PASS batch
     size_t pass_snap_bytes = 0;
     bool pass_latched_off = false;   // AUTO: a tile barrier timed out once on this context: STEP from then on
+    bool pass_latched_by_test = false; // ... and it was vm_dbg_pass_force_timeout's doing (only then the hook may lift it)
     int pass_fallbacks = 0;          // how often that happened (vm_dbg_pass_fallbacks)
     int pass_test_timeout = 0;       // vm_dbg_pass_force_timeout: the next PASS launches behave as if a barrier timed out
     int sweep_threads = 0;           // 0 = automatic

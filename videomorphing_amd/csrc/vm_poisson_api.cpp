@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -657,21 +658,131 @@ extern "C" int vm_frame_download_v(vm_frame *f, float *v_xy)
 
 // RCCL is resolved at first use so that the library loads (and the CPU-side
 // tests run) on hosts without a usable librccl.
+namespace {
+struct Rccl {
+    typedef int (*bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    typedef int (*initall_fn)(void **, int, const int *);
+    typedef int (*destroy_fn)(void *);
+    typedef int (*group_fn)(void);
+    bcast_fn bcast = nullptr;
+    initall_fn init_all = nullptr;
+    destroy_fn destroy = nullptr;
+    group_fn group_start = nullptr, group_end = nullptr;
+    bool tried = false;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!r.tried) {
+        r.tried = true;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            r.bcast = (Rccl::bcast_fn)dlsym(h, "ncclBroadcast");
+            r.init_all = (Rccl::initall_fn)dlsym(h, "ncclCommInitAll");
+            r.destroy = (Rccl::destroy_fn)dlsym(h, "ncclCommDestroy");
+            r.group_start = (Rccl::group_fn)dlsym(h, "ncclGroupStart");
+            r.group_end = (Rccl::group_fn)dlsym(h, "ncclGroupEnd");
+        }
+    }
+    return r;
+}
+const int kNcclInt8 = 0; // ncclDataType_t: ncclInt8 / ncclChar
+} // namespace
+
 extern "C" int vm_rccl_bcast(vm_ctx *c, void *comm, void *dev_buf, uint64_t bytes, int root)
 {
     if (!c || !comm || !dev_buf) return vm_fail(VM_E_INVALID, "vm_rccl_bcast: NULL argument");
     VM_ON_DEVICE(c);
-    typedef int (*bcast_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
-    static bcast_fn fn = nullptr;
-    if (!fn) {
-        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) return vm_fail(VM_E_DEVICE, "vm_rccl_bcast: cannot load librccl: %s", dlerror());
-        fn = (bcast_fn)dlsym(h, "ncclBroadcast");
-        if (!fn) return vm_fail(VM_E_DEVICE, "vm_rccl_bcast: ncclBroadcast not found");
-    }
-    const int ncclInt8 = 0; // ncclDataType_t: ncclInt8 / ncclChar
-    int rc = fn(dev_buf, dev_buf, (size_t)bytes, ncclInt8, root, comm, c->stream);
+    Rccl &R = rccl();
+    if (!R.bcast) return vm_fail(VM_E_DEVICE, "vm_rccl_bcast: cannot load librccl / ncclBroadcast");
+    int rc = R.bcast(dev_buf, dev_buf, (size_t)bytes, kNcclInt8, root, comm, c->stream);
     if (rc != 0) return vm_fail(VM_E_DEVICE, "vm_rccl_bcast: ncclBroadcast returned %d", rc);
     return VM_OK;
+}
+
+// ncclCommInitAll: one communicator per device of ONE process (the C++ multi-device driver, examples/solve_shard.cpp)
+extern "C" int vm_rccl_comm_init_all(int n, const int *devices, void **comms_out)
+{
+    if (n < 1 || !devices || !comms_out) return vm_fail(VM_E_INVALID, "vm_rccl_comm_init_all: bad argument");
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devices[i] == devices[j])
+                return vm_fail(VM_E_INVALID, "vm_rccl_comm_init_all: device %d listed twice (RCCL wants one rank per device; contexts "
+                                             "that share a device pass comms = NULL to vm_bcast_params)", devices[i]);
+    Rccl &R = rccl();
+    if (!R.init_all) return vm_fail(VM_E_DEVICE, "vm_rccl_comm_init_all: cannot load librccl / ncclCommInitAll");
+    (void)hipGetLastError();
+    int rc = R.init_all(comms_out, n, devices);
+    (void)hipGetLastError();           // RCCL leaves stale errors behind when it probes peers
+    if (rc != 0) return vm_fail(VM_E_DEVICE, "vm_rccl_comm_init_all: ncclCommInitAll returned %d", rc);
+    return VM_OK;
+}
+
+extern "C" void vm_rccl_comm_destroy(void *comm)
+{
+    Rccl &R = rccl();
+    if (comm && R.destroy) R.destroy(comm);
+}
+
+// One process, n contexts: the shared parameter block goes root -> every context and each context adopts what IT
+// received (SURVEY 8(b)'s vm_bcast_params, 8(e)'s "exactly one ncclBroadcast of the shared parameter block").
+//   comms != NULL: comms[i] = the ncclComm_t of ctxs[i] (vm_rccl_comm_init_all); the block is staged in a device
+//                  buffer per context and broadcast inside one ncclGroup over xGMI, each on its context's stream;
+//   comms == NULL: TEST MODE for contexts that share a device (RCCL refuses two ranks on one device): the root's
+//                  device buffer is copied device-to-device into the others'.
+// Either way every context then reads ITS device copy back and sets kernel parameters + arithmetic mode from it;
+// blocks_out (n entries, may be NULL) receives the block as each context got it.
+extern "C" int vm_bcast_params(vm_ctx *const *ctxs, void *const *comms, int n, int root, const vm_param_block *blk,
+                               vm_param_block *blocks_out)
+{
+    if (!ctxs || n < 1 || root < 0 || root >= n || !blk) return vm_fail(VM_E_INVALID, "vm_bcast_params: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i] || (comms && !comms[i])) return vm_fail(VM_E_INVALID, "vm_bcast_params: context / communicator %d is NULL", i);
+    Rccl &R = rccl();
+    if (comms && (!R.bcast || !R.group_start || !R.group_end)) return vm_fail(VM_E_DEVICE, "vm_bcast_params: cannot load librccl");
+    std::vector<void *> buf(n, nullptr);
+    int rc = VM_OK;
+    auto fail = [&](int code, const char *what) { rc = vm_fail(code, "vm_bcast_params: %s", what); };
+    for (int i = 0; i < n && rc == VM_OK; ++i) {
+        VmDeviceGuard g(ctxs[i]->device);
+        if (!g.ok || hipMalloc(&buf[i], sizeof(vm_param_block)) != hipSuccess) { fail(VM_E_DEVICE, "device buffer"); break; }
+        // everybody but the root starts from zeros: what it ends up with is what travelled
+        hipError_t e = i == root ? hipMemcpyAsync(buf[i], blk, sizeof(vm_param_block), hipMemcpyHostToDevice, ctxs[i]->stream)
+                                 : hipMemsetAsync(buf[i], 0, sizeof(vm_param_block), ctxs[i]->stream);
+        if (e != hipSuccess) fail(VM_E_DEVICE, hipGetErrorString(e));
+    }
+    if (rc == VM_OK && comms) {
+        if (R.group_start() != 0) fail(VM_E_DEVICE, "ncclGroupStart");
+        for (int i = 0; i < n && rc == VM_OK; ++i) {
+            VmDeviceGuard g(ctxs[i]->device);
+            if (!g.ok || R.bcast(buf[i], buf[i], sizeof(vm_param_block), kNcclInt8, root, comms[i], ctxs[i]->stream) != 0)
+                fail(VM_E_DEVICE, "ncclBroadcast");
+        }
+        if (R.group_end() != 0 && rc == VM_OK) fail(VM_E_DEVICE, "ncclGroupEnd");
+    } else if (rc == VM_OK) {
+        VmDeviceGuard g(ctxs[root]->device);
+        if (hipStreamSynchronize(ctxs[root]->stream) != hipSuccess) fail(VM_E_DEVICE, "sync");
+        for (int i = 0; i < n && rc == VM_OK; ++i)
+            if (i != root && hipMemcpyAsync(buf[i], buf[root], sizeof(vm_param_block), hipMemcpyDeviceToDevice, ctxs[i]->stream) != hipSuccess)
+                fail(VM_E_DEVICE, "device-to-device copy");
+    }
+    for (int i = 0; i < n && rc == VM_OK; ++i) {
+        VmDeviceGuard g(ctxs[i]->device);
+        vm_param_block got;
+        if (hipMemcpyAsync(&got, buf[i], sizeof(got), hipMemcpyDeviceToHost, ctxs[i]->stream) != hipSuccess ||
+            hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) { fail(VM_E_DEVICE, "read-back"); break; }
+        if ((rc = vm_set_params(ctxs[i], &got.kp)) != VM_OK) break;
+        if ((rc = vm_set_math_mode(ctxs[i], got.math_mode)) != VM_OK) break;
+        if (blocks_out) blocks_out[i] = got;
+    }
+    for (int i = 0; i < n; ++i)
+        if (buf[i]) {
+            VmDeviceGuard g(ctxs[i]->device);
+            hipFree(buf[i]);
+        }
+    (void)hipGetLastError();
+    return rc;
 }

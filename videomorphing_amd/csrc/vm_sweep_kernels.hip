@@ -1822,6 +1822,16 @@ __device__ __forceinline__ bool tile_sweep(TileLds &S, const VmLevelView &L, con
     return true;
 }
 
+// One stamp of the in-kernel clock probe: words [6] / [7] of an iteration's activity counters collect
+// sum(exit - entry) of s_memtime (shader cycles) / s_memrealtime (constant 100 MHz) over the launches of the
+// iteration, modulo 2^32 (MI355X_MICROARCH.md: in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz).
+__device__ __forceinline__ void clock_probe(uint32_t *st, bool exit_stamp)
+{
+    const uint32_t c = (uint32_t)__builtin_amdgcn_s_memtime(), w = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    atomicAdd(&st[6], exit_stamp ? c : 0u - c);
+    atomicAdd(&st[7], exit_stamp ? w : 0u - w);
+}
+
 // DENSE, SMAX = VM_SMAX: the 256-VGPR kernel of dense sweeps (one workgroup per CU);
 // DENSE, SMAX = 7, MINF = 4: its 128-VGPR form -- every candidate gets >= 4 lanes, a phase of more than
 // T / 4 candidates takes two rounds, two workgroups share a CU (four waves per SIMD instead of two: the
@@ -1857,10 +1867,19 @@ __global__ __launch_bounds__(VM_SWEEP_T) __attribute__((amdgpu_waves_per_eu(DENS
         return;
     if (tid == 0)
         S.n_eval = 0; // ordered before its first use by the barriers of tile_sweep
+    // shader clock actually held under this kernel (bench.py: sclk_mhz_observed): the first tile of the first pair
+    // brackets its sweep with s_memtime (shader cycles) and s_memrealtime (100 MHz); the differences accumulate in
+    // stats words 6 / 7 -- minus the entry stamp now, plus the exit stamp later, so nothing stays live across the sweep
+    const bool probe = DENSE && tid == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
+    if (probe)
+        clock_probe(stats + iter_idx * VM_STAT_WORDS, false);
 
     bool improving = false;
     uint32_t st_cand = 0, st_commit = 0;
-    if (!tile_sweep<DENSE, SMAX, MINF, INTV>(S, L, P, tables, false, ox, oy, tid, T, improving, st_cand, st_commit))
+    const bool swept = tile_sweep<DENSE, SMAX, MINF, INTV>(S, L, P, tables, false, ox, oy, tid, T, improving, st_cand, st_commit);
+    if (probe)
+        clock_probe(stats + iter_idx * VM_STAT_WORDS, true);
+    if (!swept)
         return;
     if (tid == 0) {
         if (improving)
@@ -3756,6 +3775,9 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
             *my_slot = make_uint4(0, 0, 0, 0);
         return;
     }
+    // in-kernel clock probe (clock_probe above): workgroup 0 brackets its four phases
+    if (b == 0 && tid == 0)
+        clock_probe(stats0 + (size_t)iter_idx * VM_STAT_WORDS, false);
 
     // this wave's pixel slot of the tile: (tx, ty), pixel (ox + 2 tx + pj, oy + 2 ty + pi) in phase (pi, pj)
     const int slot = part * 8 + wave, tx = slot & 31, ty = slot >> 5;
@@ -4214,6 +4236,8 @@ __global__ __launch_bounds__(VM_PASS_T) __attribute__((amdgpu_waves_per_eu(2, 2)
         if (S.n_commit)
             flags[iter_idx] = 1u; // every writer stores the same 1 (see k_step)
         *my_slot = make_uint4(S.n_cand, S.n_commit, S.n_eval, part == 0 ? 1u : 0u);
+        if (b == 0)
+            clock_probe(stats0 + (size_t)iter_idx * VM_STAT_WORDS, true);
 #ifdef VM_PROF
         if (b < 256)
             vm_prof_buf[8192 + b * 2 + 1] = wall_clock64();

@@ -358,9 +358,10 @@ class Morph(object):
         return True
 
 
-def solve_batch(pyramids, max_iter, max_iter_drop_factor=1.0, fixed_work=False, run_flag=None):
+def solve_batch(pyramids, max_iter, max_iter_drop_factor=1.0, fixed_work=False, run_flag=None, constraints=None):
     """Morph::calculate_halfway_parametrization for a batch of frame pairs (same context,
-    same geometry, no constraints) in lockstep: vm_solve_batch.  Returns one list of
+    same geometry) in lockstep: vm_solve_batch / vm_solve_batch_cons.  constraints: None, one (n, 5) array of
+    (lx, ly, rx, ry, weight) shared by every pair, or a list with one such array per pair.  Returns one list of
     per-level progress dicts (finest first) per pair."""
     n = len(pyramids)
     L = pyramids[0]._L
@@ -368,8 +369,16 @@ def solve_batch(pyramids, max_iter, max_iter_drop_factor=1.0, fixed_work=False, 
     arr = (C.c_void_p * n)(*[p._h for p in pyramids])
     prog = (capi.Progress * (n * nl))()
     flag = C.cast(C.pointer(run_flag), C.c_void_p) if run_flag is not None else None
-    capi.check(L.vm_solve_batch(arr, n, float(max_iter), float(max_iter_drop_factor), flag,
-                                int(bool(fixed_work)), prog))
+    if constraints is None:
+        capi.check(L.vm_solve_batch(arr, n, float(max_iter), float(max_iter_drop_factor), flag,
+                                    int(bool(fixed_work)), prog))
+    else:
+        per = constraints if isinstance(constraints, (list, tuple)) and len(constraints) == n and np.ndim(constraints[0]) == 2 else [constraints] * n
+        keep = [_cons_array(c) for c in per]
+        ptrs = (C.c_void_p * n)(*[C.cast(a, C.c_void_p).value for a, _ in keep])
+        cnts = (C.c_int * n)(*[k for _, k in keep])
+        capi.check(L.vm_solve_batch_cons(arr, n, float(max_iter), float(max_iter_drop_factor), ptrs, cnts, flag,
+                                         int(bool(fixed_work)), prog))
     out = []
     for i in range(n):
         out.append([dict(iters=prog[i * nl + k].iters, iters_live=prog[i * nl + k].iters_live, improving=prog[i * nl + k].improving,
@@ -522,8 +531,8 @@ class Frame(object):
 
     def poisson_extend_both(self, tol=1e-5, max_it=20000):
         """both sides of this frame as one batch: ((iters1, rel1), (iters2, rel2), ms)"""
-        r = poisson_extend_frames([self], tol, max_it)
-        return r[0][0], r[0][1], r[1]
+        per_frame, ms = poisson_extend_frames([self], tol, max_it)
+        return per_frame[0][0], per_frame[0][1], ms
 
 
 def poisson_extend_frames(frames, tol=1e-5, max_it=20000):
