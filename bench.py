@@ -786,6 +786,8 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
             ctx.set_params(saved_kp)        # the sync stage runs with its own w_ui / w_tps
     # compositor: frames/s of render_halfway with device-resident inputs (Metric 2, render only)
     ex = int(0.1 * max(w, h))
+    if not any(want(x) for x in ("render", "poisson", "qpath", "pipeline8", "pipeline30", "config3")):
+        return extras
     rgb0, rgb1 = synth.make_rgb_pair(w, h)
     fr = morph.Frame(ctx, w, h, ex)
     e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
@@ -897,6 +899,7 @@ def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, base_frames, e0, e1
         q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
         group.append(q)
     frs = [morph.Frame(ctx, w, h, ex) for _ in range(per_batch)]
+    e0, e1 = morph.pin_host(e0), morph.pin_host(e1)        # the caller's frame buffers, page-locked (vm_host_register)
     for f in frs:                                           # workspaces
         f.upload(e0, e1, None, None)
         f.set_v_from_level(group[0], 1)
@@ -927,9 +930,10 @@ def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, base_frames, e0, e1
         f.close()
     for q in group:
         q.clear()
+    morph.unpin_host(e0); morph.unpin_host(e1)
     comp = (t_up + t_po + t_re) / nframes * 1e3
     return {"workload": "config[4] on one GPU: %d 1080p pairs, 8 point constraints each, BCOND_BORDER, solved in 2 batches of 15 (reference "
-                        "semantics); per frame: canvases uploaded (PCIe), v upscaled on the device, Poisson extension (ex = %d, tol 1e-5) of "
+                        "semantics); per frame: canvases uploaded from page-locked host memory (PCIe), v upscaled on the device, Poisson extension (ex = %d, tol 1e-5) of "
                         "both sides, %d frames = %d systems per batch; 9 rendered in-between frames per pair" % (nframes, ex, per_batch, 2 * per_batch),
             "ms_per_pair": round(dt * 1e3 / nframes, 1), "solve_ms_per_pair": round(t_solve * 1e3 / nframes, 1),
             "compositor_ms_per_frame": round(comp, 2),

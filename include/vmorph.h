@@ -357,6 +357,11 @@ int  vm_frame_download_ext(vm_frame *f, int side, uint8_t *ext_rgba);
 /* take v straight from a solved pyramid level (device to device, with the
  * update_result upscale) */
 int  vm_frame_set_v_from_level(vm_frame *f, vm_pyr *pyr, int lvl);
+/* Page-lock / release a host buffer the caller uploads frames from (the reference re-uploads 108 MB of float4
+ * canvases per rendered frame from pageable memory, UI/RenderWidget.cpp:229-266; here 27 MB of RGBA8 per frame
+ * pair, once): vm_frame_upload from a registered buffer runs at the link's rate.  Optional. */
+int  vm_host_register(void *ptr, uint64_t bytes);
+int  vm_host_unregister(void *ptr);
 /* ... and frame `frame` of vm_video_result (above), computed on the device */
 int  vm_frame_set_v_from_video(vm_frame *f, vm_video *v, int lvl, int frame);
 /* render_halfway_image, Algorithm/render.cu:62-96 (UI/RenderWidget.h:52-57);

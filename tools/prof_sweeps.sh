@@ -1,8 +1,8 @@
 #!/bin/bash
-# round-3 profile visit: kernel-trace stats + PMC passes (each on its own, kernel-trace only) of
+# profile visit of the sweep kernels (rounds 3-5): kernel-trace stats + PMC passes (each on its own, kernel-trace only) of
 # (i) config[1] (one 1080p pair per step), (ii) an 8-pair batch (config[2]'s per-GPU share at N = 8:
 # two streams x 4 pairs per launch), (iii) config[2] on one GPU (60 pairs, 2 x 30 per launch),
-# (iv) the compositor; the config[3] bench line.  usage (on the box, repo root): bash tools/prof_round3.sh <tag>
+# (iv) the compositor; the config[3] bench line.  usage (on the box, repo root): bash tools/prof_sweeps.sh <tag>
 tag=${1:-r03}
 O=gpurun_out/prof_$tag
 mkdir -p $O

@@ -33,7 +33,7 @@ SYMBOLS = [
     "vm_level_upload_luma", "vm_pyramid_build_rgb", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
     "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_solve_batch_cons", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
-    "vm_frame_download_ext", "vm_frame_set_v_from_level", "vm_render_halfway",
+    "vm_frame_download_ext", "vm_host_register", "vm_host_unregister", "vm_frame_set_v_from_level", "vm_render_halfway",
     "vm_render_halfway_dev", "vm_poisson_extend", "vm_poisson_extend_frames", "vm_frame_quadratic_path", "vm_frame_download_qpath", "vm_frame_download_v",
     "vm_rccl_bcast", "vm_rccl_comm_init_all", "vm_rccl_comm_destroy", "vm_bcast_params",
     "vm_video_create", "vm_video_destroy", "vm_video_levels", "vm_video_level_dims", "vm_video_upload_luma",
@@ -151,6 +151,8 @@ def load():
         "vm_frame_download_qpath": [vp, vp],
         "vm_frame_download_v": [vp, vp],
         "vm_rccl_bcast": [vp, vp, vp, C.c_uint64, i],
+        "vm_host_register": [vp, C.c_uint64],
+        "vm_host_unregister": [vp],
         "vm_rccl_comm_init_all": [i, C.POINTER(i), C.POINTER(vp)],
         "vm_bcast_params": [C.POINTER(vp), C.POINTER(vp), i, i, C.POINTER(ParamBlock), C.POINTER(ParamBlock)],
         "vm_video_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i), i, C.POINTER(vp)],

@@ -27,6 +27,11 @@ void vm_poisson_launch_iter(float4 *X, float4 *R, float4 *P, float4 *Q, const fl
 void vm_poisson_launch_paste(uchar4 *ext, const uint8_t *type, const float4 *X, int cw, int ch,
                              hipStream_t s);
 
+// the same two for the batched solver's 12-byte vectors (vm_mgb.h)
+struct VmV3;
+void vm_poisson_launch_setup3(const uchar4 *ext, const uint8_t *type, VmV3 *B, VmV3 *X, int cw, int ch, hipStream_t s);
+void vm_poisson_launch_paste3(uchar4 *ext, const uint8_t *type, const VmV3 *X, int cw, int ch, hipStream_t s);
+
 // quadratic motion path (QuadraticPath.cpp:24-223)
 void vm_qpath_launch_rhs(const float2 *v, int rs, int w, int h, float4 *B, float4 *X, hipStream_t s);
 void vm_qpath_launch_sum(const float4 *X, int w, int h, double *sums, hipStream_t s);

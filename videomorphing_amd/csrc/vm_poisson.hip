@@ -15,6 +15,7 @@
 // in double.  HBM-bound: ~5 float4 vectors touched per unknown per iteration.
 #include "vm_internal.h"
 #include "vm_poisson.h"
+#include "vm_mgb.h"
 
 namespace {
 
@@ -123,10 +124,17 @@ __device__ __forceinline__ float4 grad(const uchar4 *__restrict__ ext, const uin
     return make_float4((float)ca.x - (float)cb.x, (float)ca.y - (float)cb.y, (float)ca.z - (float)cb.z, 0);
 }
 
+// how a solver stores a vector entry: float4 (the Jacobi solver: the diagonal travels in .w) or 12-byte VmV3
+__device__ __forceinline__ void put_vec(float4 *a, size_t i, float4 v) { a[i] = v; }
+__device__ __forceinline__ void put_vec(VmV3 *a, size_t i, float4 v) { a[i] = VmV3{v.x, v.y, v.z}; }
+__device__ __forceinline__ float4 get_vec(const float4 *a, size_t i) { return a[i]; }
+__device__ __forceinline__ float4 get_vec(const VmV3 *a, size_t i) { const VmV3 v = a[i]; return make_float4(v.x, v.y, v.z, 0); }
+
 // right-hand side and diagonal, PoissonExt.cpp:214-270; also the initial guess
+template <class V>
 __global__ __launch_bounds__(256) void k_setup(const uchar4 *__restrict__ ext,
-                                               const uint8_t *__restrict__ type, float4 *B,
-                                               float4 *X, int cw, int ch, int init_x)
+                                               const uint8_t *__restrict__ type, V *B,
+                                               V *X, int cw, int ch, int init_x)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= cw || y >= ch)
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(256) void k_setup(const uchar4 *__restrict__ ext,
         if (x + 1 < cw && type[ii + 1] > 0) { float4 g = grad(ext, type, ii + 1, ii); diag += 1; b.x -= g.x; b.y -= g.y; b.z -= g.z; }
         if (y + 1 < ch && type[ii + cw] > 0) { float4 g = grad(ext, type, ii + cw, ii); diag += 1; b.x -= g.x; b.y -= g.y; b.z -= g.z; }
     }
-    b.w = diag; // the diagonal travels in the spare lane
-    B[ii] = b;
+    b.w = diag; // the diagonal travels in the spare lane (float4 form)
+    put_vec(B, ii, b);
     if (!init_x)
         return; // X already holds the prolongated coarse solution
     // initial guess: the colour already there (ring and filled pixels), mid grey on holes
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(256) void k_setup(const uchar4 *__restrict__ ext,
         const uchar4 c = ext[ii];
         x0 = is_marker(c) ? make_float4(128.f, 128.f, 128.f, 0) : make_float4((float)c.x, (float)c.y, (float)c.z, 0);
     }
-    X[ii] = x0;
+    put_vec(X, ii, x0);
 }
 
 __device__ __forceinline__ float4 apply_A(const float4 *__restrict__ P, const uint8_t *__restrict__ type,
@@ -312,8 +320,9 @@ __global__ void k_cg_rotate(VmCgScalars *sc)
 }
 
 // paste, PoissonExt.cpp:333-346
+template <class V>
 __global__ __launch_bounds__(256) void k_paste(uchar4 *ext, const uint8_t *__restrict__ type,
-                                               const float4 *__restrict__ X, int cw, int ch)
+                                               const V *__restrict__ X, int cw, int ch)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= cw || y >= ch)
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(256) void k_paste(uchar4 *ext, const uint8_t *__res
     const size_t ii = (size_t)y * cw + x;
     if (type[ii] == 0)
         return;
-    const float4 v = X[ii];
+    const float4 v = get_vec(X, ii);
     ext[ii] = make_uchar4((uint8_t)(int)fminf(fmaxf(v.x, 0.0f), 255.0f),
                           (uint8_t)(int)fminf(fmaxf(v.y, 0.0f), 255.0f),
                           (uint8_t)(int)fminf(fmaxf(v.z, 0.0f), 255.0f), 0);
@@ -517,7 +526,12 @@ void vm_poisson_launch_prepare(uchar4 *ext, uint8_t *type, const uchar4 *other, 
 void vm_poisson_launch_setup(const uchar4 *ext, const uint8_t *type, float4 *B, float4 *X, int cw, int ch,
                              hipStream_t s)
 {
-    hipLaunchKernelGGL(k_setup, grid2(cw, ch), B2, 0, s, ext, type, B, X, cw, ch, 1);
+    hipLaunchKernelGGL(k_setup<float4>, grid2(cw, ch), B2, 0, s, ext, type, B, X, cw, ch, 1);
+}
+
+void vm_poisson_launch_setup3(const uchar4 *ext, const uint8_t *type, VmV3 *B, VmV3 *X, int cw, int ch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_setup<VmV3>, grid2(cw, ch), B2, 0, s, ext, type, B, X, cw, ch, 1);
 }
 
 void vm_poisson_launch_cg_init(const float4 *B, const float4 *X, float4 *R, float4 *P, const uint8_t *type,
@@ -550,7 +564,12 @@ void vm_poisson_launch_iter(float4 *X, float4 *R, float4 *P, float4 *Q, const fl
 void vm_poisson_launch_paste(uchar4 *ext, const uint8_t *type, const float4 *X, int cw, int ch,
                              hipStream_t s)
 {
-    hipLaunchKernelGGL(k_paste, grid2(cw, ch), B2, 0, s, ext, type, X, cw, ch);
+    hipLaunchKernelGGL(k_paste<float4>, grid2(cw, ch), B2, 0, s, ext, type, X, cw, ch);
+}
+
+void vm_poisson_launch_paste3(uchar4 *ext, const uint8_t *type, const VmV3 *X, int cw, int ch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_paste<VmV3>, grid2(cw, ch), B2, 0, s, ext, type, X, cw, ch);
 }
 
 void vm_qpath_launch_rhs(const float2 *v, int rs, int w, int h, float4 *B, float4 *X, hipStream_t s)

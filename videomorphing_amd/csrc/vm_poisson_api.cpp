@@ -130,7 +130,7 @@ char *mg_carve(MgHierarchy &H, int w, int h, char *b)
     return b;
 }
 
-const float kMgOmega = 0.8f;
+const float kMgOmega = 0.8f;   // == VM_MGB_OMEGA
 const int kMgCoarseSweeps = 40;
 
 // z = M^-1 r: one V(1,1) cycle; level l's right-hand side is lv[l].b, the result ends in lv[l].x
@@ -304,7 +304,7 @@ namespace {
 struct MgbWork {          // one system's device workspace, carved from f->pws2[side - 1]
     VmMgbSys S;           // host copy of the device descriptor
     uint8_t *type;
-    float4 *Xbest;
+    VmV3 *Xbest;
     char *xcoarse;        // the x arrays of levels >= 1, contiguous (cleared per extension)
     size_t xcoarse_bytes;
     int *counts;          // nblocks per level (device)
@@ -314,11 +314,11 @@ size_t mgb_bytes(int w, int h)
 {
     const auto sz = mg_sizes(w, h);
     const size_t N0 = (size_t)w * h;
-    size_t need = al256(N0) + al256(sizeof(VmMgbScalars)) + al256(VM_MGB_MAXLEV * sizeof(int)) + 5 * al256(N0 * 16);
+    size_t need = 2 * al256(N0) + al256(sizeof(VmMgbScalars)) + al256(VM_MGB_MAXLEV * sizeof(int)) + 5 * al256(N0 * 12);
     for (size_t l = 0; l < sz.size(); ++l) {
         const size_t N = (size_t)sz[l].first * sz[l].second;
         const size_t nb = (size_t)((sz[l].first + 63) / 64) * ((sz[l].second + 3) / 4);
-        need += 3 * al256(N * 4) + 2 * al256(N * 16) + 2 * al256(nb * 4);
+        need += (l ? 4 * al256(N * 4) : 0) + 2 * al256(N * 12) + 2 * al256(nb * 4);
     }
     return need;
 }
@@ -331,32 +331,39 @@ void mgb_carve(MgbWork &W, int w, int h, char *b)
     W.S.type = W.type;
     W.S.sc = (VmMgbScalars *)b; b += al256(sizeof(VmMgbScalars));
     W.counts = (int *)b; b += al256(VM_MGB_MAXLEV * sizeof(int));
-    W.S.X = (float4 *)b; b += al256(N0 * 16);
-    W.S.P[0] = (float4 *)b; b += al256(N0 * 16);
-    W.S.P[1] = (float4 *)b; b += al256(N0 * 16);
-    W.S.Q = (float4 *)b; b += al256(N0 * 16);
-    W.Xbest = (float4 *)b; b += al256(N0 * 16);
+    W.S.X = (VmV3 *)b; b += al256(N0 * 12);
+    W.S.P[0] = (VmV3 *)b; b += al256(N0 * 12);
+    W.S.P[1] = (VmV3 *)b; b += al256(N0 * 12);
+    W.S.Q = (VmV3 *)b; b += al256(N0 * 12);
+    W.Xbest = (VmV3 *)b; b += al256(N0 * 12);
     W.S.nlev = (int)sz.size();
     for (size_t l = 0; l < sz.size(); ++l) {
         VmMgbLevel &L = W.S.lv[l];
         L.w = sz[l].first; L.h = sz[l].second;
         L.gx = (L.w + 63) / 64; L.gy = (L.h + 3) / 4;
         const size_t N = (size_t)L.w * L.h, nb = (size_t)L.gx * L.gy;
-        L.we = (float *)b; b += al256(N * 4);
-        L.ws = (float *)b; b += al256(N * 4);
-        L.dg = (float *)b; b += al256(N * 4);
-        L.b = (float4 *)b; b += al256(N * 16);
+        L.info = nullptr;
+        L.we = L.ws = L.dg = L.k = nullptr;
+        if (l == 0) {                       // one byte of operator per cell
+            L.info = (uint8_t *)b; b += al256(N);
+        } else {
+            L.we = (float *)b; b += al256(N * 4);
+            L.ws = (float *)b; b += al256(N * 4);
+            L.dg = (float *)b; b += al256(N * 4);
+            L.k = (float *)b; b += al256(N * 4);
+        }
+        L.b = (VmV3 *)b; b += al256(N * 12);
         L.flags = (uint32_t *)b; b += al256(nb * 4);
         L.blocks = (uint32_t *)b; b += al256(nb * 4);
         L.nblocks = W.counts + l;
     }
     // the x arrays last and together: level 0's (z), then the coarse ones, which are cleared per extension (a
     // fine cell may read the correction of a coarse cell that is no unknown and sits in a block nobody sweeps)
-    W.S.lv[0].x = (float4 *)b; b += al256(N0 * 16);
+    W.S.lv[0].x = (VmV3 *)b; b += al256(N0 * 12);
     W.xcoarse = b;
     for (size_t l = 1; l < sz.size(); ++l) {
-        W.S.lv[l].x = (float4 *)b;
-        b += al256((size_t)sz[l].first * sz[l].second * 16);
+        W.S.lv[l].x = (VmV3 *)b;
+        b += al256((size_t)sz[l].first * sz[l].second * 12);
     }
     W.xcoarse_bytes = (size_t)(b - W.xcoarse);
 }
@@ -366,18 +373,18 @@ void mgb_vcycle(const VmMgbSys *dev, int nsys, const MgbWork &W0, const std::vec
 {
     const int nlev = W0.S.nlev;
     if (nlev == 1) {
-        vm_mgb_launch_coarsest(dev, nsys, 0, kMgOmega, kMgCoarseSweeps, active, s);
+        vm_mgb_launch_coarsest(dev, nsys, 0, kMgCoarseSweeps, active, s);
         vm_mgb_launch_dot_rz(dev, nsys, nb[0], k, active, s);
         return;
     }
     const int tail = nlev - 2;      // levels tail, tail + 1 run in one workgroup
     for (int l = 0; l < tail; ++l)
-        vm_mgb_launch_restrict(dev, nsys, l, nb[l + 1], kMgOmega, active, s);
-    vm_mgb_launch_tail(dev, nsys, tail, kMgOmega, kMgCoarseSweeps, active, s);
+        vm_mgb_launch_restrict(dev, nsys, l, nb[l], active, s);
+    vm_mgb_launch_tail(dev, nsys, tail, kMgCoarseSweeps, active, s);
     if (tail == 0)
         vm_mgb_launch_dot_rz(dev, nsys, nb[0], k, active, s);
     for (int l = tail - 1; l >= 0; --l)
-        vm_mgb_launch_prolong(dev, nsys, l, nb[l], kMgOmega, k, active, s);
+        vm_mgb_launch_prolong(dev, nsys, l, nb[l], k, active, s);
 }
 
 double mgb_rel(const VmMgbScalars &h, int par)
@@ -427,7 +434,7 @@ static int poisson_solve_batch(vm_ctx *c, vm_frame *const *frames, const int *si
         uchar4 *ext = f->ext[side - 1];
         const uchar4 *other = f->crop[side == 1 ? 1 : 0]; // PoissonExt.cpp:54-57
         vm_poisson_launch_prepare(ext, W[i].type, other, f->v, f->w, f->h, f->rs, f->ex, side == 1 ? 1 : -1, s);
-        vm_poisson_launch_setup(ext, W[i].type, W[i].S.lv[0].b, W[i].S.X, cw, ch, s);
+        vm_poisson_launch_setup3(ext, W[i].type, W[i].S.lv[0].b, W[i].S.X, cw, ch, s);
         VM_HIP(hipMemsetAsync(W[i].S.sc, 0, sizeof(VmMgbScalars), s));
         if (W[i].xcoarse_bytes) VM_HIP(hipMemsetAsync(W[i].xcoarse, 0, W[i].xcoarse_bytes, s));
     }
@@ -469,7 +476,7 @@ static int poisson_solve_batch(vm_ctx *c, vm_frame *const *frames, const int *si
                 // the recursively updated residual can pass below what the stored iterate attains and the iteration
                 // then drifts: near the tolerance the best iterate seen at a check is kept
                 if (worst <= 30.0 * tol) {
-                    VM_HIP(hipMemcpyAsync(W[i].Xbest, W[i].S.X, N0 * sizeof(float4), hipMemcpyDeviceToDevice, s));
+                    VM_HIP(hipMemcpyAsync(W[i].Xbest, W[i].S.X, N0 * sizeof(VmV3), hipMemcpyDeviceToDevice, s));
                     saved[i] = 1;
                 }
             } else {
@@ -478,7 +485,7 @@ static int poisson_solve_batch(vm_ctx *c, vm_frame *const *frames, const int *si
             if (worst <= tol || it >= max_it || stale[i] >= 3 || worst > 1e3 * best[i]) {
                 active &= ~(1ull << i);
                 if (saved[i] && best_it[i] != it)
-                    VM_HIP(hipMemcpyAsync(W[i].S.X, W[i].Xbest, N0 * sizeof(float4), hipMemcpyDeviceToDevice, s));
+                    VM_HIP(hipMemcpyAsync(W[i].S.X, W[i].Xbest, N0 * sizeof(VmV3), hipMemcpyDeviceToDevice, s));
                 else if (!saved[i]) { best[i] = worst; best_it[i] = it; }     // what X holds
             }
         }
@@ -492,7 +499,7 @@ static int poisson_solve_batch(vm_ctx *c, vm_frame *const *frames, const int *si
         VM_HIP(hipGetLastError());
     }
     for (int i = 0; i < nsys; ++i) {
-        vm_poisson_launch_paste(frames[i]->ext[sides[i] - 1], W[i].type, W[i].S.X, cw, ch, s);
+        vm_poisson_launch_paste3(frames[i]->ext[sides[i] - 1], W[i].type, W[i].S.X, cw, ch, s);
         iters[i] = best_it[i];
         rels[i] = best[i];
     }

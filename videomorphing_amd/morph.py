@@ -546,6 +546,17 @@ def poisson_extend_frames(frames, tol=1e-5, max_it=20000):
     return [((it[2 * i], rr[2 * i]), (it[2 * i + 1], rr[2 * i + 1])) for i in range(n)], ms.value
 
 
+def pin_host(array):
+    """page-lock a numpy array frames are uploaded from (vm_host_register); returns the array"""
+    a = np.ascontiguousarray(array)
+    capi.check(capi.load().vm_host_register(a.ctypes.data, a.nbytes))
+    return a
+
+
+def unpin_host(array):
+    capi.check(capi.load().vm_host_unregister(array.ctypes.data))
+
+
 def make_extended(rgb, ex):
     """Extended RGBA8 canvas of Pyramid::build, pyramid.cu:186-200: filled with
     (255,255,255,255), the image pasted at (ex,ex) with alpha 0."""
