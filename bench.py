@@ -51,6 +51,8 @@ ALG_BYTES_PER_VISIT = 100.0      # 76 B read + 24 B written per 
 FLOP_PER_EVAL = 25 * 45 + 2 * 30  # 25 ssim() of ~45 flop-eq + 2 bilinear taps of ~30
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_FLOPS = 157e12         # MI355X_MICROARCH.md: f32 vector peak
+POISSON_ALG_BYTES = 190.0        # algorithmic bytes per unknown and PCG iteration of the Poisson solver
+POISSON_PMC_BYTES_PER_FRAME = 14235337989   # profiles/r05_compositor_pmc_summary.csv (one 1080p frame, both sides, 20 + 20 iterations)
 SCHED = ("k_optimize<true> (TILE schedule, dense kernel)", "k_optimize<false> (TILE schedule, lean kernel for pruned sweeps)",
          "k_step (STEP schedule, one launch per phase)",
          "k_sparse (SPARSE schedule: one launch per batch of iterations of a pruned level)",
@@ -299,8 +301,10 @@ def main():
     else:
         el_max, pix_total, pix_live_total = el, pix_iters, pix_live
 
-    # (scale_reference first: measured after the other extras -- the same job, fresh contexts -- it takes 970 instead of
-    # 838 ms; not the clocks, not the hardware queues, not the churn of pyramids (tools/dev_alloc_history.py): unexplained)
+    # (rounds 3-4 ran scale_reference first because after the other extras it took 970 instead of 838 ms.  Round 5 found the
+    # cause -- tools/dev_scale_ref_bisect.sh: the TEMPORAL extra, and in it the video lanes' graded stream priorities: their
+    # low-priority streams took hardware queues the runtime never handed back, so two of the job's three streams then shared
+    # one.  Fixed in vm_video.cpp (only lane 0 asks for a priority stream now); the order no longer matters: 836 ms either way.)
     extras = {}
     scale_ref = None
     want_scale_ref = rank == 0 and world == 1 and config == 1 and not args.size and not (args.no_extras or args.no_scale_ref)
@@ -811,6 +815,20 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         fr.upload(e0, e1, None, None)
         r1, r2 = fr.poisson_extend(1, tol=1e-5), fr.poisson_extend(2, tol=1e-5)
         pe["tol_1e-05_one_side_at_a_time"] = {"ms_per_frame": round(r1[2] + r2[2], 2), "cg_iterations": [r1[0], r2[0]]}
+        # roofline of the solve: algorithmic bytes = unknowns x PCG iterations x 190 B (level 0: restriction 16 +
+        # prolongation 28 + direction / operator 49 + update 73; coarse levels ~25) over the HIP-event time of the batch;
+        # PMC traffic per frame from the committed profile of the same workload (tools/prof_compositor.py)
+        unknowns = (w + 2 * ex) * (h + 2 * ex) - (w - 2) * (h - 2)         # outside pixels + the one-pixel ring inside
+        its = pe["tol_1e-05"]["cg_iterations"]
+        alg = unknowns * sum(its) * POISSON_ALG_BYTES
+        gbs = alg / (pe["tol_1e-05"]["ms_per_frame"] * 1e-3) / 1e9
+        pe["roofline"] = {"bound": "hbm", "kernel": "multigrid-PCG solve of both sides as one batch (13 launches per iteration; dominant kernel "
+                                                     "k_mgb_dirspmv, 0.33 of peak by itself: profiles/r05_compositor_*)",
+                          "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                          "traffic": POISSON_PMC_BYTES_PER_FRAME if (w, h, ex) == (1920, 1080, 192) and its == [20, 20] else None,
+                          "traffic_source": "profiles/r05_compositor_pmc_summary.csv: sum over the k_mgb_* kernels of one frame (both sides, "
+                                            "20 + 20 iterations), FETCH_SIZE doubled per the gfx950 note",
+                          "alg_bytes_per_unknown_iteration": POISSON_ALG_BYTES, "unknowns_per_side": unknowns}
         extras["poisson_extend_1080p_ex%d" % ex] = pe
     # quadratic motion path of that frame (QuadraticPath.cpp), SURVEY 8(f) rank 4
     if want("qpath"):

@@ -227,32 +227,45 @@ def test_cpp_multi_device_driver_matches_python(solve_shard, gpu_ctx, tmp_path):
     assert np.abs(v_cpp).max() > 0.1
 
 
+_BCAST_CHILD = """
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from videomorphing_amd import capi, morph
+L = capi.load()
+ctx = morph.Context(0, capi.MATH_EXACT)
+comm = (C.c_void_p * 1)()
+dev = (C.c_int * 1)(0)
+capi.check(L.vm_rccl_comm_init_all(1, dev, comm))
+blk = capi.ParamBlock()
+prm = morph.Parameters()
+prm.w_tps, prm.eps = 0.07, 0.02
+blk.kp = morph.KernParameters(prm)
+blk.max_iter, blk.max_iter_drop_factor, blk.start_res, blk.math_mode = 77.0, 2.0, 24, capi.MATH_FAST
+got = (capi.ParamBlock * 1)()
+hs = (C.c_void_p * 1)(ctx._h)
+capi.check(L.vm_bcast_params(hs, comm, 1, 0, C.byref(blk), got))
+L.vm_rccl_comm_destroy(comm[0])
+assert bytes(got[0]) == bytes(blk)
+kp = capi.KernParams()
+capi.check(L.vm_get_params(ctx._h, C.byref(kp)))
+assert abs(kp.w_tps - 0.07) < 1e-7 and abs(kp.eps - 0.02) < 1e-7
+two = (C.c_int * 2)(0, 0)
+comms2 = (C.c_void_p * 2)()
+assert L.vm_rccl_comm_init_all(2, two, comms2) != capi.VM_OK and "listed twice" in L.vm_last_error().decode()
+ctx.close()
+print("BCAST-OK")
+"""
+
+
 @pytest.mark.gpu
-def test_bcast_params_over_rccl_on_one_device(gpu_ctx):
+def test_bcast_params_over_rccl_on_one_device(tmp_path):
     """vm_rccl_comm_init_all + vm_bcast_params with a real communicator (one rank: this box's one GPU): the block goes
     through ncclBroadcast inside an ncclGroup and the context adopts it; two contexts on one device are refused by
-    vm_rccl_comm_init_all with the pointer to the test mode"""
-    import ctypes as C
-    from videomorphing_amd import morph
-    L = capi.load()
-    ctx = morph.Context(0, capi.MATH_EXACT)
-    comm = (C.c_void_p * 1)()
-    dev = (C.c_int * 1)(0)
-    capi.check(L.vm_rccl_comm_init_all(1, dev, comm))
-    blk = capi.ParamBlock()
-    prm = morph.Parameters()
-    prm.w_tps, prm.eps = 0.07, 0.02
-    blk.kp = morph.KernParameters(prm)
-    blk.max_iter, blk.max_iter_drop_factor, blk.start_res, blk.math_mode = 77.0, 2.0, 24, capi.MATH_FAST
-    got = (capi.ParamBlock * 1)()
-    hs = (C.c_void_p * 1)(ctx._h)
-    capi.check(L.vm_bcast_params(hs, comm, 1, 0, C.byref(blk), got))
-    L.vm_rccl_comm_destroy(comm[0])
-    assert bytes(got[0]) == bytes(blk)
-    kp = capi.KernParams()
-    capi.check(L.vm_get_params(ctx._h, C.byref(kp)))
-    assert abs(kp.w_tps - 0.07) < 1e-7 and abs(kp.eps - 0.02) < 1e-7
-    two = (C.c_int * 2)(0, 0)
-    comms2 = (C.c_void_p * 2)()
-    assert L.vm_rccl_comm_init_all(2, two, comms2) != capi.VM_OK and "listed twice" in L.vm_last_error().decode()
-    ctx.close()
+    vm_rccl_comm_init_all with the pointer to the test mode.  In a child process of its own, like
+    tests/test_gpu_rccl.py: RCCL and the HIP runtime must come from ONE ROCm copy, and the pytest process may already
+    hold torch's (measured: the system's librccl beside torch's HIP runtime aborts at interpreter exit)."""
+    import sys
+    script = tmp_path / "bcast_child.py"
+    script.write_text(_BCAST_CHILD % ROOT)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BCAST-OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

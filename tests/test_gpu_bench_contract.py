@@ -118,6 +118,10 @@ def test_bench_extras_of_round_5():
     pe = d["poisson_extend_1080p_ex192"]
     assert pe["tol_1e-05"]["cg_iterations"] == pe["tol_1e-05_one_side_at_a_time"]["cg_iterations"]
     assert pe["tol_1e-05"]["ms_per_frame"] < pe["tol_1e-05_one_side_at_a_time"]["ms_per_frame"]
+    prf = pe["roofline"]        # the compositor's HBM-bound kernel family has its own roofline entry
+    assert prf["bound"] == "hbm" and prf["unit"] == "GB/s" and abs(prf["frac"] - prf["achieved"] / prf["peak"]) < 1e-3
+    assert prf["unknowns_per_side"] == 2304 * 1464 - 1918 * 1078 and 0.05 < prf["frac"] < 1.0
+    assert prf["traffic"] is None or prf["traffic"] > prf["unknowns_per_side"] * 40 * prf["alg_bytes_per_unknown_iteration"]
 
 
 def test_bench_gpus_2_self_launches_two_ranks():

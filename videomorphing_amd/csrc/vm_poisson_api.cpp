@@ -684,7 +684,11 @@ Rccl &rccl()
     std::lock_guard<std::mutex> lock(mu);
     if (!r.tried) {
         r.tried = true;
-        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        // an RCCL the process already holds first (a host framework's own copy: RCCL and the HIP runtime must come
+        // from ONE ROCm installation), then the system's
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (h) {
             r.bcast = (Rccl::bcast_fn)dlsym(h, "ncclBroadcast");

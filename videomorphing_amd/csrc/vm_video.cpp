@@ -510,11 +510,16 @@ static int ensure_lanes(vm_video *v, int n)
         // Lane 0 always runs the coarsest level in flight -- the chain of launch-bound steps the
         // whole solve waits for -- so its stream gets the highest priority: a finer level's
         // chip-filling dense kernel on another lane must not sit in front of those launches.
+        // VM_LANE_PRIORITY (development): 0 = no priority streams at all, 1 = lane 0 high, the others
+        // plain (default), 2 = graded (lane j at greatest + j: rounds 2-4 -- its low-priority streams take
+        // hardware queues of their own that the runtime does not hand back: see profiles/r05_notes.md 7)
         {
+            static const int mode = getenv("VM_LANE_PRIORITY") ? atoi(getenv("VM_LANE_PRIORITY")) : 1;
             int least = 0, greatest = 0;
             hipStream_t ps = nullptr;
             const int j = (int)v->lanes.size();
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
+            if ((mode == 2 || (mode == 1 && j == 0)) &&
+                hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
                 hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, std::min(greatest + j, least)) == hipSuccess) {
                 (void)hipStreamDestroy(ln.c->stream);
                 ln.c->stream = ps;
@@ -529,6 +534,8 @@ static int ensure_lanes(vm_video *v, int n)
         ln.c->sweep_mode = p->sweep_mode;
         ln.c->sweep_parts = p->sweep_parts;
         ln.c->commit_order = p->commit_order;
+        ln.c->sparse_resident = p->sparse_resident;       // the debug switches too: a hook set on the
+        ln.c->pass_test_timeout = p->pass_test_timeout;   // video's context acts on the lanes that do its work
     }
     return VM_OK;
 }
