@@ -192,7 +192,7 @@ def main():
     # ---- inputs: pyramids resident in HBM before the timed region ----
     def frames(ids):
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(8, max(1, len(ids)))) as ex:   # numpy releases the GIL
+        with ThreadPoolExecutor(max_workers=min(effective_cpus(), 16, max(1, len(ids)))) as ex:   # numpy releases the GIL
             return list(ex.map(lambda f: synth.make_pair(w, h, frame=f), ids))
 
     def pyramid(c, imgs):
@@ -338,8 +338,9 @@ def main():
 def config2_setup(mine, ctxs, frames, pyramid, max_batch):
     """config[2] on one rank: the rank's pairs `mine` as pyramids resident in HBM, in len(ctxs) contiguous
     chunks -- one context (HIP stream + host thread) each --, a chunk solved in even batches of <= max_batch
-    pairs per launch.  8 distinct frames per rank, reused cyclically.  Returns (pyrs, B, nctx, distinct)."""
-    distinct = mine[:8]
+    pairs per launch.  Every pair is its own frame of the synthetic video (rounds 1-4 reused 8 frames cyclically:
+    which of them cycle then set the executed units of the whole job).  Returns (pyrs, B, nctx, distinct)."""
+    distinct = list(mine)
     imgs = frames(distinct)
     nctx = min(len(ctxs), max(1, len(mine)))
     chunk_of = [k * nctx // max(len(mine), 1) for k in range(len(mine))]
@@ -562,7 +563,7 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
         "ms_per_step": round(el_max / steps * 1e3, 2),
         "higher_is_better": True, "scaling": "strong" if config == 2 else "weak", "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic" if config != 2 else "synthetic (%d distinct frames per rank, reused cyclically over its pairs)" % distinct_frames,
+        "data": "synthetic" if config != 2 else "synthetic (%d distinct frames on rank 0: every pair its own frame)" % distinct_frames,
         "config": {"workload": workload_name(config, w, h, nlev, blk, B, args, world, pairs_this_rank),
                    "math_mode": "fast" if blk.math_mode == capi.MATH_FAST else "exact",
                    "semantics": ("every level gets max_iter = 500 sweeps ('500 iters/level'); a level that stops improving needs no more "
