@@ -804,6 +804,14 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         ms = [fr.render_halfway_dev(0.5, 0.1 * k, 1) for k in range(1, 10)]
         render_ms = sum(ms) / len(ms)
         extras["render_frames_per_s"] = round(1000.0 / render_ms, 1)
+        # ... and with a quadratic path in the frame (the renderer then follows u as well: twice the dependent taps); the
+        # figure above is the reference app's state -- its quadratic-path stage is commented out, `_qpath` stays zero
+        qp = (0.25 * synth.displacement(w, h)).astype(np.float32)
+        fr.upload(None, None, None, qp)
+        fr.render_halfway_dev(0.5, 0.5, 1)
+        ms = [fr.render_halfway_dev(0.5, 0.1 * k, 1) for k in range(1, 10)]
+        extras["render_frames_per_s_with_quadratic_path"] = round(1000.0 / (sum(ms) / len(ms)), 1)
+        fr.upload(None, None, None, None)
     # Poisson boundary extension of both sides of that frame (config[4]'s other stage): the two sides as one batch
     # (vm_poisson_extend_frames), and -- for the record of what batching buys -- one side at a time
     if want("poisson"):

@@ -425,6 +425,30 @@ def test_render_identity(gpu_ctx):
     assert np.array_equal(fr.render_halfway(0.0, 0.5, 2), e1[ex:ex + h, ex:ex + w, :3])
 
 
+@pytest.mark.parametrize("geo", [0.0, 0.35, 1.0])
+def test_render_without_a_quadratic_path_equals_a_zero_one(gpu_ctx, oracle, geo):
+    """a frame whose quadratic path was never uploaded or computed (the reference app's state: the stage is commented
+    out, UI/MdiEditor.cpp:1898-1903) is rendered without the 21 taps of u -- a zero path stays zero through the
+    fixed-point steps (render.cu:16-60), so the bytes equal those of an explicit zero path and the oracle's; uploading
+    a path, computing one, and dropping it again switch the form back and forth"""
+    w, h, ex = 150, 90, 15
+    e0, e1, v = _frame_inputs(w, h, ex)
+    zero = np.zeros((h, w, 2), np.float32)
+    u = (0.3 * np.random.RandomState(9).randn(h, w, 2)).astype(np.float32)
+    ref0 = oracle.render_halfway(w, h, ex, 0.4, geo, 1, e0.astype(np.float32), e1.astype(np.float32), v, zero)
+    refu = oracle.render_halfway(w, h, ex, 0.4, geo, 1, e0.astype(np.float32), e1.astype(np.float32), v, u)
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(e0, e1, v, None)
+    assert np.array_equal(fr.render_halfway(0.4, geo, 1), ref0)          # no path: the short form
+    fr.upload(e0, e1, v, zero)
+    assert np.array_equal(fr.render_halfway(0.4, geo, 1), ref0)          # an explicit zero path: the long form, same bytes
+    fr.upload(e0, e1, v, u)
+    assert np.array_equal(fr.render_halfway(0.4, geo, 1), refu)
+    fr.upload(e0, e1, v, None)                                           # dropped again: the buffer is cleared
+    assert np.array_equal(fr.render_halfway(0.4, geo, 1), ref0) and not fr.download_qpath().any()
+    fr.close()
+
+
 def test_poisson_extend(gpu_ctx, oracle):
     """classification + fill are byte-identical to the oracle; the solved colours
     agree within +-1 level (both solvers truncate a float solution to integers) on

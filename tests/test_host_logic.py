@@ -183,7 +183,7 @@ def test_bench_config2_chunks_and_batches():
         ctxs = [Ctx() for _ in range(nctx_in)]
         pyrs, B, nctx, distinct = bench.config2_setup(list(range(100, 100 + npairs)), ctxs, frames, lambda c, img: Pyr(c, img), max_batch)
         assert (B, nctx) == (want_B, want_nctx), (npairs, nctx_in, max_batch, B, nctx)
-        assert len(pyrs) == npairs and distinct == min(npairs, 8)
+        assert len(pyrs) == npairs and distinct == npairs        # every pair its own frame (rounds 1-4: 8 reused cyclically)
         owners = [ctxs.index(p._ctx) for p in pyrs]
         assert owners == sorted(owners) and set(owners) == set(range(nctx))            # contiguous chunks, every context used
         assert max(owners.count(k) for k in range(nctx)) - min(owners.count(k) for k in range(nctx)) <= 1

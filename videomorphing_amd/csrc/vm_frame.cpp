@@ -67,7 +67,8 @@ extern "C" int vm_frame_upload(vm_frame *f, const uint8_t *e0, const uint8_t *e1
         }
     if (v) VM_HIP(hipMemcpy2DAsync(f->v, (size_t)f->rs * 8, v, (size_t)f->w * 8, (size_t)f->w * 8, f->h, hipMemcpyHostToDevice, s));
     if (q) VM_HIP(hipMemcpy2DAsync(f->u, (size_t)f->rs * 8, q, (size_t)f->w * 8, (size_t)f->w * 8, f->h, hipMemcpyHostToDevice, s));
-    else VM_HIP(hipMemsetAsync(f->u, 0, (size_t)f->rs * f->h * 8, s));
+    else if (!f->u_zero) VM_HIP(hipMemsetAsync(f->u, 0, (size_t)f->rs * f->h * 8, s));
+    f->u_zero = q == nullptr;
     VM_HIP(hipStreamSynchronize(s));
     return VM_OK;
 }
@@ -147,7 +148,7 @@ static int render_dev(vm_frame *f, float color_fa, float geo_fa, int color_from,
     VM_ON_DEVICE(c);
     if (ms) VM_HIP(hipEventRecord(c->ev0, c->stream));
     vm_launch_render(f->out, f->w * 3, f->w, f->h, f->rs, f->ex, color_fa, geo_fa, color_from,
-                     f->ext[0], f->ext[1], f->v, f->u, c->stream);
+                     f->ext[0], f->ext[1], f->v, f->u_zero ? nullptr : f->u, c->stream);
     VM_HIP(hipGetLastError());
     if (ms) {
         VM_HIP(hipEventRecord(c->ev1, c->stream));

@@ -176,6 +176,9 @@ struct vm_frame {
     uchar4 *ext[2] = {nullptr, nullptr};  // (w+2ex) x (h+2ex) RGBA8 canvases
     uchar4 *crop[2] = {nullptr, nullptr}; // w x h originals (CPoissonExt::_image1/_image2, PoissonExt.cpp:26-27)
     float2 *v = nullptr, *u = nullptr;    // h x rs
+    bool u_zero = true;                   // the quadratic path is all zeros (never uploaded / computed: the reference app's
+                                          // state, UI/MdiEditor.cpp:1898-1903): vm_render_halfway then skips its 21 taps of u --
+                                          // a zero path stays zero through the fixed-point steps, the bytes are the same
     uint8_t *out = nullptr;               // h x w x 3
     // Poisson workspace (allocated on first use): pws = the quadratic path's and the A/B solvers', pws2[side - 1] =
     // one per side for the batched solver (both sides of a frame are in flight together)

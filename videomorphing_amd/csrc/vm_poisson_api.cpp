@@ -625,6 +625,7 @@ extern "C" int vm_frame_quadratic_path(vm_frame *f, float tol, int max_it, int *
     VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
     vm_qpath_launch_sum(H.X, f->w, f->h, sums, s);
     vm_qpath_launch_shift(H.X, f->w, f->h, sums, f->u, f->rs, s);
+    f->u_zero = false;
     VM_HIP(hipGetLastError());
     VM_HIP(hipEventRecord(c->ev1, s));
     VM_HIP(hipEventSynchronize(c->ev1));
