@@ -887,9 +887,8 @@ struct PassToken {
             // succeeds.  Create it only if it is not there (world-readable is all flock() needs).
             d->fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
             if (d->fd < 0 && errno == ENOENT) {
-                const mode_t um = umask(0);
                 d->fd = open(path.c_str(), O_RDONLY | O_CREAT | O_CLOEXEC, 0666);
-                umask(um);
+                if (d->fd >= 0) (void)fchmod(d->fd, 0666); // readable by every user of the device whatever this process' umask
             }
             if (d->fd < 0) {
                 // no lock file: exclusivity across processes cannot be had.  Refuse PASS rather than run it on a
