@@ -32,6 +32,15 @@ static int vm_step_max_tiles()
 #ifndef VM_SPARSE_TILES
 #define VM_SPARSE_TILES 12 // SPARSE takes a pruned level over once <= this many tiles per iteration were active
 #endif
+// AUTO: STEP / PASS while the previous batch searched at least this many pixels per iteration and pair (below it the
+// pruned TILE kernel or SPARSE take over); VM_STEP_MIN_CAND overrides (dev switch)
+static double vm_step_min_cand()
+{
+    static const char *e = getenv("VM_STEP_MIN_CAND");
+    static const double v = e ? atof(e) : 200.0;
+    return v;
+}
+
 static int vm_sparse_tiles()
 {
     static const char *e = getenv("VM_SPARSE_TILES"); // dev switch
@@ -1164,7 +1173,7 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
     while (done < cap) {
         const int nb = std::min(batch, cap - done);
         const bool split = c->sweep_mode == VM_SWEEP_SPLIT || c->sweep_mode == VM_SWEEP_STEP || c->sweep_mode == VM_SWEEP_PASS ||
-                           (may_split && cand_prev >= 200.0 * n);
+                           (may_split && cand_prev >= vm_step_min_cand() * n);
         // one launch per pass (PASS) where it is admitted, else one per phase (STEP), unless
         // the two-kernel SPLIT is forced
         const bool pass = split && may_pass;
