@@ -483,9 +483,9 @@ static int poisson_solve_batch(vm_ctx *c, vm_frame *const *frames, const int *si
                     saved[i] = 1;
                 }
             } else {
-                ++stale[i];
+                stale[i] = it - best_it[i];      // iterations since the best residual seen
             }
-            if (worst <= tol || it >= max_it || stale[i] >= 3 || worst > 1e3 * best[i]) {
+            if (worst <= tol || it >= max_it || stale[i] >= 12 || worst > 1e3 * best[i]) {
                 active &= ~(1ull << i);
                 if (saved[i] && best_it[i] != it)
                     VM_HIP(hipMemcpyAsync(W[i].S.X, W[i].Xbest, N0 * sizeof(VmV3), hipMemcpyDeviceToDevice, s));
