@@ -7,7 +7,9 @@
 
 namespace {
 
+#ifndef MGB_G
 #define MGB_G 4 // list entries per workgroup in the kernels that end in dot products (their atomics per byte / 4)
+#endif
 
 __device__ __forceinline__ float4 f4_axpy(float a, float4 x, float4 y) // a x + y
 {
@@ -212,6 +214,22 @@ __device__ __forceinline__ double slot_sum(const double (*a)[16], int c)
     return s;
 }
 
+// the three channel sums of two accumulators for the whole workgroup: six threads add the slots up (one round trip),
+// everybody reads the results from LDS -- instead of 48 loads issued by every thread of every workgroup
+__device__ __forceinline__ void slot_sums2(const double (*a)[16], const double (*b)[16], double *sa, double *sb)
+{
+    __shared__ double sh[6];
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    if (tid < 6)
+        sh[tid] = slot_sum(tid < 3 ? a : b, tid % 3);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        sa[c] = sh[c];
+        sb[c] = sh[3 + c];
+    }
+}
+
 __device__ __forceinline__ void slot_clear(double (*a)[16])
 {
     const int tid = threadIdx.y * blockDim.x + threadIdx.x;
@@ -377,11 +395,11 @@ __global__ __launch_bounds__(256) void k_mgb_dirspmv(const VmMgbSys *__restrict_
         slot_clear(S.sc->rr[par]);
     float be[3] = {0, 0, 0};
     if (!FIRST) {
+        double cur[3], prev[3];
+        slot_sums2(S.sc->rz[par], S.sc->rz[par ^ 1], cur, prev);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double prev = slot_sum(S.sc->rz[par ^ 1], c);
-            be[c] = prev > 0 ? (float)(slot_sum(S.sc->rz[par], c) / prev) : 0.0f;
-        }
+        for (int c = 0; c < 3; ++c)
+            be[c] = prev[c] > 0 ? (float)(cur[c] / prev[c]) : 0.0f;
     }
     const VmV3 *__restrict__ Z = L.x;
     const VmV3 *__restrict__ Po = S.P[par ^ 1];
@@ -427,10 +445,12 @@ __global__ __launch_bounds__(256) void k_mgb_update(const VmMgbSys *__restrict__
         slot_clear(S.sc->pq[par ^ 1]);
     }
     float al[3];
+    {
+        double rz[3], pq[3];
+        slot_sums2(S.sc->rz[par], S.sc->pq[par], rz, pq);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double pq = slot_sum(S.sc->pq[par], c);
-        al[c] = pq > 0 ? (float)(slot_sum(S.sc->rz[par], c) / pq) : 0.0f;
+        for (int c = 0; c < 3; ++c)
+            al[c] = pq[c] > 0 ? (float)(rz[c] / pq[c]) : 0.0f;
     }
     const VmV3 *__restrict__ P = S.P[par], *__restrict__ Q = S.Q;
     VmV3 *X = S.X, *R = L.b;
