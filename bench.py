@@ -52,7 +52,7 @@ FLOP_PER_EVAL = 25 * 45 + 2 * 30  # 25 ssim() of ~45 flop-eq + 2
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_FLOPS = 157e12         # MI355X_MICROARCH.md: f32 vector peak
 POISSON_ALG_BYTES = 190.0        # algorithmic bytes per unknown and PCG iteration of the Poisson solver
-POISSON_PMC_BYTES_PER_SYSTEM_ITERATION = 14235337989 / 40.0   # profiles/r05_compositor_pmc_summary.csv: one 1080p frame, both sides, 20 + 20 iterations
+POISSON_PMC_BYTES_PER_SYSTEM_ITERATION = 12218022348 / 34.0   # profiles/r05_compositor_pmc_summary.csv: one 1080p frame, both sides, 17 + 17 iterations
 SCHED = ("k_optimize<true> (TILE schedule, dense kernel)", "k_optimize<false> (TILE schedule, lean kernel for pruned sweeps)",
          "k_step (STEP schedule, one launch per phase)",
          "k_sparse (SPARSE schedule: one launch per batch of iterations of a pruned level)",
@@ -832,11 +832,11 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         alg = unknowns * sum(its) * POISSON_ALG_BYTES
         gbs = alg / (pe["tol_1e-05"]["ms_per_frame"] * 1e-3) / 1e9
         pe["roofline"] = {"bound": "hbm", "kernel": "multigrid-PCG solve of both sides as one batch (13 launches per iteration; dominant kernel "
-                                                     "k_mgb_dirspmv, 0.33 of peak by itself: profiles/r05_compositor_*)",
+                                                     "k_mgb_dirspmv, 0.41 of peak by itself: profiles/r05_compositor_*)",
                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                           "traffic": round(POISSON_PMC_BYTES_PER_SYSTEM_ITERATION * sum(its)) if (w, h, ex) == (1920, 1080, 192) else None,
                           "traffic_source": "profiles/r05_compositor_pmc_summary.csv: sum over the k_mgb_* kernels of one frame (both sides, "
-                                            "20 + 20 iterations) / 40, x this run's iterations; FETCH_SIZE doubled per the gfx950 note",
+                                            "17 + 17 iterations) / 34, x this run's iterations; FETCH_SIZE doubled per the gfx950 note",
                           "alg_bytes_per_unknown_iteration": POISSON_ALG_BYTES, "unknowns_per_side": unknowns}
         extras["poisson_extend_1080p_ex%d" % ex] = pe
     # quadratic motion path of that frame (QuadraticPath.cpp), SURVEY 8(f) rank 4
