@@ -192,7 +192,8 @@ def main():
     # ---- inputs: pyramids resident in HBM before the timed region ----
     def frames(ids):
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(effective_cpus(), 16, max(1, len(ids)))) as ex:   # numpy releases the GIL
+        # (the ranks of one node share its cores: each takes its share)
+        with ThreadPoolExecutor(max_workers=max(1, min(effective_cpus() // max(world, 1), 16, len(ids)))) as ex:   # numpy releases the GIL
             return list(ex.map(lambda f: synth.make_pair(w, h, frame=f), ids))
 
     def pyramid(c, imgs):
