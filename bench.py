@@ -914,28 +914,43 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
 
 def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, base_frames, e0, e1, ex, render_ms, nframes=30, per_batch=4):
     """config[4] on one GPU (see run_extras): returns the extras entry"""
+    from concurrent.futures import ThreadPoolExecutor
     cons = synth.make_constraints(w, h, 8)
     prm = morph.Parameters()
     prm.max_iter, prm.max_iter_drop_factor, prm.start_res, prm.bcond = int(blk.max_iter), blk.max_iter_drop_factor, blk.start_res, capi.BCOND_BORDER
     for c in cons:
         prm.add_point_pair(*c[:4], weight=float(c[4]))
-    ctx.set_params(morph.KernParameters(prm))
-    ca, nc = morph._cons_array(cons)
+    # the solve the way config[2] runs a rank's share: default_streams() contexts (streams, one host thread each), the
+    # frames in contiguous chunks, a chunk as one batch; the compositor then reads the fields from the solver contexts'
+    # pyramids (same device: vm_frame_set_v_from_level drains the solver's stream first)
+    nstreams = default_streams(nframes)
+    sctx = [morph.Context(ctx.device, blk.math_mode) for _ in range(nstreams)]
+    for c in sctx:
+        c.set_params(morph.KernParameters(prm))
+    chunk_of = [k * nstreams // nframes for k in range(nframes)]
     group = []
     for k in range(nframes):
-        q = morph.Pyramid(ctx)
+        q = morph.Pyramid(sctx[chunk_of[k]])
         q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
         group.append(q)
+    chunks = [[q for q, cix in zip(group, chunk_of) if cix == s] for s in range(nstreams)]
     frs = [morph.Frame(ctx, w, h, ex) for _ in range(per_batch)]
     e0, e1 = morph.pin_host(e0), morph.pin_host(e1)        # the caller's frame buffers, page-locked (vm_host_register)
     for f in frs:                                           # workspaces
         f.upload(e0, e1, None, None)
         f.set_v_from_level(group[0], 1)
     morph.poisson_extend_frames(frs, tol=1e-3)
+    solve_chunk = lambda ch: morph.solve_batch(ch, blk.max_iter, blk.max_iter_drop_factor, fixed_work=False, constraints=cons)
+    with ThreadPoolExecutor(max_workers=nstreams) as ex_:   # warm-up: schedule workspaces, graphs
+        list(ex_.map(solve_chunk, chunks))
+    for c in sctx:
+        c.sync()
     ctx.sync(); t1 = time.perf_counter()
-    for g0 in range(0, nframes, 15):
-        morph.solve_batch(group[g0:g0 + 15], blk.max_iter, blk.max_iter_drop_factor, fixed_work=False, constraints=cons)
-    ctx.sync(); t_solve = time.perf_counter() - t1
+    with ThreadPoolExecutor(max_workers=nstreams) as ex_:
+        list(ex_.map(solve_chunk, chunks))
+    for c in sctx:
+        c.sync()
+    t_solve = time.perf_counter() - t1
     t_up = t_po = t_re = 0.0
     its = []
     for g0 in range(0, nframes, per_batch):
@@ -958,11 +973,15 @@ def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, base_frames, e0, e1
         f.close()
     for q in group:
         q.clear()
+    per_chunk = len(chunks[0])
+    del group, chunks
+    for c in sctx:
+        c.close()
     morph.unpin_host(e0); morph.unpin_host(e1)
     comp = (t_up + t_po + t_re) / nframes * 1e3
-    return {"workload": "config[4] on one GPU: %d 1080p pairs, 8 point constraints each, BCOND_BORDER, solved in 2 batches of 15 (reference "
+    return {"workload": "config[4] on one GPU: %d 1080p pairs, 8 point constraints each, BCOND_BORDER, solved on %d streams x one batch of %d (reference "
                         "semantics); per frame: canvases uploaded from page-locked host memory (PCIe), v upscaled on the device, Poisson extension (ex = %d, tol 1e-5) of "
-                        "both sides, %d frames = %d systems per batch; 9 rendered in-between frames per pair" % (nframes, ex, per_batch, 2 * per_batch),
+                        "both sides, %d frames = %d systems per batch; 9 rendered in-between frames per pair" % (nframes, nstreams, per_chunk, ex, per_batch, 2 * per_batch),
             "ms_per_pair": round(dt * 1e3 / nframes, 1), "solve_ms_per_pair": round(t_solve * 1e3 / nframes, 1),
             "compositor_ms_per_frame": round(comp, 2),
             "compositor_split_ms_per_frame": {"upload_pcie_and_v_upscale": round(t_up / nframes * 1e3, 2), "poisson_both_sides": round(t_po / nframes * 1e3, 2),

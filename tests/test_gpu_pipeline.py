@@ -171,3 +171,27 @@ def test_poisson_batch_refuses_mixed_frames(gpu_ctx):
         morph.poisson_extend_frames([a, a])
     a.close()
     b.close()
+
+
+def test_frame_takes_its_field_from_a_pyramid_of_another_context(gpu_ctx):
+    """vm_frame_set_v_from_level across two contexts of ONE device (a solver stream beside the compositor's, as
+    bench.py's config[4] pipeline runs them): the field equals the one taken from a pyramid of the frame's own context"""
+    w, h = 160, 110
+    i0, i1 = synth.make_pair(w, h)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 12, 1.0, 32
+    other = morph.Context(0, capi.MATH_EXACT)
+    fields = []
+    for c in (gpu_ctx, other):
+        c.set_math_mode(capi.MATH_EXACT)
+        c.set_params(morph.KernParameters(prm))
+        pyr = morph.Pyramid(c)
+        pyr.build(i0, i1, 32)
+        morph.solve_batch([pyr], 12, 1.0)
+        fr = morph.Frame(gpu_ctx, w, h, 8)
+        fr.set_v_from_level(pyr, 1)
+        fields.append(fr.download_v())
+        fr.close()
+        pyr.clear()
+    other.close()
+    assert np.array_equal(fields[0].view(np.uint32), fields[1].view(np.uint32)) and np.abs(fields[0]).max() > 0.1

@@ -110,9 +110,13 @@ extern "C" int vm_frame_set_v_from_level(vm_frame *f, vm_pyr *p, int lvl)
 {
     if (!f || !p || lvl < 0 || lvl >= (int)p->lv.size())
         return vm_fail(VM_E_INVALID, "vm_frame_set_v_from_level: bad argument");
-    if (p->ctx != f->ctx) return vm_fail(VM_E_INVALID, "frame and pyramid belong to different contexts");
-    if (!vm_ctx_alive(f->ctx)) return vm_fail(VM_E_INVALID, "%s: the context was destroyed", __func__);
+    if (!vm_ctx_alive(f->ctx) || !vm_ctx_alive(p->ctx)) return vm_fail(VM_E_INVALID, "%s: a context was destroyed", __func__);
+    // a pyramid solved on ANOTHER context of the same device (a solver stream beside the compositor's): its stream is
+    // drained first, then the field is read on the frame's stream; another device is refused
+    if (p->ctx != f->ctx && p->ctx->device != f->ctx->device)
+        return vm_fail(VM_E_INVALID, "frame and pyramid live on different devices (%d, %d)", f->ctx->device, p->ctx->device);
     VM_ON_DEVICE(f->ctx);
+    if (p->ctx != f->ctx) VM_HIP(hipStreamSynchronize(p->ctx->stream));
     vm_level &l = p->lv[lvl];
     vm_launch_upscale(f->v, f->w, f->h, f->rs, l.view.v, l.w, l.h, l.rs, f->ctx->stream);
     VM_HIP(hipGetLastError());

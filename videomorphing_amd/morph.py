@@ -90,6 +90,7 @@ class Context(object):
         h = C.c_void_p()
         capi.check(self._L.vm_ctx_create(int(device), C.byref(h)))
         self._h = h
+        self.device = int(device)
         self.set_math_mode(math_mode)
 
     def close(self):
