@@ -195,3 +195,20 @@ def test_frame_takes_its_field_from_a_pyramid_of_another_context(gpu_ctx):
         pyr.clear()
     other.close()
     assert np.array_equal(fields[0].view(np.uint32), fields[1].view(np.uint32)) and np.abs(fields[0]).max() > 0.1
+
+
+def test_upload_from_page_locked_host_memory(gpu_ctx):
+    """vm_host_register / vm_host_unregister: canvases uploaded from a page-locked buffer arrive unchanged; registering
+    twice and unregistering what was never registered are not errors"""
+    w, h, ex = 96, 64, 10
+    e0, e1, v = _frame_pair(w, h, ex, 2)
+    p0 = morph.pin_host(e0)
+    morph.pin_host(p0)                                   # already registered: fine
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(p0, e1, v, None)
+    assert np.array_equal(fr.download_ext(1), e0) and np.array_equal(fr.download_ext(2), e1)
+    morph.unpin_host(p0)
+    morph.unpin_host(np.zeros(16, np.uint8))             # never registered: fine
+    with pytest.raises(capi.VmError):
+        capi.check(capi.load().vm_host_register(None, 16))
+    fr.close()
