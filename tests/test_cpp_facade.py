@@ -227,6 +227,33 @@ def test_cpp_multi_device_driver_matches_python(solve_shard, gpu_ctx, tmp_path):
     assert np.abs(v_cpp).max() > 0.1
 
 
+@pytest.mark.gpu
+def test_cpp_driver_over_rccl_with_one_rank(solve_shard, gpu_ctx, tmp_path):
+    """the same driver WITHOUT the one-device switch and G = 1: ncclCommInitAll over this box's one device, the parameter
+    block through ncclBroadcast inside an ncclGroup (vm_bcast_params' production route), then the shard -- the fields
+    equal the Python path's, and the process exits cleanly with RCCL loaded"""
+    from videomorphing_amd import morph
+    w, h, N = 120, 80, 2
+    frames = [synth.make_pair(w, h, frame=k, amp=0.5 + 0.3 * k) for k in range(N)]
+    np.concatenate([np.stack([a, b]).ravel() for a, b in frames]).astype(np.float32).tofile(str(tmp_path / "fr.f32"))
+    out = tmp_path / "v.f32"
+    r = subprocess.run([solve_shard, "1", str(w), str(h), str(N), str(tmp_path / "fr.f32"), str(out), "15", "16", "exact"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    assert "rank 0 on device 0: 2 pairs" in r.stdout and "max_iter 15 start_res 16 math 0" in r.stdout
+    v_cpp = np.fromfile(str(out), np.float32).reshape(N, h, w, 2)
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    prm = morph.Parameters()
+    prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 15, 1.0, 16
+    for k, (i0, i1) in enumerate(frames):
+        pyr = morph.Pyramid(gpu_ctx)
+        pyr.build(i0, i1, 16)
+        t = morph.MatchingThread(prm, pyr)
+        t.start()
+        t.wait()
+        assert np.array_equal(v_cpp[k].view(np.uint32), pyr._vector[0].view(np.uint32)), k
+
+
 _BCAST_CHILD = """
 import ctypes as C, sys
 sys.path.insert(0, %r)

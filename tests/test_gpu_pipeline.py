@@ -212,3 +212,34 @@ def test_upload_from_page_locked_host_memory(gpu_ctx):
     with pytest.raises(capi.VmError):
         capi.check(capi.load().vm_host_register(None, 16))
     fr.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_poisson_on_random_outside_regions(gpu_ctx, oracle, seed):
+    """fuzz of the batched solver's geometry handling: canvases whose outside region (alpha > 0) is the frame border plus
+    random rectangles and single pixels punched into BOTH images (scattered unknowns, blocks with one unknown, coarse
+    cells without any) -- both sides in one batch agree with the oracle's CG within one colour level"""
+    rng = np.random.RandomState(seed)
+    w, h, ex = 140 + 7 * (seed % 3), 72 + 5 * (seed % 2), 9 + seed % 4
+    e0, e1, v = _frame_pair(w, h, ex, seed)
+    e0, e1 = e0.copy(), e1.copy()
+    for e in (e0, e1):
+        for _ in range(6):
+            rw, rh = rng.randint(1, 24), rng.randint(1, 12)
+            x0, y0 = rng.randint(0, w - rw), rng.randint(0, h - rh)
+            e[ex + y0:ex + y0 + rh, ex + x0:ex + x0 + rw, 3] = 255
+        for _ in range(10):
+            e[ex + rng.randint(0, h), ex + rng.randint(0, w), 3] = 255
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(e0, e1, v, None)
+    refs = {}
+    for side, ext, other in ((1, e0, e1), (2, e1, e0)):
+        refs[side], _, _ = oracle.poisson_extend(ext, w, h, ex, other[ex:ex + h, ex:ex + w].copy(), v, side, tol=1e-9)
+    (i1, rr1), (i2, rr2), _ = fr.poisson_extend_both(tol=1e-6)
+    assert i1 > 0 and i2 > 0 and rr1 <= 1e-6 and rr2 <= 1e-6
+    for side in (1, 2):
+        out = fr.download_ext(side)
+        assert out[..., 3].max() == 0
+        d = np.abs(out[..., :3].astype(int) - refs[side][..., :3].astype(int))
+        assert d.max() <= 1, (side, d.max(), (d > 0).mean())
+    fr.close()
