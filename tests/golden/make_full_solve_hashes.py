@@ -12,7 +12,10 @@ container, minutes per 1080p solve on 8 cores, tens of minutes for 4K); the GPU 
 test_full_solve_exact_matches_oracle_hashes then needs seconds per solve on the GPU box instead of the
 5-12 minutes the oracle takes there.
 
-usage: python tests/golden/make_full_solve_hashes.py [--only 1080p|4k] [--frames 0,1,...]   (merges into the JSON)
+  --tex8: the same solve with the oracle's texture fetches filtered like CUDA's (vmo_set_tex_filter(1): 8-bit bilinear
+          weights, rounded) -- the fixture of the HIP path's VM_MATH_REF_TEX8 build at full size (key "<case>/frame<k>/tex8").
+
+usage: python tests/golden/make_full_solve_hashes.py [--only 1080p|4k] [--frames 0,1,...] [--tex8]   (merges into the JSON)
 """
 import json
 import os
@@ -37,6 +40,8 @@ def main():
     args = sys.argv[1:]
     only = args[args.index("--only") + 1] if "--only" in args else None
     frames_arg = [int(x) for x in args[args.index("--frames") + 1].split(",")] if "--frames" in args else None
+    tex8 = "--tex8" in args
+    oracle.lib().vmo_set_tex_filter(1 if tex8 else 0)
     try:
         doc = json.load(open(OUT))
     except Exception:
@@ -48,12 +53,12 @@ def main():
         if only and name != only:
             continue
         for f in (frames_arg or frames):
-            key = "%s/frame%d" % (name, f)
+            key = "%s/frame%d%s" % (name, f, "/tex8" if tex8 else "")
             i0, i1 = synth.make_pair(w, h, frame=f)
             t0 = time.time()
             per = []
             lo = oracle.solve(synth.build_pyramid(i0, i1, nlev), oracle.default_params(), 500, 1.0, threads=threads, per_level=per)
-            doc["solves"][key] = {"size": [w, h], "levels": nlev, "frame": f, "inputs": FH.input_hash(i0, i1),
+            doc["solves"][key] = {"size": [w, h], "levels": nlev, "frame": f, "tex_filter": 1 if tex8 else 0, "inputs": FH.input_hash(i0, i1),
                                   "iters_coarse_to_fine": [int(p[1]) for p in per],
                                   "max_abs_v": float(np.abs(lo.field("v")).max()),
                                   "sha256": FH.state_hashes(lo), "oracle_s": round(time.time() - t0, 1), "oracle_threads": threads}

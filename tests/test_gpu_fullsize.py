@@ -114,9 +114,14 @@ def test_full_solve_exact_matches_oracle_hashes(gpu_ctx, key, fix):
             pytest.skip("this host's numpy generates other synthetic inputs than the fixture's; the 4K oracle run takes minutes")
         import oracle as O
         per = []
-        lo = O.solve(synth.build_pyramid(i0, i1, nlev), O.default_params(), 500, 1.0, threads=_all_cpus(), per_level=per)
+        O.lib().vmo_set_tex_filter(fix.get("tex_filter", 0))
+        try:
+            lo = O.solve(synth.build_pyramid(i0, i1, nlev), O.default_params(), 500, 1.0, threads=_all_cpus(), per_level=per)
+        finally:
+            O.lib().vmo_set_tex_filter(0)
         want_iters, want = [int(p[1]) for p in per], FH.state_hashes(lo)
-    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    # (a "/tex8" case: the oracle solved it with CUDA's 8-bit texture filter weights -- the HIP path's VM_MATH_REF_TEX8 build)
+    gpu_ctx.set_math_mode(capi.MATH_REF_TEX8 if fix.get("tex_filter", 0) else capi.MATH_EXACT)
     prm = morph.Parameters()
     prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 500, 1.0, 32
     gpu_ctx.set_params(morph.KernParameters(prm))
@@ -130,6 +135,7 @@ def test_full_solve_exact_matches_oracle_hashes(gpu_ctx, key, fix):
     assert got == want, {f: (got[f] == want[f]) for f in want}
     assert abs(float(np.abs(pyr[1].v).max()) - fix["max_abs_v"]) < 1e-6 or FH.input_hash(i0, i1) != fix["inputs"]
     pyr.clear()
+    gpu_ctx.set_math_mode(capi.MATH_EXACT)
 
 
 def test_dense_sweep_exact_4k(gpu_ctx, oracle):
