@@ -458,9 +458,9 @@ __device__ __forceinline__ void qp_jopt(const float2 *__restrict__ v, int rs, in
     jo[0] = nj[0] * la; jo[2] = nj[2] * la; jo[1] = nj[1] * lb; jo[3] = nj[3] * lb;
 }
 
-// right-hand sides, :137-170, both channels in one float4 (bx, by, 0, 0); X = 0
-__global__ __launch_bounds__(256) void k_qp_rhs(const float2 *__restrict__ v, int rs, int w, int h, float4 *B,
-                                                float4 *X)
+// right-hand sides, :137-170, both channels in one vector (bx, by, 0[, 0]); X = 0
+template <class V>
+__global__ __launch_bounds__(256) void k_qp_rhs(const float2 *__restrict__ v, int rs, int w, int h, V *B, V *X)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h)
@@ -473,16 +473,17 @@ __global__ __launch_bounds__(256) void k_qp_rhs(const float2 *__restrict__ v, in
     if (x + 1 < w) { qp_jopt(v, rs, x + 1, y, je); bx -= je[0] - 1.0f; by -= je[2]; }
     if (y + 1 < h) { qp_jopt(v, rs, x, y + 1, js); bx -= js[1]; by -= js[3] - 1.0f; }
     const size_t ii = (size_t)y * w + x;
-    B[ii] = make_float4(bx, by, 0, 0);
-    X[ii] = make_float4(0, 0, 0, 0);
+    put_vec(B, ii, make_float4(bx, by, 0, 0));
+    put_vec(X, ii, make_float4(0, 0, 0, 0));
 }
 
-__global__ __launch_bounds__(256) void k_qp_sum(const float4 *__restrict__ X, int w, int h, double *dst)
+template <class V>
+__global__ __launch_bounds__(256) void k_qp_sum(const V *__restrict__ X, int w, int h, double *dst)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     double a = 0, b = 0;
     if (x < w && y < h) {
-        const float4 v = X[(size_t)y * w + x];
+        const float4 v = get_vec(X, (size_t)y * w + x);
         a = v.x;
         b = v.y;
     }
@@ -491,21 +492,21 @@ __global__ __launch_bounds__(256) void k_qp_sum(const float4 *__restrict__ X, in
 
 // B -= mean(B) (the float sums leave the right-hand side a hair off the range of the singular
 // operator), or u = X - mean(X) (CG from zero converges to the zero-mean solution)
-__global__ __launch_bounds__(256) void k_qp_shift(float4 *X, int w, int h, const double *__restrict__ sums,
-                                                  float2 *u, int rs)
+template <class V>
+__global__ __launch_bounds__(256) void k_qp_shift(V *X, int w, int h, const double *__restrict__ sums, float2 *u, int rs)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h)
         return;
     const double n = (double)w * h;
     const size_t ii = (size_t)y * w + x;
-    float4 v = X[ii];
+    float4 v = get_vec(X, ii);
     v.x = (float)((double)v.x - sums[0] / n);
     v.y = (float)((double)v.y - sums[1] / n);
     if (u)
         u[(size_t)y * rs + x] = make_float2(v.x, v.y);
     else
-        X[ii] = v;
+        put_vec(X, ii, v);
 }
 
 } // namespace
@@ -574,17 +575,32 @@ void vm_poisson_launch_paste3(uchar4 *ext, const uint8_t *type, const VmV3 *X, i
 
 void vm_qpath_launch_rhs(const float2 *v, int rs, int w, int h, float4 *B, float4 *X, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_qp_rhs, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, v, rs, w, h, B, X);
+    hipLaunchKernelGGL(k_qp_rhs<float4>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, v, rs, w, h, B, X);
+}
+
+void vm_qpath_launch_rhs3(const float2 *v, int rs, int w, int h, VmV3 *B, VmV3 *X, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_qp_rhs<VmV3>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, v, rs, w, h, B, X);
 }
 
 // sums[0..2] += column sums of X (sums must be zeroed by the caller)
 void vm_qpath_launch_sum(const float4 *X, int w, int h, double *sums, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_qp_sum, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums);
+    hipLaunchKernelGGL(k_qp_sum<float4>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums);
+}
+
+void vm_qpath_launch_sum3(const VmV3 *X, int w, int h, double *sums, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_qp_sum<VmV3>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums);
 }
 
 // u == nullptr: X -= mean in place; else u = X - mean
 void vm_qpath_launch_shift(float4 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_qp_shift, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, u, rs);
+    hipLaunchKernelGGL(k_qp_shift<float4>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, u, rs);
+}
+
+void vm_qpath_launch_shift3(VmV3 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_qp_shift<VmV3>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, u, rs);
 }

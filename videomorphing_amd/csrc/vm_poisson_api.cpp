@@ -401,43 +401,38 @@ double mgb_rel(const VmMgbScalars &h, int par)
 
 } // namespace
 
-// Poisson extension of nsys systems (frames[i], sides[i]) of one context and one canvas size as ONE batch
-static int poisson_solve_batch(vm_ctx *c, vm_frame *const *frames, const int *sides, int nsys, float tol, int max_it,
-                               int *iters, double *rels)
+// make sure *ws holds the batched solver's workspace of a w x h system
+static int mgb_reserve(void **ws, size_t *ws_bytes, int w, int h)
+{
+    const size_t need = mgb_bytes(w, h);
+    if (*ws_bytes < need) {
+        hipFree(*ws);
+        *ws = nullptr;
+        *ws_bytes = 0;
+        VM_HIP(hipMalloc(ws, need));
+        *ws_bytes = need;
+    }
+    return VM_OK;
+}
+
+// The batched PCG proper: nsys systems of one size whose workspaces are carved, whose type maps, right-hand sides
+// (lv[0].b) and initial guesses (X) are enqueued on the context's stream.  Leaves every system's solution in its X
+// (the best iterate seen near the tolerance), its iteration count and relative residual in iters / rels.
+static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, int max_it, int *iters, double *rels)
 {
     hipStream_t s = c->stream;
-    const int cw = frames[0]->cw, ch = frames[0]->ch;
-    const size_t N0 = (size_t)cw * ch, need = mgb_bytes(cw, ch);
-    std::vector<MgbWork> W(nsys);
-    for (int i = 0; i < nsys; ++i) {
-        vm_frame *f = frames[i];
-        const int sd = sides[i] - 1;
-        if (f->pws2_bytes[sd] < need) {
-            hipFree(f->pws2[sd]);
-            f->pws2[sd] = nullptr;
-            f->pws2_bytes[sd] = 0;
-            VM_HIP(hipMalloc(&f->pws2[sd], need));
-            f->pws2_bytes[sd] = need;
-        }
-        mgb_carve(W[i], cw, ch, (char *)f->pws2[sd]);
-    }
+    const size_t N0 = (size_t)W[0].S.lv[0].w * W[0].S.lv[0].h;
     if (!c->mgb_sys) VM_HIP(hipMalloc((void **)&c->mgb_sys, VM_MGB_MAXSYS * sizeof(VmMgbSys)));
     VmMgbSys *dev = (VmMgbSys *)c->mgb_sys;
     std::vector<VmMgbSys> hs(nsys);
     for (int i = 0; i < nsys; ++i) hs[i] = W[i].S;
     VM_HIP(hipMemcpyAsync(dev, hs.data(), nsys * sizeof(VmMgbSys), hipMemcpyHostToDevice, s));
     const int nlev = W[0].S.nlev;
-    // classify, fill, right-hand side + initial guess (per system), then the hierarchy and its block lists (batched)
     for (int i = 0; i < nsys; ++i) {
-        vm_frame *f = frames[i];
-        const int side = sides[i];
-        uchar4 *ext = f->ext[side - 1];
-        const uchar4 *other = f->crop[side == 1 ? 1 : 0]; // PoissonExt.cpp:54-57
-        vm_poisson_launch_prepare(ext, W[i].type, other, f->v, f->w, f->h, f->rs, f->ex, side == 1 ? 1 : -1, s);
-        vm_poisson_launch_setup3(ext, W[i].type, W[i].S.lv[0].b, W[i].S.X, cw, ch, s);
         VM_HIP(hipMemsetAsync(W[i].S.sc, 0, sizeof(VmMgbScalars), s));
         if (W[i].xcoarse_bytes) VM_HIP(hipMemsetAsync(W[i].xcoarse, 0, W[i].xcoarse_bytes, s));
     }
+    // the hierarchy and its block lists (batched)
     vm_mgb_launch_level0(dev, nsys, W[0].S.lv[0].gx, W[0].S.lv[0].gy, s);
     for (int l = 1; l < nlev; ++l)
         vm_mgb_launch_coarsen(dev, nsys, l, W[0].S.lv[l].gx, W[0].S.lv[l].gy, s);
@@ -504,10 +499,35 @@ static int poisson_solve_batch(vm_ctx *c, vm_frame *const *frames, const int *si
         VM_HIP(hipGetLastError());
     }
     for (int i = 0; i < nsys; ++i) {
-        vm_poisson_launch_paste3(frames[i]->ext[sides[i] - 1], W[i].type, W[i].S.X, cw, ch, s);
         iters[i] = best_it[i];
         rels[i] = best[i];
     }
+    return VM_OK;
+}
+
+// Poisson extension of nsys systems (frames[i], sides[i]) of one context and one canvas size as ONE batch
+static int poisson_solve_batch(vm_ctx *c, vm_frame *const *frames, const int *sides, int nsys, float tol, int max_it,
+                               int *iters, double *rels)
+{
+    hipStream_t s = c->stream;
+    const int cw = frames[0]->cw, ch = frames[0]->ch;
+    std::vector<MgbWork> W(nsys);
+    // classify, fill, right-hand side + initial guess (per system)
+    for (int i = 0; i < nsys; ++i) {
+        vm_frame *f = frames[i];
+        const int side = sides[i];
+        int rc = mgb_reserve(&f->pws2[side - 1], &f->pws2_bytes[side - 1], cw, ch);
+        if (rc != VM_OK) return rc;
+        mgb_carve(W[i], cw, ch, (char *)f->pws2[side - 1]);
+        uchar4 *ext = f->ext[side - 1];
+        const uchar4 *other = f->crop[side == 1 ? 1 : 0]; // PoissonExt.cpp:54-57
+        vm_poisson_launch_prepare(ext, W[i].type, other, f->v, f->w, f->h, f->rs, f->ex, side == 1 ? 1 : -1, s);
+        vm_poisson_launch_setup3(ext, W[i].type, W[i].S.lv[0].b, W[i].S.X, cw, ch, s);
+    }
+    int rc = mgb_solve(c, W, nsys, tol, max_it, iters, rels);
+    if (rc != VM_OK) return rc;
+    for (int i = 0; i < nsys; ++i)
+        vm_poisson_launch_paste3(frames[i]->ext[sides[i] - 1], W[i].type, W[i].S.X, cw, ch, s);
     VM_HIP(hipGetLastError());
     return VM_OK;
 }
@@ -602,34 +622,59 @@ extern "C" int vm_frame_quadratic_path(vm_frame *f, float tol, int max_it, int *
     VM_ON_DEVICE(c);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipStream_t s = c->stream;
-    const size_t need = mg_bytes(f->w, f->h);
-    if (f->pws_bytes < need) {
-        hipFree(f->pws);
-        f->pws = nullptr;
-        f->pws_bytes = 0;
-        VM_HIP(hipMalloc(&f->pws, need));
-        f->pws_bytes = need;
-    }
-    MgHierarchy H;
-    mg_carve(H, f->w, f->h, (char *)f->pws);
-    VM_HIP(hipEventRecord(c->ev0, s));
-    vm_qpath_launch_rhs(f->v, f->rs, f->w, f->h, H.B, H.X, s);
-    // project the right-hand side onto the range of the singular operator
-    double *sums = H.sc->pq;
-    VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
-    vm_qpath_launch_sum(H.B, f->w, f->h, sums, s);
-    vm_qpath_launch_shift(H.B, f->w, f->h, sums, nullptr, 0, s);
-    vm_mg_launch_level0_full(H.lv[0], s);
-    for (size_t l = 1; l < H.lv.size(); ++l)
-        vm_mg_launch_coarsen(H.lv[l - 1], H.lv[l], s);
-    VM_HIP(hipGetLastError());
+    static const char *solver = getenv("VM_POISSON_SOLVER");
+    static const bool mg1 = solver && !strcmp(solver, "mg1");     // round 4's solver, for A/B runs
     int it = 0;
     double rel = 0;
-    int rc = mg_pcg(c, H, tol, max_it, &it, &rel);
-    if (rc != VM_OK) return rc;
-    VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
-    vm_qpath_launch_sum(H.X, f->w, f->h, sums, s);
-    vm_qpath_launch_shift(H.X, f->w, f->h, sums, f->u, f->rs, s);
+    VM_HIP(hipEventRecord(c->ev0, s));
+    if (mg1) {
+        const size_t need = mg_bytes(f->w, f->h);
+        if (f->pws_bytes < need) {
+            hipFree(f->pws);
+            f->pws = nullptr;
+            f->pws_bytes = 0;
+            VM_HIP(hipMalloc(&f->pws, need));
+            f->pws_bytes = need;
+        }
+        MgHierarchy H;
+        mg_carve(H, f->w, f->h, (char *)f->pws);
+        vm_qpath_launch_rhs(f->v, f->rs, f->w, f->h, H.B, H.X, s);
+        // project the right-hand side onto the range of the singular operator
+        double *sums = H.sc->pq;
+        VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
+        vm_qpath_launch_sum(H.B, f->w, f->h, sums, s);
+        vm_qpath_launch_shift(H.B, f->w, f->h, sums, nullptr, 0, s);
+        vm_mg_launch_level0_full(H.lv[0], s);
+        for (size_t l = 1; l < H.lv.size(); ++l)
+            vm_mg_launch_coarsen(H.lv[l - 1], H.lv[l], s);
+        VM_HIP(hipGetLastError());
+        int rc = mg_pcg(c, H, tol, max_it, &it, &rel);
+        if (rc != VM_OK) return rc;
+        VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
+        vm_qpath_launch_sum(H.X, f->w, f->h, sums, s);
+        vm_qpath_launch_shift(H.X, f->w, f->h, sums, f->u, f->rs, s);
+    } else {
+        // the batched solver on the whole grid: every pixel an unknown without a tie (type 2 everywhere), so the level-0
+        // operator is the graph Laplacian of the pixel grid with Neumann ends (QuadraticPath.cpp:137-170); the
+        // workspace is side 1's of the Poisson extension (the frame is no larger than its canvas, the two run in turn)
+        int rc = mgb_reserve(&f->pws2[0], &f->pws2_bytes[0], std::max(f->w, f->cw), std::max(f->h, f->ch));
+        if (rc != VM_OK) return rc;
+        std::vector<MgbWork> W(1);
+        mgb_carve(W[0], f->w, f->h, (char *)f->pws2[0]);
+        VM_HIP(hipMemsetAsync(W[0].type, 2, (size_t)f->w * f->h, s));
+        vm_qpath_launch_rhs3(f->v, f->rs, f->w, f->h, W[0].S.lv[0].b, W[0].S.X, s);
+        // project the right-hand side onto the range of the singular operator
+        double *sums = &W[0].S.sc->bb[0][0];
+        VM_HIP(hipMemsetAsync(W[0].S.sc, 0, sizeof(VmMgbScalars), s));
+        vm_qpath_launch_sum3(W[0].S.lv[0].b, f->w, f->h, sums, s);
+        vm_qpath_launch_shift3(W[0].S.lv[0].b, f->w, f->h, sums, nullptr, 0, s);
+        VM_HIP(hipGetLastError());
+        rc = mgb_solve(c, W, 1, tol, max_it, &it, &rel);
+        if (rc != VM_OK) return rc;
+        VM_HIP(hipMemsetAsync(W[0].S.sc, 0, sizeof(VmMgbScalars), s));
+        vm_qpath_launch_sum3(W[0].S.X, f->w, f->h, sums, s);
+        vm_qpath_launch_shift3(W[0].S.X, f->w, f->h, sums, f->u, f->rs, s);
+    }
     f->u_zero = false;
     VM_HIP(hipGetLastError());
     VM_HIP(hipEventRecord(c->ev1, s));
