@@ -1,4 +1,6 @@
-"""dev: EXACT sweeps (TILE and SPLIT schedules) == oracle, bitwise, on random sizes / conditions"""
+"""dev: EXACT sweeps (TILE, SPLIT and STEP schedules) == oracle, bitwise, on random sizes / conditions
+
+usage: dev_fuzz_exact.py [seed] [trials] [tex8]   (tex8: the REF_TEX8 build against the oracle with CUDA's filter weights)"""
 import sys, os, ctypes as C
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +9,9 @@ from videomorphing_amd import capi, morph, synth
 import oracle as O
 import test_gpu_parity as T
 
-ctx = morph.Context(0, capi.MATH_EXACT)
+TEX8 = len(sys.argv) > 3 and sys.argv[3] == "tex8"
+O.lib().vmo_set_tex_filter(1 if TEX8 else 0)
+ctx = morph.Context(0, capi.MATH_REF_TEX8 if TEX8 else capi.MATH_EXACT)
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
