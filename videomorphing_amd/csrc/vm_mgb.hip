@@ -162,12 +162,9 @@ template <bool L0> struct PreSmoothed {
     const VmV3 *__restrict__ b;
     __device__ __forceinline__ float4 operator()(size_t q, int = 0, int = 0) const
     {
+        // b is fetched beside k, not behind it (one round trip): level 0's is defined on the whole canvas (0 off the
+        // ring); a coarse cell nobody restricts to holds a stale b, which the select drops
         const float k = op.k(q);
-        if (L0) {           // b is defined on the whole canvas (0 off the ring): fetch it beside the info byte
-            const float4 v = ld3(b, q);
-            return k == 0.0f ? make_float4(0, 0, 0, 0) : make_float4(k * v.x, k * v.y, k * v.z, 0);
-        }
-        // coarse levels: b of a cell nobody restricts to is stale -- fetched all the same (one round trip), dropped by the select
         const float4 v = ld3(b, q);
         return k == 0.0f ? make_float4(0, 0, 0, 0) : make_float4(k * v.x, k * v.y, k * v.z, 0);
     }
