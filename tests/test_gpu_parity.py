@@ -415,6 +415,43 @@ def test_render_exact(gpu_ctx, oracle, color_from, geo, col):
     assert np.array_equal(out, ref), "differing bytes: %d" % (out != ref).sum()
 
 
+@pytest.mark.parametrize("kind", ["rough", "large", "shear", "outside", "nan"])
+@pytest.mark.parametrize("with_path", [False, True])
+def test_render_window_hard_cases(gpu_ctx, oracle, kind, with_path):
+    """the renderer serves its 21 taps of v (and u) from an LDS window placed where a tile's pixels land
+    (k_render_win, vm_render.hip) and falls back to global gathers per tap outside it -- byte-identical to the oracle
+    (render.cu:16-60) also where the window does not help: a rough field (every tap somewhere else), a warp larger than
+    any margin, a shear (the tile's pixels land far from its centre's), taps leaving the image on every side (the
+    clamped staging against tap2's clamps), a frame size that is no multiple of the tile, and non-finite values in
+    the field (the window is placed nowhere useful; no out-of-bounds access, same bytes as the oracle)"""
+    w, h, ex = 203, 77, 9
+    e0, e1, _ = _frame_inputs(w, h, ex)
+    rng = np.random.RandomState(41)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    if kind == "rough":
+        v = (14.0 * rng.randn(h, w, 2)).astype(np.float32)
+    elif kind == "large":
+        v = np.stack([55.0 + 3.0 * np.sin(yy / 7.0), -38.0 + 2.0 * np.cos(xx / 9.0)], -1).astype(np.float32)
+    elif kind == "shear":
+        v = np.stack([0.9 * (yy - h / 2), 0.7 * (xx - w / 2)], -1).astype(np.float32)
+    elif kind == "outside":
+        v = np.stack([0.6 * (xx - w / 2) + 30.0 * np.sign(xx - w / 2), 0.8 * (yy - h / 2) + 20.0 * np.sign(yy - h / 2)], -1).astype(np.float32)
+    else:
+        v = (3.0 * rng.randn(h, w, 2)).astype(np.float32)
+        v[::13, ::11, 0] = np.nan
+        v[5::17, 3::7, 1] = np.inf
+        v[h // 2, w // 2] = (-np.inf, np.nan)      # a tile centre or close to one
+    u = (2.5 * rng.randn(h, w, 2)).astype(np.float32) if with_path else None
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    fr.upload(e0, e1, v, u)
+    uo = u if with_path else np.zeros((h, w, 2), np.float32)
+    for geo in (0.0, 0.2, 0.5, 0.9, 1.0):
+        out = fr.render_halfway(0.3, geo, 1)
+        ref = oracle.render_halfway(w, h, ex, 0.3, geo, 1, e0.astype(np.float32), e1.astype(np.float32), v, uo)
+        assert np.array_equal(out, ref), (kind, with_path, geo, int((out != ref).sum()))
+    fr.close()
+
+
 def test_render_identity(gpu_ctx):
     """KAT 9: v = 0, u = 0 reproduces the original crop / the exact blend"""
     w, h, ex = 64, 48, 6
