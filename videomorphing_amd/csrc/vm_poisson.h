@@ -36,7 +36,8 @@ void vm_poisson_launch_paste3(uchar4 *ext, const uint8_t *type, const VmV3 *X, i
 void vm_qpath_launch_rhs(const float2 *v, int rs, int w, int h, float4 *B, float4 *X, hipStream_t s);
 void vm_qpath_launch_sum(const float4 *X, int w, int h, double *sums, hipStream_t s);
 void vm_qpath_launch_shift(float4 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s);
-// the same on 12-byte vectors (the batched solver's layout, vm_mgb.h)
+// the same on 12-byte vectors (the batched solver's layout, vm_mgb.h); sums: VM_QP_SLOTS lines of 16 doubles
+#define VM_QP_SLOTS 8
 void vm_qpath_launch_rhs3(const float2 *v, int rs, int w, int h, VmV3 *B, VmV3 *X, hipStream_t s);
 void vm_qpath_launch_sum3(const VmV3 *X, int w, int h, double *sums, hipStream_t s);
 void vm_qpath_launch_shift3(VmV3 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s);

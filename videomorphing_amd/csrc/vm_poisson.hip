@@ -16,6 +16,8 @@
 #include "vm_internal.h"
 #include "vm_poisson.h"
 #include "vm_mgb.h"
+#include <algorithm>
+static_assert(VM_QP_SLOTS <= VM_MGB_SLOTS, "the quadratic path parks its sums in the batched solver's bb lines");
 
 namespace {
 
@@ -477,32 +479,44 @@ __global__ __launch_bounds__(256) void k_qp_rhs(const float2 *__restrict__ v, in
     put_vec(X, ii, make_float4(0, 0, 0, 0));
 }
 
+// dst[slot * 16 + {0, 1}] += column sums of X.  Grid-stride over rows of 64-cell segments with a bounded number of
+// workgroups, the atomics spread over `nslots` lines (one workgroup per 64x4 cells adding to ONE address took 99 us
+// on a 1080p field: 8100 same-address double atomics in a row)
 template <class V>
-__global__ __launch_bounds__(256) void k_qp_sum(const V *__restrict__ X, int w, int h, double *dst)
+__global__ __launch_bounds__(256) void k_qp_sum(const V *__restrict__ X, int w, int h, double *dst, int nslots)
 {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int gx = (w + 63) / 64, gy = (h + 3) / 4, nb = gx * gy;
     double a = 0, b = 0;
-    if (x < w && y < h) {
-        const float4 v = get_vec(X, (size_t)y * w + x);
-        a = v.x;
-        b = v.y;
+    for (int blk = blockIdx.x; blk < nb; blk += gridDim.x) {
+        const int x = (blk % gx) * 64 + threadIdx.x, y = (blk / gx) * 4 + threadIdx.y;
+        if (x < w && y < h) {
+            const float4 v = get_vec(X, (size_t)y * w + x);
+            a += v.x;
+            b += v.y;
+        }
     }
-    block_sum3(a, b, 0.0, dst);
+    block_sum3(a, b, 0.0, dst + (size_t)(blockIdx.x % nslots) * 16);
 }
 
 // B -= mean(B) (the float sums leave the right-hand side a hair off the range of the singular
 // operator), or u = X - mean(X) (CG from zero converges to the zero-mean solution)
 template <class V>
-__global__ __launch_bounds__(256) void k_qp_shift(V *X, int w, int h, const double *__restrict__ sums, float2 *u, int rs)
+__global__ __launch_bounds__(256) void k_qp_shift(V *X, int w, int h, const double *__restrict__ sums, int nslots, float2 *u,
+                                                  int rs)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h)
         return;
+    double s0 = 0, s1 = 0;
+    for (int k = 0; k < nslots; ++k) {
+        s0 += sums[k * 16];
+        s1 += sums[k * 16 + 1];
+    }
     const double n = (double)w * h;
     const size_t ii = (size_t)y * w + x;
     float4 v = get_vec(X, ii);
-    v.x = (float)((double)v.x - sums[0] / n);
-    v.y = (float)((double)v.y - sums[1] / n);
+    v.x = (float)((double)v.x - s0 / n);
+    v.y = (float)((double)v.y - s1 / n);
     if (u)
         u[(size_t)y * rs + x] = make_float2(v.x, v.y);
     else
@@ -583,24 +597,30 @@ void vm_qpath_launch_rhs3(const float2 *v, int rs, int w, int h, VmV3 *B, VmV3 *
     hipLaunchKernelGGL(k_qp_rhs<VmV3>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, v, rs, w, h, B, X);
 }
 
-// sums[0..2] += column sums of X (sums must be zeroed by the caller)
-void vm_qpath_launch_sum(const float4 *X, int w, int h, double *sums, hipStream_t s)
+// sums[0..1] += column sums of X (sums must be zeroed by the caller)
+static inline dim3 sum_grid(int w, int h)
 {
-    hipLaunchKernelGGL(k_qp_sum<float4>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums);
+    return dim3(std::min(((w + 63) / 64) * ((h + 3) / 4), 1024));
 }
 
+void vm_qpath_launch_sum(const float4 *X, int w, int h, double *sums, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_qp_sum<float4>, sum_grid(w, h), dim3(64, 4), 0, s, X, w, h, sums, 1);
+}
+
+// ... spread over VM_QP_SLOTS lines of 16 doubles (the batched solver's scalar block has room for 8)
 void vm_qpath_launch_sum3(const VmV3 *X, int w, int h, double *sums, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_qp_sum<VmV3>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums);
+    hipLaunchKernelGGL(k_qp_sum<VmV3>, sum_grid(w, h), dim3(64, 4), 0, s, X, w, h, sums, VM_QP_SLOTS);
 }
 
 // u == nullptr: X -= mean in place; else u = X - mean
 void vm_qpath_launch_shift(float4 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_qp_shift<float4>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, u, rs);
+    hipLaunchKernelGGL(k_qp_shift<float4>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, 1, u, rs);
 }
 
 void vm_qpath_launch_shift3(VmV3 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_qp_shift<VmV3>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, u, rs);
+    hipLaunchKernelGGL(k_qp_shift<VmV3>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, VM_QP_SLOTS, u, rs);
 }
