@@ -952,24 +952,60 @@ def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, base_frames, e0, e1
     for c in sctx:
         c.sync()
     t_solve = time.perf_counter() - t1
-    t_up = t_po = t_re = 0.0
-    its = []
-    for g0 in range(0, nframes, per_batch):
-        qs = group[g0:g0 + per_batch]
-        t2 = time.perf_counter()
-        for f, q in zip(frs, qs):
-            f.upload(e0, e1, None, None)
-            f.set_v_from_level(q, 1)
-        ctx.sync(); t3 = time.perf_counter()
-        res, _ = morph.poisson_extend_frames(frs[:len(qs)], tol=1e-5)
-        ctx.sync(); t4 = time.perf_counter()
-        for f in frs[:len(qs)]:
-            for k in range(1, 10):
-                f.render_halfway_dev(0.1 * k, 0.1 * k, 1)
-        ctx.sync(); t5 = time.perf_counter()
-        t_up += t3 - t2; t_po += t4 - t3; t_re += t5 - t4
-        its += [s[0] for r in res for s in r]
+    def compositor(grp):
+        t_up = t_po = t_re = 0.0
+        its = []
+        for g0 in range(0, nframes, per_batch):
+            qs = grp[g0:g0 + per_batch]
+            t2 = time.perf_counter()
+            for f, q in zip(frs, qs):
+                f.upload(e0, e1, None, None)
+                f.set_v_from_level(q, 1)
+            ctx.sync(); t3 = time.perf_counter()
+            res, _ = morph.poisson_extend_frames(frs[:len(qs)], tol=1e-5)
+            ctx.sync(); t4 = time.perf_counter()
+            for f in frs[:len(qs)]:
+                for k in range(1, 10):
+                    f.render_halfway_dev(0.1 * k, 0.1 * k, 1)
+            ctx.sync(); t5 = time.perf_counter()
+            t_up += t3 - t2; t_po += t4 - t3; t_re += t5 - t4
+            its += [s[0] for r in res for s in r]
+        return t_up, t_po, t_re, its
+
+    t_up, t_po, t_re, its = compositor(group)
     dt = time.perf_counter() - t1
+    # ... and as a STREAM of such jobs: the compositor of job N (this context's stream, one host thread) runs while job
+    # N + 1 is solved on the solver streams -- a second set of pyramids, so that the compositor reads fields nobody is
+    # writing; wall time of the overlapped pair of stages = the steady-state time per job
+    piped = None
+    try:
+        group_b = []
+        for k in range(nframes):
+            q = morph.Pyramid(sctx[chunk_of[k]])
+            q.build(base_frames[k % 4][0], base_frames[k % 4][1], blk.start_res, nlevels=nlev)
+            group_b.append(q)
+        chunks_b = [[q for q, cix in zip(group_b, chunk_of) if cix == s_] for s_ in range(nstreams)]
+        for c in sctx:
+            c.sync()
+        ctx.sync(); t6 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nstreams + 1) as ex_:
+            fs = [ex_.submit(solve_chunk, ch) for ch in chunks_b]
+            fc = ex_.submit(compositor, group)
+            for f_ in fs:
+                f_.result()
+            t_solve_b = time.perf_counter() - t6
+            fc.result()
+        for c in sctx:
+            c.sync()
+        ctx.sync(); dt_p = time.perf_counter() - t6
+        piped = {"ms_per_pair": round(dt_p * 1e3 / nframes, 1), "solve_ms_per_pair_while_compositing": round(t_solve_b * 1e3 / nframes, 1),
+                 "rendered_frames_per_s": round(nframes * 9 / dt_p, 1),
+                 "what": "steady state of a stream of such jobs: job N's compositor overlapped with job N + 1's solve (separate streams, one more host thread)"}
+        for q in group_b:
+            q.clear()
+        del group_b, chunks_b
+    except capi.VmError as e:
+        piped = {"error": str(e)[-160:]}
     for f in frs:
         f.close()
     for q in group:
@@ -992,7 +1028,9 @@ def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, base_frames, e0, e1
             # Poisson extension (and the canvas upload) of the pair amortised over its 9 rendered frames
             "render_frames_per_s": {"render_only": round(1000.0 / render_ms, 1) if render_ms else None,
                                     "with_poisson_amortised": round(nframes * 9 / (t_up + t_po + t_re), 1),
-                                    "whole_pipeline_incl_solve": round(nframes * 9 / dt, 1)}}
+                                    "whole_pipeline_incl_solve": round(nframes * 9 / dt, 1),
+                                    "whole_pipeline_stages_overlapped": piped and piped.get("rendered_frames_per_s")},
+            "stages_overlapped": piped}
 
 
 def sync_stage_extra(np, morph, ctx, w, h, d, blk):

@@ -115,6 +115,9 @@ def test_bench_extras_of_round_5():
     assert 8 <= lo <= hi <= 40                                     # tol 1e-5: 20 iterations on the synthetic frames
     m2 = p30["render_frames_per_s"]
     assert m2["render_only"] > m2["with_poisson_amortised"] > m2["whole_pipeline_incl_solve"] > 0
+    ov = p30["stages_overlapped"]       # job N's compositor beside job N + 1's solve: never slower than 1.15 x the stages in a row
+    assert "error" not in ov and 0 < ov["ms_per_pair"] < 1.15 * p30["ms_per_pair"]
+    assert m2["whole_pipeline_stages_overlapped"] == ov["rendered_frames_per_s"]
     pe = d["poisson_extend_1080p_ex192"]
     assert pe["tol_1e-05"]["cg_iterations"] == pe["tol_1e-05_one_side_at_a_time"]["cg_iterations"]
     assert pe["tol_1e-05"]["ms_per_frame"] < pe["tol_1e-05_one_side_at_a_time"]["ms_per_frame"]
