@@ -7,6 +7,7 @@ multiply-add, v_rcp/v_sqrt) is held to the float tolerances of SURVEY.md
 section 8(d), written next to each assertion.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -14,6 +15,7 @@ import pytest
 from videomorphing_amd import capi, morph, synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 STATE = ["luma", "mean", "var", "cross", "value", "tps_b", "ui_axy", "ui_b", "counter", "tps_axy"]
 
@@ -450,6 +452,40 @@ def test_render_window_hard_cases(gpu_ctx, oracle, kind, with_path):
         ref = oracle.render_halfway(w, h, ex, 0.3, geo, 1, e0.astype(np.float32), e1.astype(np.float32), v, uo)
         assert np.array_equal(out, ref), (kind, with_path, geo, int((out != ref).sum()))
     fr.close()
+
+
+def test_render_plain_kernel_agrees(gpu_ctx):
+    """the plain gather kernel (VM_RENDER=plain -- also the path of fields of 4 GiB and more, which the window
+    kernel's 32-bit texel offsets do not reach) renders the same bytes as the window kernel: a child process with
+    the switch set hashes four frames of a 640x360 pair with a rough path, this process hashes its own"""
+    import hashlib, subprocess, sys, textwrap
+    prog = textwrap.dedent("""
+        import hashlib, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from videomorphing_amd import capi, morph, synth
+        w, h, ex = 640, 360, 24
+        rgb0, rgb1 = synth.make_rgb_pair(w, h)
+        rng = np.random.RandomState(3)
+        v = (4.0 * synth.displacement(w, h) + 0.5 * rng.randn(h, w, 2)).astype(np.float32)
+        u = (1.5 * rng.randn(h, w, 2)).astype(np.float32)
+        fr = morph.Frame(morph.Context(0, capi.MATH_FAST), w, h, ex)
+        hh = hashlib.sha256()
+        for path in (None, u):
+            fr.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), v, path)
+            for geo in (0.15, 0.8):
+                hh.update(fr.render_halfway(0.4, geo, 1).tobytes())
+        print("HASH", hh.hexdigest())
+    """) % ROOT
+    def run(mode):
+        env = dict(os.environ)
+        env.pop("VM_RENDER", None)
+        if mode:
+            env["VM_RENDER"] = mode
+        r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+    assert run("plain") == run(None)
 
 
 def test_render_identity(gpu_ctx):
