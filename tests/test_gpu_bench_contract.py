@@ -109,7 +109,8 @@ def test_bench_extras_of_round_5():
     p30 = d["pipeline_config4_30_frames"]
     assert "30 1080p pairs" in p30["workload"] and "BCOND_BORDER" in p30["workload"]
     split = p30["compositor_split_ms_per_frame"]
-    assert abs(sum(split.values()) - p30["compositor_ms_per_frame"]) < 0.05
+    assert abs(sum(split.values()) - p30["compositor_ms_per_frame"]) < 0.1 * p30["compositor_ms_per_frame"]   # the lanes' own clocks / lanes vs the wall
+    assert p30["compositor_lanes"] == 2
     assert abs(p30["solve_ms_per_pair"] + p30["compositor_ms_per_frame"] - p30["ms_per_pair"]) < 0.15 * p30["ms_per_pair"]
     lo, hi = p30["pcg_iterations_min_max"]
     assert 8 <= lo <= hi <= 40                                     # tol 1e-5: 20 iterations on the synthetic frames
