@@ -507,14 +507,14 @@ static int ensure_lanes(vm_video *v, int n)
             vm_ctx_destroy(ln.c);
             return vm_fail(VM_E_DEVICE, "vm_video_solve: out of device memory (pipeline lane)");
         }
-        // Lane 0 always runs the coarsest level in flight -- the chain of launch-bound steps the
-        // whole solve waits for -- so its stream gets the highest priority: a finer level's
-        // chip-filling dense kernel on another lane must not sit in front of those launches.
-        // VM_LANE_PRIORITY (development): 0 = no priority streams at all, 1 = lane 0 high, the others
-        // plain (default), 2 = graded (lane j at greatest + j: rounds 2-4 -- its low-priority streams take
-        // hardware queues of their own that the runtime does not hand back: see profiles/r05_notes.md 7)
-        {
-            static const int mode = getenv("VM_LANE_PRIORITY") ? atoi(getenv("VM_LANE_PRIORITY")) : 1;
+        // Lanes run on plain streams.  Rounds 2-4 gave them PRIORITY streams (lane 0, which runs the coarsest level in
+        // flight -- the chain of launch-bound steps the whole solve waits for -- the highest): the solve does not
+        // care (404-405 ms either way), but a priority stream takes a hardware queue of its own which the runtime
+        // does not hand back after hipStreamDestroy, and every later multi-stream job of the process then runs with
+        // streams sharing queues (config[2]'s three streams +17 % behind the graded scheme; the six streams of the
+        // config[4] pipeline +19 % behind even one high-priority lane: profiles/r05_notes.md 7).
+        // VM_LANE_PRIORITY (development): 0 = none (default), 1 = lane 0 high, 2 = graded (lane j at greatest + j)
+            static const int mode = getenv("VM_LANE_PRIORITY") ? atoi(getenv("VM_LANE_PRIORITY")) : 0;
             int least = 0, greatest = 0;
             hipStream_t ps = nullptr;
             const int j = (int)v->lanes.size();
