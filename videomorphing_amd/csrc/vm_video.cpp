@@ -514,6 +514,7 @@ static int ensure_lanes(vm_video *v, int n)
         // streams sharing queues (config[2]'s three streams +17 % behind the graded scheme; the six streams of the
         // config[4] pipeline +19 % behind even one high-priority lane: profiles/r05_notes.md 7).
         // VM_LANE_PRIORITY (development): 0 = none (default), 1 = lane 0 high, 2 = graded (lane j at greatest + j)
+        {
             static const int mode = getenv("VM_LANE_PRIORITY") ? atoi(getenv("VM_LANE_PRIORITY")) : 0;
             int least = 0, greatest = 0;
             hipStream_t ps = nullptr;
