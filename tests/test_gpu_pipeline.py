@@ -197,6 +197,41 @@ def test_frame_takes_its_field_from_a_pyramid_of_another_context(gpu_ctx):
     assert np.array_equal(fields[0].view(np.uint32), fields[1].view(np.uint32)) and np.abs(fields[0]).max() > 0.1
 
 
+def test_two_compositor_lanes_side_by_side(gpu_ctx):
+    """the compositor on two contexts driven by two host threads at once (bench.py's config[4] pipeline):
+    every frame's extension (both sides, two frames per batch), quadratic path and three renders give what the same
+    frames give one lane after the other -- same PCG iteration counts, rendered bytes within one level (the dot
+    products are accumulated by atomics) -- over several rounds, so that the lanes' launches really interleave"""
+    from concurrent.futures import ThreadPoolExecutor
+    w, h, ex = 320, 200, 24
+    data = [_frame_pair(w, h, ex, s) for s in (1, 2, 5, 6)]
+    lanes = [gpu_ctx, morph.Context(0, capi.MATH_FAST)]
+    frs = [[morph.Frame(c, w, h, ex) for _ in range(2)] for c in lanes]
+
+    def work(li, rounds):
+        out = None
+        for _ in range(rounds):
+            for f, (e0, e1, v) in zip(frs[li], data[2 * li:2 * li + 2]):
+                f.upload(e0, e1, v, None)
+            res, _ = morph.poisson_extend_frames(frs[li], tol=1e-5)
+            qp = [f.quadratic_path(tol=1e-4)[0] for f in frs[li]]
+            out = ([tuple(s_[0] for s_ in r) for r in res], qp,
+                   [f.render_halfway(0.3, g, 1) for f in frs[li] for g in (0.2, 0.5, 0.8)])
+        return out
+
+    alone = [work(0, 1), work(1, 1)]
+    with ThreadPoolExecutor(max_workers=2) as ex_:
+        both = list(ex_.map(lambda li: work(li, 6), (0, 1)))
+    for a, b in zip(alone, both):
+        assert a[0] == b[0] and a[1] == b[1], (a[:2], b[:2])
+        for x, y in zip(a[2], b[2]):
+            assert np.abs(x.astype(int) - y.astype(int)).max() <= 1
+    for lane in frs:
+        for f in lane:
+            f.close()
+    lanes[1].close()
+
+
 def test_upload_from_page_locked_host_memory(gpu_ctx):
     """vm_host_register / vm_host_unregister: canvases uploaded from a page-locked buffer arrive unchanged; registering
     twice and unregistering what was never registered are not errors"""
