@@ -167,6 +167,29 @@ __device__ __forceinline__ TapIdx tap_index(float x, float y, float fw, float fh
 #ifndef VM_RENDER_RR
 #define VM_RENDER_RR 10
 #endif
+// tap_rgb with the lean indices (the canvas is far below 4 GiB whenever the field is)
+__device__ __forceinline__ float3 tap_rgb_lean(const uchar4 *__restrict__ img, float fw, float fh, int wm1, int hm1, uint32_t w, float x,
+                                               float y)
+{
+    const float xb = x - 0.5f, yb = y - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    const float a = xb - fi, b = yb - fj;
+    fi = __builtin_amdgcn_fmed3f(fi, -1.0f, fw);
+    fj = __builtin_amdgcn_fmed3f(fj, -1.0f, fh);
+    const int i = (int)fi, j = (int)fj;
+    const uint32_t i0 = (uint32_t)med3_i32(i, 0, wm1), i1 = (uint32_t)med3_i32(i + 1, 0, wm1);
+    const uint32_t r0 = __umul24((uint32_t)med3_i32(j, 0, hm1), w), r1 = __umul24((uint32_t)med3_i32(j + 1, 0, hm1), w);
+    const char *base = (const char *)img;
+    const uchar4 t00 = *(const uchar4 *)(base + ((r0 + i0) << 2)), t10 = *(const uchar4 *)(base + ((r0 + i1) << 2));
+    const uchar4 t01 = *(const uchar4 *)(base + ((r1 + i0) << 2)), t11 = *(const uchar4 *)(base + ((r1 + i1) << 2));
+    const float w00 = (1 - a) * (1 - b), w10 = a * (1 - b), w01 = (1 - a) * b, w11 = a * b;
+    float3 r;
+    r.x = w00 * (float)t00.x + w10 * (float)t10.x + w01 * (float)t01.x + w11 * (float)t11.x;
+    r.y = w00 * (float)t00.y + w10 * (float)t10.y + w01 * (float)t01.y + w11 * (float)t11.y;
+    r.z = w00 * (float)t00.z + w10 * (float)t10.z + w01 * (float)t01.z + w11 * (float)t11.z;
+    return r;
+}
+
 constexpr int RW = 32, RH = 8, RR = VM_RENDER_RR, WW = RW + 2 * RR + 1, WH = RH + 2 * RR + 1;
 
 typedef const volatile __attribute__((address_space(3))) unsigned long long *LdsWords;
@@ -182,7 +205,7 @@ __global__ __launch_bounds__(256) void k_render_win(uint8_t *__restrict__ out, i
                                                     float color_fa, float geo_fa, int color_from,
                                                     const uchar4 *__restrict__ ext0, const uchar4 *__restrict__ ext1,
                                                     const float2 *__restrict__ vf, const float2 *__restrict__ uf, int tiles_x,
-                                                    int ntiles)
+                                                    int ntiles, bool lean_canvas)
 {
     __shared__ float2 win_v[WH * WW];
     __shared__ float2 win_u[HAS_U ? WH * WW : 1];
@@ -274,8 +297,14 @@ __global__ __launch_bounds__(256) void k_render_win(uint8_t *__restrict__ out, i
             u.y = alpha * tu.y + (1 - alpha) * u.y;
         }
     }
-    float3 c0 = tap_rgb(ext0, cw, ch, px - v.x + ex + 0.5f, py - v.y + ex + 0.5f);
-    float3 c1 = tap_rgb(ext1, cw, ch, px + v.x + ex + 0.5f, py + v.y + ex + 0.5f);
+    float3 c0, c1;
+    if (lean_canvas) {
+        c0 = tap_rgb_lean(ext0, (float)cw, (float)ch, cw - 1, ch - 1, (uint32_t)cw, px - v.x + ex + 0.5f, py - v.y + ex + 0.5f);
+        c1 = tap_rgb_lean(ext1, (float)cw, (float)ch, cw - 1, ch - 1, (uint32_t)cw, px + v.x + ex + 0.5f, py + v.y + ex + 0.5f);
+    } else {
+        c0 = tap_rgb(ext0, cw, ch, px - v.x + ex + 0.5f, py - v.y + ex + 0.5f);
+        c1 = tap_rgb(ext1, cw, ch, px + v.x + ex + 0.5f, py + v.y + ex + 0.5f);
+    }
     double r, g, b;
     if (color_from == 0) {
         r = c0.x + 0.5; g = c0.y + 0.5; b = c0.z + 0.5;
@@ -374,11 +403,13 @@ void vm_launch_render(uint8_t *out, int out_pitch, int w, int h, int rs, int ex,
         return;
     }
     const int tiles_x = (w + RW - 1) / RW, ntiles = tiles_x * ((h + RH - 1) / RH);
+    const uint64_t cw = (uint64_t)w + 2 * (uint64_t)ex, ch = (uint64_t)h + 2 * (uint64_t)ex;
+    const bool lean_canvas = cw * ch * 4ull < (1ull << 32) && cw < (1u << 24) && ch < (1u << 24);   // 32-bit texel offsets, 24-bit rows
     dim3 b(RW, RH), g(((ntiles + 7) / 8) * 8);
     if (u)
         hipLaunchKernelGGL(k_render_win<true>, g, b, 0, s, out, out_pitch, w, h, rs, ex, color_fa, geo_fa, color_from, ext0,
-                           ext1, v, u, tiles_x, ntiles);
+                           ext1, v, u, tiles_x, ntiles, lean_canvas);
     else
         hipLaunchKernelGGL(k_render_win<false>, g, b, 0, s, out, out_pitch, w, h, rs, ex, color_fa, geo_fa, color_from, ext0,
-                           ext1, v, u, tiles_x, ntiles);
+                           ext1, v, u, tiles_x, ntiles, lean_canvas);
 }
