@@ -156,7 +156,7 @@ __device__ __forceinline__ TapIdx tap_index(float x, float y, float fw, float fh
 // the texture path takes ~19 cycles per 64-lane 8-byte gather and CU (4 gathers per tap), and its ~56 VALU
 // instructions per tap (two of them quarter-rate multiplies, 64-bit address arithmetic per texel) cost the same in
 // issue slots: an LDS window alone (112 us) or lean indices alone (97 us) leave the 98 us where they were, both
-// together give 64 us.  A workgroup of RW x RH pixels stages one window of the field around where its pixels land --
+// together give 64 us.  A workgroup of RW x RH = 32 x 16 pixels stages one window of the field around where its pixels land --
 // the block displaced by the warp of its centre, RR cells of margin for the variation of the warp across the block
 // and the path of the fixed-point iteration -- with CLAMPED source coordinates, so that window cell (i - ox, j - oy)
 // holds exactly the texel tap2 fetches for the raw floor index i (tap2's clamps of i0, i0 + 1 to the image commute
@@ -190,7 +190,10 @@ __device__ __forceinline__ float3 tap_rgb_lean(const uchar4 *__restrict__ img, f
     return r;
 }
 
-constexpr int RW = 32, RH = 8, RR = VM_RENDER_RR, WW = RW + 2 * RR + 1, WH = RH + 2 * RR + 1;
+#ifndef VM_RENDER_RH
+#define VM_RENDER_RH 16     // 32 x 16 pixels per workgroup: 3.8 staged cells per pixel (8 rows: 6.0; 63.0 -> 60.7 us per frame)
+#endif
+constexpr int RW = 32, RH = VM_RENDER_RH, RR = VM_RENDER_RR, WW = RW + 2 * RR + 1, WH = RH + 2 * RR + 1;
 
 typedef const volatile __attribute__((address_space(3))) unsigned long long *LdsWords;
 
@@ -201,7 +204,7 @@ __device__ __forceinline__ float2 lds8(LdsWords win, uint32_t c)
 }
 
 template <bool HAS_U>
-__global__ __launch_bounds__(256) void k_render_win(uint8_t *__restrict__ out, int out_pitch, int w, int h, int rs, int ex,
+__global__ __launch_bounds__(RW * RH) void k_render_win(uint8_t *__restrict__ out, int out_pitch, int w, int h, int rs, int ex,
                                                     float color_fa, float geo_fa, int color_from,
                                                     const uchar4 *__restrict__ ext0, const uchar4 *__restrict__ ext1,
                                                     const float2 *__restrict__ vf, const float2 *__restrict__ uf, int tiles_x,
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void k_render_win(uint8_t *__restrict__ out, i
         ox = bx - (int)rintf(dx) - RR;
         oy = by - (int)rintf(dy) - RR;
     }
-    for (int i = tid; i < WH * WW; i += 256) {
+    for (int i = tid; i < WH * WW; i += RW * RH) {
         const int wy = i / WW, wx = i - wy * WW;
         const int src = min(max(oy + wy, 0), hm1) * rs + min(max(ox + wx, 0), wm1);
         win_v[i] = vf[src];
