@@ -4,7 +4,7 @@ BASELINE.json's full sizes, fingerprinted.
   config[1]: 1920x1080 pair, 6 levels (start_res 32), max_iter 500, drop 1, the reference's stopping
              rule (morph.cu:150-168, 1353-1391) -- synthetic frames 0..11 (7 and 8: the finest level keeps
              exchanging moves until iteration 500 in this arithmetic);
-  config[3]: 3840x2160 pair, 7 levels, same settings -- frames 0 (500 sweeps at 4K) and 1.
+  config[3]: 3840x2160 pair, 7 levels, same settings -- frames 0..3 (0 and 3: 500 sweeps at 4K).
 
 Per solve: the per-level iteration counts (coarse to fine), SHA-256 of every state array of the finest
 level (tests/fullsize_hash.py) and a fingerprint of the synthetic inputs.  CPU only (runs in the build
@@ -14,7 +14,7 @@ test_full_solve_exact_matches_oracle_hashes then needs seconds per solve on the 
 
   --tex8: the same solve with the oracle's texture fetches filtered like CUDA's (vmo_set_tex_filter(1): 8-bit bilinear
           weights, rounded) -- the fixture of the HIP path's VM_MATH_REF_TEX8 build at full size (key "<case>/frame<k>/tex8";
-          committed: 1080p frames 0, 1, 2, 6, 9, 11 and 4K frame 0).
+          committed: 1080p frames 0, 1, 2, 6, 9, 11 and 4K frames 0, 1).
 
 usage: python tests/golden/make_full_solve_hashes.py [--only 1080p|4k] [--frames 0,1,...] [--tex8]   (merges into the JSON)
 """
@@ -34,7 +34,7 @@ import oracle  # noqa: E402
 import fullsize_hash as FH  # noqa: E402
 
 OUT = os.path.join(HERE, "full_solve_hashes.json")
-CASES = {"1080p": (1920, 1080, 6, tuple(range(12))), "4k": (3840, 2160, 7, (0, 1))}
+CASES = {"1080p": (1920, 1080, 6, tuple(range(12))), "4k": (3840, 2160, 7, (0, 1, 2, 3))}
 
 
 def main():

@@ -2,7 +2,7 @@
 
 Against the oracle's own whole solves through fixtures (tests/golden/full_solve_hashes.json: per-level
 iteration counts + SHA-256 of the finest level's state, written by the oracle in the build container):
-  * config[1] on twelve synthetic frames and config[3] (4K, 7 levels) on two, plus seven of them in the
+  * config[1] on twelve synthetic frames and config[3] (4K, 7 levels) on four, plus eight of them in the
     reference binary's texture arithmetic (REF_TEX8)  (test_full_solve_exact_matches_oracle_hashes).
 Against the oracle itself, bit for bit (EXACT arithmetic; the oracle needs ~10-20 s of the
 box's host cores for each):
@@ -96,7 +96,7 @@ def _full_solve_cases():
 def test_full_solve_exact_matches_oracle_hashes(gpu_ctx, key, fix):
     """Whole coarse-to-fine EXACT solves at BASELINE.json's full sizes against the ORACLE's, through fixtures: the
     oracle solved config[1] (1920x1080, 6 levels, max_iter 500, the reference's stopping rule, morph.cu:150-168,
-    1353-1391) on synthetic frames 0..11 and config[3] (3840x2160, 7 levels) on frames 0 and 1 in the build
+    1353-1391) on synthetic frames 0..11 and config[3] (3840x2160, 7 levels) on frames 0..3 in the build
     container (tests/golden/make_full_solve_hashes.py; 17-36 s per 1080p solve, minutes for 4K) and left the
     per-level iteration counts and SHA-256 of every state array of the finest level in
     tests/golden/full_solve_hashes.json.  The HIP path must reproduce every count and every hash: bit-identical
