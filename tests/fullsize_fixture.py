@@ -1,0 +1,74 @@
+"""Inputs of the full-size compositor fixtures (tests/golden/make_fullsize_compositor.py writes the oracle's outputs
+for them in the build container; tests/test_gpu_fullsize_compositor.py feeds the same inputs to the HIP path on the GPU
+box).  Everything here is an analytic function of the pixel grid or a Mersenne-Twister uniform stream -- float64
+multiplies, adds, floor; sin / cos only through synth.displacement, which the solver fixtures already rely on -- so both
+hosts generate the same bits; every fixture carries a fingerprint of its inputs all the same.
+
+  field(w, h, frame)     halfway field v of config[4]'s shape: 0.85 x the synthetic ground truth (|v| up to ~ 16 px at
+                         1080p) + three octaves of value noise (+- 1 px, 80 / 40 / 20 px features) + +-0.05 px of white
+                         noise (the rounding-level roughness a solved field carries)
+  path(w, h, frame)      a quadratic motion path u of a few pixels (render.cu:16-60 bends the trajectory by 4 t (1 - t) u)
+  padded(rgb, ex)        an RGBA8 canvas (h + 2 ex, w + 2 ex): the frame with its border pixels replicated outwards,
+                         alpha 0 -- what a finished extension looks like to the renderer, without needing one
+"""
+import hashlib
+
+import numpy as np
+
+from videomorphing_amd import synth
+
+
+def _noise2(w, h, seed, base, amp):
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    a = synth.value_noise(x, y, base, seed, 3) - 0.875          # range of three octaves: [0, 1.75]
+    b = synth.value_noise(x, y, base, seed + 1, 3) - 0.875
+    return amp * np.stack([a, b], axis=-1)
+
+
+def field(w, h, frame=0):
+    rng = np.random.RandomState(9000 + frame)
+    v = 0.85 * synth.displacement(w, h) + _noise2(w, h, synth.SEED + 11 + 2 * frame, max(w, h) / 24.0, 1.2)
+    v += 0.1 * (rng.rand(h, w, 2) - 0.5)
+    return v.astype(np.float32)
+
+
+def path(w, h, frame=0):
+    d = synth.displacement(w, h)
+    u = 0.2 * np.stack([-d[..., 1], d[..., 0]], axis=-1) + _noise2(w, h, synth.SEED + 71 + 2 * frame, max(w, h) / 12.0, 0.8)
+    return u.astype(np.float32)
+
+
+def padded(rgb, ex):
+    h, w = rgb.shape[:2]
+    out = np.zeros((h + 2 * ex, w + 2 * ex, 4), np.uint8)
+    out[..., :3] = np.pad(rgb, ((ex, ex), (ex, ex), (0, 0)), mode="edge")
+    return out
+
+
+def sha(*arrays):
+    """SHA-256 over dtype, shape and bytes of every array (the fixtures' fingerprints of inputs and outputs)"""
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(("%s|%s|" % (a.dtype.str, "x".join(map(str, a.shape)))).encode())
+        h.update(a.view(np.uint8).tobytes() if a.dtype != np.uint8 else a.tobytes())
+    return h.hexdigest()
+
+
+# ---- the ring of a Poisson-extended canvas as four bands (top, bottom, left, right), and a compact encoding --------
+
+def ring_bands(ext, w, h, ex):
+    """the RGB of everything outside the w x h frame of an extended canvas: (top, bottom, left, right)"""
+    e = ext[..., :3]
+    return e[:ex], e[ex + h:], e[ex:ex + h, :ex], e[ex:ex + h, ex + w:]
+
+
+def delta_encode(band, axis):
+    """uint8 differences along `axis` modulo 256 (a smooth extension becomes mostly 0 / 1 / 255: zlib does the rest)"""
+    b = band.astype(np.int16)
+    d = np.diff(b, axis=axis, prepend=0)
+    return (d & 0xFF).astype(np.uint8)
+
+
+def delta_decode(d, axis):
+    return (np.cumsum(d.astype(np.int64), axis=axis) & 0xFF).astype(np.uint8)

@@ -16,7 +16,11 @@ test_full_solve_exact_matches_oracle_hashes then needs seconds per solve on the 
           weights, rounded) -- the fixture of the HIP path's VM_MATH_REF_TEX8 build at full size (key "<case>/frame<k>/tex8";
           committed: 1080p frames 0, 1, 2, 6, 9, 11 and 4K frames 0, 1).
 
-usage: python tests/golden/make_full_solve_hashes.py [--only 1080p|4k] [--frames 0,1,...] [--tex8]   (merges into the JSON)
+  --cons: config[4]'s solver settings instead -- 1920x1080, the frame's 8 point constraints (synth.make_constraints:
+          morph.cu:345-388 splat, :471-505 coarse system) and BCOND_BORDER (:507-562, pixel_on_border :648-668), 500 per
+          level (key "1080p/frame<k>/cons"; committed: frames 0, 7, 15, 29); the hashes then include ui_axy.
+
+usage: python tests/golden/make_full_solve_hashes.py [--only 1080p|4k] [--frames 0,1,...] [--tex8] [--cons]   (merges into the JSON)
 """
 import json
 import os
@@ -42,6 +46,7 @@ def main():
     only = args[args.index("--only") + 1] if "--only" in args else None
     frames_arg = [int(x) for x in args[args.index("--frames") + 1].split(",")] if "--frames" in args else None
     tex8 = "--tex8" in args
+    cons_mode = "--cons" in args
     oracle.lib().vmo_set_tex_filter(1 if tex8 else 0)
     try:
         doc = json.load(open(OUT))
@@ -51,18 +56,23 @@ def main():
                "solves": {}}
     threads = len(os.sched_getaffinity(0))
     for name, (w, h, nlev, frames) in CASES.items():
-        if only and name != only:
+        if (only and name != only) or (cons_mode and name != "1080p"):
             continue
-        for f in (frames_arg or frames):
-            key = "%s/frame%d%s" % (name, f, "/tex8" if tex8 else "")
+        for f in (frames_arg or ((0, 7, 15, 29) if cons_mode else frames)):
+            key = "%s/frame%d%s%s" % (name, f, "/tex8" if tex8 else "", "/cons" if cons_mode else "")
             i0, i1 = synth.make_pair(w, h, frame=f)
             t0 = time.time()
             per = []
-            lo = oracle.solve(synth.build_pyramid(i0, i1, nlev), oracle.default_params(), 500, 1.0, threads=threads, per_level=per)
+            cons = synth.make_constraints(w, h, 8) if cons_mode else ()
+            P = oracle.default_params(bcond=2) if cons_mode else oracle.default_params()          # 2 = BCOND_BORDER, parameters.h:9-14
+            lo = oracle.solve(synth.build_pyramid(i0, i1, nlev), P, 500, 1.0, cons=cons, threads=threads, per_level=per)
             doc["solves"][key] = {"size": [w, h], "levels": nlev, "frame": f, "tex_filter": 1 if tex8 else 0, "inputs": FH.input_hash(i0, i1),
                                   "iters_coarse_to_fine": [int(p[1]) for p in per],
                                   "max_abs_v": float(np.abs(lo.field("v")).max()),
                                   "sha256": FH.state_hashes(lo), "oracle_s": round(time.time() - t0, 1), "oracle_threads": threads}
+            if cons_mode:
+                doc["solves"][key].update({"bcond": 2, "constraints": [[float(x) for x in c] for c in cons]})
+                doc["solves"][key]["sha256"]["ui_axy"] = FH.sha(lo.field("ui_axy"))
             print(key, doc["solves"][key]["iters_coarse_to_fine"], doc["solves"][key]["oracle_s"], "s", flush=True)
             json.dump(doc, open(OUT, "w"), indent=1, sort_keys=True)
             del lo

@@ -120,22 +120,70 @@ def test_full_solve_exact_matches_oracle_hashes(gpu_ctx, key, fix):
         finally:
             O.lib().vmo_set_tex_filter(0)
         want_iters, want = [int(p[1]) for p in per], FH.state_hashes(lo)
-    # (a "/tex8" case: the oracle solved it with CUDA's 8-bit texture filter weights -- the HIP path's VM_MATH_REF_TEX8 build)
-    gpu_ctx.set_math_mode(capi.MATH_REF_TEX8 if fix.get("tex_filter", 0) else capi.MATH_EXACT)
-    prm = morph.Parameters()
-    prm.max_iter, prm.max_iter_drop_factor, prm.start_res = 500, 1.0, 32
-    gpu_ctx.set_params(morph.KernParameters(prm))
-    pyr = morph.Pyramid(gpu_ctx)
-    pyr.build(i0, i1, 32)
-    assert pyr.size() == nlev + 1
-    prog = (capi.Progress * (nlev - 1))()
-    capi.check(pyr._L.vm_solve(pyr._h, 500.0, 1.0, None, 0, None, 0, prog))
-    assert [int(prog[el].iters) for el in range(nlev - 2, -1, -1)] == want_iters
-    got = FH.state_hashes(pyr[1])
-    assert got == want, {f: (got[f] == want[f]) for f in want}
-    assert abs(float(np.abs(pyr[1].v).max()) - fix["max_abs_v"]) < 1e-6 or FH.input_hash(i0, i1) != fix["inputs"]
-    pyr.clear()
-    gpu_ctx.set_math_mode(capi.MATH_EXACT)
+    # (a "/tex8" case: the oracle solved it with CUDA's 8-bit texture filter weights -- the HIP path's VM_MATH_REF_TEX8 build;
+    #  a "/cons" case: config[4]'s solver settings -- the frame's point constraints and BCOND_BORDER, morph.cu:345-388, 471-562)
+    cons = np.asarray(fix.get("constraints", []), np.float32).reshape(-1, 5)
+    pyr = None
+    try:        # the context is shared by the session: whatever fails here, it goes back to EXACT with default parameters
+        gpu_ctx.set_math_mode(capi.MATH_REF_TEX8 if fix.get("tex_filter", 0) else capi.MATH_EXACT)
+        prm = morph.Parameters()
+        prm.max_iter, prm.max_iter_drop_factor, prm.start_res, prm.bcond = 500, 1.0, 32, fix.get("bcond", capi.BCOND_NONE)
+        gpu_ctx.set_params(morph.KernParameters(prm))
+        pyr = morph.Pyramid(gpu_ctx)
+        pyr.build(i0, i1, 32)
+        assert pyr.size() == nlev + 1
+        prog = (capi.Progress * (nlev - 1))()
+        cs, ncs = morph._cons_array(cons)
+        capi.check(pyr._L.vm_solve(pyr._h, 500.0, 1.0, cs, ncs, None, 0, prog))
+        assert [int(prog[el].iters) for el in range(nlev - 2, -1, -1)] == want_iters
+        got = FH.state_hashes(pyr[1])
+        if "ui_axy" in want:
+            got["ui_axy"] = FH.sha(pyr[1].field("ui_axy"))
+        assert got == want, {f: (got[f] == want[f]) for f in want}
+        assert abs(float(np.abs(pyr[1].v).max()) - fix["max_abs_v"]) < 1e-6 or FH.input_hash(i0, i1) != fix["inputs"]
+    finally:
+        if pyr is not None:
+            pyr.clear()
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+        gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
+
+
+def test_constrained_solves_as_one_batch_match_oracle_hashes(gpu_ctx):
+    """config[4]'s solver call itself: the four "/cons" fixtures (1080p frames 0, 7, 15, 29; 8 point constraints each, BCOND_BORDER,
+    500 per level) solved TOGETHER by one vm_solve_batch_cons in EXACT -- the way bench.py's config[4] pipeline solves a
+    rank's share -- reproduce every per-level iteration count and every SHA-256 the oracle left for the single solves:
+    a pair's trajectory does not depend on its batch-mates (UI splat + border lock: morph.cu:345-388, 471-562, 648-668)."""
+    import fullsize_hash as FH
+    cases = [(k, f) for k, f in _full_solve_cases() if k.endswith("/cons")]
+    if len(cases) < 2:
+        pytest.skip("no constrained full-size fixtures")
+    pyrs = []
+    try:
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+        prm = morph.Parameters()
+        prm.max_iter, prm.max_iter_drop_factor, prm.start_res, prm.bcond = 500, 1.0, 32, capi.BCOND_BORDER
+        gpu_ctx.set_params(morph.KernParameters(prm))
+        cons = []
+        for key, fix in cases:
+            w, h = fix["size"]
+            i0, i1 = synth.make_pair(w, h, frame=fix["frame"])
+            if FH.input_hash(i0, i1) != fix["inputs"]:
+                pytest.skip("this host's numpy generates other synthetic inputs than the fixture's")
+            q = morph.Pyramid(gpu_ctx)
+            q.build(i0, i1, 32)
+            pyrs.append(q)
+            cons.append(np.asarray(fix["constraints"], np.float32).reshape(-1, 5))
+        res = morph.solve_batch(pyrs, 500, 1.0, fixed_work=False, constraints=cons)
+        for (key, fix), q, r in zip(cases, pyrs, res):
+            nlev = fix["levels"]
+            assert [int(r[el]["iters"]) for el in range(nlev - 2, -1, -1)] == fix["iters_coarse_to_fine"], key
+            got = FH.state_hashes(q[1])
+            got["ui_axy"] = FH.sha(q[1].field("ui_axy"))
+            assert got == fix["sha256"], (key, {f: (got[f] == fix["sha256"][f]) for f in got})
+    finally:
+        for q in pyrs:
+            q.clear()
+        gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))
 
 
 def test_dense_sweep_exact_4k(gpu_ctx, oracle):

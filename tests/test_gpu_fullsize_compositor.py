@@ -1,0 +1,164 @@
+"""Everything BASELINE config[4] adds to config[1]'s solver, at its STATED size (1920x1080, ex = 192, canvases 2304x1464),
+against the ORACLE through fixtures written in the build container (tests/golden/make_fullsize_compositor.py; inputs
+regenerated here by tests/fullsize_fixture.py and fingerprinted):
+
+  * render_halfway_image (render.cu:16-60): 25 frames (t x color_from x {no path, path}) byte-identical to the
+    oracle's, through SHA-256;
+  * CPoissonExt (PoissonExt.cpp:49-362): both sides of frames 0 and 7 against the oracle's double-precision CG at 1e-9,
+    the whole 1.30 M-pixel ring: SURVEY 8(d)'s bound max |colour difference| <= 1 at every tolerance bench.py times
+    (TIMED_TOLS, imported by bench.py), one frame per call and four frames per batch, with the statistics (fraction of
+    bytes off by one, worst difference) written to gpurun_out/ for DESIGN section 4;
+  * CQuadraticPath (QuadraticPath.cpp:24-223): u within 2e-3 px of the oracle's CG at 1e-10.
+
+The constrained / BCOND_BORDER solves of config[4] at 1080p are in tests/test_gpu_fullsize.py (the "/cons" hash fixtures).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fullsize_fixture as FX
+from videomorphing_amd import morph, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+W, H, EX = 1920, 1080, 192
+
+# The tolerances the Poisson stage may be TIMED at (bench.py imports this): exactly those this file proves to meet
+# SURVEY 8(d)'s "max abs colour diff <= 1" on the full-size canvas, single call and 4-frame batch.  1e-4 is NOT among
+# them: the oracle's own CG stopped at 1e-4 is off by up to 3 levels there, and so may any solver be.
+TIMED_TOLS = (1e-5, 1e-6)
+
+
+def _sha_text(arr):
+    return bytes(np.asarray(arr, np.uint8)).decode()
+
+
+def test_render_1080p_matches_oracle_hashes(gpu_ctx):
+    doc = json.load(open(os.path.join(GOLD, "render_1080p_hashes.json")))
+    assert doc["size"] == [W, H] and doc["ex"] == EX
+    frame = doc["frame"]
+    rgb0, rgb1 = synth.make_rgb_pair(W, H, frame=frame)
+    v, u = FX.field(W, H, frame), FX.path(W, H, frame)
+    e0, e1 = FX.padded(rgb0, EX), FX.padded(rgb1, EX)
+    if FX.sha(e0, e1, v, u) != doc["inputs"]:
+        pytest.skip("this host's numpy generates other fixture inputs than the build container's")
+    fr = morph.Frame(gpu_ctx, W, H, EX)
+    try:
+        bad = []
+        for with_path in (0, 1):
+            fr.upload(e0, e1, v, u if with_path else None)
+            for case in doc["cases"]:
+                if case["path"] != with_path:
+                    continue
+                img = fr.render_halfway(case["color_fa"], case["geo_fa"], case["color_from"])
+                if FX.sha(img) != case["sha256"]:
+                    bad.append((case, round(float(img.mean()), 4)))
+        assert not bad, bad
+        assert len(doc["cases"]) == 25
+    finally:
+        fr.close()
+
+
+def _ring_reference(frame):
+    z = np.load(os.path.join(GOLD, "poisson_1080p_ring_f%d.npz" % frame))
+    ref = {}
+    for side in (1, 2):
+        ref[side] = [FX.delta_decode(z["s%d_%s" % (side, n)], 1) for n in ("top", "bottom", "left", "right")]
+    return z, ref
+
+
+def _ring_stats(out, ref_bands):
+    """(max |diff|, fraction of ring bytes off by exactly one, fraction off by more) of a canvas against the oracle's ring"""
+    worst, n1, n2, n = 0, 0, 0, 0
+    for got, want in zip(FX.ring_bands(out, W, H, EX), ref_bands):
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        worst = max(worst, int(d.max()))
+        n1 += int((d == 1).sum())
+        n2 += int((d > 1).sum())
+        n += d.size
+    return worst, n1 / n, n2 / n
+
+
+def test_poisson_1080p_against_the_oracle_ring(gpu_ctx):
+    frames = (0, 7)
+    data, refs = {}, {}
+    for f in frames + (15, 29):                     # 15, 29: batch-mates without a fixture
+        rgb0, rgb1 = synth.make_rgb_pair(W, H, frame=f)
+        data[f] = (morph.make_extended(rgb0, EX), morph.make_extended(rgb1, EX), FX.field(W, H, f))
+    for f in frames:
+        z, refs[f] = _ring_reference(f)
+        if FX.sha(*data[f]) != _sha_text(z["inputs"]):
+            pytest.skip("this host's numpy generates other fixture inputs than the build container's")
+    frs = [morph.Frame(gpu_ctx, W, H, EX) for _ in range(4)]
+    report = []
+    try:
+        for tol in (1e-4,) + TIMED_TOLS:
+            # one frame per call (both sides = one batch of two systems)
+            for f in frames:
+                fr = frs[0]
+                fr.upload(*data[f], None)
+                (i1, r1), (i2, r2), ms = fr.poisson_extend_both(tol=tol)
+                assert r1 <= tol and r2 <= tol
+                for side, it in ((1, i1), (2, i2)):
+                    out = fr.download_ext(side)
+                    assert out[..., 3].max() == 0
+                    # the frame itself is untouched but for its outermost pixels (type 1: unknowns tied to their colour)
+                    assert np.array_equal(out[EX + 1:EX + H - 1, EX + 1:EX + W - 1, :3], data[f][side - 1][EX + 1:EX + H - 1, EX + 1:EX + W - 1, :3])
+                    worst, f1, f2 = _ring_stats(out, refs[f][side])
+                    report.append({"tol": tol, "batch": 1, "frame": f, "side": side, "iters": it, "max_abs_diff": worst,
+                                   "frac_off_by_1": round(f1, 6), "frac_off_by_more": round(f2, 8), "ms_both_sides": round(ms, 3)})
+            # four frames per batch (eight systems), the shape bench.py's config[4] pipeline runs
+            order = (0, 15, 7, 29)
+            for fr, f in zip(frs, order):
+                fr.upload(*data[f], None)
+            res, ms = morph.poisson_extend_frames(frs, tol=tol)
+            for fr, f, r in zip(frs, order, res):
+                assert r[0][1] <= tol and r[1][1] <= tol
+                if f not in refs:
+                    continue
+                for side in (1, 2):
+                    worst, f1, f2 = _ring_stats(fr.download_ext(side), refs[f][side])
+                    report.append({"tol": tol, "batch": 4, "frame": f, "side": side, "iters": r[side - 1][0], "max_abs_diff": worst,
+                                   "frac_off_by_1": round(f1, 6), "frac_off_by_more": round(f2, 8), "ms_per_frame": round(ms / 4, 3)})
+    finally:
+        for fr in frs:
+            fr.close()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(report, open(os.path.join(ROOT, "gpurun_out", "poisson_1080p_vs_oracle.json"), "w"), indent=1)
+    for r in report:
+        print(r)
+    # max abs colour diff <= 1 -- at every tolerance that may be timed; 1e-4 is recorded, and bounded by what
+    # the oracle's own CG does at that tolerance (3 levels)
+    for r in report:
+        assert r["max_abs_diff"] <= (1 if r["tol"] in TIMED_TOLS else 3), r
+    # one system's result does not depend on its batch-mates' convergence (per-system residual cadence): same iteration counts
+    for tol in TIMED_TOLS:
+        for f in frames:
+            for side in (1, 2):
+                a = [r["iters"] for r in report if (r["tol"], r["frame"], r["side"]) == (tol, f, side)]
+                assert len(set(a)) == 1, (tol, f, side, a)
+
+
+def test_quadratic_path_1080p_against_the_oracle_lattice(gpu_ctx):
+    z = np.load(os.path.join(GOLD, "qpath_1080p_lattice.npz"))
+    frame = int(z["frame"])
+    v = FX.field(W, H, frame)
+    if FX.sha(v) != _sha_text(z["inputs"]):
+        pytest.skip("this host's numpy generates other fixture inputs than the build container's")
+    rgb0, rgb1 = synth.make_rgb_pair(W, H, frame=frame)
+    fr = morph.Frame(gpu_ctx, W, H, EX)
+    try:
+        fr.upload(FX.padded(rgb0, EX), FX.padded(rgb1, EX), v, None)
+        it, rr, ms = fr.quadratic_path(tol=1e-5, max_it=200)
+        u = fr.download_qpath()
+    finally:
+        fr.close()
+    s, lines = int(z["stride"]), [int(k) for k in z["lines"]]
+    d = max(float(np.abs(u[::s, ::s] - z["lattice"]).max()), float(np.abs(u[lines] - z["rows"]).max()),
+            float(np.abs(u[:, lines] - z["cols"]).max()))
+    print("quadratic path 1080p: %d iterations, residual %.2e, %.2f ms, max |u - oracle| = %.2e px (max |u| %.3f)" % (it, rr, ms, d, float(z["abs_max"])))
+    assert rr <= 1e-5 and d <= 2e-3, (rr, d)          # SURVEY 8(f) rank 4 / tests at small sizes: 2e-3 px
+    assert abs(float(np.abs(u).max()) - float(z["abs_max"])) < 2e-3

@@ -1,6 +1,5 @@
 """dev: the Poisson extension at 1080p (ex = 192), ms per frame (both sides, tol 1e-5): one side at a time, both sides
 as one batch, 2 / 4 frames as one batch; iteration counts; byte agreement between the forms.
-VM_POISSON_SOLVER=mg1 in the environment runs round 4's one-system whole-canvas solver for the A/B.
 usage: tools/dev_poisson_batch.py [tol]"""
 import os
 import sys
@@ -41,12 +40,12 @@ def timed(fn):
     return r, (time.perf_counter() - t0) * 1e3
 
 
-solver = os.environ.get("VM_POISSON_SOLVER", "mgb (batched, ring-only)")
+solver = "mgb (batched, ring-only)"
 r, ms = timed(lambda: [(f.poisson_extend(1, tol=tol), f.poisson_extend(2, tol=tol)) for f in frs])
 print("%s: one side at a time: %.2f ms per frame (wall), device ms per side %s, iterations %s" % (
     solver, ms / nf, [round(a[2], 2) for p in r for a in p][:4], [a[0] for p in r for a in p]))
 ref = [(f.download_ext(1), f.download_ext(2)) for f in frs]
-if "VM_POISSON_SOLVER" not in os.environ:
+if True:
     for nb in (1, 2, 4):
         r, ms = timed(lambda: [morph.poisson_extend_frames(frs[k:k + nb], tol=tol) for k in range(0, nf, nb)])
         its = [s[0] for call in r for fr_ in call[0] for s in fr_]

@@ -51,7 +51,6 @@ UNITS = [
     ("vm_sweep_kernels.hip", "vm_sweep_kernels_fast.o", ["-DVM_EXACT=0", "-ffp-contract=off"]),
     ("vm_render.hip", "vm_render.o", ["-ffp-contract=off"]),
     ("vm_poisson.hip", "vm_poisson.o", ["-ffp-contract=off"]),
-    ("vm_mg.hip", "vm_mg.o", ["-ffp-contract=fast"]),
     ("vm_mgb.hip", "vm_mgb.o", ["-ffp-contract=fast"]),
     ("vm_pyramid.hip", "vm_pyramid.o", ["-ffp-contract=off"]),
     ("vm_temporal.hip", "vm_temporal.o", ["-ffp-contract=off"]),

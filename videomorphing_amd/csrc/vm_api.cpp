@@ -176,6 +176,9 @@ extern "C" int vm_ctx_create(int device, vm_ctx **out)
     hipError_t e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e2 == hipSuccess) e2 = hipEventCreate(&c->ev0);
     if (e2 == hipSuccess) e2 = hipEventCreate(&c->ev1);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming);
+    if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->xfer_ev, hipEventDisableTiming);
+    if (e2 == hipSuccess) e2 = hipEventRecord(c->done_ev, c->stream);
     if (e2 == hipSuccess) e2 = hipMalloc((void **)&c->tables, sizeof(tab));
     if (e2 == hipSuccess) e2 = hipMemcpy(c->tables, tab, sizeof(tab), hipMemcpyHostToDevice);
     if (e2 == hipSuccess) e2 = hipMalloc((void **)&c->flags, c->flags_cap * sizeof(uint32_t));
@@ -216,6 +219,8 @@ static void ctx_free(vm_ctx *c)
     for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->done_ev) hipEventDestroy(c->done_ev);
+    if (c->xfer_ev) hipEventDestroy(c->xfer_ev);
     if (c->stream) hipStreamDestroy(c->stream);
     (void)hipGetLastError();
     delete c;
@@ -1388,6 +1393,9 @@ int vm_optimize_levels(vm_ctx *c, vm_level **lv, int n, float max_iter, volatile
         }
         batch = std::min(batch * 4, 64);
     }
+    // everything this call wrote into the levels is enqueued: consumers on other streams wait on this event
+    // (vm_frame_set_v_from_level across contexts) instead of draining this stream from the host
+    VM_HIP(hipEventRecord(c->done_ev, s));
     for (int i = 0; i < n && out; ++i) {
         out[i].iters = executed[i];
         out[i].iters_live = live[i] < 0 ? executed[i] : std::min(live[i], executed[i]);

@@ -44,7 +44,7 @@ extern "C" void vm_frame_destroy(vm_frame *f)
         else hipDeviceSynchronize();
         hipFree(f->ext[0]); hipFree(f->ext[1]);
         hipFree(f->crop[0]); hipFree(f->crop[1]);
-        hipFree(f->v); hipFree(f->u); hipFree(f->out); hipFree(f->pws); hipFree(f->pws2[0]); hipFree(f->pws2[1]);
+        hipFree(f->v); hipFree(f->u); hipFree(f->out); hipFree(f->pws2[0]); hipFree(f->pws2[1]);
         (void)hipGetLastError();
     }
     delete f;
@@ -111,12 +111,27 @@ extern "C" int vm_frame_set_v_from_level(vm_frame *f, vm_pyr *p, int lvl)
     if (!f || !p || lvl < 0 || lvl >= (int)p->lv.size())
         return vm_fail(VM_E_INVALID, "vm_frame_set_v_from_level: bad argument");
     if (!vm_ctx_alive(f->ctx) || !vm_ctx_alive(p->ctx)) return vm_fail(VM_E_INVALID, "%s: a context was destroyed", __func__);
-    // a pyramid solved on ANOTHER context of the same device (a solver stream beside the compositor's): its stream is
-    // drained first, then the field is read on the frame's stream; another device is refused
+    // a pyramid solved on ANOTHER context of the same device (a solver stream beside the compositor's): the frame's
+    // stream waits for an EVENT of the solver's stream, the host never drains that stream -- a hipStreamSynchronize from
+    // here could land inside the solver thread's graph capture (hipErrorStreamCaptureUnsupported) and would make the
+    // compositor wait for whatever else that solver has queued since.  If nobody is inside a call on the pyramid's
+    // context, a fresh event covers everything enqueued there so far; if a solver call is running (the NEXT job, on
+    // other pyramids: a pyramid must not be read while it is being solved), the event its last completed call
+    // recorded -- after the last write of this pyramid's levels -- is the one to wait for.  Another device is refused.
     if (p->ctx != f->ctx && p->ctx->device != f->ctx->device)
         return vm_fail(VM_E_INVALID, "frame and pyramid live on different devices (%d, %d)", f->ctx->device, p->ctx->device);
     VM_ON_DEVICE(f->ctx);
-    if (p->ctx != f->ctx) VM_HIP(hipStreamSynchronize(p->ctx->stream));
+    if (p->ctx != f->ctx) {
+        vm_ctx *pc = p->ctx;
+        if (pc->mu.try_lock()) {
+            hipError_t e = hipEventRecord(pc->xfer_ev, pc->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(f->ctx->stream, pc->xfer_ev, 0);
+            pc->mu.unlock();
+            if (e != hipSuccess) return vm_fail(VM_E_DEVICE, "vm_frame_set_v_from_level: %s", hipGetErrorString(e));
+        } else {
+            VM_HIP(hipStreamWaitEvent(f->ctx->stream, pc->done_ev, 0));
+        }
+    }
     vm_level &l = p->lv[lvl];
     vm_launch_upscale(f->v, f->w, f->h, f->rs, l.view.v, l.w, l.h, l.rs, f->ctx->stream);
     VM_HIP(hipGetLastError());

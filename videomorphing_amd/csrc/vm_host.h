@@ -63,6 +63,10 @@ struct vm_ctx {
     vm_kern_params kp{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // done_ev: recorded on `stream` (under `mu`, never inside a graph capture) whenever a solver call has enqueued its
+    // last write of a level; xfer_ev: scratch for the same purpose in a consumer that holds `mu` itself.  Another
+    // context's stream waits on one of them instead of the host draining this stream (vm_frame_set_v_from_level)
+    hipEvent_t done_ev = nullptr, xfer_ev = nullptr;
     uint32_t *tables = nullptr;      // VM_TAB_WORDS words
     uint32_t *flags = nullptr;       // per-iteration "improving" flags (device)
     uint32_t *flags_host = nullptr;  // pinned mirror
@@ -180,10 +184,8 @@ struct vm_frame {
                                           // state, UI/MdiEditor.cpp:1898-1903): vm_render_halfway then skips its 21 taps of u --
                                           // a zero path stays zero through the fixed-point steps, the bytes are the same
     uint8_t *out = nullptr;               // h x w x 3
-    // Poisson workspace (allocated on first use): pws = the quadratic path's and the A/B solvers', pws2[side - 1] =
-    // one per side for the batched solver (both sides of a frame are in flight together)
-    void *pws = nullptr;
-    size_t pws_bytes = 0;
+    // solver workspace (allocated on first use), pws2[side - 1]: one per side (both sides of a frame are in flight
+    // together); the quadratic path uses side 1's
     void *pws2[2] = {nullptr, nullptr};
     size_t pws2_bytes[2] = {0, 0};
 };

@@ -1,18 +1,24 @@
-// vm_mgb.h -- the Poisson extension's multigrid-preconditioned CG, batched over systems, ring-only, fused
-// (round 5; launchers of vm_mgb.hip).  Same mathematics as vm_mg.hip (one V(1,1) cycle of the 2x2-aggregation
-// multigrid per PCG iteration, damped Jacobi 0.8, 40 sweeps on the coarsest grid; PoissonExt.cpp:214-329 is the
-// system, MKL DSS the reference's solver), restructured around what the counters of round 4's form showed:
+// vm_mgb.h -- the compositor's linear solver: multigrid-preconditioned CG, batched over systems, ring-only, fused
+// (launchers of vm_mgb.hip).  The system is PoissonExt.cpp:214-312's screened 5-point operator (MKL DSS is the
+// reference's solver, :321-329) or the quadratic path's Neumann Laplacian (QuadraticPath.cpp:111-215); one V(1,1)
+// cycle of a 2x2-aggregation multigrid per PCG iteration:
 //   * a SYSTEM is one side of one frame; blockIdx.z = system, so both sides of a frame (CPoissonExt::run's two
 //     prepare / poissonExtend pairs, PoissonExt.cpp:29-35, which do not depend on each other) -- and several frames --
 //     share every launch: the coarse grids of the cycle are launch-bound, not byte-bound;
-//   * every grid of the hierarchy is swept over the 64x4-cell blocks that hold an unknown only (a compact block
-//     list per level, built once per extension): the unknowns are the ring around the original image, 39 % of the
-//     canvas of a 1080p frame with ex = 192;
-//   * the pre-smoothed iterate x = omega b / dg is never stored (restriction and prolongation recompute it from b
-//     and dg at the five points they touch), r.z rides in the level-0 prolongation, p = z + beta p in the
-//     operator application (p ping-pongs), the scalar bookkeeping kernels are gone (accumulators indexed by the
-//     iteration's parity, cleared by the kernel that provably runs between their last reader and next writer):
-//     13 launches per PCG iteration instead of 22, ~250 instead of ~370 bytes per unknown.
+//   * every grid of the hierarchy is swept over the cells that hold an unknown only (compact lists of 64x4-cell
+//     blocks for the streaming PCG kernels and of 64x16-cell tiles for the cycle, built once per extension): the
+//     unknowns are the ring around the original image, 39 % of the canvas of a 1080p frame with ex = 192;
+//   * the smoother is RED-BLACK GAUSS-SEIDEL, symmetric (red, black before the coarse correction; black, red after
+//     it: the preconditioner stays symmetric positive definite), computed inside the restriction and prolongation
+//     kernels from an LDS tile of the right-hand side with a two-cell apron: the pre-smoothed iterate is never
+//     stored, its residual is zero on black cells and a sum over four black neighbours on red ones, and the
+//     post-smoothing needs the red cells' values only.  Same bytes per cycle as one damped-Jacobi sweep each way
+//     (rounds 4-5), 11 instead of 17 PCG iterations to 1e-5 on the 2304x1464 canvas;
+//   * r.z rides in the level-0 prolongation, p = z + beta p in the operator application (p ping-pongs), the scalar
+//     bookkeeping lives in accumulators indexed by the iteration's parity, cleared by the kernel that provably runs
+//     between their last reader and next writer;
+//   * all grids of <= ~6 k cells together (the last four of nine for a 1080p canvas, down to <= 64 cells) are one
+//     workgroup's work in LDS: 13 launches per PCG iteration.
 #ifndef VM_MGB_H
 #define VM_MGB_H
 
@@ -36,7 +42,7 @@ struct VmMgbLevel {
     int gx, gy;              // blocks of 64 x 4 cells covering the grid
     // the operator.  Level 0 (weights 0 / 1, diagonal 0 .. 5): ONE byte per cell, info = dg << 4 | N << 3 | S << 2 |
     // W << 1 | E (edge present towards that neighbour) -- 1 byte of operator per cell and kernel instead of 16;
-    // coarser levels: the edge weights to the east / south neighbour, the diagonal, and k = omega / dg (0: no
+    // coarser levels: the edge weights to the east / south neighbour, the diagonal, and k = 1 / dg (0: no
     // unknown), which is what the neighbours of a cell are needed for
     uint8_t *info;
     float *we, *ws, *dg, *k;
@@ -44,6 +50,8 @@ struct VmMgbLevel {
     uint32_t *flags;         // per block: does it hold an unknown (set-up scratch)
     uint32_t *blocks;        // the blocks that do, packed bx | by << 16, row-major
     int *nblocks;            // their number (device)
+    uint32_t *tiles;         // the 64 x 16-cell tiles (four blocks of a column) that hold an unknown, packed bx | ty << 16
+    int *ntiles;
 };
 
 struct VmMgbScalars {
@@ -61,7 +69,12 @@ struct VmMgbSys {
     VmMgbScalars *sc;
 };
 
-#define VM_MGB_OMEGA 0.8f       // damped Jacobi (a compile-time constant of the kernels: omega / dg of level 0 is a 5-entry table)
+#define VM_MGB_COARSEST 64      // the hierarchy ends at a grid of at most this many cells ...
+#define VM_MGB_COARSE_SWEEPS 2  // ... which gets this many symmetric Gauss-Seidel sweeps each way (R B R B, B R B R) from zero
+// the tail of the cycle -- every level from `tail` on -- runs in ONE workgroup with the iterates in LDS: the levels'
+// cell counts must fit these pools (float4 entries): all of them / all but the first
+#define VM_MGB_TAIL_X 6144
+#define VM_MGB_TAIL_B 2048
 
 // set-up: level 0 from the type map, Galerkin coarsening (2x2 aggregates, edge weights x 1/2), block flags on the way
 void vm_mgb_launch_level0(const VmMgbSys *sys, int nsys, int gx, int gy, hipStream_t s);
@@ -70,11 +83,10 @@ void vm_mgb_launch_compact(const VmMgbSys *sys, int nsys, int nlev_max, hipStrea
 // r = b - A x (in place, level 0's b), bb, rr[1]
 void vm_mgb_launch_init(const VmMgbSys *sys, int nsys, int nb0, uint64_t active, hipStream_t s);
 // V-cycle pieces
-void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nb_fine, uint64_t active, hipStream_t s);   // lv[l+1].b from lv[l], over lv[l]'s blocks
-void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nb_fine, int k, uint64_t active, hipStream_t s);   // lv[l].x; l == 0: rz[k & 1] += r.z
-void vm_mgb_launch_tail(const VmMgbSys *sys, int nsys, int l, int sweeps, uint64_t active, hipStream_t s);             // levels l, l + 1 (the coarsest) in one workgroup
-void vm_mgb_launch_coarsest(const VmMgbSys *sys, int nsys, int l, int sweeps, uint64_t active, hipStream_t s);
-void vm_mgb_launch_dot_rz(const VmMgbSys *sys, int nsys, int nb0, int k, uint64_t active, hipStream_t s);                           // hierarchies of <= 2 levels only
+void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nt_fine, uint64_t active, hipStream_t s);   // lv[l+1].b from lv[l], over lv[l]'s tiles
+void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nt_fine, int k, uint64_t active, hipStream_t s);   // lv[l].x; l == 0: rz[k & 1] += r.z
+void vm_mgb_launch_tail(const VmMgbSys *sys, int nsys, int l, uint64_t active, hipStream_t s);             // levels l .. nlev - 1 in one workgroup
+void vm_mgb_launch_dot_rz(const VmMgbSys *sys, int nsys, int nb0, int k, uint64_t active, hipStream_t s);                           // hierarchies that are all tail only
 // PCG on level 0
 void vm_mgb_launch_dirspmv(const VmMgbSys *sys, int nsys, int nb0, int k, uint64_t active, hipStream_t s);   // p = z + beta p, q = A p, pq[k & 1]
 void vm_mgb_launch_update(const VmMgbSys *sys, int nsys, int nb0, int k, uint64_t active, hipStream_t s);    // x += alpha p, r -= alpha q, rr[k & 1]

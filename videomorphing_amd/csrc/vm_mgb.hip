@@ -1,8 +1,8 @@
-// vm_mgb.hip -- batched, ring-only, fused multigrid-preconditioned CG of the Poisson extension (gfx950).
-// See vm_mgb.h for the design; vm_mg.hip holds the one-system, whole-canvas form it grew from (still the
-// solver of the quadratic motion path, whose unknowns are the whole grid).  Every kernel: blockIdx.z = system,
-// a workgroup = 256 threads = one 64 x 4-cell block of the level's compact block list (or MGB_G of them where the
-// kernel ends in a dot product); HBM-bound streams over the ring of unknowns.
+// vm_mgb.hip -- batched, ring-only, fused multigrid-preconditioned CG (gfx950): the solver of the Poisson extension
+// (PoissonExt.cpp:214-329) and of the quadratic motion path (QuadraticPath.cpp:111-305), whose unknowns are the whole
+// grid.  See vm_mgb.h for the design.  Every kernel: blockIdx.z = system; the PCG kernels: a workgroup = 256 threads =
+// MGB_G 64 x 4-cell blocks of level 0's compact block list, HBM-bound streams over the ring of unknowns; the cycle's
+// kernels: a workgroup = one 64 x 16-cell tile of the level's tile list, staged in LDS with a two-cell apron.
 #include "vm_mgb.h"
 
 namespace {
@@ -52,11 +52,10 @@ __device__ __forceinline__ bool list_cell(const VmMgbLevel &L, int e, int nb, in
 // ---------------------------------------------------------------------------
 // The operator of a level, by accessor.  (A u)(p) = dg u(p) - sum over the edges of p of w u(neighbour).
 
-// omega / dg for the integer diagonals of level 0 (the float divisions the stored form would make, as constants)
+// 1 / dg for the integer diagonals of level 0 (the float divisions the stored form would make, as constants)
 __device__ __forceinline__ float k_of_dg0(uint32_t d)
 {
-    return d == 1 ? VM_MGB_OMEGA / 1.0f : d == 2 ? VM_MGB_OMEGA / 2.0f : d == 3 ? VM_MGB_OMEGA / 3.0f
-         : d == 4 ? VM_MGB_OMEGA / 4.0f : d == 5 ? VM_MGB_OMEGA / 5.0f : 0.0f;
+    return d == 1 ? 1.0f : d == 2 ? 0.5f : d == 3 ? 1.0f / 3.0f : d == 4 ? 0.25f : d == 5 ? 0.2f : 0.0f;
 }
 
 template <bool L0> struct Op;
@@ -95,7 +94,7 @@ template <> struct Op<true> {
     __device__ __forceinline__ float ws(size_t q) const { return (float)((info[q] >> 2) & 1u); }
 };
 
-// coarser levels: float weights, diagonal, k = omega / dg
+// coarser levels: float weights, diagonal, k = 1 / dg
 template <> struct Op<false> {
     const float *__restrict__ pwe, *__restrict__ pws, *__restrict__ pdg, *__restrict__ pk;
     int w, h;
@@ -151,37 +150,6 @@ struct FromArray {          // a vector in memory
     const VmV3 *__restrict__ a;
     __device__ __forceinline__ float4 operator()(size_t q, int = 0, int = 0) const { return ld3(a, q); }
 };
-struct FromLds {            // ... in LDS
-    const float4 *a;
-    __device__ __forceinline__ float4 operator()(size_t q, int = 0, int = 0) const { return a[q]; }
-};
-
-// the pre-smoothed iterate of a level, never stored: x = (omega / dg) b  (damped Jacobi from zero)
-template <bool L0> struct PreSmoothed {
-    Op<L0> op;
-    const VmV3 *__restrict__ b;
-    __device__ __forceinline__ float4 operator()(size_t q, int = 0, int = 0) const
-    {
-        // b is fetched beside k, not behind it (one round trip): level 0's is defined on the whole canvas (0 off the
-        // ring); a coarse cell nobody restricts to holds a stale b, which the select drops
-        const float k = op.k(q);
-        const float4 v = ld3(b, q);
-        return k == 0.0f ? make_float4(0, 0, 0, 0) : make_float4(k * v.x, k * v.y, k * v.z, 0);
-    }
-};
-
-// ... plus the coarse correction: x1 = x + P xc
-template <bool L0> struct Corrected {
-    PreSmoothed<L0> pre;
-    const VmV3 *__restrict__ xc;
-    int cw;
-    __device__ __forceinline__ float4 operator()(size_t q, int x, int y) const
-    {
-        const float4 f = pre(q), c = ld3(xc, (size_t)(y >> 1) * cw + (x >> 1));
-        return make_float4(f.x + c.x, f.y + c.y, f.z + c.z, 0);
-    }
-};
-
 // block reduction of three doubles, then one double atomic per block and channel into the block's slot
 __device__ __forceinline__ void block_sum3(double a, double b, double c, double (*dst)[16])
 {
@@ -301,14 +269,15 @@ __global__ __launch_bounds__(256) void k_mgb_coarsen(const VmMgbSys *__restrict_
         if (X > 0) d += ww;
         if (Y > 0) d += wn;
         C.dg[k] = d;
-        C.k[k] = d > 0 ? VM_MGB_OMEGA / d : 0.0f;
+        C.k[k] = d > 0 ? 1.0f / d : 0.0f;
     }
     const int any = __syncthreads_or(d > 0);
     if (threadIdx.x == 0 && threadIdx.y == 0)
         C.flags[blockIdx.y * C.gx + blockIdx.x] = any ? 1u : 0u;
 }
 
-// block flags -> compact row-major block list, one workgroup per (level, system)
+// block flags -> compact row-major lists of the blocks and of the 64 x 16-cell tiles (four blocks of a column) that
+// hold an unknown, one workgroup per (level, system)
 __global__ __launch_bounds__(1024) void k_mgb_compact(const VmMgbSys *__restrict__ sys)
 {
     const VmMgbSys &S = sys[blockIdx.z];
@@ -318,28 +287,41 @@ __global__ __launch_bounds__(1024) void k_mgb_compact(const VmMgbSys *__restrict
     const VmMgbLevel &L = S.lv[l];
     __shared__ int wcount[16];
     __shared__ int base;
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, n = L.gx * L.gy;
-    if (t == 0) base = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 1024) {
-        const int i = c0 + t;
-        const bool f = i < n && L.flags[i] != 0;
-        const unsigned long long m = __ballot(f);
-        if (lane == 0) wcount[wave] = __popcll(m);
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    for (int pass = 0; pass < 2; ++pass) {               // 0: blocks, 1: tiles
+        const int rows = pass ? (L.gy + 3) / 4 : L.gy, n = L.gx * rows;
+        uint32_t *list = pass ? L.tiles : L.blocks;
+        if (t == 0) base = 0;
         __syncthreads();
-        int off = base;
-        for (int k = 0; k < wave; ++k) off += wcount[k];
-        if (f)
-            L.blocks[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(i % L.gx) | ((uint32_t)(i / L.gx) << 16);
-        __syncthreads();
-        if (t == 0) {
-            int tot = 0;
-            for (int k = 0; k < 16; ++k) tot += wcount[k];
-            base += tot;
+        for (int c0 = 0; c0 < n; c0 += 1024) {
+            const int i = c0 + t, bx = i % L.gx, r = i / L.gx;
+            bool f = false;
+            if (i < n) {
+                if (pass) {
+                    for (int q = 4 * r; q < 4 * r + 4 && q < L.gy; ++q)
+                        f = f || L.flags[q * L.gx + bx] != 0;
+                } else {
+                    f = L.flags[i] != 0;
+                }
+            }
+            const unsigned long long m = __ballot(f);
+            if (lane == 0) wcount[wave] = __popcll(m);
+            __syncthreads();
+            int off = base;
+            for (int k = 0; k < wave; ++k) off += wcount[k];
+            if (f)
+                list[off + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)bx | ((uint32_t)r << 16);
+            __syncthreads();
+            if (t == 0) {
+                int tot = 0;
+                for (int k = 0; k < 16; ++k) tot += wcount[k];
+                base += tot;
+            }
+            __syncthreads();
         }
+        if (t == 0) (pass ? L.ntiles : L.nblocks)[0] = base;
         __syncthreads();
     }
-    if (t == 0) L.nblocks[0] = base;
 }
 
 // ---------------------------------------------------------------------------
@@ -495,12 +477,120 @@ __global__ __launch_bounds__(256) void k_mgb_dot_rz(const VmMgbSys *__restrict__
 }
 
 // ---------------------------------------------------------------------------
-// V(1,1) cycle
+// V(1,1) cycle with symmetric red-black Gauss-Seidel smoothing.  Colour of a cell: red <=> (x + y) even.
+//
+// Pre-smoothing from a zero guess, red then black:      x_r = b_r / dg_r,   x_b = (b_b + sum_nb w x_r) / dg_b.
+// Its residual is zero on black cells (their equations were just solved) and sum_nb w x_b on red cells (dg_r x_r = b_r),
+// so the restriction to a 2 x 2 aggregate is the sum over its two red cells of four weighted black neighbours.
+// Post-smoothing of x1 = x + P xc, black then red:      x_b' = (b_b + sum w x1_r) / dg_b,   x_r' = (b_r + sum w x_b') / dg_r
+// needs x1 on RED cells only, which is b_r / dg_r + xc(parent): pointwise.  Both kernels therefore stage ONE LDS tile
+// of the right-hand side with a two-cell apron (64 x 16 cells + apron = 68 x 20), run two half-sweeps inside it and
+// never store the pre-smoothed iterate.  A workgroup = 256 threads = one tile of the level's tile list; thread
+// (tx, ty) owns the cells (tx, 4 ty .. 4 ty + 3) of the tile: two red, two black.
 
-// C.b = P^T (F.b - A x),  x = (omega / dg) F.b recomputed at the five points of every fine cell.  One thread per
-// FINE cell of a block of F's list: a wave covers 32 x 2 fine cells (lane = x & 31 | (y & 1) << 5), so the 2 x 2
-// aggregate is two lane exchanges, and a workgroup (4 waves) exactly one 64 x 4 fine block = 32 x 2 coarse cells.
-// (A coarse cell no fine block reaches holds no unknown: its right-hand side is never read.)
+constexpr int TW = 64, TH = 16, HL = 2, LW = TW + 2 * HL, LH = TH + 2 * HL, LN = LW * LH;
+constexpr int NHALO = LN - TW * TH;                 // apron cells of a tile: 336
+constexpr int NRING1 = (TW + 2) * (TH + 2) - TW * TH; // the cells at distance 1 around the tile: 164
+
+__device__ __forceinline__ float4 f4_scale(float k, float4 v) { return make_float4(k * v.x, k * v.y, k * v.z, 0); }
+
+// the operator records of a staged tile, by cell of the 68 x 20 LDS window
+template <bool L0> struct TileOp;
+template <> struct TileOp<true> {       // level 0: the info byte (unit weights)
+    uint8_t m[LN];
+    __device__ __forceinline__ float4 nbsum(const float4 *v, int c) const
+    {
+        const uint32_t b = m[c];
+        const float4 e = v[c + 1], w = v[c - 1], s = v[c + LW], n = v[c - LW];
+        float4 a = make_float4(0, 0, 0, 0);
+        if (b & 1u) { a.x += e.x; a.y += e.y; a.z += e.z; }
+        if (b & 2u) { a.x += w.x; a.y += w.y; a.z += w.z; }
+        if (b & 4u) { a.x += s.x; a.y += s.y; a.z += s.z; }
+        if (b & 8u) { a.x += n.x; a.y += n.y; a.z += n.z; }
+        return a;
+    }
+};
+template <> struct TileOp<false> {      // coarser levels: weights of the edges to the east / south neighbour
+    float2 w[LN];
+    __device__ __forceinline__ float4 nbsum(const float4 *v, int c) const
+    {
+        const float wE = w[c].x, wW = w[c - 1].x, wS = w[c].y, wN = w[c - LW].y;
+        const float4 e = v[c + 1], ww = v[c - 1], s = v[c + LW], n = v[c - LW];
+        // a missing edge has weight 0 and its neighbour's LDS value is 0 or finite (stage_cell): plain multiply-adds
+        float4 a = make_float4(wE * e.x, wE * e.y, wE * e.z, 0);
+        a = f4_axpy(wW, ww, a);
+        a = f4_axpy(wS, s, a);
+        a = f4_axpy(wN, n, a);
+        return a;
+    }
+};
+
+// Stage cell c of the window (grid cell (x, y)): the operator record, 1 / dg in .w, and the value the first half-sweep
+// leaves there -- red: b / dg (+ the coarse correction of its aggregate when xc is given), black: b.  A cell outside
+// the grid or without an unknown gets zeros (selected, never multiplied: memory nobody wrote may hold anything).
+// Returns b (zeros likewise).
+template <bool L0>
+__device__ __forceinline__ float4 stage_cell(const VmMgbLevel &L, const Op<L0> &A, TileOp<L0> &op, float4 *vals, int c, int x, int y,
+                                             const VmV3 *__restrict__ xc, int cw)
+{
+    const bool in = x >= 0 && x < L.w && y >= 0 && y < L.h;
+    const size_t ii = in ? (size_t)y * L.w + x : 0;
+    float inv;
+    if constexpr (L0) {
+        const uint32_t m = in ? (uint32_t)A.info[ii] : 0u;
+        op.m[c] = (uint8_t)m;
+        inv = k_of_dg0(m >> 4);
+    } else {
+        const float k = A.pk[ii], we = A.pwe[ii], ws = A.pws[ii];
+        inv = in ? k : 0.0f;
+        op.w[c] = make_float2(in && x + 1 < L.w ? we : 0.0f, in && y + 1 < L.h ? ws : 0.0f);
+    }
+    const float4 braw = ld3(L.b, ii);
+    float4 cor = make_float4(0, 0, 0, 0);
+    if (xc)
+        cor = ld3(xc, in ? (size_t)(y >> 1) * cw + (x >> 1) : 0);
+    const bool unk = inv > 0.0f;
+    const float4 b = f4_sel(unk, braw, make_float4(0, 0, 0, 0));
+    const bool red = ((x + y) & 1) == 0;
+    float4 v = b;
+    if (red)
+        v = f4_sel(unk, make_float4(inv * b.x + cor.x, inv * b.y + cor.y, inv * b.z + cor.z, 0), make_float4(0, 0, 0, 0));
+    v.w = inv;
+    vals[c] = v;
+    return b;
+}
+
+// window index of apron cell number k (0 .. NHALO - 1): two rows above, two below, two columns left and right
+__device__ __forceinline__ int halo_cell(int k)
+{
+    if (k < 2 * LW) return k;                                   // rows 0, 1
+    k -= 2 * LW;
+    if (k < 2 * LW) return (LH - 2) * LW + k;                   // rows LH - 2, LH - 1
+    k -= 2 * LW;
+    const int row = HL + (k >> 2), q = k & 3;                   // 4 cells per interior row: columns 0, 1, LW - 2, LW - 1
+    return row * LW + (q < 2 ? q : LW - 4 + q);
+}
+// ... and of cell number k (0 .. NRING1 - 1) of the ring at distance 1 around the tile
+__device__ __forceinline__ int ring1_cell(int k)
+{
+    if (k < TW + 2) return (HL - 1) * LW + (HL - 1) + k;        // the row above
+    k -= TW + 2;
+    if (k < TW + 2) return (HL + TH) * LW + (HL - 1) + k;       // the row below
+    k -= TW + 2;
+    return (HL + (k >> 1)) * LW + ((k & 1) ? HL + TW : HL - 1); // left / right column
+}
+
+// black half-sweep on window cell c (its .w = 1 / dg): x = (b + sum_nb w x_red) / dg; returns what stood there (b)
+template <bool L0>
+__device__ __forceinline__ float4 black_update(const TileOp<L0> &op, float4 *vals, int c, float4 &xnew)
+{
+    const float4 me = vals[c];
+    const float4 s = op.nbsum(vals, c);
+    xnew = f4_sel(me.w > 0.0f, make_float4(me.w * (me.x + s.x), me.w * (me.y + s.y), me.w * (me.z + s.z), me.w), make_float4(0, 0, 0, 0));
+    return me;
+}
+
+// C.b = P^T (F.b - A x),  x = red-black pre-smoothing of F.b from zero, over F's tile list
 template <bool L0>
 __global__ __launch_bounds__(256) void k_mgb_restrict(const VmMgbSys *__restrict__ sys, int l, uint64_t active)
 {
@@ -508,29 +598,55 @@ __global__ __launch_bounds__(256) void k_mgb_restrict(const VmMgbSys *__restrict
         return;
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &FL = S.lv[l], &C = S.lv[l + 1];
-    int x0, y0;
-    if (!list_block(FL, blockIdx.x, FL.nblocks[0], x0, y0))
+    if ((int)blockIdx.x >= FL.ntiles[0])
         return;
+    const uint32_t tb = FL.tiles[blockIdx.x];
+    const int x0 = (int)(tb & 0xffffu) * TW, y0 = (int)(tb >> 16) * TH;
     const Op<L0> F(FL);
-    const PreSmoothed<L0> xs{F, FL.b};
-    const int tid = threadIdx.y * 64 + threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int x = x0 + (wave & 1) * 32 + (lane & 31), y = y0 + (wave >> 1) * 2 + (lane >> 5);
-    float4 r = make_float4(0, 0, 0, 0);
-    if (x < F.w && y < F.h) {
-        const size_t ii = (size_t)y * F.w + x;
-        const float dg = F.dg(ii);
-        // every load issued before the diagonal is known (apply fetches unconditionally; the select drops what a
-        // cell that is no unknown computed from stale memory)
-        const float4 ax = F.apply(xs, x, y, ii, dg), bb = ld3(FL.b, ii);
-        r = f4_sel(dg > 0, make_float4(bb.x - ax.x, bb.y - ax.y, bb.z - ax.z, 0), r);
+    __shared__ float4 vals[LN];
+    __shared__ TileOp<L0> op;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        stage_cell<L0>(FL, F, op, vals, (HL + 4 * ty + j) * LW + HL + tx, x0 + tx, y0 + 4 * ty + j, nullptr, 0);
+    for (int k = tid; k < NHALO; k += 256) {
+        const int c = halo_cell(k);
+        stage_cell<L0>(FL, F, op, vals, c, x0 - HL + c % LW, y0 - HL + c / LW, nullptr, 0);
     }
-    r.x += __shfl_xor(r.x, 1); r.y += __shfl_xor(r.y, 1); r.z += __shfl_xor(r.z, 1);
-    r.x += __shfl_xor(r.x, 32); r.y += __shfl_xor(r.y, 32); r.z += __shfl_xor(r.z, 32);
-    if ((lane & 33) == 0 && x < F.w && y < F.h)
-        st3(C.b, (size_t)(y >> 1) * C.w + (x >> 1), r);
+    __syncthreads();
+    // black half-sweep: the thread's own two black cells, and the black cells of the ring at distance 1.  A black
+    // cell reads red neighbours only and writes itself: in place.
+    const int jb = (tx & 1) ^ 1;                         // own cells j = jb, jb + 2 are black ((tx + j) odd)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int c = (HL + 4 * ty + jb + 2 * m) * LW + HL + tx;
+        float4 xn;
+        black_update<L0>(op, vals, c, xn);
+        vals[c] = xn;
+    }
+    if (tid < NRING1) {
+        const int c = ring1_cell(tid);
+        if (((c % LW + c / LW) & 1) != 0) {              // window parity == grid parity (HL, x0, y0 are even)
+            float4 xn;
+            black_update<L0>(op, vals, c, xn);
+            vals[c] = xn;
+        }
+    }
+    __syncthreads();
+    // residual on the thread's two red cells, summed over the aggregate (its other red cell is the neighbouring lane's)
+    const int jr = tx & 1;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int row = 4 * ty + jr + 2 * m, c = (HL + row) * LW + HL + tx;
+        float4 r = vals[c].w > 0.0f ? op.nbsum(vals, c) : make_float4(0, 0, 0, 0);
+        r.x += __shfl_xor(r.x, 1); r.y += __shfl_xor(r.y, 1); r.z += __shfl_xor(r.z, 1);
+        const int X = (x0 + tx) >> 1, Y = (y0 + row) >> 1;
+        if ((tx & 1) == 0 && X < C.w && Y < C.h)
+            st3(C.b, (size_t)Y * C.w + X, r);
+    }
 }
 
-// F.x = x1 + (omega / dg) (F.b - A x1),  x1 = x + P C.x (coarse correction + post-smoothing);
+// F.x = black, red post-smoothing of x + P C.x (x = the red-black pre-smoothing of F.b from zero), over F's tile list;
 // level 0 (L0): rz[k & 1] += F.b . F.x  = r.z
 template <bool L0>
 __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict__ sys, int l, int k, uint64_t active)
@@ -539,145 +655,216 @@ __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict_
         return;
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &FL = S.lv[l], &C = S.lv[l + 1];
-    const Op<L0> F(FL);
-    const int nb = FL.nblocks[0];
-    const Corrected<L0> x1{{F, FL.b}, C.x, C.w};
+    const bool live = (int)blockIdx.x < FL.ntiles[0];
     double rz[3] = {0, 0, 0};
+    if (live) {
+        const uint32_t tb = FL.tiles[blockIdx.x];
+        const int x0 = (int)(tb & 0xffffu) * TW, y0 = (int)(tb >> 16) * TH;
+        const Op<L0> F(FL);
+        __shared__ float4 vals[LN];
+        __shared__ TileOp<L0> op;
+        const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+        float4 bown[4];
 #pragma unroll
-    for (int g = 0; g < (L0 ? MGB_G : 1); ++g) {
-        int x, y;
-        if (!list_cell(FL, L0 ? blockIdx.x * MGB_G + g : blockIdx.x, nb, x, y))
-            continue;
-        const size_t ii = (size_t)y * F.w + x;
-        const float dg = F.dg(ii);
-        float4 o = make_float4(0, 0, 0, 0);
-        {
-            const float4 c = x1(ii, x, y), s = F.apply(x1, x, y, ii, dg), b = ld3(FL.b, ii);
-            const float kk = F.k(ii);
-            o = f4_sel(dg > 0, make_float4(c.x + kk * (b.x - s.x), c.y + kk * (b.y - s.y), c.z + kk * (b.z - s.z), 0), o);
-            if (L0 && dg > 0) {
-                rz[0] += (double)b.x * o.x; rz[1] += (double)b.y * o.y; rz[2] += (double)b.z * o.z;
+        for (int j = 0; j < 4; ++j)
+            bown[j] = stage_cell<L0>(FL, F, op, vals, (HL + 4 * ty + j) * LW + HL + tx, x0 + tx, y0 + 4 * ty + j, C.x, C.w);
+        for (int kk = tid; kk < NHALO; kk += 256) {
+            const int c = halo_cell(kk);
+            stage_cell<L0>(FL, F, op, vals, c, x0 - HL + c % LW, y0 - HL + c / LW, C.x, C.w);
+        }
+        __syncthreads();
+        // (the cells' results and right-hand sides sit in registers indexed by j: the colour-dependent cell is picked by
+        //  selects -- a run-time index would put the arrays in scratch)
+        const int jb = (tx & 1) ^ 1, jr = tx & 1;
+        const bool odd = (tx & 1) != 0;                  // own cells 1, 3 are red, 0, 2 black
+        float4 out[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c = (HL + 4 * ty + jb + 2 * m) * LW + HL + tx;
+            float4 xn;
+            black_update<L0>(op, vals, c, xn);
+            vals[c] = xn;
+            out[2 * m] = xn;                             // the black one of the pair (2 m, 2 m + 1); the red one follows
+            out[2 * m + 1] = xn;
+        }
+        if (tid < NRING1) {
+            const int c = ring1_cell(tid);
+            if (((c % LW + c / LW) & 1) != 0) {
+                float4 xn;
+                black_update<L0>(op, vals, c, xn);
+                vals[c] = xn;
             }
         }
-        st3(FL.x, ii, o);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c = (HL + 4 * ty + jr + 2 * m) * LW + HL + tx;
+            const float inv = vals[c].w;
+            const float4 s = op.nbsum(vals, c), b = f4_sel(odd, bown[2 * m + 1], bown[2 * m]);
+            const float4 xr = f4_sel(inv > 0.0f, make_float4(inv * (b.x + s.x), inv * (b.y + s.y), inv * (b.z + s.z), 0), make_float4(0, 0, 0, 0));
+            out[2 * m] = f4_sel(odd, out[2 * m], xr);            // even tx: cell 2 m is red
+            out[2 * m + 1] = f4_sel(odd, xr, out[2 * m + 1]);    // odd tx: cell 2 m + 1 is red
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + tx, y = y0 + 4 * ty + j;
+            if (x < FL.w && y < FL.h) {
+                st3(FL.x, (size_t)y * FL.w + x, out[j]);
+                if (L0) {       // b is zero where there is no unknown (stage_cell)
+                    rz[0] += (double)bown[j].x * out[j].x; rz[1] += (double)bown[j].y * out[j].y; rz[2] += (double)bown[j].z * out[j].z;
+                }
+            }
+        }
     }
     if (L0)
         block_sum3(rz[0], rz[1], rz[2], S.sc->rz[k & 1]);
 }
 
-// the coarsest grid alone (hierarchies of one level: canvases of <= 1024 cells)
+// ---------------------------------------------------------------------------
+// The tail of the cycle: every level from l0 on (their cells fit VM_MGB_TAIL_X / _B, vm_mgb.h) in ONE workgroup, the
+// iterates and the coarser right-hand sides in LDS, the operators read from memory (a few thousand cells: L2).
+
+struct TailLevel {
+    int w, h, n;
+    int xo, bo;          // offsets of the level's iterate / right-hand side in the LDS pools (bo < 0: level l0, b in memory)
+};
+
+// one Gauss-Seidel half-sweep of colour `red` on a tail level: x = (b + sum_nb w x) / dg
 template <bool L0>
-__global__ __launch_bounds__(1024) void k_mgb_coarsest(const VmMgbSys *__restrict__ sys, int l, int sweeps, uint64_t active)
+__device__ __forceinline__ void tail_half(const VmMgbLevel &L, const TailLevel &T, float4 *x, const float4 *bl, bool red, bool first_red)
 {
-    if (!sys_active(active))
-        return;
-    const VmMgbLevel &L = sys[blockIdx.z].lv[l];
     const Op<L0> A(L);
-    __shared__ float4 xa[1024], xb[1024];
-    const int t = threadIdx.x, n = L.w * L.h;
-    const int x = t % L.w, y = t / L.w;
-    float dg = 0, k = 0;
-    float4 b = make_float4(0, 0, 0, 0);
-    Stencil st{0, 0, 0, 0};
-    if (t < n) {
-        dg = A.dg(t);
-        k = A.k(t);
-        if (dg > 0) b = ld3(L.b, t);
-        st = stencil_of(A, x, y, (size_t)t);
-    }
-    float4 cur = make_float4(k * b.x, k * b.y, k * b.z, 0);
-    float4 *src = xa, *dst = xb;
-    src[t] = cur;
-    __syncthreads();
-    for (int it = 1; it < sweeps; ++it) {
-        if (t < n && dg > 0) {
-            const float4 s = st.apply(src, t, L.w, dg, cur);
-            cur = make_float4(cur.x + k * (b.x - s.x), cur.y + k * (b.y - s.y), cur.z + k * (b.z - s.z), 0);
+    for (int i = threadIdx.x; i < T.n; i += 1024) {
+        const int cx = i % T.w, cy = i / T.w;
+        if ((((cx + cy) & 1) == 0) != red)
+            continue;
+        const float inv = A.k((size_t)i);
+        float4 o = make_float4(0, 0, 0, 0);
+        if (inv > 0.0f) {
+            const float4 b = bl ? bl[i] : ld3(L.b, (size_t)i);
+            float4 s = make_float4(0, 0, 0, 0);
+            if (!first_red) {       // (the first red half-sweep starts from zero: x = b / dg)
+                const Stencil st = stencil_of(A, cx, cy, (size_t)i);
+                if (st.wE != 0.0f) s = f4_axpy(st.wE, x[i + 1], s);
+                if (st.wW != 0.0f) s = f4_axpy(st.wW, x[i - 1], s);
+                if (st.wS != 0.0f) s = f4_axpy(st.wS, x[i + T.w], s);
+                if (st.wN != 0.0f) s = f4_axpy(st.wN, x[i - T.w], s);
+            }
+            o = make_float4(inv * (b.x + s.x), inv * (b.y + s.y), inv * (b.z + s.z), 0);
         }
-        dst[t] = cur;
-        __syncthreads();
-        float4 *tmp = src;
-        src = dst;
-        dst = tmp;
+        x[i] = o;
     }
-    if (t < n)
-        st3(L.x, t, cur);
+    __syncthreads();
 }
 
-// The two coarsest grids of the cycle in ONE workgroup (F: at most 4096 cells, C: the coarsest, at most 1024):
-// pre-smoothing of F (in LDS), residual restriction, the Jacobi sweeps on C, coarse correction + post-smoothing.
+// restriction of the pre-smoothed level's residual: bc[C] = sum over the aggregate's red cells of sum_nb w x_black
 template <bool L0>
-__global__ __launch_bounds__(1024) void k_mgb_tail(const VmMgbSys *__restrict__ sys, int l, int sweeps, uint64_t active)
+__device__ __forceinline__ void tail_restrict(const VmMgbLevel &L, const TailLevel &T, const TailLevel &TC, const float4 *x, float4 *bc)
+{
+    const Op<L0> A(L);
+    for (int i = threadIdx.x; i < TC.n; i += 1024) {
+        const int X = i % TC.w, Y = i / TC.w;
+        float4 r = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {                    // the aggregate's red cells: (2X, 2Y) and (2X + 1, 2Y + 1)
+            const int cx = 2 * X + d, cy = 2 * Y + d;
+            if (cx >= T.w || cy >= T.h)
+                continue;
+            const size_t q = (size_t)cy * T.w + cx;
+            if (!(A.k(q) > 0.0f))
+                continue;
+            const Stencil st = stencil_of(A, cx, cy, q);
+            if (st.wE != 0.0f) r = f4_axpy(st.wE, x[q + 1], r);
+            if (st.wW != 0.0f) r = f4_axpy(st.wW, x[q - 1], r);
+            if (st.wS != 0.0f) r = f4_axpy(st.wS, x[q + T.w], r);
+            if (st.wN != 0.0f) r = f4_axpy(st.wN, x[q - T.w], r);
+        }
+        bc[i] = r;
+    }
+    __syncthreads();
+}
+
+template <bool L0>
+__global__ __launch_bounds__(1024) void k_mgb_tail(const VmMgbSys *__restrict__ sys, int l0, uint64_t active)
 {
     if (!sys_active(active))
         return;
     const VmMgbSys &S = sys[blockIdx.z];
-    const VmMgbLevel &FL = S.lv[l], &CL = S.lv[l + 1];
-    const Op<L0> F(FL);
-    const Op<false> C(CL);
-    __shared__ float4 xf[4096], xa[1024], xb[1024];
-    const int t = threadIdx.x, nF = F.w * F.h, nC = C.w * C.h;
-    const PreSmoothed<L0> xs{F, FL.b};
-    for (int i = t; i < nF; i += 1024)
-        xf[i] = xs(i);
+    __shared__ float4 xp[VM_MGB_TAIL_X], bp[VM_MGB_TAIL_B];
+    __shared__ TailLevel T[VM_MGB_MAXLEV];
+    const int nl = S.nlev - l0;                          // levels of the tail: T[0] = level l0
+    if (threadIdx.x == 0) {
+        int xo = 0, bo = 0;
+        for (int j = 0; j < nl; ++j) {
+            const VmMgbLevel &L = S.lv[l0 + j];
+            T[j] = TailLevel{L.w, L.h, L.w * L.h, xo, j ? bo : -1};
+            xo += L.w * L.h;
+            if (j) bo += L.w * L.h;
+        }
+    }
     __syncthreads();
-    const FromLds XF{xf};
-    const int X = t % C.w, Y = t / C.w;
-    float dg = 0, k = 0;
-    float4 b = make_float4(0, 0, 0, 0);
-    Stencil st{0, 0, 0, 0};
-    if (t < nC) {
-        for (int bb = 0; bb < 2; ++bb)
-            for (int a = 0; a < 2; ++a) {
-                const int x = 2 * X + a, y = 2 * Y + bb;
-                if (x >= F.w || y >= F.h)
-                    continue;
-                const size_t ii = (size_t)y * F.w + x;
-                const float fdg = F.dg(ii);
-                if (!(fdg > 0))
-                    continue;
-                const float4 ax = F.apply(XF, x, y, ii, fdg), fb = ld3(FL.b, ii);
-                b.x += fb.x - ax.x;
-                b.y += fb.y - ax.y;
-                b.z += fb.z - ax.z;
+    // down: pre-smoothing (red from zero, black), restriction
+    for (int j = 0; j + 1 < nl; ++j) {
+        const VmMgbLevel &L = S.lv[l0 + j];
+        float4 *x = xp + T[j].xo;
+        const float4 *b = j ? bp + T[j].bo : nullptr;
+        if (j == 0) {
+            tail_half<L0>(L, T[0], x, b, true, true);
+            tail_half<L0>(L, T[0], x, b, false, false);
+            tail_restrict<L0>(L, T[0], T[1], x, bp + T[1].bo);
+        } else {
+            tail_half<false>(L, T[j], x, b, true, true);
+            tail_half<false>(L, T[j], x, b, false, false);
+            tail_restrict<false>(L, T[j], T[j + 1], x, bp + T[j + 1].bo);
+        }
+    }
+    // the coarsest grid: symmetric sweeps from zero
+    {
+        const int j = nl - 1;
+        const VmMgbLevel &L = S.lv[l0 + j];
+        float4 *x = xp + T[j].xo;
+        const float4 *b = j ? bp + T[j].bo : nullptr;
+        for (int sw = 0; sw < 2 * VM_MGB_COARSE_SWEEPS; ++sw) {
+            const bool fwd = sw < VM_MGB_COARSE_SWEEPS;  // red, black ... then black, red ...
+            if (j == 0) {
+                tail_half<L0>(L, T[j], x, b, fwd, sw == 0);
+                tail_half<L0>(L, T[j], x, b, !fwd, false);
+            } else {
+                tail_half<false>(L, T[j], x, b, fwd, sw == 0);
+                tail_half<false>(L, T[j], x, b, !fwd, false);
             }
-        dg = C.dg(t);
-        k = C.k(t);
-        st = stencil_of(C, X, Y, (size_t)t);
-    }
-    float4 cur = make_float4(k * b.x, k * b.y, k * b.z, 0);
-    float4 *src = xa, *dst = xb;
-    src[t] = cur;
-    __syncthreads();
-    for (int it = 1; it < sweeps; ++it) {
-        if (t < nC && dg > 0) {
-            const float4 s = st.apply(src, t, C.w, dg, cur);
-            cur = make_float4(cur.x + k * (b.x - s.x), cur.y + k * (b.y - s.y), cur.z + k * (b.z - s.z), 0);
         }
-        dst[t] = cur;
+    }
+    // up: coarse correction on the red cells (the black half-sweep that follows overwrites the black ones from red
+    // values only), post-smoothing black, red
+    for (int j = nl - 2; j >= 0; --j) {
+        const VmMgbLevel &L = S.lv[l0 + j];
+        float4 *x = xp + T[j].xo;
+        const float4 *xc = xp + T[j + 1].xo;
+        const float4 *b = j ? bp + T[j].bo : nullptr;
+        const int w = T[j].w, cw = T[j + 1].w;
+        for (int i = threadIdx.x; i < T[j].n; i += 1024) {
+            const int cx = i % w, cy = i / w;
+            if (((cx + cy) & 1) == 0) {
+                const float4 c = xc[(cy >> 1) * cw + (cx >> 1)], f = x[i];
+                // a red cell without an unknown holds 0 and stays 0: its aggregate may hold unknowns and a correction
+                const bool unk = (j == 0 && L0) ? (S.lv[l0].info[i] >> 4) != 0 : L.k[i] > 0.0f;
+                if (unk)
+                    x[i] = make_float4(f.x + c.x, f.y + c.y, f.z + c.z, 0);
+            }
+        }
         __syncthreads();
-        float4 *tmp = src;
-        src = dst;
-        dst = tmp;
-    }
-    // x1 = x + P xc (in place), then F.x = x1 + (omega / dg) (F.b - A x1)
-    for (int i = t; i < nF; i += 1024) {
-        const int x = i % F.w, y = i / F.w;
-        const float4 c = src[(y >> 1) * C.w + (x >> 1)], f = xf[i];
-        xf[i] = make_float4(f.x + c.x, f.y + c.y, f.z + c.z, 0);
-    }
-    __syncthreads();
-    for (int i = t; i < nF; i += 1024) {
-        const int x = i % F.w, y = i / F.w;
-        const float fdg = F.dg(i);
-        float4 o = make_float4(0, 0, 0, 0);
-        if (fdg > 0) {
-            const float4 c = xf[i], s = F.apply(XF, x, y, (size_t)i, fdg), fb = ld3(FL.b, i);
-            const float kf = F.k(i);
-            o = make_float4(c.x + kf * (fb.x - s.x), c.y + kf * (fb.y - s.y), c.z + kf * (fb.z - s.z), 0);
+        if (j == 0) {
+            tail_half<L0>(L, T[0], x, b, false, false);
+            tail_half<L0>(L, T[0], x, b, true, false);
+        } else {
+            tail_half<false>(L, T[j], x, b, false, false);
+            tail_half<false>(L, T[j], x, b, true, false);
         }
-        st3(FL.x, i, o);
     }
+    const VmMgbLevel &L = S.lv[l0];
+    for (int i = threadIdx.x; i < T[0].n; i += 1024)
+        st3(L.x, (size_t)i, xp[i]);
 }
 
 const dim3 blk2(64, 4);
@@ -708,36 +895,28 @@ void vm_mgb_launch_init(const VmMgbSys *sys, int nsys, int nb0, uint64_t active,
     hipLaunchKernelGGL(k_mgb_init, dim3(groups(nb0), 1, nsys), blk2, 0, s, sys, active);
 }
 
-void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nb_fine, uint64_t active, hipStream_t s)
+void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nt_fine, uint64_t active, hipStream_t s)
 {
     if (l == 0)
-        hipLaunchKernelGGL(k_mgb_restrict<true>, dim3(nb_fine, 1, nsys), blk2, 0, s, sys, l, active);
+        hipLaunchKernelGGL(k_mgb_restrict<true>, dim3(nt_fine, 1, nsys), blk2, 0, s, sys, l, active);
     else
-        hipLaunchKernelGGL(k_mgb_restrict<false>, dim3(nb_fine, 1, nsys), blk2, 0, s, sys, l, active);
+        hipLaunchKernelGGL(k_mgb_restrict<false>, dim3(nt_fine, 1, nsys), blk2, 0, s, sys, l, active);
 }
 
-void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nb_fine, int k, uint64_t active, hipStream_t s)
+void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nt_fine, int k, uint64_t active, hipStream_t s)
 {
     if (l == 0)
-        hipLaunchKernelGGL(k_mgb_prolong<true>, dim3(groups(nb_fine), 1, nsys), blk2, 0, s, sys, l, k, active);
+        hipLaunchKernelGGL(k_mgb_prolong<true>, dim3(nt_fine, 1, nsys), blk2, 0, s, sys, l, k, active);
     else
-        hipLaunchKernelGGL(k_mgb_prolong<false>, dim3(nb_fine, 1, nsys), blk2, 0, s, sys, l, k, active);
+        hipLaunchKernelGGL(k_mgb_prolong<false>, dim3(nt_fine, 1, nsys), blk2, 0, s, sys, l, k, active);
 }
 
-void vm_mgb_launch_tail(const VmMgbSys *sys, int nsys, int l, int sweeps, uint64_t active, hipStream_t s)
+void vm_mgb_launch_tail(const VmMgbSys *sys, int nsys, int l, uint64_t active, hipStream_t s)
 {
     if (l == 0)
-        hipLaunchKernelGGL(k_mgb_tail<true>, dim3(1, 1, nsys), dim3(1024), 0, s, sys, l, sweeps, active);
+        hipLaunchKernelGGL(k_mgb_tail<true>, dim3(1, 1, nsys), dim3(1024), 0, s, sys, l, active);
     else
-        hipLaunchKernelGGL(k_mgb_tail<false>, dim3(1, 1, nsys), dim3(1024), 0, s, sys, l, sweeps, active);
-}
-
-void vm_mgb_launch_coarsest(const VmMgbSys *sys, int nsys, int l, int sweeps, uint64_t active, hipStream_t s)
-{
-    if (l == 0)
-        hipLaunchKernelGGL(k_mgb_coarsest<true>, dim3(1, 1, nsys), dim3(1024), 0, s, sys, l, sweeps, active);
-    else
-        hipLaunchKernelGGL(k_mgb_coarsest<false>, dim3(1, 1, nsys), dim3(1024), 0, s, sys, l, sweeps, active);
+        hipLaunchKernelGGL(k_mgb_tail<false>, dim3(1, 1, nsys), dim3(1024), 0, s, sys, l, active);
 }
 
 void vm_mgb_launch_dot_rz(const VmMgbSys *sys, int nsys, int nb0, int k, uint64_t active, hipStream_t s)

@@ -6,13 +6,11 @@
 // screened 5-point Poisson system that PoissonExt.cpp:214-312 assembles.
 //
 // How: the reference builds a CSR matrix on the host and factorises it with
-// Intel MKL DSS (PoissonExt.cpp:321-329).  Here nothing is assembled: the
-// operator is applied matrix-free from the 1-byte type map, the three colour
-// channels ride together in one float4 per pixel (16-byte coalesced accesses),
-// and the system is solved by Jacobi-preconditioned conjugate gradients whose
-// scalars (alpha, beta, residual norms) stay in device memory, so an iteration
-// is three kernel launches with no host round trip.  Dot products accumulate
-// in double.  HBM-bound: ~5 float4 vectors touched per unknown per iteration.
+// Intel MKL DSS (PoissonExt.cpp:321-329).  Here nothing is assembled: this file
+// holds classification, fill, right-hand side / initial guess and paste; the
+// system itself is solved matrix-free by the batched multigrid-preconditioned
+// CG of vm_mgb.hip (three colour channels per 12-byte vector entry).  The
+// quadratic motion path's set-up kernels (QuadraticPath.cpp:24-223) live here too.
 #include "vm_internal.h"
 #include "vm_poisson.h"
 #include "vm_mgb.h"
@@ -169,18 +167,6 @@ __global__ __launch_bounds__(256) void k_setup(const uchar4 *__restrict__ ext,
     put_vec(X, ii, x0);
 }
 
-__device__ __forceinline__ float4 apply_A(const float4 *__restrict__ P, const uint8_t *__restrict__ type,
-                                          float diag, size_t ii, int x, int y, int cw, int ch)
-{
-    float4 c = P[ii];
-    float4 s = make_float4(diag * c.x, diag * c.y, diag * c.z, 0);
-    if (y - 1 >= 0 && type[ii - cw] > 0) { float4 n = P[ii - cw]; s.x -= n.x; s.y -= n.y; s.z -= n.z; }
-    if (x - 1 >= 0 && type[ii - 1] > 0) { float4 n = P[ii - 1]; s.x -= n.x; s.y -= n.y; s.z -= n.z; }
-    if (x + 1 < cw && type[ii + 1] > 0) { float4 n = P[ii + 1]; s.x -= n.x; s.y -= n.y; s.z -= n.z; }
-    if (y + 1 < ch && type[ii + cw] > 0) { float4 n = P[ii + cw]; s.x -= n.x; s.y -= n.y; s.z -= n.z; }
-    return s;
-}
-
 // block reduction of three doubles, then one double atomic per block and channel
 __device__ __forceinline__ void block_sum3(double a, double b, double c, double *dst)
 {
@@ -199,126 +185,6 @@ __device__ __forceinline__ void block_sum3(double a, double b, double c, double 
         if (s != 0) atomicAdd(&dst[tid], s);
     }
     __syncthreads();
-}
-
-// r = b - A x, z = r / diag, p = z;  scal.rz[c] = r.z, scal.bb[c] = b.b, scal.rr[c] = r.r
-__global__ __launch_bounds__(256) void k_cg_init(const float4 *__restrict__ B, const float4 *__restrict__ X,
-                                                 float4 *R, float4 *P, const uint8_t *__restrict__ type,
-                                                 VmCgScalars *sc, int cw, int ch)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    double rz[3] = {0, 0, 0}, bb[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
-    if (x < cw && y < ch) {
-        const size_t ii = (size_t)y * cw + x;
-        if (type[ii] > 0) {
-            const float4 b = B[ii];
-            const float4 ax = apply_A(X, type, b.w, ii, x, y, cw, ch);
-            const float4 r = make_float4(b.x - ax.x, b.y - ax.y, b.z - ax.z, 0);
-            const float inv = 1.0f / b.w;
-            R[ii] = r;
-            P[ii] = make_float4(r.x * inv, r.y * inv, r.z * inv, 0);
-            rz[0] = (double)r.x * r.x * inv; rz[1] = (double)r.y * r.y * inv; rz[2] = (double)r.z * r.z * inv;
-            bb[0] = (double)b.x * b.x; bb[1] = (double)b.y * b.y; bb[2] = (double)b.z * b.z;
-            rr[0] = (double)r.x * r.x; rr[1] = (double)r.y * r.y; rr[2] = (double)r.z * r.z;
-        } else {
-            R[ii] = make_float4(0, 0, 0, 0);
-            P[ii] = make_float4(0, 0, 0, 0);
-        }
-    }
-    block_sum3(rz[0], rz[1], rz[2], sc->rz);
-    block_sum3(bb[0], bb[1], bb[2], sc->bb);
-    block_sum3(rr[0], rr[1], rr[2], sc->rr);
-}
-
-// q = A p;  pq[c] += p.q
-__global__ __launch_bounds__(256) void k_cg_spmv(const float4 *__restrict__ P, float4 *Q,
-                                                 const float4 *__restrict__ B,
-                                                 const uint8_t *__restrict__ type, VmCgScalars *sc,
-                                                 int cw, int ch)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    double pq[3] = {0, 0, 0};
-    if (x < cw && y < ch) {
-        const size_t ii = (size_t)y * cw + x;
-        if (type[ii] > 0) {
-            const float4 q = apply_A(P, type, B[ii].w, ii, x, y, cw, ch);
-            const float4 p = P[ii];
-            Q[ii] = q;
-            pq[0] = (double)p.x * q.x; pq[1] = (double)p.y * q.y; pq[2] = (double)p.z * q.z;
-        }
-    }
-    block_sum3(pq[0], pq[1], pq[2], sc->pq);
-}
-
-// alpha = rz/pq;  x += alpha p;  r -= alpha q;  rz_new += r.(r/diag);  rr_new += r.r
-__global__ __launch_bounds__(256) void k_cg_update(float4 *X, float4 *R, const float4 *__restrict__ P,
-                                                   const float4 *__restrict__ Q,
-                                                   const float4 *__restrict__ B,
-                                                   const uint8_t *__restrict__ type, VmCgScalars *sc,
-                                                   int cw, int ch)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
-    if (x < cw && y < ch) {
-        const size_t ii = (size_t)y * cw + x;
-        if (type[ii] > 0) {
-            float al[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                al[c] = sc->pq[c] > 0 ? (float)(sc->rz[c] / sc->pq[c]) : 0.0f;
-            const float4 p = P[ii], q = Q[ii];
-            float4 xx = X[ii], r = R[ii];
-            xx.x += al[0] * p.x; xx.y += al[1] * p.y; xx.z += al[2] * p.z;
-            r.x -= al[0] * q.x; r.y -= al[1] * q.y; r.z -= al[2] * q.z;
-            X[ii] = xx;
-            R[ii] = r;
-            const float inv = 1.0f / B[ii].w;
-            rz[0] = (double)r.x * r.x * inv; rz[1] = (double)r.y * r.y * inv; rz[2] = (double)r.z * r.z * inv;
-            rr[0] = (double)r.x * r.x; rr[1] = (double)r.y * r.y; rr[2] = (double)r.z * r.z;
-        }
-    }
-    block_sum3(rz[0], rz[1], rz[2], sc->rz_new);
-    block_sum3(rr[0], rr[1], rr[2], sc->rr_new);
-}
-
-// beta = rz_new/rz;  p = r/diag + beta p
-__global__ __launch_bounds__(256) void k_cg_dir(float4 *P, const float4 *__restrict__ R,
-                                                const float4 *__restrict__ B,
-                                                const uint8_t *__restrict__ type,
-                                                const VmCgScalars *sc, int cw, int ch)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= cw || y >= ch)
-        return;
-    const size_t ii = (size_t)y * cw + x;
-    if (type[ii] == 0)
-        return;
-    float be[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        be[c] = sc->rz[c] > 0 ? (float)(sc->rz_new[c] / sc->rz[c]) : 0.0f;
-    const float inv = 1.0f / B[ii].w;
-    const float4 r = R[ii];
-    float4 p = P[ii];
-    p.x = r.x * inv + be[0] * p.x;
-    p.y = r.y * inv + be[1] * p.y;
-    p.z = r.z * inv + be[2] * p.z;
-    P[ii] = p;
-}
-
-// rotate the scalars for the next iteration; record the residual history
-__global__ void k_cg_rotate(VmCgScalars *sc)
-{
-    if (threadIdx.x < 3) {
-        const int c = threadIdx.x;
-        sc->rz[c] = sc->rz_new[c];
-        sc->rr[c] = sc->rr_new[c];
-        sc->rz_new[c] = 0;
-        sc->rr_new[c] = 0;
-        sc->pq[c] = 0;
-    }
-    if (threadIdx.x == 0)
-        sc->iters += 1;
 }
 
 // paste, PoissonExt.cpp:333-346
@@ -345,84 +211,6 @@ __global__ __launch_bounds__(256) void k_crop(uchar4 *dst, const uchar4 *__restr
     if (x >= w || y >= h)
         return;
     dst[(size_t)y * w + x] = ext[(size_t)(y + ex) * (w + 2 * ex) + x + ex];
-}
-
-// nested iteration: the same problem on a 4x coarser canvas gives the fine solve its
-// low frequencies (the outside band is ~0.1 max(W,H) pixels wide, which plain CG has to
-// cross one pixel per iteration).  A coarse pixel is outside (2) if its 4x4 block holds
-// only outside pixels, interior (0) if only interior ones, else an anchor (1) carrying
-// the mean colour of the block's non-outside pixels; outside blocks carry the mean of
-// their real colours (marker if none).
-__global__ __launch_bounds__(256) void k_coarsen(const uchar4 *__restrict__ ext, const uint8_t *__restrict__ type,
-                                                 uchar4 *ext_c, uint8_t *type_c, int cw, int ch, int cw2, int ch2)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= cw2 || y >= ch2)
-        return;
-    int n_out = 0, n_ring = 0, n_col = 0, n_anchor = 0;
-    float3 col = make_float3(0, 0, 0), anc = make_float3(0, 0, 0);
-    for (int j = 0; j < 4; ++j)
-        for (int i = 0; i < 4; ++i) {
-            const int fx = 4 * x + i, fy = 4 * y + j;
-            if (fx >= cw || fy >= ch)
-                continue;
-            const size_t ii = (size_t)fy * cw + fx;
-            const uint8_t t = type[ii];
-            const uchar4 c = ext[ii];
-            if (t == 2) {
-                ++n_out;
-                if (!is_marker(c)) { ++n_col; col.x += c.x; col.y += c.y; col.z += c.z; }
-            } else {
-                if (t == 1) ++n_ring;
-                ++n_anchor; anc.x += c.x; anc.y += c.y; anc.z += c.z;
-            }
-        }
-    uint8_t t = 0;
-    uchar4 o = make_uchar4(255, 0, 255, 0);
-    if (n_out > 0 && n_anchor == 0) {
-        t = 2;
-        if (n_col > 0)
-            o = make_uchar4((uint8_t)(col.x / n_col + 0.5f), (uint8_t)(col.y / n_col + 0.5f), (uint8_t)(col.z / n_col + 0.5f), 0);
-    } else if (n_out > 0 || n_ring > 0) {
-        t = 1;
-        o = make_uchar4((uint8_t)(anc.x / n_anchor + 0.5f), (uint8_t)(anc.y / n_anchor + 0.5f), (uint8_t)(anc.z / n_anchor + 0.5f), 0);
-    } else if (n_anchor > 0) {
-        o = make_uchar4((uint8_t)(anc.x / n_anchor + 0.5f), (uint8_t)(anc.y / n_anchor + 0.5f), (uint8_t)(anc.z / n_anchor + 0.5f), 0);
-    }
-    const size_t k = (size_t)y * cw2 + x;
-    type_c[k] = t;
-    ext_c[k] = o;
-}
-
-// bilinear prolongation of the coarse solution as the fine initial guess
-__global__ __launch_bounds__(256) void k_prolong(const float4 *__restrict__ Xc, const uint8_t *__restrict__ type_c,
-                                                 float4 *X, const uint8_t *__restrict__ type, int cw, int ch,
-                                                 int cw2, int ch2)
-{
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= cw || y >= ch)
-        return;
-    const size_t ii = (size_t)y * cw + x;
-    if (type[ii] == 0) { X[ii] = make_float4(0, 0, 0, 0); return; }
-    const float fx = (x + 0.5f) * 0.25f - 0.5f, fy = (y + 0.5f) * 0.25f - 0.5f;
-    const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
-    const float a = fx - x0, b = fy - y0;
-    float4 acc = make_float4(0, 0, 0, 0);
-    float wsum = 0;
-    for (int j = 0; j < 2; ++j)
-        for (int i = 0; i < 2; ++i) {
-            const int qx = min(max(x0 + i, 0), cw2 - 1), qy = min(max(y0 + j, 0), ch2 - 1);
-            const size_t k = (size_t)qy * cw2 + qx;
-            if (type_c[k] == 0)
-                continue;
-            const float wgt = (i ? a : 1 - a) * (j ? b : 1 - b);
-            const float4 c = Xc[k];
-            acc.x += wgt * c.x; acc.y += wgt * c.y; acc.z += wgt * c.z;
-            wsum += wgt;
-        }
-    if (wsum > 1e-6f)
-        X[ii] = make_float4(acc.x / wsum, acc.y / wsum, acc.z / wsum, 0);
-    // else: keep the default guess written by k_setup
 }
 
 inline dim3 grid2(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
@@ -538,58 +326,14 @@ void vm_poisson_launch_prepare(uchar4 *ext, uint8_t *type, const uchar4 *other, 
     hipLaunchKernelGGL(k_fill, grid2(cw, ch), B2, 0, s, ext, type, other, v, w, h, rs, ex, sign);
 }
 
-void vm_poisson_launch_setup(const uchar4 *ext, const uint8_t *type, float4 *B, float4 *X, int cw, int ch,
-                             hipStream_t s)
-{
-    hipLaunchKernelGGL(k_setup<float4>, grid2(cw, ch), B2, 0, s, ext, type, B, X, cw, ch, 1);
-}
-
 void vm_poisson_launch_setup3(const uchar4 *ext, const uint8_t *type, VmV3 *B, VmV3 *X, int cw, int ch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_setup<VmV3>, grid2(cw, ch), B2, 0, s, ext, type, B, X, cw, ch, 1);
 }
 
-void vm_poisson_launch_cg_init(const float4 *B, const float4 *X, float4 *R, float4 *P, const uint8_t *type,
-                               VmCgScalars *sc, int cw, int ch, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_cg_init, grid2(cw, ch), B2, 0, s, B, X, R, P, type, sc, cw, ch);
-}
-
-void vm_poisson_launch_coarsen(const uchar4 *ext, const uint8_t *type, uchar4 *ext_c, uint8_t *type_c, int cw,
-                               int ch, int cw2, int ch2, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_coarsen, grid2(cw2, ch2), B2, 0, s, ext, type, ext_c, type_c, cw, ch, cw2, ch2);
-}
-
-void vm_poisson_launch_prolong(const float4 *Xc, const uint8_t *type_c, float4 *X, const uint8_t *type, int cw,
-                               int ch, int cw2, int ch2, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_prolong, grid2(cw, ch), B2, 0, s, Xc, type_c, X, type, cw, ch, cw2, ch2);
-}
-
-void vm_poisson_launch_iter(float4 *X, float4 *R, float4 *P, float4 *Q, const float4 *B,
-                            const uint8_t *type, VmCgScalars *sc, int cw, int ch, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_cg_spmv, grid2(cw, ch), B2, 0, s, P, Q, B, type, sc, cw, ch);
-    hipLaunchKernelGGL(k_cg_update, grid2(cw, ch), B2, 0, s, X, R, P, Q, B, type, sc, cw, ch);
-    hipLaunchKernelGGL(k_cg_dir, grid2(cw, ch), B2, 0, s, P, R, B, type, sc, cw, ch);
-    hipLaunchKernelGGL(k_cg_rotate, dim3(1), dim3(64), 0, s, sc);
-}
-
-void vm_poisson_launch_paste(uchar4 *ext, const uint8_t *type, const float4 *X, int cw, int ch,
-                             hipStream_t s)
-{
-    hipLaunchKernelGGL(k_paste<float4>, grid2(cw, ch), B2, 0, s, ext, type, X, cw, ch);
-}
-
 void vm_poisson_launch_paste3(uchar4 *ext, const uint8_t *type, const VmV3 *X, int cw, int ch, hipStream_t s)
 {
     hipLaunchKernelGGL(k_paste<VmV3>, grid2(cw, ch), B2, 0, s, ext, type, X, cw, ch);
-}
-
-void vm_qpath_launch_rhs(const float2 *v, int rs, int w, int h, float4 *B, float4 *X, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_qp_rhs<float4>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, v, rs, w, h, B, X);
 }
 
 void vm_qpath_launch_rhs3(const float2 *v, int rs, int w, int h, VmV3 *B, VmV3 *X, hipStream_t s)
@@ -603,23 +347,13 @@ static inline dim3 sum_grid(int w, int h)
     return dim3(std::min(((w + 63) / 64) * ((h + 3) / 4), 1024));
 }
 
-void vm_qpath_launch_sum(const float4 *X, int w, int h, double *sums, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_qp_sum<float4>, sum_grid(w, h), dim3(64, 4), 0, s, X, w, h, sums, 1);
-}
-
-// ... spread over VM_QP_SLOTS lines of 16 doubles (the batched solver's scalar block has room for 8)
+// the atomics spread over VM_QP_SLOTS lines of 16 doubles (the solver's scalar block has room for 8)
 void vm_qpath_launch_sum3(const VmV3 *X, int w, int h, double *sums, hipStream_t s)
 {
     hipLaunchKernelGGL(k_qp_sum<VmV3>, sum_grid(w, h), dim3(64, 4), 0, s, X, w, h, sums, VM_QP_SLOTS);
 }
 
 // u == nullptr: X -= mean in place; else u = X - mean
-void vm_qpath_launch_shift(float4 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_qp_shift<float4>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, 1, u, rs);
-}
-
 void vm_qpath_launch_shift3(VmV3 *X, int w, int h, const double *sums, float2 *u, int rs, hipStream_t s)
 {
     hipLaunchKernelGGL(k_qp_shift<VmV3>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, X, w, h, sums, VM_QP_SLOTS, u, rs);

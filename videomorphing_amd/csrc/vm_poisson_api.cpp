@@ -2,7 +2,6 @@
 // (CPoissonExt::run body for one side, Algorithm/PoissonExt.cpp:19-41) and the
 // RCCL broadcast helper.
 #include "vm_host.h"
-#include "vm_mg.h"
 #include "vm_mgb.h"
 #include "vm_poisson.h"
 
@@ -16,288 +15,38 @@
 
 namespace {
 
-// one grid of the nested iteration (level 0 = the frame's canvas)
-struct Grid {
-    int cw, ch;
-    uchar4 *ext;     // level 0: the frame's canvas; coarser: in the workspace
-    uint8_t *type;
-    float4 *B, *X, *R, *P, *Q;
-};
-
 size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-size_t grid_bytes(int cw, int ch, bool own_ext)
-{
-    const size_t N = (size_t)cw * ch;
-    return al256(N) + 5 * al256(N * 16) + (own_ext ? al256(N * 4) : 0);
-}
-
-char *grid_carve(Grid &g, char *b, bool own_ext)
-{
-    const size_t N = (size_t)g.cw * g.ch;
-    g.type = (uint8_t *)b; b += al256(N);
-    g.B = (float4 *)b; b += al256(N * 16);
-    g.X = (float4 *)b; b += al256(N * 16);
-    g.R = (float4 *)b; b += al256(N * 16);
-    g.P = (float4 *)b; b += al256(N * 16);
-    g.Q = (float4 *)b; b += al256(N * 16);
-    if (own_ext) { g.ext = (uchar4 *)b; b += al256(N * 4); }
-    return b;
-}
-
-// Jacobi-PCG on one grid from the X it holds, until the relative residual <= tol
-int run_cg(vm_ctx *c, Grid &g, VmCgScalars *sc, float tol, int max_it, int *iters, double *rel)
-{
-    hipStream_t s = c->stream;
-    VM_HIP(hipMemsetAsync(sc, 0, sizeof(VmCgScalars), s));
-    vm_poisson_launch_cg_init(g.B, g.X, g.R, g.P, g.type, sc, g.cw, g.ch, s);
-    VmCgScalars h;
-    int it = 0;
-    double worst = 0;
-    const int check = 32;
-    while (true) {
-        VM_HIP(hipMemcpyAsync(&h, sc, sizeof(h), hipMemcpyDeviceToHost, s));
-        VM_HIP(hipStreamSynchronize(s));
-        worst = 0;
-        for (int k = 0; k < 3; ++k)
-            if (h.bb[k] > 0) worst = std::max(worst, std::sqrt(h.rr[k] / h.bb[k]));
-        if (!(worst == worst)) return vm_fail(VM_E_NUMERIC, "vm_poisson_extend: CG broke down (NaN)");
-        if (worst <= tol || it >= max_it) break;
-        const int nb = std::min(check, max_it - it);
-        for (int k = 0; k < nb; ++k)
-            vm_poisson_launch_iter(g.X, g.R, g.P, g.Q, g.B, g.type, sc, g.cw, g.ch, s);
-        VM_HIP(hipGetLastError());
-        it += nb;
-    }
-    *iters = it;
-    *rel = worst;
-    return VM_OK;
-}
-// ---------------------------------------------------------------------------
-// multigrid-preconditioned CG (vm_mg.hip)
-
-struct MgHierarchy {
-    std::vector<VmMgLevel> lv;
-    float4 *X = nullptr, *B = nullptr, *R = nullptr, *P = nullptr, *Q = nullptr;
-    float4 *Xbest = nullptr; // the iterate with the smallest residual seen so far
-    VmPcgScalars *sc = nullptr;
-};
-
-// grid sizes: halve (rounding up) until the coarsest grid fits one workgroup
+// grid sizes: halve (rounding up) down to a grid of at most VM_MGB_COARSEST cells
 std::vector<std::pair<int, int>> mg_sizes(int w, int h)
 {
     std::vector<std::pair<int, int>> v{{w, h}};
-    while ((size_t)v.back().first * v.back().second > 1024)
+    while ((size_t)v.back().first * v.back().second > VM_MGB_COARSEST && (int)v.size() < VM_MGB_MAXLEV)
         v.push_back({(v.back().first + 1) / 2, (v.back().second + 1) / 2});
     return v;
 }
 
-size_t mg_bytes(int w, int h)
+// the first level of the cycle's one-workgroup tail: from there on all iterates fit VM_MGB_TAIL_X cells of LDS and all
+// right-hand sides but the first VM_MGB_TAIL_B
+int mg_tail_level(const std::vector<std::pair<int, int>> &sz)
 {
-    size_t need = al256(sizeof(VmPcgScalars));
-    const auto sz = mg_sizes(w, h);
-    for (size_t l = 0; l < sz.size(); ++l) {
-        const size_t N = (size_t)sz[l].first * sz[l].second;
-        need += 3 * al256(N * 4) + 3 * al256(N * 16); // we, ws, dg + x, b, t
+    size_t below = 0;       // cells of the levels after l
+    int l = (int)sz.size() - 1;
+    while (l > 0) {
+        const size_t here = (size_t)sz[l].first * sz[l].second, up = (size_t)sz[l - 1].first * sz[l - 1].second;
+        if (below + here + up > VM_MGB_TAIL_X || below + here > VM_MGB_TAIL_B)
+            break;
+        below += here;
+        --l;
     }
-    need += 5 * al256((size_t)w * h * 16);             // X, B, P, Q, Xbest  (R = level 0's b)
-    return need;
+    return l;
 }
 
-char *mg_carve(MgHierarchy &H, int w, int h, char *b)
-{
-    H.sc = (VmPcgScalars *)b; b += al256(sizeof(VmPcgScalars));
-    const auto sz = mg_sizes(w, h);
-    H.lv.resize(sz.size());
-    for (size_t l = 0; l < sz.size(); ++l) {
-        VmMgLevel &L = H.lv[l];
-        L.w = sz[l].first; L.h = sz[l].second;
-        const size_t N = (size_t)L.w * L.h;
-        L.we = (float *)b; b += al256(N * 4);
-        L.ws = (float *)b; b += al256(N * 4);
-        L.dg = (float *)b; b += al256(N * 4);
-        L.x = (float4 *)b; b += al256(N * 16);
-        L.b = (float4 *)b; b += al256(N * 16);
-        L.t = (float4 *)b; b += al256(N * 16);
-    }
-    const size_t N0 = (size_t)w * h;
-    H.X = (float4 *)b; b += al256(N0 * 16);
-    H.B = (float4 *)b; b += al256(N0 * 16);
-    H.P = (float4 *)b; b += al256(N0 * 16);
-    H.Q = (float4 *)b; b += al256(N0 * 16);
-    H.Xbest = (float4 *)b; b += al256(N0 * 16);
-    H.R = H.lv[0].b;
-    return b;
-}
-
-const float kMgOmega = 0.8f;   // == VM_MGB_OMEGA
-const int kMgCoarseSweeps = 40;
-
-// z = M^-1 r: one V(1,1) cycle; level l's right-hand side is lv[l].b, the result ends in lv[l].x
-void mg_vcycle(MgHierarchy &H, size_t l, hipStream_t s)
-{
-    VmMgLevel &F = H.lv[l];
-    if (l + 1 == H.lv.size()) {
-        vm_mg_launch_coarsest(F, kMgOmega, kMgCoarseSweeps, s);
-        return;
-    }
-    if (l + 2 == H.lv.size() && (size_t)F.w * F.h <= 4096) { // the launch-bound tail of the cycle: one workgroup
-        vm_mg_launch_coarse_tail(F, H.lv[l + 1], kMgOmega, kMgCoarseSweeps, s);
-        std::swap(F.x, F.t);
-        return;
-    }
-    vm_mg_launch_jacobi0(F, kMgOmega, s);
-    vm_mg_launch_resid_restrict(F, H.lv[l + 1], s);
-    mg_vcycle(H, l + 1, s);
-    vm_mg_launch_prolong_smooth(F, H.lv[l + 1], kMgOmega, s);
-    std::swap(F.x, F.t);
-}
-
-// PCG from the guess in H.X until the relative residual of every channel is <= tol.
-// The hierarchy's operators (lv[*].we/ws/dg) and H.B must be set.  The residual is the
-// recursively updated one; in float32 it can pass below what the stored iterate attains and
-// the iteration then drifts (notably on the singular Neumann system, where |x| >> |b|), so
-// the best iterate seen at the checks is kept and returned, and the loop ends when the
-// residual has not improved for three checks or has grown 1000-fold.
-int mg_pcg(vm_ctx *c, MgHierarchy &H, float tol, int max_it, int *iters, double *rel)
-{
-    hipStream_t s = c->stream;
-    VmMgLevel &L0 = H.lv[0];
-    const size_t bytes = (size_t)L0.w * L0.h * sizeof(float4);
-    VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
-    vm_mg_launch_pcg_init(L0, H.B, H.X, H.R, H.sc, s);
-    VmPcgScalars h;
-    int it = 0, best_it = 0, stale = 0;
-    double worst = 0, best = 1e300;
-    const int check = 4;
-    while (true) {
-        VM_HIP(hipMemcpyAsync(&h, H.sc, sizeof(h), hipMemcpyDeviceToHost, s));
-        VM_HIP(hipStreamSynchronize(s));
-        worst = 0;
-        for (int k = 0; k < 3; ++k) {
-            if (!(h.bb[k] == h.bb[k]) || !(h.rr[k] == h.rr[k]) || std::isinf(h.bb[k]) || std::isinf(h.rr[k]))
-                return vm_fail(VM_E_NUMERIC, it == 0 ? "multigrid PCG: the right-hand side is not finite"
-                                                     : "multigrid PCG broke down (NaN)");
-            if (h.bb[k] > 0) worst = std::max(worst, std::sqrt(h.rr[k] / h.bb[k]));
-        }
-        if (worst < best) {
-            best = worst;
-            best_it = it;
-            stale = 0;
-            VM_HIP(hipMemcpyAsync(H.Xbest, H.X, bytes, hipMemcpyDeviceToDevice, s));
-        } else {
-            ++stale;
-        }
-        if (worst <= tol || it >= max_it || stale >= 3 || worst > 1e3 * best) break;
-        const int nb = std::min(check, max_it - it);
-        for (int k = 0; k < nb; ++k, ++it) {
-            mg_vcycle(H, 0, s);                                    // z = M^-1 r  (in L0.x)
-            vm_mg_launch_pcg_dot(L0, H.R, L0.x, H.sc, s);          // rz_new = r.z
-            vm_mg_launch_pcg_dir(L0, H.P, L0.x, H.sc, it == 0, s); // p = z + beta p
-            vm_mg_launch_pcg_spmv(L0, H.P, H.Q, H.sc, s);          // q = A p
-            vm_mg_launch_pcg_update(L0, H.X, H.R, H.P, H.Q, H.sc, s);
-        }
-        VM_HIP(hipGetLastError());
-    }
-    if (best_it != it)
-        VM_HIP(hipMemcpyAsync(H.X, H.Xbest, bytes, hipMemcpyDeviceToDevice, s));
-    *iters = best_it;
-    *rel = best;
-    return VM_OK;
-}
 } // namespace
 
-// Jacobi-PCG with nested iteration over 4x / 16x coarser canvases: the round-1 solver, kept
-// for A/B measurements (VM_POISSON_SOLVER=jacobi)
-static int poisson_solve_nested(vm_frame *f, int side, float tol, int max_it, int *total_it, double *rel_out)
-{
-    vm_ctx *c = f->ctx;
-    hipStream_t s = c->stream;
-    Grid g[3];
-    int ng = 1;
-    g[0].cw = f->cw; g[0].ch = f->ch;
-    while (ng < 3 && std::min(g[ng - 1].cw, g[ng - 1].ch) >= 256) {
-        g[ng].cw = (g[ng - 1].cw + 3) / 4;
-        g[ng].ch = (g[ng - 1].ch + 3) / 4;
-        ++ng;
-    }
-    size_t need = al256(sizeof(VmCgScalars));
-    for (int k = 0; k < ng; ++k) need += grid_bytes(g[k].cw, g[k].ch, k > 0);
-    if (f->pws_bytes < need) {
-        hipFree(f->pws);
-        f->pws = nullptr;
-        f->pws_bytes = 0;
-        VM_HIP(hipMalloc(&f->pws, need));
-        f->pws_bytes = need;
-    }
-    char *b = (char *)f->pws;
-    VmCgScalars *sc = (VmCgScalars *)b;
-    b += al256(sizeof(VmCgScalars));
-    for (int k = 0; k < ng; ++k) b = grid_carve(g[k], b, k > 0);
-    g[0].ext = f->ext[side - 1];
-    const uchar4 *other = f->crop[side == 1 ? 1 : 0]; // PoissonExt.cpp:54-57
-    const int sign = side == 1 ? 1 : -1;
-    vm_poisson_launch_prepare(g[0].ext, g[0].type, other, f->v, f->w, f->h, f->rs, f->ex, sign, s);
-    for (int k = 1; k < ng; ++k)
-        vm_poisson_launch_coarsen(g[k - 1].ext, g[k - 1].type, g[k].ext, g[k].type, g[k - 1].cw, g[k - 1].ch,
-                                  g[k].cw, g[k].ch, s);
-    VM_HIP(hipGetLastError());
-    // nested iteration, coarsest grid first; the coarse solves only feed initial guesses,
-    // the finest grid is the reference's system and is solved to `tol`
-    int it = 0;
-    double rel = 0;
-    for (int k = ng - 1; k >= 0; --k) {
-        vm_poisson_launch_setup(g[k].ext, g[k].type, g[k].B, g[k].X, g[k].cw, g[k].ch, s);
-        if (k < ng - 1)
-            vm_poisson_launch_prolong(g[k + 1].X, g[k + 1].type, g[k].X, g[k].type, g[k].cw, g[k].ch,
-                                      g[k + 1].cw, g[k + 1].ch, s);
-        int rc = run_cg(c, g[k], sc, k == 0 ? tol : std::max(tol, 1e-4f), k == 0 ? max_it : 4000, &it, &rel);
-        if (rc != VM_OK) return rc;
-        if (k == 0) *total_it = it;
-    }
-    vm_poisson_launch_paste(g[0].ext, g[0].type, g[0].X, g[0].cw, g[0].ch, s);
-    *rel_out = rel;
-    return VM_OK;
-}
-
-// multigrid-preconditioned CG on the reference's system, one system at a time over the whole canvas: round 4's
-// form, kept for A/B measurements (VM_POISSON_SOLVER=mg1)
-static int poisson_solve_mg(vm_frame *f, int side, float tol, int max_it, int *total_it, double *rel_out)
-{
-    vm_ctx *c = f->ctx;
-    hipStream_t s = c->stream;
-    const size_t N = (size_t)f->cw * f->ch;
-    const size_t need = al256(N) + mg_bytes(f->cw, f->ch);
-    if (f->pws_bytes < need) {
-        hipFree(f->pws);
-        f->pws = nullptr;
-        f->pws_bytes = 0;
-        VM_HIP(hipMalloc(&f->pws, need));
-        f->pws_bytes = need;
-    }
-    char *b = (char *)f->pws;
-    uint8_t *type = (uint8_t *)b;
-    b += al256(N);
-    MgHierarchy H;
-    mg_carve(H, f->cw, f->ch, b);
-    uchar4 *ext = f->ext[side - 1];
-    const uchar4 *other = f->crop[side == 1 ? 1 : 0]; // PoissonExt.cpp:54-57
-    const int sign = side == 1 ? 1 : -1;
-    vm_poisson_launch_prepare(ext, type, other, f->v, f->w, f->h, f->rs, f->ex, sign, s);
-    vm_poisson_launch_setup(ext, type, H.B, H.X, f->cw, f->ch, s); // right-hand side + initial guess
-    vm_mg_launch_level0_type(type, H.lv[0], s);
-    for (size_t l = 1; l < H.lv.size(); ++l)
-        vm_mg_launch_coarsen(H.lv[l - 1], H.lv[l], s);
-    VM_HIP(hipGetLastError());
-    int rc = mg_pcg(c, H, tol, max_it, total_it, rel_out);
-    if (rc != VM_OK) return rc;
-    vm_poisson_launch_paste(ext, type, H.X, f->cw, f->ch, s);
-    return VM_OK;
-}
-
 // ---------------------------------------------------------------------------
-// The default solver (round 5): the same multigrid-preconditioned CG, batched over systems (a system = one side of
-// one frame), swept over the ring of unknowns only, with the fused kernels of vm_mgb.hip.
+// The solver: multigrid-preconditioned CG, batched over systems (a system = one side of one frame), swept over the
+// ring of unknowns only, with the fused kernels of vm_mgb.hip.
 
 namespace {
 
@@ -307,18 +56,19 @@ struct MgbWork {          // one system's device workspace, carved from f->pws2[
     VmV3 *Xbest;
     char *xcoarse;        // the x arrays of levels >= 1, contiguous (cleared per extension)
     size_t xcoarse_bytes;
-    int *counts;          // nblocks per level (device)
+    int *counts;          // nblocks per level, then ntiles per level (device)
+    int tail;             // first level of the cycle's one-workgroup tail
 };
 
 size_t mgb_bytes(int w, int h)
 {
     const auto sz = mg_sizes(w, h);
     const size_t N0 = (size_t)w * h;
-    size_t need = 2 * al256(N0) + al256(sizeof(VmMgbScalars)) + al256(VM_MGB_MAXLEV * sizeof(int)) + 5 * al256(N0 * 12);
+    size_t need = 2 * al256(N0) + al256(sizeof(VmMgbScalars)) + al256(2 * VM_MGB_MAXLEV * sizeof(int)) + 5 * al256(N0 * 12);
     for (size_t l = 0; l < sz.size(); ++l) {
         const size_t N = (size_t)sz[l].first * sz[l].second;
         const size_t nb = (size_t)((sz[l].first + 63) / 64) * ((sz[l].second + 3) / 4);
-        need += (l ? 4 * al256(N * 4) : 0) + 2 * al256(N * 12) + 2 * al256(nb * 4);
+        need += (l ? 4 * al256(N * 4) : 0) + 2 * al256(N * 12) + 3 * al256(nb * 4);
     }
     return need;
 }
@@ -330,7 +80,8 @@ void mgb_carve(MgbWork &W, int w, int h, char *b)
     W.type = (uint8_t *)b; b += al256(N0);
     W.S.type = W.type;
     W.S.sc = (VmMgbScalars *)b; b += al256(sizeof(VmMgbScalars));
-    W.counts = (int *)b; b += al256(VM_MGB_MAXLEV * sizeof(int));
+    W.counts = (int *)b; b += al256(2 * VM_MGB_MAXLEV * sizeof(int));
+    W.tail = mg_tail_level(sz);
     W.S.X = (VmV3 *)b; b += al256(N0 * 12);
     W.S.P[0] = (VmV3 *)b; b += al256(N0 * 12);
     W.S.P[1] = (VmV3 *)b; b += al256(N0 * 12);
@@ -356,6 +107,8 @@ void mgb_carve(MgbWork &W, int w, int h, char *b)
         L.flags = (uint32_t *)b; b += al256(nb * 4);
         L.blocks = (uint32_t *)b; b += al256(nb * 4);
         L.nblocks = W.counts + l;
+        L.tiles = (uint32_t *)b; b += al256(nb * 4);
+        L.ntiles = W.counts + VM_MGB_MAXLEV + l;
     }
     // the x arrays last and together: level 0's (z), then the coarse ones, which are cleared per extension (a
     // fine cell may read the correction of a coarse cell that is no unknown and sits in a block nobody sweeps)
@@ -368,23 +121,19 @@ void mgb_carve(MgbWork &W, int w, int h, char *b)
     W.xcoarse_bytes = (size_t)(b - W.xcoarse);
 }
 
-// z = M^-1 r of every active system: one V(1,1) cycle; iteration k's r.z lands in rz[k & 1]
-void mgb_vcycle(const VmMgbSys *dev, int nsys, const MgbWork &W0, const std::vector<int> &nb, int k, uint64_t active, hipStream_t s)
+// z = M^-1 r of every active system: one V(1,1) cycle; iteration k's r.z lands in rz[k & 1].  nb / nt: blocks / tiles
+// per level (the largest count among the systems)
+void mgb_vcycle(const VmMgbSys *dev, int nsys, const MgbWork &W0, const std::vector<int> &nb, const std::vector<int> &nt, int k,
+                uint64_t active, hipStream_t s)
 {
-    const int nlev = W0.S.nlev;
-    if (nlev == 1) {
-        vm_mgb_launch_coarsest(dev, nsys, 0, kMgCoarseSweeps, active, s);
-        vm_mgb_launch_dot_rz(dev, nsys, nb[0], k, active, s);
-        return;
-    }
-    const int tail = nlev - 2;      // levels tail, tail + 1 run in one workgroup
+    const int tail = W0.tail;       // levels tail .. nlev - 1 run in one workgroup
     for (int l = 0; l < tail; ++l)
-        vm_mgb_launch_restrict(dev, nsys, l, nb[l], active, s);
-    vm_mgb_launch_tail(dev, nsys, tail, kMgCoarseSweeps, active, s);
+        vm_mgb_launch_restrict(dev, nsys, l, nt[l], active, s);
+    vm_mgb_launch_tail(dev, nsys, tail, active, s);
     if (tail == 0)
         vm_mgb_launch_dot_rz(dev, nsys, nb[0], k, active, s);
     for (int l = tail - 1; l >= 0; --l)
-        vm_mgb_launch_prolong(dev, nsys, l, nb[l], k, active, s);
+        vm_mgb_launch_prolong(dev, nsys, l, nt[l], k, active, s);
 }
 
 double mgb_rel(const VmMgbScalars &h, int par)
@@ -438,12 +187,15 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
         vm_mgb_launch_coarsen(dev, nsys, l, W[0].S.lv[l].gx, W[0].S.lv[l].gy, s);
     vm_mgb_launch_compact(dev, nsys, nlev, s);
     VM_HIP(hipGetLastError());
-    std::vector<int> cnt((size_t)nsys * VM_MGB_MAXLEV), nb(nlev, 0);
+    std::vector<int> cnt((size_t)nsys * 2 * VM_MGB_MAXLEV), nb(nlev, 0), nt(nlev, 0);
     for (int i = 0; i < nsys; ++i)
-        VM_HIP(hipMemcpyAsync(&cnt[(size_t)i * VM_MGB_MAXLEV], W[i].counts, nlev * sizeof(int), hipMemcpyDeviceToHost, s));
+        VM_HIP(hipMemcpyAsync(&cnt[(size_t)i * 2 * VM_MGB_MAXLEV], W[i].counts, 2 * VM_MGB_MAXLEV * sizeof(int), hipMemcpyDeviceToHost, s));
     VM_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < nsys; ++i)
-        for (int l = 0; l < nlev; ++l) nb[l] = std::max(nb[l], cnt[(size_t)i * VM_MGB_MAXLEV + l]);
+        for (int l = 0; l < nlev; ++l) {
+            nb[l] = std::max(nb[l], cnt[(size_t)i * 2 * VM_MGB_MAXLEV + l]);
+            nt[l] = std::max(nt[l], cnt[(size_t)i * 2 * VM_MGB_MAXLEV + VM_MGB_MAXLEV + l]);
+        }
     if (nb[0] == 0) {                       // no unknown anywhere: nothing to extend
         for (int i = 0; i < nsys; ++i) { iters[i] = 0; rels[i] = 0; }
         return VM_OK;
@@ -452,18 +204,19 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     vm_mgb_launch_init(dev, nsys, nb[0], active, s);
     std::vector<VmMgbScalars> h(nsys);
     std::vector<double> best(nsys, 1e300);
-    std::vector<int> best_it(nsys, 0), stale(nsys, 0), saved(nsys, 0);
+    std::vector<int> best_it(nsys, 0), stale(nsys, 0), saved(nsys, 0), next_check(nsys, 0);
     int it = 0;
-    // the residuals are read every 4 iterations (a read drains the stream) until one of the systems still iterating is
-    // within a factor 30 of the tolerance -- the cycle gains a decade in about four iterations -- and every iteration
-    // from there: a solve then stops at the iteration that reaches the tolerance instead of up to three later
-    int check = 4;
+    // A system's residual is looked at every 4 iterations (a read drains the stream) until it is within a factor 30
+    // of the tolerance -- the cycle gains a decade in two to three iterations -- and every iteration from there: a solve
+    // stops at the iteration that reaches the tolerance instead of up to three later.  The cadence is the SYSTEM's own
+    // (next_check): where it stops, and so what it pastes, does not depend on its batch-mates.
     while (true) {
         for (int i = 0; i < nsys; ++i)
-            if ((active >> i) & 1) VM_HIP(hipMemcpyAsync(&h[i], W[i].S.sc, sizeof(VmMgbScalars), hipMemcpyDeviceToHost, s));
+            if (((active >> i) & 1) && next_check[i] == it)
+                VM_HIP(hipMemcpyAsync(&h[i], W[i].S.sc, sizeof(VmMgbScalars), hipMemcpyDeviceToHost, s));
         VM_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < nsys; ++i) {
-            if (!((active >> i) & 1)) continue;
+            if (!((active >> i) & 1) || next_check[i] != it) continue;
             const double worst = mgb_rel(h[i], (it - 1) & 1);   // it == 0: parity 1, where k_mgb_init left r.r
             if (worst < 0)
                 return vm_fail(VM_E_NUMERIC, it == 0 ? "multigrid PCG: the right-hand side is not finite" : "multigrid PCG broke down (NaN)");
@@ -486,13 +239,14 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
                     VM_HIP(hipMemcpyAsync(W[i].S.X, W[i].Xbest, N0 * sizeof(VmV3), hipMemcpyDeviceToDevice, s));
                 else if (!saved[i]) { best[i] = worst; best_it[i] = it; }     // what X holds
             }
+            next_check[i] = std::min(max_it, it + (best[i] <= 30.0 * tol ? 1 : 4));
         }
         if (!active) break;
+        int upto = max_it;
         for (int i = 0; i < nsys; ++i)
-            if (((active >> i) & 1) && best[i] <= 30.0 * tol) check = 1;
-        const int nbt = std::min(check, max_it - it);
-        for (int k = 0; k < nbt; ++k, ++it) {
-            mgb_vcycle(dev, nsys, W[0], nb, it, active, s);
+            if ((active >> i) & 1) upto = std::min(upto, next_check[i]);
+        for (; it < upto; ++it) {
+            mgb_vcycle(dev, nsys, W[0], nb, nt, it, active, s);
             vm_mgb_launch_dirspmv(dev, nsys, nb[0], it, active, s);
             vm_mgb_launch_update(dev, nsys, nb[0], it, active, s);
         }
@@ -541,14 +295,10 @@ extern "C" int vm_poisson_extend(vm_frame *f, int side, float tol, int max_it, i
     VM_ON_DEVICE(c);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipStream_t s = c->stream;
-    static const char *solver = getenv("VM_POISSON_SOLVER");
-    static const bool jacobi = solver && !strcmp(solver, "jacobi"), mg1 = solver && !strcmp(solver, "mg1");
     VM_HIP(hipEventRecord(c->ev0, s));
     int total_it = 0;
     double rel = 0;
-    int rc = jacobi ? poisson_solve_nested(f, side, tol, max_it, &total_it, &rel)
-             : mg1  ? poisson_solve_mg(f, side, tol, max_it, &total_it, &rel)
-                    : poisson_solve_batch(c, &f, &side, 1, tol, max_it, &total_it, &rel);
+    int rc = poisson_solve_batch(c, &f, &side, 1, tol, max_it, &total_it, &rel);
     if (rc != VM_OK) return rc;
     VM_HIP(hipGetLastError());
     VM_HIP(hipEventRecord(c->ev1, s));
@@ -622,38 +372,10 @@ extern "C" int vm_frame_quadratic_path(vm_frame *f, float tol, int max_it, int *
     VM_ON_DEVICE(c);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipStream_t s = c->stream;
-    static const char *solver = getenv("VM_POISSON_SOLVER");
-    static const bool mg1 = solver && !strcmp(solver, "mg1");     // round 4's solver, for A/B runs
     int it = 0;
     double rel = 0;
     VM_HIP(hipEventRecord(c->ev0, s));
-    if (mg1) {
-        const size_t need = mg_bytes(f->w, f->h);
-        if (f->pws_bytes < need) {
-            hipFree(f->pws);
-            f->pws = nullptr;
-            f->pws_bytes = 0;
-            VM_HIP(hipMalloc(&f->pws, need));
-            f->pws_bytes = need;
-        }
-        MgHierarchy H;
-        mg_carve(H, f->w, f->h, (char *)f->pws);
-        vm_qpath_launch_rhs(f->v, f->rs, f->w, f->h, H.B, H.X, s);
-        // project the right-hand side onto the range of the singular operator
-        double *sums = H.sc->pq;
-        VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
-        vm_qpath_launch_sum(H.B, f->w, f->h, sums, s);
-        vm_qpath_launch_shift(H.B, f->w, f->h, sums, nullptr, 0, s);
-        vm_mg_launch_level0_full(H.lv[0], s);
-        for (size_t l = 1; l < H.lv.size(); ++l)
-            vm_mg_launch_coarsen(H.lv[l - 1], H.lv[l], s);
-        VM_HIP(hipGetLastError());
-        int rc = mg_pcg(c, H, tol, max_it, &it, &rel);
-        if (rc != VM_OK) return rc;
-        VM_HIP(hipMemsetAsync(H.sc, 0, sizeof(VmPcgScalars), s));
-        vm_qpath_launch_sum(H.X, f->w, f->h, sums, s);
-        vm_qpath_launch_shift(H.X, f->w, f->h, sums, f->u, f->rs, s);
-    } else {
+    {
         // the batched solver on the whole grid: every pixel an unknown without a tie (type 2 everywhere), so the level-0
         // operator is the graph Laplacian of the pixel grid with Neumann ends (QuadraticPath.cpp:137-170); the
         // workspace is side 1's of the Poisson extension (the frame is no larger than its canvas, the two run in turn)
