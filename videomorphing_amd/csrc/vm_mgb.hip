@@ -11,6 +11,12 @@ namespace {
 #define MGB_G 4 // list entries per workgroup in the kernels that end in dot products (their atomics per byte / 4)
 #endif
 
+// Every array pointer of this file comes out of a descriptor in memory (VmMgbSys), which makes it a GENERIC pointer to the
+// compiler: flat_load / flat_store, which tick the LDS counter as well as the memory counter -- an s_waitcnt for an LDS
+// read or a scalar load then also waits for every store in flight.  The arrays are hipMalloc'ed: say so.
+#define VM_G __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ VM_G T *G(T *p) { return (VM_G T *)p; }
+
 __device__ __forceinline__ float4 f4_axpy(float a, float4 x, float4 y) // a x + y
 {
     return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), 0);
@@ -19,12 +25,18 @@ __device__ __forceinline__ float4 f4_sub(float4 s, float4 u) { return make_float
 __device__ __forceinline__ float4 f4_sel(bool c, float4 a, float4 b) { return c ? a : b; }
 
 // the solver's vectors carry three colour channels: 12 bytes per cell in memory (global_load / store_dwordx3), float4 in registers
+// (a 12-byte copy, not three float accesses: those would be merged into a dwordx2 and a dword)
 __device__ __forceinline__ float4 ld3(const VmV3 *__restrict__ a, size_t q)
 {
-    const VmV3 v = a[q];
+    VmV3 v;
+    __builtin_memcpy(&v, G(a) + q, sizeof(VmV3));
     return make_float4(v.x, v.y, v.z, 0);
 }
-__device__ __forceinline__ void st3(VmV3 *a, size_t q, float4 v) { a[q] = VmV3{v.x, v.y, v.z}; }
+__device__ __forceinline__ void st3(VmV3 *a, size_t q, float4 v)
+{
+    const VmV3 t{v.x, v.y, v.z};
+    __builtin_memcpy(G(a) + q, &t, sizeof(VmV3));
+}
 
 __device__ __forceinline__ bool sys_active(uint64_t active) { return (active >> blockIdx.z) & 1; }
 
@@ -33,7 +45,7 @@ __device__ __forceinline__ bool list_block(const VmMgbLevel &L, int e, int nb, i
 {
     if (e >= nb)
         return false;
-    const uint32_t b = L.blocks[e];
+    const uint32_t b = G(L.blocks)[e];
     x0 = (int)(b & 0xffffu) * 64;
     y0 = (int)(b >> 16) * 4;
     return true;
@@ -62,9 +74,9 @@ template <bool L0> struct Op;
 
 // level 0: one byte per cell (vm_mgb.h), unit weights
 template <> struct Op<true> {
-    const uint8_t *__restrict__ info;
+    const VM_G uint8_t *__restrict__ info;
     int w, h;
-    __device__ __forceinline__ explicit Op(const VmMgbLevel &L) : info(L.info), w(L.w), h(L.h) {}
+    __device__ __forceinline__ explicit Op(const VmMgbLevel &L) : info(G(L.info)), w(L.w), h(L.h) {}
     __device__ __forceinline__ float dg(size_t q) const { return (float)(info[q] >> 4); }
     __device__ __forceinline__ float k(size_t q) const { return k_of_dg0(info[q] >> 4); }
     // E, W, S, N: the order of vm_mg.hip's mg_apply; a unit weight's fma(-1, u, s) is s - u exactly.  All five values
@@ -96,9 +108,9 @@ template <> struct Op<true> {
 
 // coarser levels: float weights, diagonal, k = 1 / dg
 template <> struct Op<false> {
-    const float *__restrict__ pwe, *__restrict__ pws, *__restrict__ pdg, *__restrict__ pk;
+    const VM_G float *__restrict__ pwe, *__restrict__ pws, *__restrict__ pdg, *__restrict__ pk;
     int w, h;
-    __device__ __forceinline__ explicit Op(const VmMgbLevel &L) : pwe(L.we), pws(L.ws), pdg(L.dg), pk(L.k), w(L.w), h(L.h) {}
+    __device__ __forceinline__ explicit Op(const VmMgbLevel &L) : pwe(G(L.we)), pws(G(L.ws)), pdg(G(L.dg)), pk(G(L.k)), w(L.w), h(L.h) {}
     __device__ __forceinline__ float dg(size_t q) const { return pdg[q]; }
     __device__ __forceinline__ float k(size_t q) const { return pk[q]; }
     // all four weights and all five values fetched at once (indices clamped to the grid, missing edges have weight 0
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(256) void k_mgb_level0(const VmMgbSys *__restrict__
 {
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &L = S.lv[0];
-    const uint8_t *__restrict__ type = S.type;
+    const VM_G uint8_t *__restrict__ type = G(S.type);
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     uint32_t dg = 0;
     if (x < L.w && y < L.h) {
@@ -224,11 +236,11 @@ __global__ __launch_bounds__(256) void k_mgb_level0(const VmMgbSys *__restrict__
             if (y + 1 < L.h && type[ii + L.w] > 0) { m |= 4u; ++dg; }
             if (y > 0 && type[ii - L.w] > 0) { m |= 8u; ++dg; }
         }
-        L.info[ii] = (uint8_t)(dg << 4 | m);
+        G(L.info)[ii] = (uint8_t)(dg << 4 | m);
     }
     const int any = __syncthreads_or(dg > 0);
     if (threadIdx.x == 0 && threadIdx.y == 0)
-        L.flags[blockIdx.y * L.gx + blockIdx.x] = any ? 1u : 0u;
+        G(L.flags)[blockIdx.y * L.gx + blockIdx.x] = any ? 1u : 0u;
 }
 
 // Galerkin coarse operator of level l from level l - 1 (2x2 aggregates, piecewise-constant interpolation, the
@@ -263,17 +275,17 @@ __global__ __launch_bounds__(256) void k_mgb_coarsen(const VmMgbSys *__restrict_
             }
         const size_t k = (size_t)Y * C.w + X;
         we *= 0.5f; ws *= 0.5f; ww *= 0.5f; wn *= 0.5f;
-        C.we[k] = we;
-        C.ws[k] = ws;
+        G(C.we)[k] = we;
+        G(C.ws)[k] = ws;
         d = fmaxf(sc, 0.0f) + we + ws;
         if (X > 0) d += ww;
         if (Y > 0) d += wn;
-        C.dg[k] = d;
-        C.k[k] = d > 0 ? 1.0f / d : 0.0f;
+        G(C.dg)[k] = d;
+        G(C.k)[k] = d > 0 ? 1.0f / d : 0.0f;
     }
     const int any = __syncthreads_or(d > 0);
     if (threadIdx.x == 0 && threadIdx.y == 0)
-        C.flags[blockIdx.y * C.gx + blockIdx.x] = any ? 1u : 0u;
+        G(C.flags)[blockIdx.y * C.gx + blockIdx.x] = any ? 1u : 0u;
 }
 
 // block flags -> compact row-major lists of the blocks and of the 64 x 16-cell tiles (four blocks of a column) that
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(256) void k_mgb_init(const VmMgbSys *__restrict__ s
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &L = S.lv[0];
     const Op<true> A(L);
-    const int nb = L.nblocks[0];
+    const int nb = G(L.nblocks)[0];
     const FromArray X{S.X};
     double bb[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
 #pragma unroll
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(256) void k_mgb_init(const VmMgbSys *__restrict__ s
         if (!list_cell(L, blockIdx.x * MGB_G + g, nb, x, y))
             continue;
         const size_t ii = (size_t)y * L.w + x;
-        const uint32_t m = L.info[ii];
+        const uint32_t m = G(L.info)[ii];
         const float dg = (float)(m >> 4);
         const float4 b = ld3(L.b, ii), ax = A.apply(X, x, y, ii, dg, m);
         if (dg > 0) {
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(256) void k_mgb_dirspmv(const VmMgbSys *__restrict_
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &L = S.lv[0];
     const Op<true> A(L);
-    const int nb = L.nblocks[0], par = k & 1;
+    const int nb = G(L.nblocks)[0], par = k & 1;
     if (blockIdx.x == 0)
         slot_clear(S.sc->rr[par]);
     float be[3] = {0, 0, 0};
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(256) void k_mgb_dirspmv(const VmMgbSys *__restrict_
         if (!list_cell(L, blockIdx.x * MGB_G + g, nb, x, y))
             continue;
         const size_t ii = (size_t)y * L.w + x;
-        const uint32_t m = L.info[ii];
+        const uint32_t m = G(L.info)[ii];
         const float dg = (float)(m >> 4);
         const bool unk = (m >> 4) != 0;
         const float4 zero = make_float4(0, 0, 0, 0);
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(256) void k_mgb_update(const VmMgbSys *__restrict__
         return;
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &L = S.lv[0];
-    const int nb = L.nblocks[0], par = k & 1;
+    const int nb = G(L.nblocks)[0], par = k & 1;
     if (blockIdx.x == 0) {
         slot_clear(S.sc->rz[par ^ 1]);
         slot_clear(S.sc->pq[par ^ 1]);
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(256) void k_mgb_update(const VmMgbSys *__restrict__
         r.x -= al[0] * q.x; r.y -= al[1] * q.y; r.z -= al[2] * q.z;
         st3(X, ii, xx);
         st3(R, ii, r);
-        if (L.info[ii] >> 4) {
+        if (G(L.info)[ii] >> 4) {
             rr[0] += (double)r.x * r.x; rr[1] += (double)r.y * r.y; rr[2] += (double)r.z * r.z;
         }
     }
@@ -461,14 +473,14 @@ __global__ __launch_bounds__(256) void k_mgb_dot_rz(const VmMgbSys *__restrict__
         return;
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &L = S.lv[0];
-    const int nb = L.nblocks[0];
+    const int nb = G(L.nblocks)[0];
     double rz[3] = {0, 0, 0};
     for (int g = 0; g < MGB_G; ++g) {
         int x, y;
         if (!list_cell(L, blockIdx.x * MGB_G + g, nb, x, y))
             continue;
         const size_t ii = (size_t)y * L.w + x;
-        if (L.info[ii] >> 4) {
+        if (G(L.info)[ii] >> 4) {
             const float4 r = ld3(L.b, ii), z = ld3(L.x, ii);
             rz[0] += (double)r.x * z.x; rz[1] += (double)r.y * z.y; rz[2] += (double)r.z * z.z;
         }
@@ -598,9 +610,9 @@ __global__ __launch_bounds__(256) void k_mgb_restrict(const VmMgbSys *__restrict
         return;
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &FL = S.lv[l], &C = S.lv[l + 1];
-    if ((int)blockIdx.x >= FL.ntiles[0])
+    if ((int)blockIdx.x >= G(FL.ntiles)[0])
         return;
-    const uint32_t tb = FL.tiles[blockIdx.x];
+    const uint32_t tb = G(FL.tiles)[blockIdx.x];
     const int x0 = (int)(tb & 0xffffu) * TW, y0 = (int)(tb >> 16) * TH;
     const Op<L0> F(FL);
     __shared__ float4 vals[LN];
@@ -655,10 +667,10 @@ __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict_
         return;
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &FL = S.lv[l], &C = S.lv[l + 1];
-    const bool live = (int)blockIdx.x < FL.ntiles[0];
+    const bool live = (int)blockIdx.x < G(FL.ntiles)[0];
     double rz[3] = {0, 0, 0};
     if (live) {
-        const uint32_t tb = FL.tiles[blockIdx.x];
+        const uint32_t tb = G(FL.tiles)[blockIdx.x];
         const int x0 = (int)(tb & 0xffffu) * TW, y0 = (int)(tb >> 16) * TH;
         const Op<L0> F(FL);
         __shared__ float4 vals[LN];
@@ -705,11 +717,13 @@ __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict_
             out[2 * m] = f4_sel(odd, out[2 * m], xr);            // even tx: cell 2 m is red
             out[2 * m + 1] = f4_sel(odd, xr, out[2 * m + 1]);    // odd tx: cell 2 m + 1 is red
         }
+        const int fw = FL.w, fh = FL.h;
+        VmV3 *const fx = FL.x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int x = x0 + tx, y = y0 + 4 * ty + j;
-            if (x < FL.w && y < FL.h) {
-                st3(FL.x, (size_t)y * FL.w + x, out[j]);
+            if (x < fw && y < fh) {
+                st3(fx, (size_t)y * fw + x, out[j]);
                 if (L0) {       // b is zero where there is no unknown (stage_cell)
                     rz[0] += (double)bown[j].x * out[j].x; rz[1] += (double)bown[j].y * out[j].y; rz[2] += (double)bown[j].z * out[j].z;
                 }
@@ -848,7 +862,7 @@ __global__ __launch_bounds__(1024) void k_mgb_tail(const VmMgbSys *__restrict__ 
             if (((cx + cy) & 1) == 0) {
                 const float4 c = xc[(cy >> 1) * cw + (cx >> 1)], f = x[i];
                 // a red cell without an unknown holds 0 and stays 0: its aggregate may hold unknowns and a correction
-                const bool unk = (j == 0 && L0) ? (S.lv[l0].info[i] >> 4) != 0 : L.k[i] > 0.0f;
+                const bool unk = (j == 0 && L0) ? (G(S.lv[l0].info)[i] >> 4) != 0 : G(L.k)[i] > 0.0f;
                 if (unk)
                     x[i] = make_float4(f.x + c.x, f.y + c.y, f.z + c.z, 0);
             }

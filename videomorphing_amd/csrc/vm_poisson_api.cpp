@@ -53,7 +53,6 @@ namespace {
 struct MgbWork {          // one system's device workspace, carved from f->pws2[side - 1]
     VmMgbSys S;           // host copy of the device descriptor
     uint8_t *type;
-    VmV3 *Xbest;
     char *xcoarse;        // the x arrays of levels >= 1, contiguous (cleared per extension)
     size_t xcoarse_bytes;
     int *counts;          // nblocks per level, then ntiles per level (device)
@@ -64,7 +63,7 @@ size_t mgb_bytes(int w, int h)
 {
     const auto sz = mg_sizes(w, h);
     const size_t N0 = (size_t)w * h;
-    size_t need = 2 * al256(N0) + al256(sizeof(VmMgbScalars)) + al256(2 * VM_MGB_MAXLEV * sizeof(int)) + 5 * al256(N0 * 12);
+    size_t need = 2 * al256(N0) + al256(sizeof(VmMgbScalars)) + al256(2 * VM_MGB_MAXLEV * sizeof(int)) + 4 * al256(N0 * 12);
     for (size_t l = 0; l < sz.size(); ++l) {
         const size_t N = (size_t)sz[l].first * sz[l].second;
         const size_t nb = (size_t)((sz[l].first + 63) / 64) * ((sz[l].second + 3) / 4);
@@ -86,7 +85,6 @@ void mgb_carve(MgbWork &W, int w, int h, char *b)
     W.S.P[0] = (VmV3 *)b; b += al256(N0 * 12);
     W.S.P[1] = (VmV3 *)b; b += al256(N0 * 12);
     W.S.Q = (VmV3 *)b; b += al256(N0 * 12);
-    W.Xbest = (VmV3 *)b; b += al256(N0 * 12);
     W.S.nlev = (int)sz.size();
     for (size_t l = 0; l < sz.size(); ++l) {
         VmMgbLevel &L = W.S.lv[l];
@@ -166,7 +164,7 @@ static int mgb_reserve(void **ws, size_t *ws_bytes, int w, int h)
 
 // The batched PCG proper: nsys systems of one size whose workspaces are carved, whose type maps, right-hand sides
 // (lv[0].b) and initial guesses (X) are enqueued on the context's stream.  Leaves every system's solution in its X
-// (the best iterate seen near the tolerance), its iteration count and relative residual in iters / rels.
+// (the iterate it stopped at), its iteration count and relative residual in iters / rels.
 static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, int max_it, int *iters, double *rels)
 {
     hipStream_t s = c->stream;
@@ -204,7 +202,7 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     vm_mgb_launch_init(dev, nsys, nb[0], active, s);
     std::vector<VmMgbScalars> h(nsys);
     std::vector<double> best(nsys, 1e300);
-    std::vector<int> best_it(nsys, 0), stale(nsys, 0), saved(nsys, 0), next_check(nsys, 0);
+    std::vector<int> best_it(nsys, 0), next_check(nsys, 0);
     int it = 0;
     // A system's residual is looked at every 4 iterations (a read drains the stream) until it is within a factor 30
     // of the tolerance -- the cycle gains a decade in two to three iterations -- and every iteration from there: a solve
@@ -223,21 +221,14 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
             if (worst < best[i]) {
                 best[i] = worst;
                 best_it[i] = it;
-                stale[i] = 0;
-                // the recursively updated residual can pass below what the stored iterate attains and the iteration
-                // then drifts: near the tolerance the best iterate seen at a check is kept
-                if (worst <= 30.0 * tol) {
-                    VM_HIP(hipMemcpyAsync(W[i].Xbest, W[i].S.X, N0 * sizeof(VmV3), hipMemcpyDeviceToDevice, s));
-                    saved[i] = 1;
-                }
-            } else {
-                stale[i] = it - best_it[i];      // iterations since the best residual seen
             }
-            if (worst <= tol || it >= max_it || stale[i] >= 12 || worst > 1e3 * best[i]) {
+            // a system stops when it reaches the tolerance -- or gives up: no better residual for 12 iterations, a
+            // residual 1000 times the best one seen, max_it.  What it leaves in X is its CURRENT iterate and what it
+            // reports is that iterate's residual (the callers turn a residual above the tolerance into VM_E_NUMERIC)
+            if (worst <= tol || it >= max_it || it - best_it[i] >= 12 || worst > 1e3 * best[i]) {
                 active &= ~(1ull << i);
-                if (saved[i] && best_it[i] != it)
-                    VM_HIP(hipMemcpyAsync(W[i].S.X, W[i].Xbest, N0 * sizeof(VmV3), hipMemcpyDeviceToDevice, s));
-                else if (!saved[i]) { best[i] = worst; best_it[i] = it; }     // what X holds
+                best[i] = worst;
+                best_it[i] = it;
             }
             next_check[i] = std::min(max_it, it + (best[i] <= 30.0 * tol ? 1 : 4));
         }
