@@ -15,6 +15,13 @@ import hashlib
 
 import numpy as np
 
+# The tolerances the Poisson stage may be TIMED at (bench.py takes its tolerances from here): exactly those
+# tests/test_gpu_fullsize_compositor.py proves to meet SURVEY 8(d)'s "max abs colour diff <= 1" against the oracle's CG at
+# 1e-9 on the full-size canvas, one frame per call and four frames per batch.  1e-4 is measured there too (max 1 with this
+# solver, 5 % of the bytes off by one) but not timed: the oracle's own CG stopped at 1e-4 is off by up to 3 levels at this
+# size, so the bound at that tolerance rests on one solver's error distribution, not on the tolerance.
+POISSON_TIMED_TOLS = (1e-5, 1e-6)
+
 from videomorphing_amd import synth
 
 

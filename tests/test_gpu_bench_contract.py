@@ -175,3 +175,46 @@ def test_bench_refuses_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-extras", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_config4_on_two_ranks_equals_one_rank(tmp_path):
+    """BASELINE config[4] under N > 1 (`for config 5: 30 pairs/4 GPUs`): `bench.py --config 4 --gpus 2` block-shards
+    the pairs over two ranks (here 4 pairs of 480x270 on this box's one device, the two collectives over gloo), every rank
+    runs solve -> Poisson -> nine renders for ITS pairs, the point constraints arrive inside the one broadcast.  Against
+    the same job on ONE rank: every pair's halfway field is identical bit for bit (a pair's solve does not depend on its
+    batch-mates or its rank), its frames are identical up to the Poisson solver's atomics (dot products accumulated by
+    double-precision atomics in run-dependent order: colours within one level, most frames identical to the byte)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    docs = {}
+    for n in (1, 2):
+        dg = str(tmp_path / ("dig%d.json" % n))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--config", "4", "--pairs", "4",
+                            "--size", "480x270", "--steps", "1", "--warmup", "0", "--digest", dg],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["unit"] == "frames/s" and d["scaling"] == "strong" and d["config"]["pairs"] == 4
+        assert "BCOND_BORDER" in d["config"]["workload"] and "8 point constraints" in d["config"]["workload"]
+        pl = d["pipeline"]
+        assert [p["pairs"] for p in pl["per_rank"]] == ([4] if n == 1 else [2, 2])
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (4 * 9) - 1.0) < 0.01          # frames/s x s per step = the job's 36 frames
+        assert pl["solve_mpix_iters_per_s"] > 0 and 5 <= pl["rank0"]["pcg_iterations_min_max"][0] <= pl["rank0"]["pcg_iterations_min_max"][1] <= 40
+        assert "160 bytes" in d["config"]["collectives"]            # 8 constraints x 5 floats ride in the broadcast
+        files = [dg] if n == 1 else [dg + ".0", dg + ".1"]
+        merged = {"fields": {}, "frames": {}, "frame_bytes": {}}
+        for f in files:
+            doc = json.load(open(f))
+            for k in merged:
+                merged[k].update(doc[k])
+        docs[n] = merged
+    assert sorted(docs[1]["fields"]) == sorted(docs[2]["fields"]) == ["0", "1", "2", "3"]
+    assert docs[1]["fields"] == docs[2]["fields"]                     # halfway fields: bit-identical
+    assert sorted(docs[1]["frames"]) == sorted(docs[2]["frames"]) and len(docs[1]["frames"]) == 36
+    same = sum(docs[1]["frames"][k] == docs[2]["frames"][k] for k in docs[1]["frames"])
+    assert same >= 18, same
+    import numpy as np
+    for k in docs[1]["frame_bytes"]:
+        a, b = np.asarray(docs[1]["frame_bytes"][k], int), np.asarray(docs[2]["frame_bytes"][k], int)
+        assert np.abs(a - b).max() <= 1

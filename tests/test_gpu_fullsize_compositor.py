@@ -6,7 +6,7 @@ regenerated here by tests/fullsize_fixture.py and fingerprinted):
     oracle's, through SHA-256;
   * CPoissonExt (PoissonExt.cpp:49-362): both sides of frames 0 and 7 against the oracle's double-precision CG at 1e-9,
     the whole 1.30 M-pixel ring: SURVEY 8(d)'s bound max |colour difference| <= 1 at every tolerance bench.py times
-    (TIMED_TOLS, imported by bench.py), one frame per call and four frames per batch, with the statistics (fraction of
+    (fullsize_fixture.POISSON_TIMED_TOLS, which bench.py takes its tolerances from), one frame per call and four frames per batch, with the statistics (fraction of
     bytes off by one, worst difference) written to gpurun_out/ for DESIGN section 4;
   * CQuadraticPath (QuadraticPath.cpp:24-223): u within 2e-3 px of the oracle's CG at 1e-10.
 
@@ -26,10 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 W, H, EX = 1920, 1080, 192
 
-# The tolerances the Poisson stage may be TIMED at (bench.py imports this): exactly those this file proves to meet
-# SURVEY 8(d)'s "max abs colour diff <= 1" on the full-size canvas, single call and 4-frame batch.  1e-4 is NOT among
-# them: the oracle's own CG stopped at 1e-4 is off by up to 3 levels there, and so may any solver be.
-TIMED_TOLS = (1e-5, 1e-6)
+TIMED_TOLS = FX.POISSON_TIMED_TOLS      # what bench.py times (tests/fullsize_fixture.py)
 
 
 def _sha_text(arr):

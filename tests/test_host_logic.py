@@ -197,3 +197,32 @@ def test_bench_config2_chunks_and_batches():
         assert sorted(res) == sorted(id(p) for p in pyrs)
         assert all(1 <= len(g) <= B and len(set(p._ctx for p in g)) == 1 for g in groups)
         assert sum(len(g) for g in groups) == npairs
+
+
+def test_config4_plan_of_30_pairs_on_4_ranks():
+    """config[4]'s static plan (SURVEY 8(e): `for config 5: 30 pairs/4 GPUs`): block partition 8 / 7 / 8 / 7, every rank's
+    pairs in contiguous solver chunks, every pair in exactly one compositor batch of <= 4 frames, the batches dealt to
+    the lanes in turn"""
+    seen = []
+    for r in range(4):
+        mine, chunk_of, lanes = bench.config4_plan(30, 4, r)
+        assert mine == dist.shard_pairs(30, 4, r) and len(mine) == (8, 7, 8, 7)[r]
+        assert chunk_of == sorted(chunk_of) and set(chunk_of) == {0, 1}           # two solver streams for < 24 pairs
+        flat = [k for lane in lanes for b in lane for k in b]
+        assert sorted(flat) == list(range(len(mine))) and all(1 <= len(b) <= 4 for lane in lanes for b in lane)
+        seen += mine
+    assert seen == list(range(30))
+    mine, chunk_of, lanes = bench.config4_plan(30, 1, 0)
+    assert len(mine) == 30 and set(chunk_of) == {0, 1, 2} and [chunk_of.count(c) for c in (0, 1, 2)] == [10, 10, 10]
+    assert [len(l) for l in lanes] == [4, 4] and lanes[0][0] == [0, 1, 2, 3] and lanes[1][0] == [4, 5, 6, 7] and lanes[1][-1] == [28, 29]
+    assert bench.config4_plan(3, 4, 2)[0] == [2] and bench.config4_plan(3, 4, 3)[0] == [] and bench.config4_plan(2, 4, 1) == ([], [], [[], []])
+
+
+def test_bench_times_the_poisson_stage_only_at_verified_tolerances():
+    import fullsize_fixture as FX
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    assert bench.POISSON_TOL in FX.POISSON_TIMED_TOLS and 1e-6 in FX.POISSON_TIMED_TOLS and 1e-4 not in FX.POISSON_TIMED_TOLS
+    # no literal tolerance is passed to the Poisson entry points but the untimed workspace warm-ups
+    import re
+    lits = re.findall(r"poisson_extend\w*\([^)]*tol=([0-9.e-]+)", src)
+    assert set(lits) <= {"1e-3"}, lits
