@@ -562,21 +562,38 @@ def load_poisson_pmc(path=None):
         return None
 
 
+def sweep_source_hash():
+    """fingerprint of the sources the sweep kernels are compiled from (tools/pmc_summary.py stamps every entry of
+    profiles/traffic_latest.json with it when the entry is merged)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("vm_sweep_kernels.hip", "vm_morph_common.h", "vm_internal.h"):
+        h.update(open(os.path.join(ROOT, "videomorphing_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def load_pmc(config, pairs_per_launch, path=None):
     """HBM bytes per launch of the sweep kernels from the committed PMC profile of THIS workload
     shape (config, pairs per launch); counters need rocprofv3, so they are never of this run.
-    No matching entry: no PMC figures (a figure taken at another batch size would be wrong)."""
+    No matching entry: no PMC figures (a figure taken at another batch size would be wrong).
+    Returns (bytes per kernel, launches per kernel, source text, SQ counters per kernel, stale): stale is True when the
+    sweep kernels' sources have changed since the entry was profiled (or the entry carries no fingerprint) -- the one
+    roofline input the driver cannot re-derive must not outlive the kernels it describes unnoticed."""
     tp = path or os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         tj = json.load(open(tp))
     except Exception:
-        return {}, {}, None, {}
+        return {}, {}, None, {}, None
     for e in tj.get("entries", []):
         if e.get("config") == config and e.get("pairs_per_launch") == pairs_per_launch:
+            try:
+                stale = e.get("sweep_source_sha256") != sweep_source_hash()
+            except Exception:
+                stale = True
             return e.get("per_kernel", {}) or {}, e.get("per_kernel_launches", {}) or {}, \
                 "%s[config %d, %d pair(s) per launch]: %s" % (
-                    os.path.relpath(tp, ROOT), config, pairs_per_launch, e.get("source", "")[:200]), e.get("sq_per_kernel", {}) or {}
-    return {}, {}, None, {}
+                    os.path.relpath(tp, ROOT), config, pairs_per_launch, e.get("source", "")[:200]), e.get("sq_per_kernel", {}) or {}, stale
+    return {}, {}, None, {}, None
 
 
 def sq_measured(sq, prefix):
@@ -627,7 +644,7 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
     achieved = alg_nominal / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     # ---- HBM traffic per launch from the PMC passes of the committed profile of this workload
     # shape (not of this run: counters need rocprofv3)
-    pmc_k, pmc_n, traffic_src, sq_k = load_pmc(config, B)
+    pmc_k, pmc_n, traffic_src, sq_k, traffic_stale = load_pmc(config, B)
     # ---- per kernel: launches, average duration (HIP events around each batch of launches on
     # the context's stream), algorithmic bytes per launch, nominal and real fraction of HBM peak
     per_kernel = []
@@ -713,6 +730,7 @@ def report(args, config, world, w, h, nlev, blk, capi, B, nctx, FIXED, sizes, pr
                      "frac": dom["nominal_frac"] if dom else None,
                      "traffic": dom.get("pmc_bytes_per_launch") if dom else None,
                      "traffic_source": traffic_src,
+                     "traffic_stale": traffic_stale,     # True: the sweep kernels' sources changed since that profile was taken
                      "launch_us": dom["avg_us"] if dom else None,
                      "alg_bytes_per_launch": dom["alg_bytes_per_launch"] if dom else None,
                      "share_of_sweep_time": dom["share_of_sweep_time"] if dom else None,

@@ -38,6 +38,7 @@ def test_bench_json_line():
               "achieved_executed", "frac_executed", "traffic_source", "hbm_real_frac", "valu_frac", "active_pixel_ratio", "per_kernel"):
         assert k in rf, k
     assert "frac_nominal" not in rf and "achieved_nominal" not in rf
+    assert rf["traffic_stale"] is False       # the committed profile was taken with the sweep kernels' sources as they are
     assert rf["frac_executed"] <= rf["credited_not_moved"]["frac_of_peak"] and 0 < rf["valu_frac"] < 1 and 0 < rf["active_pixel_ratio"] <= 1
     # SURVEY 8(d)'s formula on the executed rate: value x 282.7 B / 8 TB/s
     assert abs(rf["survey_formula_executed"] - d["value"] * 1e6 * 282.7 / 8e12) < 2e-5

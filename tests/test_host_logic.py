@@ -139,11 +139,12 @@ def test_bench_reads_the_counters_of_its_own_workload_shape(tmp_path):
          "per_kernel_launches": {"k_optimize_fast<true, 13, 2, true>": 3, "k_optimize_fast<true, 7, 4, true>": 1, "k_pass_fast": 2000},
          "sq_per_kernel": {"k_pass_fast": sq}},
         {"config": 2, "pairs_per_launch": 30, "source": "fixture", "per_kernel": {"k_optimize_fast<true, 13, 2, false>": 24e6},
-         "per_kernel_launches": {"k_optimize_fast<true, 13, 2, false>": 8000}, "sq_per_kernel": {}}]}
+         "per_kernel_launches": {"k_optimize_fast<true, 13, 2, false>": 8000}, "sq_per_kernel": {}, "sweep_source_sha256": bench.sweep_source_hash()}]}
     path = str(tmp_path / "traffic.json")
     json.dump(fix, open(path, "w"))
-    k, n, src, sqk = bench.load_pmc(1, 1, path)
+    k, n, src, sqk, stale = bench.load_pmc(1, 1, path)
     assert src and "config 1, 1 pair" in src and "fixture" in src
+    assert stale is True              # no fingerprint of the sweep kernels' sources in that entry: cannot be vouched for
     assert bench.pmc_bytes(k, n, "k_pass_fast") == 1.45e6
     assert bench.pmc_bytes(k, n, "k_optimize_fast<true") == (3 * 20e6 + 120e6) / 4       # launch-weighted over both variants
     assert bench.pmc_bytes(k, n, "k_step_fast") is None
@@ -153,15 +154,24 @@ def test_bench_reads_the_counters_of_its_own_workload_shape(tmp_path):
     assert m["valu_issue_slots_used"] == round(4000.0 * 4.0 / (1024.0 * 80.0 / 8.0), 4)
     assert bench.sq_measured(sqk, "k_step_fast") is None
     # a batch line never borrows the single pair's counters; an unknown shape gets nothing
-    k30, n30, _, _ = bench.load_pmc(2, 30, path)
+    k30, n30, _, _, stale30 = bench.load_pmc(2, 30, path)
+    assert stale30 is False           # stamped with the sources as they are now
     assert bench.pmc_bytes(k30, n30, "k_pass_fast") is None and bench.pmc_bytes(k30, n30, "k_optimize_fast<true") == 24e6
-    assert bench.load_pmc(2, 17, path) == ({}, {}, None, {})
-    assert bench.load_pmc(1, 1, str(tmp_path / "missing.json")) == ({}, {}, None, {})
-    # the committed file: schema only
+    assert bench.load_pmc(2, 17, path) == ({}, {}, None, {}, None)
+    assert bench.load_pmc(1, 1, str(tmp_path / "missing.json")) == ({}, {}, None, {}, None)
+    # ... and tools/pmc_summary.py stamps what it merges with the same fingerprint bench.py computes
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pmc_summary.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    assert ps.sweep_source_hash() == bench.sweep_source_hash()
+    # the committed file: schema, and a fingerprint on every entry (a kernel change that forgets to refresh the profile
+    # shows up as "traffic_stale": true in the bench line, not silently)
     tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")))
     assert isinstance(tj.get("entries"), list) and tj["entries"]
     for e in tj["entries"]:
         assert isinstance(e["config"], int) and isinstance(e["pairs_per_launch"], int) and isinstance(e["per_kernel"], dict)
+        assert len(e.get("sweep_source_sha256", "")) == 64
 
 
 def test_bench_config2_chunks_and_batches():

@@ -4,9 +4,25 @@ the HBM traffic of the sweep kernels from two --pmc passes (FETCH_SIZE, WRITE_SI
   python tools/pmc_summary.py <fetch_dir> <write_dir> <out_csv> <out_json> "<command profiled>" [kernel,substrings]
   python tools/pmc_summary.py --merge <traffic.json> <entry.json> <config> <pairs_per_launch>
       (profiles/traffic_latest.json holds one entry per workload shape: bench.py only quotes PMC
-      bytes taken at the same config and pairs per launch)
+      bytes taken at the same config and pairs per launch; the entry is stamped with the fingerprint of the
+      sweep kernels' sources, and bench.py reports "traffic_stale": true when they have changed since)
+  python tools/pmc_summary.py --stamp <traffic.json>    (stamp entries that have no fingerprint with the current one:
+      only right while the sources are what the entries were profiled with)
 """
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the sources the sweep kernels are compiled from: an entry of traffic_latest.json carries their fingerprint, and bench.py
+# marks the PMC / SQ figures it quotes from an entry as stale when the sources have changed since (bench.sweep_source_hash)
+SWEEP_SOURCES = ("vm_sweep_kernels.hip", "vm_morph_common.h", "vm_internal.h")
+
+
+def sweep_source_hash():
+    h = hashlib.sha256()
+    for f in SWEEP_SOURCES:
+        h.update(open(os.path.join(ROOT, "videomorphing_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
 
 SWEEP = ("k_optimize", "k_step", "k_decide", "k_commit", "k_pass", "k_sparse")
 
@@ -33,7 +49,8 @@ def merge():
         cur = {}
     ents = [e for e in cur.get("entries", []) if not (e.get("config") == config and e.get("pairs_per_launch") == pairs)]
     ents.append({"config": config, "pairs_per_launch": pairs, "per_kernel": entry["per_kernel"],
-                 "per_kernel_launches": entry.get("per_kernel_launches", {}), "source": entry["source"]})
+                 "per_kernel_launches": entry.get("per_kernel_launches", {}), "source": entry["source"],
+                 "sweep_source_sha256": sweep_source_hash()})
     ents.sort(key=lambda e: (e["config"], e["pairs_per_launch"]))
     json.dump({"entries": ents, "correction": entry["correction"]}, open(path, "w"), indent=1)
 
@@ -62,6 +79,12 @@ def main():
         return merge()
     if sys.argv[1] == "--merge-sq":
         return merge_sq()
+    if sys.argv[1] == "--stamp":
+        cur = json.load(open(sys.argv[2]))
+        for e in cur["entries"]:
+            e.setdefault("sweep_source_sha256", sweep_source_hash())
+        json.dump(cur, open(sys.argv[2], "w"), indent=1)
+        return
     fd, wd, out_csv, out_json, cmd = sys.argv[1:6]
     if len(sys.argv) > 6:
         SWEEP = tuple(sys.argv[6].split(","))
