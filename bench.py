@@ -119,7 +119,7 @@ def parse_args(argv=None):
     ap.add_argument("--extras", default="", help="development: comma-separated names of the extras to run (default: all): semantics, "
                                                  "math, batched, temporal, sync, render, poisson, qpath, pipeline8, pipeline30, config3")
     ap.add_argument("--scale-ref-last", action="store_true", help="development: run scale_reference AFTER the other extras (the order "
-                                                                    "rounds 3-4 found 16 %% slower; tools/dev_scale_ref_bisect.sh)")
+                                                                    "rounds 3-4 found 16 %% slower; profiles/r05_notes.md section 7)")
     ap.add_argument("--size", default=None, help="WxH override (development only)")
     ap.add_argument("--sweep-threads", type=int, default=0, help="threads per sweep workgroup, 0 = the library's choice (development only)")
     ap.add_argument("--sweep-parts", type=int, default=0, help="workgroups per tile of the STEP schedule, 0 = the library's choice (development only)")
@@ -185,7 +185,7 @@ def main():
         config4_main(args, np, torch, dist, vdist, capi, morph, synth, blk, _cons, rank, local_rank, world, coll_dev, w, h)
         return
 
-    # config 2: two streams per GPU by default -- measured on MI355X (tools/dev_inflight.sh, 8 / 60 pairs
+    # config 2: two streams per GPU by default -- measured on MI355X (profiles/r03_notes.md, 8 / 60 pairs
     # on one GPU): 1 stream 21.3 / 38.2, 2 streams 25.3 / 47.9, 4 streams 20.2 / 46.2 G pixel*iters/s
     # (beyond two the host's launch rate, ~3.5 us per eager launch under the runtime's lock, binds) --,
     # three from 24 pairs per GPU on (r04, ms per job, 2 -> 3 streams: 60 pairs 859 -> 838, 30 pairs 569 -> 558,
@@ -318,9 +318,9 @@ def main():
         el_max, pix_total, pix_live_total = el, pix_iters, pix_live
 
     # (rounds 3-4 ran scale_reference first because after the other extras it took 970 instead of 838 ms.  Round 5 found the
-    # cause -- tools/dev_scale_ref_bisect.sh: the TEMPORAL extra, and in it the video lanes' graded stream priorities: their
+    # cause -- profiles/r05_scale_ref_bisect.txt: the TEMPORAL extra, and in it the video lanes' graded stream priorities: their
     # low-priority streams took hardware queues the runtime never handed back, so two of the job's three streams then shared
-    # one.  Fixed in vm_video.cpp (only lane 0 asks for a priority stream now); the order no longer matters: 836 ms either way.)
+    # one.  Fixed in vm_video.cpp (the lanes run on plain streams); the order no longer matters: 836 ms either way.)
     extras = {}
     scale_ref = None
     want_scale_ref = rank == 0 and world == 1 and config == 1 and not args.size and not (args.no_extras or args.no_scale_ref)

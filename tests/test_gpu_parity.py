@@ -733,7 +733,7 @@ def test_fast_energy_on_converged_solves_sits_at_the_chaos_floor(gpu_ctx, oracle
     CONVERGED small levels (the reference's stopping rule, <= 2000 sweeps; three sizes): two equally legal
     EXACT runs -- the commits of a phase folded row-major (= the oracle, bit for bit) vs reversed, an order
     the reference leaves to float atomics -- end 0.14 - 0.72 % apart in total energy (r03:
-    tools/dev_tolerances.py), FAST ends 0.01 - 0.83 % from EXACT.  So the bound is stated against that
+    profiles/r03_notes.md), FAST ends 0.01 - 0.83 % from EXACT.  So the bound is stated against that
     floor: mean |E_FAST - E_EXACT| / E_EXACT <= max(0.5 %, 1.5 x the mean floor), no size beyond 1.2 %, and
     the fields themselves within RMS 0.02 px (the floor's own RMS is 0.006 - 0.01 px)."""
     P = _params(oracle)

@@ -57,8 +57,8 @@ def test_config4_pipeline_against_oracle(gpu_ctx, oracle):
         fr.poisson_extend(side, tol=1e-6)           # holes far from any anchor need the tight tolerance
         out = fr.download_ext(side)
         d = np.abs(out[..., :3].astype(int) - ref[..., :3].astype(int))
-        # max abs colour diff <= 1 (measured r03, tools/dev_tolerances.py: device 1e-5 .. 1e-9 vs
-        # the oracle's CG at 1e-9 and at 1e-12 -- which agree with each other exactly -- differ by at most 1 level)
+        # max abs colour diff <= 1 (at config[4]'s full size: tests/test_gpu_fullsize_compositor.py, against
+        # fixtures of the oracle's CG at 1e-9, at every tolerance bench.py times)
         assert d.max() <= 1, (d.max(), (d > 0).mean())
         (e0, e1)[side - 1][...] = out
     # --- render three morph times from the device-resident canvases

@@ -1,4 +1,4 @@
-"""round-5 experiment: k_render_win (v window in LDS) against the plain gather kernel (VM_RENDER=gather): ms per 1080p frame at
+"""round-5 experiment: k_render_win (v window in LDS) against the plain gather kernel (VM_RENDER=plain: the only value vm_render.hip recognises): ms per 1080p frame at
 nine in-between positions, with and without a quadratic path in the frame; the outputs must agree byte for byte (run
 twice, once per mode: the hash printed at the end is the comparison)"""
 import hashlib, os, sys
