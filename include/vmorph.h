@@ -486,6 +486,13 @@ void vm_rccl_comm_destroy(void *nccl_comm);
  * device-to-device on that device instead. */
 int  vm_bcast_params(vm_ctx *const *ctxs, void *const *nccl_comms, int n, int root,
                      const vm_param_block *blk, vm_param_block *blocks_out);
+/* The same one broadcast for a payload of the caller's length -- BASELINE config[4]: the parameter block followed by the
+ * frames' point constraints (Parameters::lp / rp / cnt resolved to vm_constraint rows, parameters.h:16-26, consumed at
+ * Algorithm/morph.cu:345-388, 471-505), the layout videomorphing_amd/dist.py:pack_block ships between processes.  `src`
+ * (host, `bytes` long) goes from ctxs[root] to all n contexts over RCCL (nccl_comms == NULL: the one-device test mode
+ * of vm_bcast_params); dst_host[i] (host, `bytes` each) receives what context i got.  Nothing is interpreted. */
+int  vm_bcast_bytes(vm_ctx *const *ctxs, void *const *nccl_comms, int n, int root, const void *src, uint64_t bytes,
+                    void *const *dst_host);
 
 #ifdef __cplusplus
 }

@@ -70,10 +70,24 @@ public:
         return out;
     }
 
+    vm_frame *handle() const { return f_; }
+
 private:
     vm_frame *f_ = nullptr;
     int w_, h_, ex_;
 };
+
+// CPoissonExt::run's loop body (PoissonExt.cpp:24-36) for several frames of one context at once: both sides of every
+// frame are independent systems and share every launch (vm_poisson_extend_frames).  Returns the PCG iteration counts,
+// [2 i] = side 1 of frames[i], [2 i + 1] = side 2.
+inline std::vector<int> poisson_extend_frames(const std::vector<Frame *> &frames, float tol = 1e-5f, int max_it = 20000)
+{
+    std::vector<vm_frame *> h;
+    for (Frame *f : frames) h.push_back(f->handle());
+    std::vector<int> its(2 * h.size(), 0);
+    check(vm_poisson_extend_frames(h.data(), (int)h.size(), tol, max_it, its.data(), nullptr, nullptr));
+    return its;
+}
 
 } // namespace vmorph
 #endif

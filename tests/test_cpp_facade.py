@@ -296,3 +296,68 @@ def test_bcast_params_over_rccl_on_one_device(tmp_path):
     script.write_text(_BCAST_CHILD % ROOT)
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "BCAST-OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.fixture(scope="module")
+def pipeline_shard(tmp_path_factory, vmlib):
+    exe = str(tmp_path_factory.mktemp("cppp") / "pipeline_shard")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "pipeline_shard.cpp"), "-o", exe,
+                           "-L", libdir, "-lvmorph_hip", "-Wl,-rpath," + libdir, "-lpthread"])
+    return exe
+
+
+def test_pipeline_shard_builds_and_refuses_bad_input(pipeline_shard, tmp_path):
+    r = subprocess.run([pipeline_shard], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([pipeline_shard, "2", "8", "8", "1", "2", str(tmp_path / "a"), str(tmp_path / "b"), str(tmp_path / "c"),
+                        str(tmp_path / "d"), str(tmp_path / "e")], capture_output=True, text=True)
+    assert r.returncode == 2 and "cannot read" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_config4_pipeline_on_two_contexts_matches_python(pipeline_shard, gpu_ctx, tmp_path):
+    """examples/pipeline_shard.cpp -- config[4] from one C++ process: the parameter block AND the point constraints in one
+    broadcast (vm_bcast_bytes; here its one-device test mode), 5 pairs block-sharded over G = 2 contexts, per rank
+    vm_solve_batch_cons (BCOND_BORDER) -> canvases -> v upscaled on the device -> Poisson extension in batches -> render.
+    Against the Python mirror on one context: every halfway field bit-identical (EXACT), every rendered frame within one
+    colour level (the Poisson solver's dot products are accumulated by atomics)."""
+    from videomorphing_amd import morph
+    w, h, N, ex = 150, 100, 5, 15
+    frames = [synth.make_pair(w, h, frame=k, amp=0.4 + 0.2 * k) for k in range(N)]
+    rgbs = [synth.make_rgb_pair(w, h, frame=k, amp=0.4 + 0.2 * k) for k in range(N)]
+    cons = synth.make_constraints(w, h, 8)
+    np.concatenate([np.stack([a, b]).ravel() for a, b in frames]).astype(np.float32).tofile(str(tmp_path / "fr.f32"))
+    np.concatenate([np.stack([a, b]).ravel() for a, b in rgbs]).astype(np.uint8).tofile(str(tmp_path / "rgb.u8"))
+    cons.astype(np.float32).tofile(str(tmp_path / "cons.f32"))
+    r = subprocess.run([pipeline_shard, "2", str(w), str(h), str(N), str(ex), str(tmp_path / "fr.f32"), str(tmp_path / "rgb.u8"), str(tmp_path / "cons.f32"),
+                        str(tmp_path / "v.f32"), str(tmp_path / "out.u8"), "18", "16", "exact", "--one-device"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "rank 0 on device 0: 3 pairs" in r.stdout and "rank 1 on device 0: 2 pairs" in r.stdout
+    assert r.stdout.count("max_iter 18 bcond 2 constraints 8") == 2, r.stdout          # block and constraints really travelled
+    v_cpp = np.fromfile(str(tmp_path / "v.f32"), np.float32).reshape(N, h, w, 2)
+    img_cpp = np.fromfile(str(tmp_path / "out.u8"), np.uint8).reshape(N, h, w, 3)
+    try:
+        gpu_ctx.set_math_mode(capi.MATH_EXACT)
+        prm = morph.Parameters()
+        prm.max_iter, prm.max_iter_drop_factor, prm.start_res, prm.bcond = 18, 1.0, 16, capi.BCOND_BORDER
+        gpu_ctx.set_params(morph.KernParameters(prm))
+        pyrs = []
+        for i0, i1 in frames:
+            q = morph.Pyramid(gpu_ctx)
+            q.build(i0, i1, 16)
+            pyrs.append(q)
+        morph.solve_batch(pyrs, 18, 1.0, constraints=cons)
+        fr = morph.Frame(gpu_ctx, w, h, ex)
+        for k, q in enumerate(pyrs):
+            fr.upload(morph.make_extended(rgbs[k][0], ex), morph.make_extended(rgbs[k][1], ex), None, None)
+            fr.set_v_from_level(q, 1)
+            assert np.array_equal(v_cpp[k].view(np.uint32), fr.download_v().view(np.uint32)), k
+            fr.poisson_extend_both(tol=1e-5)
+            img = fr.render_halfway(0.5, 0.5, 1)
+            assert np.abs(img.astype(int) - img_cpp[k].astype(int)).max() <= 1, k
+        fr.close()
+        assert np.abs(v_cpp).max() > 0.1 and img_cpp.std() > 5
+    finally:
+        gpu_ctx.set_params(morph.KernParameters(morph.Parameters()))

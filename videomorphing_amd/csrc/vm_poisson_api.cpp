@@ -502,38 +502,39 @@ extern "C" void vm_rccl_comm_destroy(void *comm)
     if (comm && R.destroy) R.destroy(comm);
 }
 
-// One process, n contexts: the shared parameter block goes root -> every context and each context adopts what IT
-// received (SURVEY 8(b)'s vm_bcast_params, 8(e)'s "exactly one ncclBroadcast of the shared parameter block").
-//   comms != NULL: comms[i] = the ncclComm_t of ctxs[i] (vm_rccl_comm_init_all); the block is staged in a device
+// One process, n contexts: a byte payload goes root -> every context (SURVEY 8(e)'s "exactly one ncclBroadcast of the
+// shared parameter block"; for config[4] the block is followed by the frames' point constraints, so the payload's length
+// is the caller's).
+//   comms != NULL: comms[i] = the ncclComm_t of ctxs[i] (vm_rccl_comm_init_all); the payload is staged in a device
 //                  buffer per context and broadcast inside one ncclGroup over xGMI, each on its context's stream;
 //   comms == NULL: TEST MODE for contexts that share a device (RCCL refuses two ranks on one device): the root's
 //                  device buffer is copied device-to-device into the others'.
-// Either way every context then reads ITS device copy back and sets kernel parameters + arithmetic mode from it;
-// blocks_out (n entries, may be NULL) receives the block as each context got it.
-extern "C" int vm_bcast_params(vm_ctx *const *ctxs, void *const *comms, int n, int root, const vm_param_block *blk,
-                               vm_param_block *blocks_out)
+// Every context then reads ITS device copy back into dst_host[i] (bytes each): what travelled, not what was sent.
+extern "C" int vm_bcast_bytes(vm_ctx *const *ctxs, void *const *comms, int n, int root, const void *src, uint64_t bytes,
+                              void *const *dst_host)
 {
-    if (!ctxs || n < 1 || root < 0 || root >= n || !blk) return vm_fail(VM_E_INVALID, "vm_bcast_params: bad argument");
+    if (!ctxs || n < 1 || root < 0 || root >= n || !src || bytes == 0 || !dst_host) return vm_fail(VM_E_INVALID, "vm_bcast_bytes: bad argument");
     for (int i = 0; i < n; ++i)
-        if (!ctxs[i] || (comms && !comms[i])) return vm_fail(VM_E_INVALID, "vm_bcast_params: context / communicator %d is NULL", i);
+        if (!ctxs[i] || !dst_host[i] || (comms && !comms[i])) return vm_fail(VM_E_INVALID, "vm_bcast_bytes: context / buffer / communicator %d is NULL", i);
     Rccl &R = rccl();
-    if (comms && (!R.bcast || !R.group_start || !R.group_end)) return vm_fail(VM_E_DEVICE, "vm_bcast_params: cannot load librccl");
+    if (comms && (!R.bcast || !R.group_start || !R.group_end)) return vm_fail(VM_E_DEVICE, "vm_bcast_bytes: cannot load librccl");
     std::vector<void *> buf(n, nullptr);
     int rc = VM_OK;
-    auto fail = [&](int code, const char *what) { rc = vm_fail(code, "vm_bcast_params: %s", what); };
+    auto fail = [&](int code, const char *what) { rc = vm_fail(code, "vm_bcast_bytes: %s", what); };
     for (int i = 0; i < n && rc == VM_OK; ++i) {
         VmDeviceGuard g(ctxs[i]->device);
-        if (!g.ok || hipMalloc(&buf[i], sizeof(vm_param_block)) != hipSuccess) { fail(VM_E_DEVICE, "device buffer"); break; }
+        if (!g.ok || hipMalloc(&buf[i], (size_t)bytes) != hipSuccess) { fail(VM_E_DEVICE, "device buffer"); break; }
         // everybody but the root starts from zeros: what it ends up with is what travelled
-        hipError_t e = i == root ? hipMemcpyAsync(buf[i], blk, sizeof(vm_param_block), hipMemcpyHostToDevice, ctxs[i]->stream)
-                                 : hipMemsetAsync(buf[i], 0, sizeof(vm_param_block), ctxs[i]->stream);
+        hipError_t e = i == root ? hipMemcpyAsync(buf[i], src, (size_t)bytes, hipMemcpyHostToDevice, ctxs[i]->stream)
+                                 : hipMemsetAsync(buf[i], 0, (size_t)bytes, ctxs[i]->stream);
+        if (e == hipSuccess && i == root) e = hipStreamSynchronize(ctxs[i]->stream);      // src belongs to the caller
         if (e != hipSuccess) fail(VM_E_DEVICE, hipGetErrorString(e));
     }
     if (rc == VM_OK && comms) {
         if (R.group_start() != 0) fail(VM_E_DEVICE, "ncclGroupStart");
         for (int i = 0; i < n && rc == VM_OK; ++i) {
             VmDeviceGuard g(ctxs[i]->device);
-            if (!g.ok || R.bcast(buf[i], buf[i], sizeof(vm_param_block), kNcclInt8, root, comms[i], ctxs[i]->stream) != 0)
+            if (!g.ok || R.bcast(buf[i], buf[i], (size_t)bytes, kNcclInt8, root, comms[i], ctxs[i]->stream) != 0)
                 fail(VM_E_DEVICE, "ncclBroadcast");
         }
         if (R.group_end() != 0 && rc == VM_OK) fail(VM_E_DEVICE, "ncclGroupEnd");
@@ -541,17 +542,13 @@ extern "C" int vm_bcast_params(vm_ctx *const *ctxs, void *const *comms, int n, i
         VmDeviceGuard g(ctxs[root]->device);
         if (hipStreamSynchronize(ctxs[root]->stream) != hipSuccess) fail(VM_E_DEVICE, "sync");
         for (int i = 0; i < n && rc == VM_OK; ++i)
-            if (i != root && hipMemcpyAsync(buf[i], buf[root], sizeof(vm_param_block), hipMemcpyDeviceToDevice, ctxs[i]->stream) != hipSuccess)
+            if (i != root && hipMemcpyAsync(buf[i], buf[root], (size_t)bytes, hipMemcpyDeviceToDevice, ctxs[i]->stream) != hipSuccess)
                 fail(VM_E_DEVICE, "device-to-device copy");
     }
     for (int i = 0; i < n && rc == VM_OK; ++i) {
         VmDeviceGuard g(ctxs[i]->device);
-        vm_param_block got;
-        if (hipMemcpyAsync(&got, buf[i], sizeof(got), hipMemcpyDeviceToHost, ctxs[i]->stream) != hipSuccess ||
+        if (hipMemcpyAsync(dst_host[i], buf[i], (size_t)bytes, hipMemcpyDeviceToHost, ctxs[i]->stream) != hipSuccess ||
             hipStreamSynchronize(ctxs[i]->stream) != hipSuccess) { fail(VM_E_DEVICE, "read-back"); break; }
-        if ((rc = vm_set_params(ctxs[i], &got.kp)) != VM_OK) break;
-        if ((rc = vm_set_math_mode(ctxs[i], got.math_mode)) != VM_OK) break;
-        if (blocks_out) blocks_out[i] = got;
     }
     for (int i = 0; i < n; ++i)
         if (buf[i]) {
@@ -559,5 +556,23 @@ extern "C" int vm_bcast_params(vm_ctx *const *ctxs, void *const *comms, int n, i
             hipFree(buf[i]);
         }
     (void)hipGetLastError();
+    return rc;
+}
+
+// The shared parameter block root -> every context (vm_bcast_bytes), and each context adopts what IT received: kernel
+// parameters + arithmetic mode.  blocks_out (n entries, may be NULL) receives the block as each context got it.
+extern "C" int vm_bcast_params(vm_ctx *const *ctxs, void *const *comms, int n, int root, const vm_param_block *blk,
+                               vm_param_block *blocks_out)
+{
+    if (!ctxs || n < 1 || root < 0 || root >= n || !blk) return vm_fail(VM_E_INVALID, "vm_bcast_params: bad argument");
+    std::vector<vm_param_block> got(n);
+    std::vector<void *> dst(n);
+    for (int i = 0; i < n; ++i) dst[i] = &got[i];
+    int rc = vm_bcast_bytes(ctxs, comms, n, root, blk, sizeof(vm_param_block), dst.data());
+    for (int i = 0; i < n && rc == VM_OK; ++i) {
+        if ((rc = vm_set_params(ctxs[i], &got[i].kp)) != VM_OK) break;
+        if ((rc = vm_set_math_mode(ctxs[i], got[i].math_mode)) != VM_OK) break;
+        if (blocks_out) blocks_out[i] = got[i];
+    }
     return rc;
 }
