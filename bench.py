@@ -1002,8 +1002,8 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         fr.set_v_from_level(p, 1)
         try:
             fr.quadratic_path(tol=1e-3)      # the workspace is allocated on first use: not timed
-            qp = fr.quadratic_path(tol=1e-5)     # the tolerance the full-size oracle fixture verifies (2e-3 px, tests/test_gpu_fullsize_compositor.py)
-            extras["quadratic_path_1080p"] = {"ms_per_frame": round(qp[2], 2), "pcg_iterations": qp[0], "tol": 1e-5,
+            qp = fr.quadratic_path(tol=1e-4)     # float32 attains 1e-4 on a solved field; 2e-3 px of the oracle at full size: tests/test_gpu_fullsize_compositor.py
+            extras["quadratic_path_1080p"] = {"ms_per_frame": round(qp[2], 2), "pcg_iterations": qp[0], "tol": 1e-4,
                                               "residual": float("%.3g" % qp[1])}
         except capi.VmError as e:        # e.g. a folded v: the blend of the Jacobians is 0/0 there
             extras["quadratic_path_1080p"] = {"error": str(e)[-120:]}

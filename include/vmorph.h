@@ -390,8 +390,8 @@ int  vm_poisson_extend_frames(vm_frame *const *frames, int n, float tol, int max
  * which stays in the frame where vm_render_halfway reads it (the reference's
  * `_qpath`).  Multigrid-preconditioned CG to the relative residual `tol` instead
  * of 10 001 plain CG iterations; the zero-mean solution.  float32 attains about
- * 1e-5 here (|u| >> |right-hand side| for smooth fields): VM_E_NUMERIC if the
- * iteration stalls above `tol` (no better residual for 12 iterations) -- or if v folds over so that
+ * 1e-4 .. 1e-5 here (|u| >> |right-hand side|; a solved, rounding-rough field: 1e-4): the best iterate
+ * is delivered, VM_E_NUMERIC if its residual exceeds `tol` -- or if v folds over so that
  * the two Jacobians' columns are anti-parallel somewhere (0/0 in QuadraticPath.cpp:96-101:
  * the reference propagates the NaN).  iters/rel_res may be NULL. */
 int  vm_frame_quadratic_path(vm_frame *f, float tol, int max_it,

