@@ -72,8 +72,9 @@ struct VmMgbSys {
 #define VM_MGB_COARSEST 64      // the hierarchy ends at a grid of at most this many cells ...
 #define VM_MGB_COARSE_SWEEPS 2  // ... which gets this many symmetric Gauss-Seidel sweeps each way (R B R B, B R B R) from zero
 // the tail of the cycle -- every level from `tail` on -- runs in ONE workgroup with the iterates in LDS: the levels'
-// cell counts must fit these pools (float4 entries): all of them / all but the first
-#define VM_MGB_TAIL_X 6144
+// cell counts must fit these pools: all of them (a float4 iterate + a float2 of edge weights per cell) / all but the first
+// (a float4 right-hand side): 120 + 32 KB of the CU's 160 KB of LDS
+#define VM_MGB_TAIL_X 5120
 #define VM_MGB_TAIL_B 2048
 
 // set-up: level 0 from the type map, Galerkin coarsening (2x2 aggregates, edge weights x 1/2), block flags on the way

@@ -735,48 +735,59 @@ __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-// The tail of the cycle: every level from l0 on (their cells fit VM_MGB_TAIL_X / _B, vm_mgb.h) in ONE workgroup, the
-// iterates and the coarser right-hand sides in LDS, the operators read from memory (a few thousand cells: L2).
+// The tail of the cycle: every level from l0 on (their cells fit VM_MGB_TAIL_X / _B, vm_mgb.h) in ONE workgroup.  All of
+// their state lives in LDS for the whole cycle -- iterates with 1 / dg in .w, the right-hand sides of the levels below
+// l0, the edge weights -- and level l0's right-hand side in registers: the ~26 dependent half-sweeps and transfers of
+// the tail touch memory only at the two ends.  Measured (four tail levels of a 1080p canvas, 4410 cells): 37.8 us per
+// cycle against 39.5 with the operators read from L2 in every half-sweep -- the tail is one workgroup on one CU and what
+// bounds it is its own instruction stream (index arithmetic per cell, waves half empty on a one-colour half-sweep: 16 waves
+// x ~500 instructions x 4 cycles per phase of level l0), not the round trips.
+
+constexpr int TAILT = 1024;                              // threads of the tail's workgroup
+constexpr int TAILK = VM_MGB_TAIL_X / TAILT;             // cells of level l0 a thread owns at most
 
 struct TailLevel {
     int w, h, n;
-    int xo, bo;          // offsets of the level's iterate / right-hand side in the LDS pools (bo < 0: level l0, b in memory)
+    int xo, bo;          // offsets of the level's iterate (and weights) / right-hand side in the LDS pools (bo < 0: level l0)
 };
 
-// one Gauss-Seidel half-sweep of colour `red` on a tail level: x = (b + sum_nb w x) / dg
-template <bool L0>
-__device__ __forceinline__ void tail_half(const VmMgbLevel &L, const TailLevel &T, float4 *x, const float4 *bl, bool red, bool first_red)
+__device__ __forceinline__ float4 tail_nbsum(const float4 *x, const float2 *wt, int i, int cx, int cy, int w)
 {
-    const Op<L0> A(L);
-    for (int i = threadIdx.x; i < T.n; i += 1024) {
+    const float2 me = wt[i];
+    float4 s = make_float4(0, 0, 0, 0);
+    if (me.x != 0.0f) s = f4_axpy(me.x, x[i + 1], s);
+    if (cx > 0) { const float wW = wt[i - 1].x; if (wW != 0.0f) s = f4_axpy(wW, x[i - 1], s); }
+    if (me.y != 0.0f) s = f4_axpy(me.y, x[i + w], s);
+    if (cy > 0) { const float wN = wt[i - w].y; if (wN != 0.0f) s = f4_axpy(wN, x[i - w], s); }
+    return s;
+}
+
+// one Gauss-Seidel half-sweep of colour `red` on a tail level: x = (b + sum_nb w x) / dg.  b: the level's right-hand
+// side in LDS, or (level l0) nullptr: the thread's registers b0.  first: the opening red half-sweep from zero, x = b / dg.
+__device__ __forceinline__ void tail_half(const TailLevel &T, float4 *x, const float2 *wt, const float4 *bl, const float4 *b0, bool red, bool first)
+{
+#pragma unroll
+    for (int k = 0; k < TAILK; ++k) {
+        const int i = threadIdx.x + TAILT * k;
+        if (i >= T.n)
+            break;
         const int cx = i % T.w, cy = i / T.w;
         if ((((cx + cy) & 1) == 0) != red)
             continue;
-        const float inv = A.k((size_t)i);
-        float4 o = make_float4(0, 0, 0, 0);
-        if (inv > 0.0f) {
-            const float4 b = bl ? bl[i] : ld3(L.b, (size_t)i);
-            float4 s = make_float4(0, 0, 0, 0);
-            if (!first_red) {       // (the first red half-sweep starts from zero: x = b / dg)
-                const Stencil st = stencil_of(A, cx, cy, (size_t)i);
-                if (st.wE != 0.0f) s = f4_axpy(st.wE, x[i + 1], s);
-                if (st.wW != 0.0f) s = f4_axpy(st.wW, x[i - 1], s);
-                if (st.wS != 0.0f) s = f4_axpy(st.wS, x[i + T.w], s);
-                if (st.wN != 0.0f) s = f4_axpy(st.wN, x[i - T.w], s);
-            }
-            o = make_float4(inv * (b.x + s.x), inv * (b.y + s.y), inv * (b.z + s.z), 0);
-        }
-        x[i] = o;
+        const float inv = x[i].w;
+        if (!(inv > 0.0f))
+            continue;                                    // no unknown: stays (0, 0, 0, 0)
+        const float4 b = bl ? bl[i] : b0[k];
+        const float4 s = first ? make_float4(0, 0, 0, 0) : tail_nbsum(x, wt, i, cx, cy, T.w);
+        x[i] = make_float4(inv * (b.x + s.x), inv * (b.y + s.y), inv * (b.z + s.z), inv);
     }
     __syncthreads();
 }
 
 // restriction of the pre-smoothed level's residual: bc[C] = sum over the aggregate's red cells of sum_nb w x_black
-template <bool L0>
-__device__ __forceinline__ void tail_restrict(const VmMgbLevel &L, const TailLevel &T, const TailLevel &TC, const float4 *x, float4 *bc)
+__device__ __forceinline__ void tail_restrict(const TailLevel &T, const TailLevel &TC, const float4 *x, const float2 *wt, float4 *bc)
 {
-    const Op<L0> A(L);
-    for (int i = threadIdx.x; i < TC.n; i += 1024) {
+    for (int i = threadIdx.x; i < TC.n; i += TAILT) {
         const int X = i % TC.w, Y = i / TC.w;
         float4 r = make_float4(0, 0, 0, 0);
 #pragma unroll
@@ -784,14 +795,11 @@ __device__ __forceinline__ void tail_restrict(const VmMgbLevel &L, const TailLev
             const int cx = 2 * X + d, cy = 2 * Y + d;
             if (cx >= T.w || cy >= T.h)
                 continue;
-            const size_t q = (size_t)cy * T.w + cx;
-            if (!(A.k(q) > 0.0f))
+            const int q = cy * T.w + cx;
+            if (!(x[q].w > 0.0f))
                 continue;
-            const Stencil st = stencil_of(A, cx, cy, q);
-            if (st.wE != 0.0f) r = f4_axpy(st.wE, x[q + 1], r);
-            if (st.wW != 0.0f) r = f4_axpy(st.wW, x[q - 1], r);
-            if (st.wS != 0.0f) r = f4_axpy(st.wS, x[q + T.w], r);
-            if (st.wN != 0.0f) r = f4_axpy(st.wN, x[q - T.w], r);
+            const float4 s = tail_nbsum(x, wt, q, cx, cy, T.w);
+            r.x += s.x; r.y += s.y; r.z += s.z;
         }
         bc[i] = r;
     }
@@ -799,12 +807,13 @@ __device__ __forceinline__ void tail_restrict(const VmMgbLevel &L, const TailLev
 }
 
 template <bool L0>
-__global__ __launch_bounds__(1024) void k_mgb_tail(const VmMgbSys *__restrict__ sys, int l0, uint64_t active)
+__global__ __launch_bounds__(TAILT) void k_mgb_tail(const VmMgbSys *__restrict__ sys, int l0, uint64_t active)
 {
     if (!sys_active(active))
         return;
     const VmMgbSys &S = sys[blockIdx.z];
     __shared__ float4 xp[VM_MGB_TAIL_X], bp[VM_MGB_TAIL_B];
+    __shared__ float2 wp[VM_MGB_TAIL_X];
     __shared__ TailLevel T[VM_MGB_MAXLEV];
     const int nl = S.nlev - l0;                          // levels of the tail: T[0] = level l0
     if (threadIdx.x == 0) {
@@ -817,67 +826,78 @@ __global__ __launch_bounds__(1024) void k_mgb_tail(const VmMgbSys *__restrict__ 
         }
     }
     __syncthreads();
-    // down: pre-smoothing (red from zero, black), restriction
-    for (int j = 0; j + 1 < nl; ++j) {
-        const VmMgbLevel &L = S.lv[l0 + j];
-        float4 *x = xp + T[j].xo;
-        const float4 *b = j ? bp + T[j].bo : nullptr;
-        if (j == 0) {
-            tail_half<L0>(L, T[0], x, b, true, true);
-            tail_half<L0>(L, T[0], x, b, false, false);
-            tail_restrict<L0>(L, T[0], T[1], x, bp + T[1].bo);
-        } else {
-            tail_half<false>(L, T[j], x, b, true, true);
-            tail_half<false>(L, T[j], x, b, false, false);
-            tail_restrict<false>(L, T[j], T[j + 1], x, bp + T[j + 1].bo);
+    // stage: 1 / dg and the weights of the edges to the east / south of every tail cell; level l0's right-hand side
+    float4 b0[TAILK];
+    {
+        const VmMgbLevel &L = S.lv[l0];
+        const Op<L0> A(L);
+#pragma unroll
+        for (int k = 0; k < TAILK; ++k) {
+            const int i = threadIdx.x + TAILT * k;
+            b0[k] = make_float4(0, 0, 0, 0);
+            if (i < T[0].n) {
+                const Stencil st = stencil_of(A, i % T[0].w, i / T[0].w, (size_t)i);
+                const float inv = A.k((size_t)i);
+                xp[i] = make_float4(0, 0, 0, inv);
+                wp[i] = make_float2(st.wE, st.wS);
+                if (inv > 0.0f) b0[k] = ld3(L.b, (size_t)i);
+            }
         }
     }
-    // the coarsest grid: symmetric sweeps from zero
+    for (int j = 1; j < nl; ++j) {
+        const VmMgbLevel &L = S.lv[l0 + j];
+        const Op<false> A(L);
+        for (int i = threadIdx.x; i < T[j].n; i += TAILT) {
+            const Stencil st = stencil_of(A, i % T[j].w, i / T[j].w, (size_t)i);
+            xp[T[j].xo + i] = make_float4(0, 0, 0, A.k((size_t)i));
+            wp[T[j].xo + i] = make_float2(st.wE, st.wS);
+        }
+    }
+    __syncthreads();
+    // down: pre-smoothing (red from zero, black), restriction
+    for (int j = 0; j + 1 < nl; ++j) {
+        float4 *x = xp + T[j].xo;
+        const float2 *wt = wp + T[j].xo;
+        const float4 *b = j ? bp + T[j].bo : nullptr;
+        tail_half(T[j], x, wt, b, b0, true, true);
+        tail_half(T[j], x, wt, b, b0, false, false);
+        tail_restrict(T[j], T[j + 1], x, wt, bp + T[j + 1].bo);
+    }
+    // the coarsest grid: symmetric sweeps from zero (red, black ... then black, red ...)
     {
         const int j = nl - 1;
-        const VmMgbLevel &L = S.lv[l0 + j];
         float4 *x = xp + T[j].xo;
+        const float2 *wt = wp + T[j].xo;
         const float4 *b = j ? bp + T[j].bo : nullptr;
         for (int sw = 0; sw < 2 * VM_MGB_COARSE_SWEEPS; ++sw) {
-            const bool fwd = sw < VM_MGB_COARSE_SWEEPS;  // red, black ... then black, red ...
-            if (j == 0) {
-                tail_half<L0>(L, T[j], x, b, fwd, sw == 0);
-                tail_half<L0>(L, T[j], x, b, !fwd, false);
-            } else {
-                tail_half<false>(L, T[j], x, b, fwd, sw == 0);
-                tail_half<false>(L, T[j], x, b, !fwd, false);
-            }
+            const bool fwd = sw < VM_MGB_COARSE_SWEEPS;
+            tail_half(T[j], x, wt, b, b0, fwd, sw == 0);
+            tail_half(T[j], x, wt, b, b0, !fwd, false);
         }
     }
     // up: coarse correction on the red cells (the black half-sweep that follows overwrites the black ones from red
     // values only), post-smoothing black, red
     for (int j = nl - 2; j >= 0; --j) {
-        const VmMgbLevel &L = S.lv[l0 + j];
         float4 *x = xp + T[j].xo;
+        const float2 *wt = wp + T[j].xo;
         const float4 *xc = xp + T[j + 1].xo;
         const float4 *b = j ? bp + T[j].bo : nullptr;
         const int w = T[j].w, cw = T[j + 1].w;
-        for (int i = threadIdx.x; i < T[j].n; i += 1024) {
+        for (int i = threadIdx.x; i < T[j].n; i += TAILT) {
             const int cx = i % w, cy = i / w;
-            if (((cx + cy) & 1) == 0) {
-                const float4 c = xc[(cy >> 1) * cw + (cx >> 1)], f = x[i];
-                // a red cell without an unknown holds 0 and stays 0: its aggregate may hold unknowns and a correction
-                const bool unk = (j == 0 && L0) ? (G(S.lv[l0].info)[i] >> 4) != 0 : G(L.k)[i] > 0.0f;
-                if (unk)
-                    x[i] = make_float4(f.x + c.x, f.y + c.y, f.z + c.z, 0);
+            const float4 f = x[i];
+            // (a red cell without an unknown holds 0 and stays 0: its aggregate may hold unknowns and a correction)
+            if (((cx + cy) & 1) == 0 && f.w > 0.0f) {
+                const float4 c = xc[(cy >> 1) * cw + (cx >> 1)];
+                x[i] = make_float4(f.x + c.x, f.y + c.y, f.z + c.z, f.w);
             }
         }
         __syncthreads();
-        if (j == 0) {
-            tail_half<L0>(L, T[0], x, b, false, false);
-            tail_half<L0>(L, T[0], x, b, true, false);
-        } else {
-            tail_half<false>(L, T[j], x, b, false, false);
-            tail_half<false>(L, T[j], x, b, true, false);
-        }
+        tail_half(T[j], x, wt, b, b0, false, false);
+        tail_half(T[j], x, wt, b, b0, true, false);
     }
     const VmMgbLevel &L = S.lv[l0];
-    for (int i = threadIdx.x; i < T[0].n; i += 1024)
+    for (int i = threadIdx.x; i < T[0].n; i += TAILT)
         st3(L.x, (size_t)i, xp[i]);
 }
 
@@ -928,9 +948,9 @@ void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nt_fine, in
 void vm_mgb_launch_tail(const VmMgbSys *sys, int nsys, int l, uint64_t active, hipStream_t s)
 {
     if (l == 0)
-        hipLaunchKernelGGL(k_mgb_tail<true>, dim3(1, 1, nsys), dim3(1024), 0, s, sys, l, active);
+        hipLaunchKernelGGL(k_mgb_tail<true>, dim3(1, 1, nsys), dim3(TAILT), 0, s, sys, l, active);
     else
-        hipLaunchKernelGGL(k_mgb_tail<false>, dim3(1, 1, nsys), dim3(1024), 0, s, sys, l, active);
+        hipLaunchKernelGGL(k_mgb_tail<false>, dim3(1, 1, nsys), dim3(TAILT), 0, s, sys, l, active);
 }
 
 void vm_mgb_launch_dot_rz(const VmMgbSys *sys, int nsys, int nb0, int k, uint64_t active, hipStream_t s)
