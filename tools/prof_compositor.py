@@ -18,13 +18,9 @@ fr = morph.Frame(ctx, w, h, ex)
 e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
 for rep in range(3):
     fr.upload(e0, e1, v, None)
-    if os.environ.get("VM_POISSON_SOLVER"):          # round 4's solvers: one side at a time
-        r1 = fr.poisson_extend(1, tol=1e-5)
-        r2 = fr.poisson_extend(2, tol=1e-5)
-    else:
-        r1, r2, _ = fr.poisson_extend_both(tol=1e-5)
+    r1, r2, _ = fr.poisson_extend_both(tol=1e-5)
     try:
-        qp = fr.quadratic_path(tol=1e-3)
+        qp = fr.quadratic_path(tol=1e-4)
     except capi.VmError as e:
         qp = str(e)
     ms = [fr.render_halfway_dev(0.1 * k, 0.1 * k, 1) for k in range(1, 10)]
