@@ -557,7 +557,9 @@ def load_poisson_pmc(path=None):
     batch (profiles/poisson_traffic_latest.json, written by tools/prof_pmc.sh + tools/pmc_summary.py); None if absent"""
     try:
         d = json.load(open(path or os.path.join(ROOT, "profiles", "poisson_traffic_latest.json")))
-        return {"bytes_per_system_iteration": float(d["bytes_per_system_iteration"]), "source": d["source"]}
+        upd = d.get("per_kernel_bytes_per_launch", {}).get("k_mgb_update")
+        return {"bytes_per_system_iteration": float(d["bytes_per_system_iteration"]), "source": d["source"],
+                "update_bytes_per_system_launch": float(upd) / float(d.get("systems_per_launch", 8)) if upd else None}
     except Exception:
         return None
 
@@ -964,6 +966,7 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         pe["tol_%g_one_side_at_a_time" % POISSON_TOL] = {"ms_per_frame": round(r1[2] + r2[2], 2), "cg_iterations": [r1[0], r2[0]]}
         # four frames per batch (eight systems per launch): the shape the config[4] pipeline runs
         frs4 = [fr] + [morph.Frame(ctx, w, h, ex) for _ in range(3)]
+        dom = None
         try:
             for tol in POISSON_TIMED_TOLS:
                 best4 = None
@@ -975,6 +978,15 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
                     res4, ms4 = morph.poisson_extend_frames(frs4, tol=tol)
                     best4 = ms4 if best4 is None else min(best4, ms4)
                 pe["tol_%g_four_frames_per_batch" % tol] = {"ms_per_frame": round(best4 / 4, 2), "cg_iterations": [s_[0] for r in res4 for s_ in r]}
+            # the dominant kernel of the solve, measured live (HIP events around every k_mgb_update launch on the stream it
+            # is launched on: vm_dbg_poisson_profile), one more 4-frame batch, not among the timed ones
+            for f4 in frs4:
+                f4.upload(e0, e1, None, None)
+                if f4 is not fr:
+                    f4.set_v_from_level(p, 1)
+            ctx.poisson_profile(True)
+            morph.poisson_extend_frames(frs4, tol=POISSON_TOL)
+            dom = ctx.poisson_profile(False)
         finally:
             for f4 in frs4[1:]:
                 f4.close()
@@ -993,6 +1005,15 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
                                                      "kernels k_mgb_update / k_mgb_dirspmv / k_mgb_prolong / k_mgb_restrict: profiles/r06_compositor_*)",
                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                           "four_frames_per_batch": {"achieved": round(gbs4, 1), "frac": round(gbs4 / HBM_PEAK_GBS, 4)},
+                          # k_mgb_update (x += alpha p, r -= alpha q, r.r: reads p, q, x, r and the operator byte, writes x, r = 73 B per
+                          # unknown of every active system), average launch of a 4-frame batch, HIP events in this run;
+                          # profiles/r06_poisson4_kernel_stats.csv holds rocprofv3's average of the same kernel
+                          "dominant_kernel": dom and dom[1] > 0 and {
+                              "kernel": "k_mgb_update", "launches": dom[1], "launch_us": round(dom[0] / dom[1], 2),
+                              "alg_bytes_per_launch": round(dom[2] / dom[1] * unknowns * 73.0),
+                              "achieved": round(dom[2] * unknowns * 73.0 / (dom[0] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(dom[2] * unknowns * 73.0 / (dom[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              "traffic": pmc and pmc.get("update_bytes_per_system_launch") and round(pmc["update_bytes_per_system_launch"] * dom[2] / dom[1])},
                           "traffic": round(pmc["bytes_per_system_iteration"] * sum(its)) if (pmc and (w, h, ex) == (1920, 1080, 192)) else None,
                           "traffic_source": pmc and pmc["source"],
                           "alg_bytes_per_unknown_iteration": POISSON_ALG_BYTES, "unknowns_per_side": unknowns, "tol": POISSON_TOL}

@@ -132,6 +132,9 @@ def test_bench_extras_of_round_5():
     assert set(k for k in pe if k.startswith("tol_")) == {"tol_1e-05", "tol_1e-06", "tol_1e-05_one_side_at_a_time", "tol_1e-05_four_frames_per_batch",
                                                            "tol_1e-06_four_frames_per_batch"}          # nothing timed at an unverified tolerance
     assert pe["tol_1e-05_four_frames_per_batch"]["ms_per_frame"] < pe["tol_1e-05"]["ms_per_frame"] and prf["four_frames_per_batch"]["frac"] > prf["frac"]
+    dk = prf["dominant_kernel"]       # measured live with HIP events (vm_dbg_poisson_profile)
+    assert dk["kernel"] == "k_mgb_update" and dk["launches"] >= 8 and 20 < dk["launch_us"] < 400 and 0.3 < dk["frac"] < 1.0
+    assert abs(dk["frac"] - dk["achieved"] / dk["peak"]) < 1e-3 and (dk["traffic"] is None or dk["traffic"] > 0.9 * dk["alg_bytes_per_launch"])
     assert p30["runs"] == 3 and len(p30["ms_per_pair_each_run"]) == 3 and p30["ms_per_pair"] <= p30["ms_per_pair_median"]
 
 

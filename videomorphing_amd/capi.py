@@ -35,7 +35,7 @@ SYMBOLS = [
     "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_solve_batch_cons", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
     "vm_frame_download_ext", "vm_host_register", "vm_host_unregister", "vm_frame_set_v_from_level", "vm_render_halfway",
     "vm_render_halfway_dev", "vm_poisson_extend", "vm_poisson_extend_frames", "vm_frame_quadratic_path", "vm_frame_download_qpath", "vm_frame_download_v",
-    "vm_rccl_bcast", "vm_rccl_comm_init_all", "vm_rccl_comm_destroy", "vm_bcast_params", "vm_bcast_bytes",
+    "vm_rccl_bcast", "vm_rccl_comm_init_all", "vm_rccl_comm_destroy", "vm_bcast_params", "vm_bcast_bytes", "vm_dbg_poisson_profile",
     "vm_video_create", "vm_video_destroy", "vm_video_levels", "vm_video_level_dims", "vm_video_upload_luma",
     "vm_video_upload_flows", "vm_video_build_rgb", "vm_video_build_flows", "vm_video_set_v", "vm_video_get_v",
     "vm_video_get_field", "vm_video_coarse_solve", "vm_video_upsample", "vm_video_init_level",
@@ -156,6 +156,7 @@ def load():
         "vm_rccl_comm_init_all": [i, C.POINTER(i), C.POINTER(vp)],
         "vm_bcast_params": [C.POINTER(vp), C.POINTER(vp), i, i, C.POINTER(ParamBlock), C.POINTER(ParamBlock)],
         "vm_bcast_bytes": [C.POINTER(vp), C.POINTER(vp), i, i, vp, C.c_uint64, C.POINTER(vp)],
+        "vm_dbg_poisson_profile": [vp, i, C.POINTER(C.c_double), C.POINTER(i), C.POINTER(C.c_double)],
         "vm_video_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i), i, C.POINTER(vp)],
         "vm_video_levels": [vp],
         "vm_video_level_dims": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(f)],

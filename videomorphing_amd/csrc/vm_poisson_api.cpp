@@ -206,6 +206,8 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     std::vector<VmMgbScalars> h(nsys);
     std::vector<double> best(nsys, 1e300);
     std::vector<int> best_it(nsys, 0), next_check(nsys, 0), saved(nsys, 0);
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    std::vector<int> prof_sys;
     int it = 0;
     // A system's residual is looked at every 4 iterations (a read drains the stream) until it is within a factor 30
     // of the tolerance -- the cycle gains a decade in two to three iterations -- and every iteration from there: a solve
@@ -254,7 +256,18 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
         for (; it < upto; ++it) {
             mgb_vcycle(dev, nsys, W[0], nb, nt, it, active, s);
             vm_mgb_launch_dirspmv(dev, nsys, nb[0], it, active, s);
-            vm_mgb_launch_update(dev, nsys, nb[0], it, active, s);
+            if (c->mgb_prof) {           // the probe of vm_dbg_poisson_profile: events around the dominant kernel's launch
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                VM_HIP(hipEventCreate(&e0));
+                VM_HIP(hipEventCreate(&e1));
+                VM_HIP(hipEventRecord(e0, s));
+                vm_mgb_launch_update(dev, nsys, nb[0], it, active, s);
+                VM_HIP(hipEventRecord(e1, s));
+                prof_ev.push_back({e0, e1});
+                prof_sys.push_back(__builtin_popcountll(active));
+            } else {
+                vm_mgb_launch_update(dev, nsys, nb[0], it, active, s);
+            }
         }
         VM_HIP(hipGetLastError());
     }
@@ -262,6 +275,40 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
         iters[i] = best_it[i];
         rels[i] = best[i];
     }
+    if (!prof_ev.empty()) {
+        VM_HIP(hipStreamSynchronize(s));
+        for (size_t k = 0; k < prof_ev.size(); ++k) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, prof_ev[k].first, prof_ev[k].second) == hipSuccess) {
+                c->mgb_prof_us += 1e3 * ms;
+                c->mgb_prof_launches += 1;
+                c->mgb_prof_unknown_launches += prof_sys[k];        // active systems of that launch (x unknowns per system: the caller's)
+            }
+            hipEventDestroy(prof_ev[k].first);
+            hipEventDestroy(prof_ev[k].second);
+        }
+    }
+    return VM_OK;
+}
+
+// Diagnostic (bench.py's roofline of the compositor's HBM-bound kernel, measured live as the contract asks: HIP events on
+// the stream the kernel is launched on): on != 0 arms the probe and clears its sums; on == 0 disarms it and returns the
+// HIP-event time of the k_mgb_update launches since (microseconds, summed), their number, and the number of ACTIVE
+// systems summed over those launches (one launch streams 73 B per unknown of every active system).
+extern "C" int vm_dbg_poisson_profile(vm_ctx *c, int on, double *update_us, int *update_launches, double *active_systems)
+{
+    if (!c) return vm_fail(VM_E_INVALID, "vm_dbg_poisson_profile: ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (on) {
+        c->mgb_prof = true;
+        c->mgb_prof_us = c->mgb_prof_unknown_launches = 0;
+        c->mgb_prof_launches = 0;
+        return VM_OK;
+    }
+    c->mgb_prof = false;
+    if (update_us) *update_us = c->mgb_prof_us;
+    if (update_launches) *update_launches = c->mgb_prof_launches;
+    if (active_systems) *active_systems = c->mgb_prof_unknown_launches;
     return VM_OK;
 }
 

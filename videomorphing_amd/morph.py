@@ -110,6 +110,13 @@ class Context(object):
     def set_tuning(self, sweep_mode=0, threads=0, parts=0):
         capi.check(self._L.vm_set_tuning(self._h, int(sweep_mode), int(threads), int(parts)))
 
+    def poisson_profile(self, on):
+        """vm_dbg_poisson_profile: arm (on = True) the HIP-event probe around the linear solver's dominant kernel, or
+        disarm it and return (summed us, launches, active systems summed over the launches)"""
+        us, n, act = C.c_double(0), C.c_int(0), C.c_double(0)
+        capi.check(self._L.vm_dbg_poisson_profile(self._h, int(bool(on)), C.byref(us), C.byref(n), C.byref(act)))
+        return us.value, n.value, act.value
+
     def set_commit_order(self, order=0):
         """diagnostic (EXACT): the order a phase's commits are folded in -- 0 row-major (the oracle's),
         1 reversed, 2 column-major, 3 column-major reversed (vm_set_commit_order)"""
