@@ -74,8 +74,10 @@ struct VmMgbSys {
 // the tail of the cycle -- every level from `tail` on -- runs in ONE workgroup with the iterates in LDS: the levels'
 // cell counts must fit these pools: all of them (a float4 iterate + a float2 of edge weights per cell) / all but the first
 // (a float4 right-hand side): 120 + 32 KB of the CU's 160 KB of LDS
+#ifndef VM_MGB_TAIL_X
 #define VM_MGB_TAIL_X 5120
 #define VM_MGB_TAIL_B 2048
+#endif
 
 // set-up: level 0 from the type map, Galerkin coarsening (2x2 aggregates, edge weights x 1/2), block flags on the way
 void vm_mgb_launch_level0(const VmMgbSys *sys, int nsys, int gx, int gy, hipStream_t s);

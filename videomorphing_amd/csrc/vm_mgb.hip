@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict_
 // x ~500 instructions x 4 cycles per phase of level l0), not the round trips.
 
 constexpr int TAILT = 1024;                              // threads of the tail's workgroup
-constexpr int TAILK = VM_MGB_TAIL_X / TAILT;             // cells of level l0 a thread owns at most
+constexpr int TAILK = (VM_MGB_TAIL_X + TAILT - 1) / TAILT; // cells of level l0 a thread owns at most
 
 struct TailLevel {
     int w, h, n;
