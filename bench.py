@@ -362,8 +362,7 @@ def config4_main(args, np, torch, dist, vdist, capi, morph, synth, blk, cons, ra
     with ThreadPoolExecutor(max_workers=max(1, min(effective_cpus() // max(world, 1), 16, max(len(mine), 1)))) as ex_:
         imgs = list(ex_.map(lambda f: synth.make_pair(w, h, frame=f), mine))
     rgb0, rgb1 = synth.make_rgb_pair(w, h)
-    e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
-    job = Config4Job(np, capi, morph, synth, local_rank, blk, cons, w, h, nlev, mine, imgs, e0, e1, ex, POISSON_TOL)
+    job = Config4Job(np, capi, morph, synth, local_rank, blk, cons, w, h, nlev, mine, imgs, rgb0, rgb1, ex, POISSON_TOL)
 
     def barrier():
         torch.cuda.synchronize()
@@ -1057,7 +1056,7 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
     # per batch (8 systems per launch), 9 rendered in-between frames per pair
     if B == 1 and want("pipeline30"):
         try:
-            extras["pipeline_config4_30_frames"] = pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, e0, e1, ex, render_ms, local_rank, frames, POISSON_TOL)
+            extras["pipeline_config4_30_frames"] = pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, rgb0, rgb1, ex, render_ms, local_rank, frames, POISSON_TOL)
         except capi.VmError as e:
             extras["pipeline_config4_30_frames"] = {"error": str(e)[-200:]}
         finally:
@@ -1113,10 +1112,11 @@ class Config4Job(object):
     context's pyramid (vm_frame_set_v_from_level across contexts: an event, no host sync), Poisson extension of both sides
     of `per_batch` frames per batch (2 x per_batch systems per launch) at `tol`, 9 rendered in-between frames per pair; the
     batches dealt to `nlanes` compositor lanes (contexts = streams, a host thread each: one lane's PCIe uploads and
-    latency-bound coarse-grid launches hide behind the other's level-0 kernels; tools/exp/compositor_lanes.py).
+    latency-bound coarse-grid launches hide behind the other's level-0 kernels; tools/exp/compositor_lanes.py).  The frames
+    go up as RGB8 (vm_frame_upload_rgb: the extended canvases are built on the device, as Pyramid::build builds them).
     Everything it allocates is released by close() (use try / finally)."""
 
-    def __init__(self, np, capi, morph, synth, device, blk, cons, w, h, nlev, frame_ids, imgs, e0, e1, ex, tol, per_batch=4, nlanes=2, lane0=None):
+    def __init__(self, np, capi, morph, synth, device, blk, cons, w, h, nlev, frame_ids, imgs, rgb0, rgb1, ex, tol, per_batch=4, nlanes=2, lane0=None):
         self.np, self.capi, self.morph = np, capi, morph
         self.blk, self.cons, self.w, self.h, self.nlev, self.ex, self.tol = blk, cons, w, h, nlev, ex, tol
         self.n = len(frame_ids)
@@ -1134,7 +1134,7 @@ class Config4Job(object):
         self.lane_ctx = [lane0 if (li == 0 and lane0 is not None) else morph.Context(device, blk.math_mode) for li in range(nlanes)]
         self.own_lane_ctx = [c for c in self.lane_ctx if c is not lane0]
         self.lane_frs = [[morph.Frame(c, w, h, ex) for _ in range(per_batch)] for c in self.lane_ctx]
-        self.e0, self.e1 = morph.pin_host(e0), morph.pin_host(e1)        # the caller's frame buffers, page-locked (vm_host_register)
+        self.e0, self.e1 = morph.pin_host(rgb0), morph.pin_host(rgb1)    # the caller's RGB8 frames, page-locked (vm_host_register)
         self.pinned = [self.e0, self.e1]
 
     def pyramids(self):
@@ -1154,7 +1154,7 @@ class Config4Job(object):
         """workspaces (schedules, graphs, the solver's hierarchy) are allocated on first use: not timed"""
         for frs in self.lane_frs:
             for f in frs:
-                f.upload(self.e0, self.e1, None, None)
+                f.upload_rgb(self.e0, self.e1)
                 f.set_v_from_level(group[0], 1)
             self.morph.poisson_extend_frames(frs, tol=1e-3)
         self.solve(group)
@@ -1181,7 +1181,7 @@ class Config4Job(object):
             qs = [grp[k] for k in batch]
             t2 = time.perf_counter()
             for f, q in zip(frs, qs):
-                f.upload(self.e0, self.e1, None, None)
+                f.upload_rgb(self.e0, self.e1)              # 12 MB over PCIe; the canvases are built on the device (pyramid.cu:186-200)
                 f.set_v_from_level(q, 1)
             c.sync(); t3 = time.perf_counter()
             res, _ = self.morph.poisson_extend_frames(frs[:len(qs)], tol=self.tol)
@@ -1270,17 +1270,17 @@ class Config4Job(object):
 
 def config4_workload(n, nstreams, per_chunk, ex, per_batch, nlanes, tol):
     return ("config[4]: %d 1080p pairs, 8 point constraints each, BCOND_BORDER, solved on %d streams x one batch of %d (reference "
-            "semantics); per frame: canvases uploaded from page-locked host memory (PCIe), v upscaled on the device, Poisson extension (ex = %d, tol %g) of "
+            "semantics); per frame: RGB8 frames uploaded from page-locked host memory (PCIe), canvases built and v upscaled on the device, Poisson extension (ex = %d, tol %g) of "
             "both sides, %d frames = %d systems per batch, the batches dealt to %d compositor lanes (streams); 9 rendered in-between frames per pair"
             % (n, nstreams, per_chunk, ex, tol, per_batch, 2 * per_batch, nlanes))
 
 
-def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, e0, e1, ex, render_ms, device, frames, tol, nframes=30, per_batch=4, reps=3):
+def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, rgb0, rgb1, ex, render_ms, device, frames, tol, nframes=30, per_batch=4, reps=3):
     """config[4] on one GPU (see run_extras): returns the extras entry.  The whole job `reps` times: min and median (one run
     each was what rounds 4-5 reported, and the driver's fresh box then differed from the quoted figures by 6-30 %)."""
     cons = synth.make_constraints(w, h, 8)
     ids = list(range(2000, 2000 + nframes))
-    job = Config4Job(np, capi, morph, synth, device, blk, cons, w, h, nlev, ids, frames(ids), e0, e1, ex, tol, per_batch, 2, lane0=ctx)
+    job = Config4Job(np, capi, morph, synth, device, blk, cons, w, h, nlev, ids, frames(ids), rgb0, rgb1, ex, tol, per_batch, 2, lane0=ctx)
     try:
         group = job.pyramids()
         job.warm_up(group)

@@ -353,6 +353,10 @@ int  vm_frame_create(vm_ctx *ctx, int w, int h, int ex, vm_frame **out);
 void vm_frame_destroy(vm_frame *f);
 int  vm_frame_upload(vm_frame *f, const uint8_t *ext0_rgba, const uint8_t *ext1_rgba,
                      const float *v_xy, const float *qpath_xy);
+/* the same from the two RGB8 frames themselves (h rows of pitch_bytes, 0 = tight): the canvases are built on the device as
+ * Pyramid::build builds them, Algorithm/pyramid.cu:186-200 (frame + zero alpha plane pasted at (ex, ex) into a canvas of
+ * (255, 255, 255, 255)); v and the quadratic path stay what they are.  12 MB over the link per 1080p pair instead of 27. */
+int  vm_frame_upload_rgb(vm_frame *f, const uint8_t *rgb0, const uint8_t *rgb1, int pitch_bytes);
 int  vm_frame_download_ext(vm_frame *f, int side, uint8_t *ext_rgba);
 /* take v straight from a solved pyramid level (device to device, with the
  * update_result upscale) */

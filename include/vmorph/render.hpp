@@ -34,6 +34,8 @@ public:
     {
         check(vm_frame_upload(f_, ext0, ext1, v, qpath));
     }
+    // the canvases built on the device from the two RGB8 frames (Pyramid::build, pyramid.cu:186-200)
+    void upload_rgb(const unsigned char *rgb0, const unsigned char *rgb1, int pitch_bytes = 0) { check(vm_frame_upload_rgb(f_, rgb0, rgb1, pitch_bytes)); }
     void set_v_from_level(Pyramid &pyr, int el) { check(vm_frame_set_v_from_level(f_, pyr.handle(), el - 1)); }
 
     // CPoissonExt::run body for one side, PoissonExt.cpp:19-41

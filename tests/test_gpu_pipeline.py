@@ -249,6 +249,40 @@ def test_upload_from_page_locked_host_memory(gpu_ctx):
     fr.close()
 
 
+@pytest.mark.parametrize("w,h,ex", [(96, 64, 10), (333, 47, 33), (65, 17, 0), (20, 12, 3)])
+def test_canvases_built_on_the_device_equal_pyramid_build(gpu_ctx, w, h, ex):
+    """vm_frame_upload_rgb: the extended canvases built on the device from the two RGB8 frames are Pyramid::build's
+    (pyramid.cu:186-200: the frame with a zero alpha plane pasted at (ex, ex) into a canvas of (255, 255, 255, 255)) byte for
+    byte, pitched input included; the crops the fills sample are the frames (the extension of both sides gives the same
+    iteration counts and colours within one level -- atomics -- as after an upload of finished canvases); v is untouched"""
+    rgb0, rgb1 = synth.make_rgb_pair(w, h, frame=3)
+    v = (0.5 * synth.displacement(w, h)).astype(np.float32)
+    fa, fb = morph.Frame(gpu_ctx, w, h, ex), morph.Frame(gpu_ctx, w, h, ex)
+    try:
+        fa.upload(morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex), v, None)
+        fb.upload(None, None, v, None)
+        fb.upload_rgb(rgb0, rgb1)
+        assert np.array_equal(fb.download_ext(1), morph.make_extended(rgb0, ex)) and np.array_equal(fb.download_ext(2), morph.make_extended(rgb1, ex))
+        assert np.array_equal(fb.download_v(), v)
+        # pitched rows (a caller's padded image buffer)
+        pad = np.zeros((h, w + 5, 3), np.uint8)
+        pad[:, :w] = rgb1
+        p0 = np.zeros((h, w + 5, 3), np.uint8)
+        p0[:, :w] = rgb0
+        capi.check(fb._L.vm_frame_upload_rgb(fb._h, p0.ctypes.data, pad.ctypes.data, 3 * (w + 5)))
+        assert np.array_equal(fb.download_ext(1), morph.make_extended(rgb0, ex)) and np.array_equal(fb.download_ext(2), morph.make_extended(rgb1, ex))
+        with pytest.raises(capi.VmError):
+            capi.check(fb._L.vm_frame_upload_rgb(fb._h, p0.ctypes.data, pad.ctypes.data, 3 * w - 1))
+        if ex > 0:
+            ra, rb = fa.poisson_extend_both(tol=1e-6), fb.poisson_extend_both(tol=1e-6)
+            assert (ra[0][0], ra[1][0]) == (rb[0][0], rb[1][0])
+            for side in (1, 2):
+                assert np.abs(fa.download_ext(side).astype(int) - fb.download_ext(side).astype(int)).max() <= 1
+    finally:
+        fa.close()
+        fb.close()
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13, 14])
 def test_poisson_on_random_outside_regions(gpu_ctx, oracle, seed):
     """fuzz of the batched solver's geometry handling: canvases whose outside region (alpha > 0) is the frame border plus

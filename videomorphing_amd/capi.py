@@ -32,7 +32,7 @@ SYMBOLS = [
     "vm_pyramid_create", "vm_pyramid_destroy", "vm_pyramid_levels", "vm_level_dims",
     "vm_level_upload_luma", "vm_pyramid_build_rgb", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
-    "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_solve_batch_cons", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload",
+    "vm_solve", "vm_optimize_level_batch", "vm_solve_batch", "vm_solve_batch_cons", "vm_upscale_result", "vm_frame_create", "vm_frame_destroy", "vm_frame_upload", "vm_frame_upload_rgb",
     "vm_frame_download_ext", "vm_host_register", "vm_host_unregister", "vm_frame_set_v_from_level", "vm_render_halfway",
     "vm_render_halfway_dev", "vm_poisson_extend", "vm_poisson_extend_frames", "vm_frame_quadratic_path", "vm_frame_download_qpath", "vm_frame_download_v",
     "vm_rccl_bcast", "vm_rccl_comm_init_all", "vm_rccl_comm_destroy", "vm_bcast_params", "vm_bcast_bytes", "vm_dbg_poisson_profile",
@@ -141,6 +141,7 @@ def load():
         "vm_upscale_result": [vp, i, i, i, vp, i],
         "vm_frame_create": [vp, i, i, i, C.POINTER(vp)],
         "vm_frame_upload": [vp, vp, vp, vp, vp],
+        "vm_frame_upload_rgb": [vp, vp, vp, i],
         "vm_frame_download_ext": [vp, i, vp],
         "vm_frame_set_v_from_level": [vp, vp, i],
         "vm_render_halfway": [vp, f, f, i, vp, i],

@@ -189,6 +189,7 @@ struct vm_frame {
                                           // state, UI/MdiEditor.cpp:1898-1903): vm_render_halfway then skips its 21 taps of u --
                                           // a zero path stays zero through the fixed-point steps, the bytes are the same
     uint8_t *out = nullptr;               // h x w x 3
+    uint8_t *rgb_stage = nullptr;         // vm_frame_upload_rgb: the two RGB8 frames as they arrive (2 x h x w x 3), allocated on first use
     // solver workspace (allocated on first use), pws2[side - 1]: one per side (both sides of a frame are in flight
     // together); the quadratic path uses side 1's
     void *pws2[2] = {nullptr, nullptr};

@@ -5,6 +5,9 @@
 #include "vm_internal.h"
 
 void vm_poisson_launch_crop(uchar4 *dst, const uchar4 *ext, int w, int h, int ex, hipStream_t s);
+// the extended canvas of Pyramid::build (pyramid.cu:186-200) from a tight RGB8 frame: (255, 255, 255, 255) around it, the
+// frame at (ex, ex) with alpha 0; and the frame's RGBA copy (the crop the other side's fill samples)
+void vm_poisson_launch_canvas(uchar4 *ext, uchar4 *crop, const uint8_t *rgb, int w, int h, int ex, hipStream_t s);
 void vm_poisson_launch_prepare(uchar4 *ext, uint8_t *type, const uchar4 *other, const float2 *v,
                                int w, int h, int rs, int ex, int sign, hipStream_t s);
 // right-hand side + initial guess, and the paste of the solution, on the solver's 12-byte vectors (vm_mgb.h)

@@ -213,6 +213,24 @@ __global__ __launch_bounds__(256) void k_crop(uchar4 *dst, const uchar4 *__restr
     dst[(size_t)y * w + x] = ext[(size_t)(y + ex) * (w + 2 * ex) + x + ex];
 }
 
+// Pyramid::build's extended canvas, pyramid.cu:186-200 (mixChannels of the frame with a zero alpha plane, pasted into a
+// canvas of (255, 255, 255, 255)): one thread per canvas pixel; the frame's RGBA copy goes to `crop` on the way
+__global__ __launch_bounds__(256) void k_canvas(uchar4 *ext, uchar4 *crop, const uint8_t *__restrict__ rgb, int w, int h, int ex)
+{
+    const int cw = w + 2 * ex, ch = h + 2 * ex;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= cw || y >= ch)
+        return;
+    const int fx = x - ex, fy = y - ex;
+    uchar4 o = make_uchar4(255, 255, 255, 255);
+    if (fx >= 0 && fx < w && fy >= 0 && fy < h) {
+        const uint8_t *p = rgb + ((size_t)fy * w + fx) * 3;
+        o = make_uchar4(p[0], p[1], p[2], 0);
+        crop[(size_t)fy * w + fx] = o;
+    }
+    ext[(size_t)y * cw + x] = o;
+}
+
 inline dim3 grid2(int w, int h) { return dim3((w + 63) / 64, (h + 3) / 4); }
 const dim3 B2(64, 4);
 
@@ -316,6 +334,11 @@ __global__ __launch_bounds__(256) void k_qp_shift(V *X, int w, int h, const doub
 void vm_poisson_launch_crop(uchar4 *dst, const uchar4 *ext, int w, int h, int ex, hipStream_t s)
 {
     hipLaunchKernelGGL(k_crop, grid2(w, h), B2, 0, s, dst, ext, w, h, ex);
+}
+
+void vm_poisson_launch_canvas(uchar4 *ext, uchar4 *crop, const uint8_t *rgb, int w, int h, int ex, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_canvas, grid2(w + 2 * ex, h + 2 * ex), B2, 0, s, ext, crop, rgb, w, h, ex);
 }
 
 void vm_poisson_launch_prepare(uchar4 *ext, uint8_t *type, const uchar4 *other, const float2 *v,

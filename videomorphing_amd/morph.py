@@ -471,6 +471,13 @@ class Frame(object):
 
     __del__ = close
 
+    def upload_rgb(self, rgb0, rgb1):
+        """the two frames as (h, w, 3) uint8: the extended canvases are built on the device (Pyramid::build,
+        pyramid.cu:186-200) -- vm_frame_upload_rgb; v and the quadratic path stay what they are"""
+        a0, a1 = np.ascontiguousarray(rgb0, dtype=np.uint8), np.ascontiguousarray(rgb1, dtype=np.uint8)
+        assert a0.shape == (self.h, self.w, 3) and a1.shape == a0.shape
+        capi.check(self._L.vm_frame_upload_rgb(self._h, a0.ctypes.data, a1.ctypes.data, 0))
+
     def upload(self, ext0=None, ext1=None, v=None, qpath=None):
         def ptr(a, dt):
             if a is None:
