@@ -216,6 +216,7 @@ static void ctx_free(vm_ctx *c)
     hipFree(c->iter_dev);
     hipFree(c->tile_list);
     hipFree(c->mgb_sys);
+    hipFree(c->mgb_shared);
     for (auto &g : c->graphs) hipGraphExecDestroy(g.exec);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);

@@ -112,6 +112,7 @@ struct vm_ctx {
     size_t tile_list_words = 0;
     int use_graphs = -1;             // -1: not decided yet, 0: off (VM_NO_GRAPH or a failed capture), 1: on
     void *mgb_sys = nullptr;         // device descriptors of the systems of the current Poisson batch (vm_poisson_api.cpp)
+    void *mgb_shared = nullptr;      // ... and their PCG scalars + block / tile counts, contiguous: ONE clear and ONE read-back per check for the whole batch
     // vm_dbg_poisson_profile: HIP-event time of the solver's dominant kernel (k_mgb_update), summed over the launches of
     // the solves since the probe was switched on, and what those launches processed
     bool mgb_prof = false;

@@ -173,15 +173,28 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     hipStream_t s = c->stream;
     const size_t N0 = (size_t)W[0].S.lv[0].w * W[0].S.lv[0].h;
     if (!c->mgb_sys) VM_HIP(hipMalloc((void **)&c->mgb_sys, VM_MGB_MAXSYS * sizeof(VmMgbSys)));
+    // the systems' PCG scalars and block / tile counts live side by side in one buffer of the context (the descriptors
+    // handed to the kernels point there): one clear per solve, one read-back per residual check for the whole batch
+    // instead of one per system
+    const size_t cnt_bytes = (size_t)VM_MGB_MAXSYS * 2 * VM_MGB_MAXLEV * sizeof(int);
+    if (!c->mgb_shared) VM_HIP(hipMalloc(&c->mgb_shared, VM_MGB_MAXSYS * sizeof(VmMgbScalars) + cnt_bytes));
+    VmMgbScalars *sc_dev = (VmMgbScalars *)c->mgb_shared;
+    int *cnt_dev = (int *)((char *)c->mgb_shared + VM_MGB_MAXSYS * sizeof(VmMgbScalars));
     VmMgbSys *dev = (VmMgbSys *)c->mgb_sys;
     std::vector<VmMgbSys> hs(nsys);
-    for (int i = 0; i < nsys; ++i) hs[i] = W[i].S;
-    VM_HIP(hipMemcpyAsync(dev, hs.data(), nsys * sizeof(VmMgbSys), hipMemcpyHostToDevice, s));
     const int nlev = W[0].S.nlev;
     for (int i = 0; i < nsys; ++i) {
-        VM_HIP(hipMemsetAsync(W[i].S.sc, 0, sizeof(VmMgbScalars), s));
-        if (W[i].xcoarse_bytes) VM_HIP(hipMemsetAsync(W[i].xcoarse, 0, W[i].xcoarse_bytes, s));
+        hs[i] = W[i].S;
+        hs[i].sc = sc_dev + i;
+        for (int l = 0; l < nlev; ++l) {
+            hs[i].lv[l].nblocks = cnt_dev + (size_t)i * 2 * VM_MGB_MAXLEV + l;
+            hs[i].lv[l].ntiles = cnt_dev + (size_t)i * 2 * VM_MGB_MAXLEV + VM_MGB_MAXLEV + l;
+        }
     }
+    VM_HIP(hipMemcpyAsync(dev, hs.data(), nsys * sizeof(VmMgbSys), hipMemcpyHostToDevice, s));
+    VM_HIP(hipMemsetAsync(sc_dev, 0, nsys * sizeof(VmMgbScalars), s));
+    for (int i = 0; i < nsys; ++i)
+        if (W[i].xcoarse_bytes) VM_HIP(hipMemsetAsync(W[i].xcoarse, 0, W[i].xcoarse_bytes, s));
     // the hierarchy and its block lists (batched)
     vm_mgb_launch_level0(dev, nsys, W[0].S.lv[0].gx, W[0].S.lv[0].gy, s);
     for (int l = 1; l < nlev; ++l)
@@ -189,8 +202,7 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     vm_mgb_launch_compact(dev, nsys, nlev, s);
     VM_HIP(hipGetLastError());
     std::vector<int> cnt((size_t)nsys * 2 * VM_MGB_MAXLEV), nb(nlev, 0), nt(nlev, 0);
-    for (int i = 0; i < nsys; ++i)
-        VM_HIP(hipMemcpyAsync(&cnt[(size_t)i * 2 * VM_MGB_MAXLEV], W[i].counts, 2 * VM_MGB_MAXLEV * sizeof(int), hipMemcpyDeviceToHost, s));
+    VM_HIP(hipMemcpyAsync(cnt.data(), cnt_dev, (size_t)nsys * 2 * VM_MGB_MAXLEV * sizeof(int), hipMemcpyDeviceToHost, s));
     VM_HIP(hipStreamSynchronize(s));
     for (int i = 0; i < nsys; ++i)
         for (int l = 0; l < nlev; ++l) {
@@ -214,9 +226,12 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     // stops at the iteration that reaches the tolerance instead of up to three later.  The cadence is the SYSTEM's own
     // (next_check): where it stops, and so what it pastes, does not depend on its batch-mates.
     while (true) {
-        for (int i = 0; i < nsys; ++i)
-            if (((active >> i) & 1) && next_check[i] == it)
-                VM_HIP(hipMemcpyAsync(&h[i], W[i].S.sc, sizeof(VmMgbScalars), hipMemcpyDeviceToHost, s));
+        {
+            int lo = nsys, hi = -1;          // the systems looked at now: one read-back of the span that holds them
+            for (int i = 0; i < nsys; ++i)
+                if (((active >> i) & 1) && next_check[i] == it) { lo = std::min(lo, i); hi = i; }
+            if (hi >= lo) VM_HIP(hipMemcpyAsync(&h[lo], sc_dev + lo, (size_t)(hi - lo + 1) * sizeof(VmMgbScalars), hipMemcpyDeviceToHost, s));
+        }
         VM_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < nsys; ++i) {
             if (!((active >> i) & 1) || next_check[i] != it) continue;
