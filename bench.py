@@ -1131,8 +1131,10 @@ class Config4Job(object):
         for c in self.sctx:
             c.set_params(self.kp)
         self.imgs = imgs
+        self.device = device
         self.lane_ctx = [lane0 if (li == 0 and lane0 is not None) else morph.Context(device, blk.math_mode) for li in range(nlanes)]
         self.own_lane_ctx = [c for c in self.lane_ctx if c is not lane0]
+        self.lane_retries, self.lane_gain, self._parked = 0, None, []
         self.lane_frs = [[morph.Frame(c, w, h, ex) for _ in range(per_batch)] for c in self.lane_ctx]
         self.e0, self.e1 = morph.pin_host(rgb0), morph.pin_host(rgb1)    # the caller's RGB8 frames, page-locked (vm_host_register)
         self.pinned = [self.e0, self.e1]
@@ -1150,13 +1152,69 @@ class Config4Job(object):
     def chunks(self, group):
         return [[q for q, cix in zip(group, self.chunk_of) if cix == s] for s in range(self.nstreams)]
 
-    def warm_up(self, group):
-        """workspaces (schedules, graphs, the solver's hierarchy) are allocated on first use: not timed"""
-        for frs in self.lane_frs:
-            for f in frs:
+    def _warm_lane(self, li, group):
+        for f in self.lane_frs[li]:
+            f.upload_rgb(self.e0, self.e1)
+            f.set_v_from_level(group[0], 1)
+        self.morph.poisson_extend_frames(self.lane_frs[li], tol=1e-3)
+
+    def _lane_probe(self, group):
+        """what the second lane buys on THIS pair of streams: seconds of one batch per lane run one lane after the other / run
+        side by side (the work itself is the probe)"""
+        from concurrent.futures import ThreadPoolExecutor
+        sub = [b[0] for b in self.lane_batches[:2]]             # the first batch of lanes 0 and 1
+
+        def one(li):
+            c, frs = self.lane_ctx[li], self.lane_frs[li]
+            qs = [group[k] for k in sub[li]]
+            for f, q in zip(frs, qs):
                 f.upload_rgb(self.e0, self.e1)
-                f.set_v_from_level(group[0], 1)
-            self.morph.poisson_extend_frames(frs, tol=1e-3)
+                f.set_v_from_level(q, 1)
+            self.morph.poisson_extend_frames(frs[:len(qs)], tol=self.tol)
+            for f in frs[:len(qs)]:
+                for k in range(1, 10):
+                    f.render_halfway_dev(0.1 * k, 0.1 * k, 1)
+            c.sync()
+        best_seq = best_par = 1e30
+        for _ in range(2):
+            t0 = time.perf_counter(); one(0); one(1); best_seq = min(best_seq, time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=2) as ex_:
+                list(ex_.map(one, (0, 1)))
+            best_par = min(best_par, time.perf_counter() - t0)
+        return best_seq / best_par
+
+    def warm_up(self, group):
+        """workspaces (schedules, graphs, the solver's hierarchy) are allocated on first use: not timed.  And the lanes are
+        CHOSEN here: the runtime deals a new stream to one of its hardware queues as it likes, and on some pairs of queues two
+        streams take turns instead of running side by side -- measured: the two lanes then need 3.2 instead of 2.4 ms per frame,
+        in about one process out of five, whatever GPU_MAX_HW_QUEUES says; a probe with do-nothing kernels
+        (vm_dbg_streams_overlap) finds the pairs that serialise outright but not all that slow the real work down.  So the
+        work itself is the probe: one batch per lane, one lane after the other against side by side; a second lane that buys
+        less than 15 % is replaced by a context on a fresh stream (the rejected one stays alive meanwhile, so that the next
+        stream lands elsewhere), at most four times."""
+        for li in range(self.nlanes):
+            self._warm_lane(li, group)
+        if self.nlanes == 2 and len(self.lane_batches[1]) > 0 and not os.environ.get("VM_NO_LANE_PROBE"):
+            for attempt in range(5):
+                self.lane_gain = self._lane_probe(group)
+                if self.lane_gain >= 1.15 or attempt == 4:
+                    break
+                self.lane_retries += 1
+                for f in self.lane_frs[1]:
+                    f.close()
+                self._parked.append(self.lane_ctx[1])
+                c = self.morph.Context(self.device, self.blk.math_mode)
+                self.lane_ctx[1] = c
+                self.own_lane_ctx = [x for x in self.own_lane_ctx if x is not self._parked[-1]] + [c]
+                self.lane_frs[1] = [self.morph.Frame(c, self.w, self.h, self.ex) for _ in range(self.per_batch)]
+                self._warm_lane(1, group)
+            for c in self._parked:
+                try:
+                    c.close()
+                except Exception:
+                    pass
+            self._parked = []
         self.solve(group)
 
     def solve(self, group):
@@ -1255,7 +1313,7 @@ class Config4Job(object):
                     q.clear()
                 except Exception:
                     pass
-        for c in self.sctx + self.own_lane_ctx:
+        for c in self.sctx + self.own_lane_ctx + self._parked:
             try:
                 c.close()
             except Exception:
@@ -1302,6 +1360,9 @@ def pipeline30(np, capi, morph, synth, ctx, blk, w, h, nlev, rgb0, rgb1, ex, ren
                 "solve_ms_per_pair": round(best["solve_s"] * 1e3 / n, 1), "solve_ms_per_pair_median": round(med("solve_s") * 1e3 / n, 1),
                 "compositor_ms_per_frame": round(best["comp_s"] * 1e3 / n, 2), "compositor_ms_per_frame_median": round(med("comp_s") * 1e3 / n, 2),
                 "compositor_lanes": job.nlanes,
+                # the second lane is chosen by measurement (Config4Job.warm_up): what it buys on one batch per lane, and how
+                # many streams were tried and given back before that
+                "second_lane_gain": job.lane_gain and round(job.lane_gain, 2), "second_lane_streams_rejected": job.lane_retries,
                 # each lane's own clock per stage, summed over the lanes / lanes (the lanes run side by side)
                 "compositor_split_ms_per_frame": {"upload_pcie_and_v_upscale": round(t_up / n * 1e3, 2), "poisson_both_sides": round(t_po / n * 1e3, 2),
                                                   "render_9_frames": round(t_re / n * 1e3, 2)},

@@ -197,6 +197,13 @@ int  vm_dbg_sparse_resident_visits(vm_ctx *ctx);
  * L2).  The first call only arms the recording (xcc_of_block is filled with 0xFF); placement
  * is a matter of speed, never of correctness. */
 int  vm_dbg_pass_placement(vm_ctx *ctx, uint8_t *xcc_of_block, int n);
+/* Do the streams of two contexts of one device run side by side?  (The reference has one device context and one stream,
+ * UI/MdiEditor.cpp:54-75; a host of this library keeps several: solver streams, compositor lanes.)  The HIP runtime
+ * multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, and two streams on one queue run their kernels
+ * one after the other; which queue a new stream gets is not the caller's to choose.  *overlap = 1 if a 100 us do-nothing
+ * kernel on each stream overlaps the other's, 0 if they serialise.  A host that needs the overlap creates another context
+ * when the answer is 0 (keeping the rejected one alive meanwhile, so that the next stream gets another queue). */
+int  vm_dbg_streams_overlap(vm_ctx *a, vm_ctx *b, int *overlap);
 /* device facts for reports: name (<=255 chars), CU count, HBM bytes */
 int  vm_device_info(vm_ctx *ctx, char *name256, int *cus, uint64_t *hbm_bytes);
 

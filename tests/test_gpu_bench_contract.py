@@ -135,6 +135,7 @@ def test_bench_extras_of_round_5():
     dk = prf["dominant_kernel"]       # measured live with HIP events (vm_dbg_poisson_profile)
     assert dk["kernel"] == "k_mgb_update" and dk["launches"] >= 8 and 20 < dk["launch_us"] < 400 and 0.3 < dk["frac"] < 1.0
     assert abs(dk["frac"] - dk["achieved"] / dk["peak"]) < 1e-3 and (dk["traffic"] is None or dk["traffic"] > 0.9 * dk["alg_bytes_per_launch"])
+    assert p30["second_lane_gain"] >= 1.0 and 0 <= p30["second_lane_streams_rejected"] <= 4      # the lanes are chosen by measurement
     assert p30["runs"] == 3 and len(p30["ms_per_pair_each_run"]) == 3 and p30["ms_per_pair"] <= p30["ms_per_pair_median"]
 
 

@@ -28,7 +28,7 @@ FIELDS = {  # name -> (id, channels)
 SYMBOLS = [
     "vm_last_error", "vm_version", "vm_ctx_create", "vm_ctx_destroy", "vm_ctx_sync",
     "vm_set_params", "vm_get_params", "vm_set_math_mode", "vm_set_tuning", "vm_set_commit_order", "vm_dbg_pass_placement", "vm_dbg_pass_force_timeout",
-    "vm_dbg_pass_fallbacks", "vm_dbg_level_set_mask", "vm_dbg_sparse_resident", "vm_dbg_sparse_resident_visits", "vm_device_info",
+    "vm_dbg_pass_fallbacks", "vm_dbg_level_set_mask", "vm_dbg_sparse_resident", "vm_dbg_sparse_resident_visits", "vm_dbg_streams_overlap", "vm_device_info",
     "vm_pyramid_create", "vm_pyramid_destroy", "vm_pyramid_levels", "vm_level_dims",
     "vm_level_upload_luma", "vm_pyramid_build_rgb", "vm_level_set_v", "vm_level_get_v", "vm_level_get_field",
     "vm_level_clear", "vm_coarse_solve", "vm_upsample_v", "vm_init_level", "vm_optimize_level",
@@ -142,6 +142,7 @@ def load():
         "vm_frame_create": [vp, i, i, i, C.POINTER(vp)],
         "vm_frame_upload": [vp, vp, vp, vp, vp],
         "vm_frame_upload_rgb": [vp, vp, vp, i],
+        "vm_dbg_streams_overlap": [vp, vp, C.POINTER(i)],
         "vm_frame_download_ext": [vp, i, vp],
         "vm_frame_set_v_from_level": [vp, vp, i],
         "vm_render_halfway": [vp, f, f, i, vp, i],

@@ -4,7 +4,12 @@
 #include "vm_host.h"
 #include "vm_poisson.h"
 
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 extern "C" int vm_frame_create(vm_ctx *c, int w, int h, int ex, vm_frame **out)
 {
@@ -93,6 +98,61 @@ extern "C" int vm_frame_upload_rgb(vm_frame *f, const uint8_t *rgb0, const uint8
     }
     VM_HIP(hipGetLastError());
     VM_HIP(hipStreamSynchronize(s));        // the host buffers belong to the caller
+    return VM_OK;
+}
+
+// Do the streams of two contexts of one device run SIDE BY SIDE?  The HIP runtime multiplexes a process's streams onto
+// GPU_MAX_HW_QUEUES hardware queues; two streams that land on the same queue run their kernels one after the other,
+// and which queue a new stream gets is not the caller's to choose.  A host that relies on two contexts overlapping (two
+// compositor lanes, the solver streams of a batch job) asks here -- a 100 us do-nothing kernel on each stream, wall time
+// of the pair against wall time of one -- and, when the answer is no, creates another context and
+// asks again (keeping the rejected one alive until it has what it wants, so that the next stream gets another queue).
+extern "C" int vm_dbg_streams_overlap(vm_ctx *a, vm_ctx *b, int *overlap)
+{
+    if (!a || !b || !overlap || a == b) return vm_fail(VM_E_INVALID, "vm_dbg_streams_overlap: bad argument");
+    if (!vm_ctx_alive(a) || !vm_ctx_alive(b)) return vm_fail(VM_E_INVALID, "%s: a context was destroyed", __func__);
+    if (a->device != b->device) return vm_fail(VM_E_INVALID, "vm_dbg_streams_overlap: the contexts live on different devices");
+    VM_ON_DEVICE(a);
+    std::lock_guard<std::recursive_mutex> la(a < b ? a->mu : b->mu), lb(a < b ? b->mu : a->mu);
+    const unsigned long long ticks = 10000;          // 100 us at 100 MHz
+    // host wall time of one kernel on a, and of one on each stream started back to back (the smallest of four tries each;
+    // the first launch is also the warm-up of the code object): side by side the pair takes what one takes, on a shared
+    // queue twice that
+    double one = 1e30, both = 1e30;
+    for (int rep = 0; rep < 8; ++rep) {
+        const bool pair = (rep & 1) != 0;
+        VM_HIP(hipStreamSynchronize(a->stream));
+        VM_HIP(hipStreamSynchronize(b->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        vm_launch_spin(ticks, 1, a->stream);
+        if (pair) vm_launch_spin(ticks, 1, b->stream);
+        VM_HIP(hipStreamSynchronize(a->stream));
+        VM_HIP(hipStreamSynchronize(b->stream));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (rep >= 2) (pair ? both : one) = std::min(pair ? both : one, us);
+    }
+    // ... and DISPATCH side by side?  Two queues can overlap single workgroups and still take turns at dispatching (queues
+    // of one pipe of the command processor): a small kernel on b then waits until a's big grid has been handed out.  A grid
+    // of 64 K short workgroups on a (~ 8 rounds of the chip), one short workgroup on b right behind it: b's finishes early
+    // if the two dispatch concurrently, with a's if they take turns.
+    double frac = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        VM_HIP(hipStreamSynchronize(a->stream));
+        VM_HIP(hipStreamSynchronize(b->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        vm_launch_spin(500, 65536, a->stream);
+        vm_launch_spin(100, 1, b->stream);
+        VM_HIP(hipStreamSynchronize(b->stream));
+        const double tb = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        VM_HIP(hipStreamSynchronize(a->stream));
+        const double ta = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        frac = std::max(frac, tb / ta);
+    }
+    VM_HIP(hipGetLastError());
+    if (getenv("VM_DBG_OVERLAP")) fprintf(stderr, "vm_dbg_streams_overlap: one %.0f us, pair %.0f us, small-behind-big finishes at %.2f of the big one\n", one, both, frac);
+    // (measured on MI355X: streams that run side by side 1.07 x and 0.30-0.37; the pairs that slow the compositor's two
+    //  lanes from 2.4 to 3.2 ms per frame 1.43 x and 0.70)
+    *overlap = (both < 1.25 * one && frac < 0.5) ? 1 : 0;
     return VM_OK;
 }
 

@@ -392,6 +392,16 @@ void vm_launch_upscale(float2 *dst, int w0, int h0, int dpitch, const float2 *v,
     hipLaunchKernelGGL(k_upscale, g, b, 0, s, dst, w0, h0, dpitch, v, w, h, rs);
 }
 
+// a kernel that only takes time: one wave reading the constant 100 MHz counter until `ticks` have passed
+__global__ __launch_bounds__(64) void k_spin(unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(8);
+}
+
+void vm_launch_spin(unsigned long long ticks, int workgroups, hipStream_t s) { hipLaunchKernelGGL(k_spin, dim3(workgroups), dim3(64), 0, s, ticks); }
+
 void vm_launch_render(uint8_t *out, int out_pitch, int w, int h, int rs, int ex, float color_fa,
                       float geo_fa, int color_from, const uchar4 *ext0, const uchar4 *ext1,
                       const float2 *v, const float2 *u, hipStream_t s)

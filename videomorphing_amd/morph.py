@@ -11,6 +11,7 @@ shape is include/vmorph/*.hpp.)
 Scope: one frame pair per Pyramid (depth 1, the independent-pair formulation).
 """
 import ctypes as C
+import os
 import threading
 import time
 import weakref
@@ -109,6 +110,13 @@ class Context(object):
 
     def set_tuning(self, sweep_mode=0, threads=0, parts=0):
         capi.check(self._L.vm_set_tuning(self._h, int(sweep_mode), int(threads), int(parts)))
+
+    def runs_beside(self, other):
+        """vm_dbg_streams_overlap: do this context's stream and `other`'s run their kernels side by side (True) or
+        did the runtime put them on one hardware queue (False)?"""
+        ov = C.c_int(0)
+        capi.check(self._L.vm_dbg_streams_overlap(self._h, other._h, C.byref(ov)))
+        return bool(ov.value)
 
     def poisson_profile(self, on):
         """vm_dbg_poisson_profile: arm (on = True) the HIP-event probe around the linear solver's dominant kernel, or
@@ -559,6 +567,23 @@ def poisson_extend_frames(frames, tol=1e-5, max_it=20000):
     it, rr, ms = (C.c_int * (2 * n))(), (C.c_float * (2 * n))(), C.c_float(0)
     capi.check(frames[0]._L.vm_poisson_extend_frames(arr, n, tol, max_it, it, rr, C.byref(ms)))
     return [((it[2 * i], rr[2 * i]), (it[2 * i + 1], rr[2 * i + 1])) for i in range(n)], ms.value
+
+
+def context_beside(device, math_mode, others, tries=8):
+    """A new Context whose stream runs side by side with the streams of all `others` (contexts of the same device): the
+    runtime deals new streams to its GPU_MAX_HW_QUEUES hardware queues as it likes, and two streams on one queue run their
+    kernels one after the other.  Candidates that share a queue with one of `others` are kept alive while the search goes on
+    (so that the next stream gets another queue) and closed at the end; after `tries` candidates the last one is returned
+    whatever it shares.  Returns (context, number of rejected candidates)."""
+    rejected = []
+    probe = not os.environ.get("VM_NO_STREAM_PROBE")          # development switch: take the first stream, as rounds 1-5 did
+    while True:
+        c = Context(device, math_mode)
+        if not probe or len(rejected) >= tries - 1 or all(c.runs_beside(o) for o in others):
+            for r in rejected:
+                r.close()
+            return c, len(rejected)
+        rejected.append(c)
 
 
 def pin_host(array):
