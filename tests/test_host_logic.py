@@ -172,6 +172,9 @@ def test_bench_reads_the_counters_of_its_own_workload_shape(tmp_path):
     for e in tj["entries"]:
         assert isinstance(e["config"], int) and isinstance(e["pairs_per_launch"], int) and isinstance(e["per_kernel"], dict)
         assert len(e.get("sweep_source_sha256", "")) == 64
+        # ... and it is the fingerprint of the sources as they are NOW: whoever edits vm_sweep_kernels.hip / vm_morph_common.h /
+        # vm_internal.h re-profiles (tools/prof_sweeps.sh + collect_profiles.sh) or the bench line says "traffic_stale": true
+        assert e["sweep_source_sha256"] == bench.sweep_source_hash(), "profiles/traffic_latest.json is older than the sweep kernels' sources"
 
 
 def test_bench_config2_chunks_and_batches():

@@ -101,6 +101,9 @@ extern "C" int vm_frame_upload_rgb(vm_frame *f, const uint8_t *rgb0, const uint8
     return VM_OK;
 }
 
+// (vm_render.hip) `workgroups` single-wave workgroups that each do nothing for `ticks` periods of the constant 100 MHz counter
+void vm_launch_spin(unsigned long long ticks, int workgroups, hipStream_t s);
+
 // Do the streams of two contexts of one device run SIDE BY SIDE?  The HIP runtime multiplexes a process's streams onto
 // GPU_MAX_HW_QUEUES hardware queues; two streams that land on the same queue run their kernels one after the other,
 // and which queue a new stream gets is not the caller's to choose.  A host that relies on two contexts overlapping (two

@@ -133,8 +133,6 @@ void vm_launch_upscale(float2 *dst, int w0, int h0, int dpitch, const float2 *v,
                        int rs, hipStream_t s);
 void vm_launch_blend_v(float2 *dst, int dpitch, const float2 *a, const float2 *b, int spitch, int w0, int h0,
                        float alpha, float beta, hipStream_t s);
-// `workgroups` single-wave workgroups that each do nothing for `ticks` periods of the constant 100 MHz counter (vm_dbg_streams_overlap)
-void vm_launch_spin(unsigned long long ticks, int workgroups, hipStream_t s);
 void vm_launch_render(uint8_t *out, int out_pitch, int w, int h, int rs, int ex, float color_fa,
                       float geo_fa, int color_from, const uchar4 *ext0, const uchar4 *ext1,
                       const float2 *v, const float2 *u, hipStream_t s);
