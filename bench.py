@@ -194,7 +194,13 @@ def main():
         my_pairs = len(vdist.shard_pairs(args.pairs, world, rank) if args.as_rank < 0 else vdist.shard_pairs(args.pairs, args.of, args.as_rank))
         args.inflight = default_streams(my_pairs)
     nctx = max(1, args.inflight)
-    ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(nctx)]
+    # (development: VM_DEV_DUMMY_STREAMS=k idle contexts created first shift which hardware queues the runtime deals the
+    #  solver streams to -- tools/exp/rep_shard.sh, profiles/r06_notes.md section 4)
+    _dummies = [morph.Context(local_rank, blk.math_mode) for _ in range(int(os.environ.get("VM_DEV_DUMMY_STREAMS", "0")))]
+    ctxs, streams_rejected = solver_contexts(morph, local_rank, blk.math_mode, nctx)
+    if os.environ.get("VM_DEV_DUMMY_STREAMS") and nctx > 1:
+        print("solver streams side by side (vm_dbg_streams_overlap):", [(i, j, ctxs[i].runs_beside(ctxs[j])) for i in range(nctx) for j in range(i + 1, nctx)],
+              "rejected on the way:", streams_rejected, file=sys.stderr)
     for c in ctxs:
         c.set_params(blk.kp)
         if args.sweep_threads or args.sweep_parts:
@@ -342,6 +348,8 @@ def main():
                      cpu, distinct_frames, len(pyrs) if config == 2 else None, pix_live_total,
                      frame_ids=ids[args.warmup * B:] if config != 2 else None)
         out.update(extras)
+        # streams this rank created and gave back because they shared a hardware queue with another solver stream (solver_contexts)
+        out["config"]["solver_streams_rejected_for_sharing_a_hardware_queue"] = streams_rejected
         if args.as_rank >= 0:
             out["as_rank"] = {"rank": args.as_rank, "of": args.of, "pairs": len(pyrs),
                               "note": "the shard this rank of the job would solve, run alone on one GPU"}
@@ -475,6 +483,22 @@ def config2_step(ps, ctxs, B, solve_group):
         return [r for res in ex.map(work, chunks) for r in res]
 
 
+def solver_contexts(morph, device, math_mode, n):
+    """n contexts (HIP streams) for a job whose pairs are solved on several streams at once -- each one checked to run SIDE
+    BY SIDE with those before it (morph.context_beside / vm_dbg_streams_overlap): the runtime deals a new stream to one of
+    its GPU_MAX_HW_QUEUES hardware queues as it likes, and two solver streams that land on one queue take turns -- measured
+    with idle streams created first to shift the deal (tools/exp/shard_dummy.sh): the 8-pair shard 519 instead of 329 ms, the
+    60-pair job 1360 instead of 856 ms, and the probe names exactly those pairs.  A default run has never hit it; a rank of
+    an N > 1 run (RCCL's own streams come first there) or a host with other streams alive may.  Returns (contexts, streams
+    rejected on the way)."""
+    ctxs, rejected = [], 0
+    for _ in range(n):
+        c, nrej = morph.context_beside(device, math_mode, ctxs)
+        ctxs.append(c)
+        rejected += nrej
+    return ctxs, rejected
+
+
 def default_streams(pairs_on_this_gpu):
     """streams (contexts, each driven by its own host thread) for config[2]'s job on one GPU"""
     return 3 if pairs_on_this_gpu >= 24 else 2
@@ -504,7 +528,7 @@ def scale_reference(args, morph, blk, local_rank, frames, solve_group, sizes, nl
     running out of memory, say) is reported in place of the figures and the headline line is printed all the same."""
     ctxs, pyrs = [], []
     try:
-        ctxs = [morph.Context(local_rank, blk.math_mode) for _ in range(default_streams(args.scale_ref_pairs))]
+        ctxs, _ = solver_contexts(morph, local_rank, blk.math_mode, default_streams(args.scale_ref_pairs))
         for c in ctxs:
             c.set_params(blk.kp)
 
@@ -1127,7 +1151,7 @@ class Config4Job(object):
         self.kp = morph.KernParameters(prm)
         _, self.chunk_of, self.lane_batches = config4_plan(self.n, 1, 0, per_batch, nlanes)      # (the rank's share is a job of its own)
         self.nstreams = max(self.chunk_of) + 1 if self.chunk_of else 1
-        self.sctx = [morph.Context(device, blk.math_mode) for _ in range(self.nstreams)]
+        self.sctx, self.solver_streams_rejected = solver_contexts(morph, device, blk.math_mode, self.nstreams)
         for c in self.sctx:
             c.set_params(self.kp)
         self.imgs = imgs
