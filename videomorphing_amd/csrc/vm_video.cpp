@@ -503,6 +503,27 @@ static int ensure_lanes(vm_video *v, int n)
         vm_video_lane ln;
         int rc = vm_ctx_create(p->device, &ln.c);
         if (rc != VM_OK) return rc;
+        // A lane's stream must run SIDE BY SIDE with the other lanes': the runtime deals a new stream to one of its hardware
+        // queues as it likes, and two streams on one queue take turns (measured on the frame-pair solver's streams: + 58 %,
+        // profiles/r06_notes.md section 4).  A candidate that shares a queue with a lane already chosen is kept alive while
+        // the next one is tried (so that it lands elsewhere) and destroyed afterwards; after six tries the last one is kept.
+        {
+            std::vector<vm_ctx *> parked;
+            for (int attempt = 0; attempt < 6; ++attempt) {
+                bool beside = true;
+                for (const vm_video_lane &o : v->lanes) {
+                    int ov = 1;
+                    if (vm_dbg_streams_overlap(ln.c, o.c, &ov) == VM_OK && !ov) { beside = false; break; }
+                }
+                if (beside) break;
+                parked.push_back(ln.c);
+                ln.c = nullptr;
+                rc = vm_ctx_create(p->device, &ln.c);
+                if (rc != VM_OK) break;
+            }
+            for (vm_ctx *q : parked) vm_ctx_destroy(q);
+            if (rc != VM_OK) return rc;
+        }
         if (hipMalloc((void **)&ln.acc, np * 3 * sizeof(long long)) != hipSuccess) {
             vm_ctx_destroy(ln.c);
             return vm_fail(VM_E_DEVICE, "vm_video_solve: out of device memory (pipeline lane)");
