@@ -314,6 +314,58 @@ def test_poisson_on_random_outside_regions(gpu_ctx, oracle, seed):
     fr.close()
 
 
+_CYCLE_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from videomorphing_amd import capi, morph, synth
+import oracle
+w, h, ex = 300, 180, 40           # canvas 380 x 260: three levels swept by the tile kernels, four in the one-workgroup tail
+rng = np.random.RandomState(21)
+rgb0, rgb1 = synth.make_rgb_pair(w, h, frame=21)
+v = (0.6 * synth.displacement(w, h) + 0.2 * rng.randn(h, w, 2)).astype(np.float32)
+e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
+e0[ex + 50:ex + 75, ex + 120:ex + 190, 3] = 255
+e1[ex:ex + 9, ex + 200:ex + 300, 3] = 255
+ctx = morph.Context(0, capi.MATH_FAST)
+fr = morph.Frame(ctx, w, h, ex)
+fr.upload(e0, e1, v, None)
+(i1, r1), (i2, r2), _ = fr.poisson_extend_both(tol=1e-6)
+assert 0 < i1 < 40 and 0 < i2 < 40 and r1 <= 1e-6 and r2 <= 1e-6
+worst = 0
+for side, ext, other in ((1, e0, e1), (2, e1, e0)):
+    ref, _, _ = oracle.poisson_extend(ext, w, h, ex, other[ex:ex + h, ex:ex + w].copy(), v, side, tol=1e-9)
+    out = fr.download_ext(side)
+    assert out[..., 3].max() == 0
+    worst = max(worst, int(np.abs(out[..., :3].astype(int) - ref[..., :3].astype(int)).max()))
+assert worst <= 1, worst
+vs = (0.5 * synth.displacement(w, h) + 0.05 * rng.randn(h, w, 2)).astype(np.float32)
+fr.upload(e0, e1, vs, None)
+qi = fr.quadratic_path(tol=1e-4)[0]
+uo, _, _ = oracle.quadratic_path(vs, tol=1e-10)
+dq = float(np.abs(fr.download_qpath() - uo).max())
+assert dq <= 2e-3, dq
+print("CYCLE_OK", i1, i2, qi, worst, dq)
+"""
+
+
+@pytest.mark.parametrize("nu", ["1", "2", "2,1,3", "1,2,1,2"])
+def test_poisson_cycle_variants(nu):
+    """the multigrid cycle's sweeps per level are a build-time choice per kind of system (vm_mgb.h: VM_MGB_NU_POISSON /
+    _QPATH); VM_MGB_NU overrides it per process.  Every combination the kernels offer -- one or two red-black sweeps each
+    way in the tile kernels of level 0 and of the coarser levels, one to nine in the tail -- is the same preconditioned
+    CG on the same system: both sides of a frame with holes within one colour level of the oracle's CG, the quadratic
+    path within 2e-3 px, whatever the cycle (a fresh process per setting: the library reads the variable once)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VM_MGB_NU=nu)
+    r = subprocess.run([sys.executable, "-c", _CYCLE_CHILD, root], env=env, capture_output=True, text=True, timeout=600,
+                       stdin=subprocess.DEVNULL)
+    assert r.returncode == 0 and "CYCLE_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_streams_overlap_probe_and_context_beside(gpu_ctx):
     """vm_dbg_streams_overlap answers for two contexts of one device whether their streams run side by side (the runtime deals
     streams to hardware queues as it likes; two on one queue -- or on queues that take turns dispatching -- serialise, which

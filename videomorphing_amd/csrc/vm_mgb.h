@@ -13,7 +13,8 @@
 //     kernels from an LDS tile of the right-hand side with a two-cell apron: the pre-smoothed iterate is never
 //     stored, its residual is zero on black cells and a sum over four black neighbours on red ones, and the
 //     post-smoothing needs the red cells' values only.  Same bytes per cycle as one damped-Jacobi sweep each way
-//     (rounds 4-5), 11 instead of 17 PCG iterations to 1e-5 on the 2304x1464 canvas;
+//     (rounds 4-5), 11 instead of 17 PCG iterations to 1e-5 on the 2304x1464 canvas; from level 2 down the cycle makes
+//     TWO sweeps each way (a four-cell apron, the recurrences written in differences: vm_mgb.hip): 9 iterations;
 //   * r.z rides in the level-0 prolongation, p = z + beta p in the operator application (p ping-pongs), the scalar
 //     bookkeeping lives in accumulators indexed by the iteration's parity, cleared by the kernel that provably runs
 //     between their last reader and next writer;
@@ -47,6 +48,10 @@ struct VmMgbLevel {
     uint8_t *info;
     float *we, *ws, *dg, *k;
     VmV3 *b, *x;
+    // smoothing sweeps each way on this level (1 or 2).  With 2 the restriction kernel leaves the pre-smoothed iterate of
+    // the RED cells in xr, packed: entry (y w + x) >> 1 (the post-smoothing starts from it; black cells are recomputed)
+    int nu;
+    VmV3 *xr;
     uint32_t *flags;         // per block: does it hold an unknown (set-up scratch)
     uint32_t *blocks;        // the blocks that do, packed bx | by << 16, row-major
     int *nblocks;            // their number (device)
@@ -70,6 +75,18 @@ struct VmMgbSys {
 };
 
 #define VM_MGB_COARSEST 64      // the hierarchy ends at a grid of at most this many cells ...
+// Red-black sweeps each way per level, from level 0 on (comma list, the last entry repeats; vm_poisson_api.cpp: mg_nu).
+// Measured on the 2304 x 1464 canvas, tol 1e-5 / 1e-6 (tools/exp/nu_sweep.sh, nu_ab.sh on one box; tools/exp/mg_prototype.py
+// is the CPU model that predicted the iteration counts), ms per frame in 4-frame batches in the bench line's setting:
+//   1 everywhere      11 / 13 iterations   2.20 / 2.52
+//   1, 1, 2           9 / 10               2.00 / 2.17   <- the extra sweeps go where the cycle is launch-bound, not byte-bound
+//   2 everywhere      7-8 / 8              as slow as 1 everywhere: level 0's wider window costs what the iterations save
+// The quadratic path's whole-grid system (1920 x 1080, tol 1e-4, a solved field) stays at 1 everywhere: 1.72 ms (8 iterations)
+// against 2.02 (8) with 1, 1, 2 and 1.89 (6) with 2 everywhere.
+#ifndef VM_MGB_NU_POISSON
+#define VM_MGB_NU_POISSON 1, 1, 2
+#define VM_MGB_NU_QPATH 1
+#endif
 #define VM_MGB_COARSE_SWEEPS 2  // ... which gets this many symmetric Gauss-Seidel sweeps each way (R B R B, B R B R) from zero
 // the tail of the cycle -- every level from `tail` on -- runs in ONE workgroup with the iterates in LDS: the levels'
 // cell counts must fit these pools: all of them (a float4 iterate + a float2 of edge weights per cell) / all but the first
@@ -86,8 +103,9 @@ void vm_mgb_launch_compact(const VmMgbSys *sys, int nsys, int nlev_max, hipStrea
 // r = b - A x (in place, level 0's b), bb, rr[1]
 void vm_mgb_launch_init(const VmMgbSys *sys, int nsys, int nb0, uint64_t active, hipStream_t s);
 // V-cycle pieces
-void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nt_fine, uint64_t active, hipStream_t s);   // lv[l+1].b from lv[l], over lv[l]'s tiles
-void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nt_fine, int k, uint64_t active, hipStream_t s);   // lv[l].x; l == 0: rz[k & 1] += r.z
+// (nu: the level's sweeps each way, VmMgbLevel::nu of every system of the batch)
+void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nu, int nt_fine, uint64_t active, hipStream_t s);   // lv[l+1].b from lv[l], over lv[l]'s tiles
+void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nu, int nt_fine, int k, uint64_t active, hipStream_t s);   // lv[l].x; l == 0: rz[k & 1] += r.z
 void vm_mgb_launch_tail(const VmMgbSys *sys, int nsys, int l, uint64_t active, hipStream_t s);             // levels l .. nlev - 1 in one workgroup
 void vm_mgb_launch_dot_rz(const VmMgbSys *sys, int nsys, int nb0, int k, uint64_t active, hipStream_t s);                           // hierarchies that are all tail only
 // PCG on level 0

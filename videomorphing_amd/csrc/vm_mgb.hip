@@ -506,14 +506,14 @@ constexpr int NRING1 = (TW + 2) * (TH + 2) - TW * TH; // the cells at distance 1
 
 __device__ __forceinline__ float4 f4_scale(float k, float4 v) { return make_float4(k * v.x, k * v.y, k * v.z, 0); }
 
-// the operator records of a staged tile, by cell of the 68 x 20 LDS window
-template <bool L0> struct TileOp;
-template <> struct TileOp<true> {       // level 0: the info byte (unit weights)
-    uint8_t m[LN];
+// the operator records of a staged tile, by cell of the LDS window (WW cells wide, WN cells)
+template <bool L0, int WW, int WN> struct TileOpT;
+template <int WW, int WN> struct TileOpT<true, WW, WN> {       // level 0: the info byte (unit weights)
+    uint8_t m[WN];
     __device__ __forceinline__ float4 nbsum(const float4 *v, int c) const
     {
         const uint32_t b = m[c];
-        const float4 e = v[c + 1], w = v[c - 1], s = v[c + LW], n = v[c - LW];
+        const float4 e = v[c + 1], w = v[c - 1], s = v[c + WW], n = v[c - WW];
         float4 a = make_float4(0, 0, 0, 0);
         if (b & 1u) { a.x += e.x; a.y += e.y; a.z += e.z; }
         if (b & 2u) { a.x += w.x; a.y += w.y; a.z += w.z; }
@@ -522,12 +522,12 @@ template <> struct TileOp<true> {       // level 0: the info byte (unit weights)
         return a;
     }
 };
-template <> struct TileOp<false> {      // coarser levels: weights of the edges to the east / south neighbour
-    float2 w[LN];
+template <int WW, int WN> struct TileOpT<false, WW, WN> {      // coarser levels: weights of the edges to the east / south neighbour
+    float2 w[WN];
     __device__ __forceinline__ float4 nbsum(const float4 *v, int c) const
     {
-        const float wE = w[c].x, wW = w[c - 1].x, wS = w[c].y, wN = w[c - LW].y;
-        const float4 e = v[c + 1], ww = v[c - 1], s = v[c + LW], n = v[c - LW];
+        const float wE = w[c].x, wW = w[c - 1].x, wS = w[c].y, wN = w[c - WW].y;
+        const float4 e = v[c + 1], ww = v[c - 1], s = v[c + WW], n = v[c - WW];
         // a missing edge has weight 0 and its neighbour's LDS value is 0 or finite (stage_cell): plain multiply-adds
         float4 a = make_float4(wE * e.x, wE * e.y, wE * e.z, 0);
         a = f4_axpy(wW, ww, a);
@@ -536,6 +536,7 @@ template <> struct TileOp<false> {      // coarser levels: weights of the edges 
         return a;
     }
 };
+template <bool L0> using TileOp = TileOpT<L0, LW, LN>;
 
 // Stage cell c of the window (grid cell (x, y)): the operator record, 1 / dg in .w, and the value the first half-sweep
 // leaves there -- red: b / dg (+ the coarse correction of its aggregate when xc is given), black: b.  A cell outside
@@ -735,6 +736,264 @@ __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict_
 }
 
 // ---------------------------------------------------------------------------
+// The same two kernels with TWO red-black sweeps each way (VmMgbLevel::nu == 2: V(2,2)).  The dependence cone of a cell
+// grows by one cell per half-sweep, so the window carries a four-cell apron (72 x 24) and every half-sweep runs over the
+// cells of its colour within a shrinking distance of the tile.  Written in differences, the right-hand side enters the
+// first two half-sweeps only:
+//   pre (from zero):   x_r1 = b_r / dg_r                          (red,   staged, distance <= 4)
+//                      x_b1 = (b_b + sum w x_r1) / dg_b           (black, <= 3)
+//                      d_r  = x_r2 - x_r1 = (sum w x_b1) / dg_r   (red,   <= 2)   x_r2 of the tile's own cells -> xr (packed)
+//                      d_b  = x_b2 - x_b1 = (sum w d_r) / dg_b    (black, <= 1)
+//                      residual: zero on black cells, sum w d_b on red ones (the tile's)
+//   post of x_r2 + P xc (red cells; the black ones are recomputed from them):
+//                      x_b3 = (b_b + sum w (x_r2 + xc)) / dg_b    (black, <= 3)
+//                      e_r  = x_r3 - (x_r2 + xc) = (b_r + sum w x_b3) / dg_r - (x_r2 + xc)   (red, <= 2)
+//                      x_b4 = x_b3 + (sum w e_r) / dg_b           (black, <= 1)
+//                      x_r4 = (b_r + sum w x_b4) / dg_r           (red, the tile's)
+// every half-sweep reads the other colour only and writes its own cells: in place, one float4 per window cell.
+// Costs 27 % more staged cells and 6 + 10 bytes per cell for xr; on the 2304 x 1464 canvas V(2,2) on every level takes
+// 7 PCG iterations to 1e-5 where V(1,1) takes 11 (tools/exp/mg_prototype.py).
+
+constexpr int HL2 = 4, LW2 = TW + 2 * HL2, LH2 = TH + 2 * HL2, LN2 = LW2 * LH2, NHALO2 = LN2 - TW * TH;   // 72 x 24, 704 apron cells
+constexpr int NSLOT2 = (NHALO2 + 255) / 256;             // apron cells per thread: 3
+template <bool L0> using WideOp = TileOpT<L0, LW2, LN2>;
+
+// window index of apron cell number k (0 .. NHALO2 - 1): four rows above, four below, four columns left and right
+__device__ __forceinline__ int halo2_cell(int k)
+{
+    if (k < HL2 * LW2) return k;
+    k -= HL2 * LW2;
+    if (k < HL2 * LW2) return (LH2 - HL2) * LW2 + k;
+    k -= HL2 * LW2;
+    const int row = HL2 + (k >> 3), q = k & 7;           // 8 cells per interior row: columns 0 .. 3, LW2 - 4 .. LW2 - 1
+    return row * LW2 + (q < HL2 ? q : LW2 - 2 * HL2 + q);
+}
+// distance (maximum norm) of window cell (cx, cy) from the tile
+__device__ __forceinline__ int tile_dist(int cx, int cy)
+{
+    const int dx = max(max(HL2 - cx, cx - (HL2 + TW - 1)), 0), dy = max(max(HL2 - cy, cy - (HL2 + TH - 1)), 0);
+    return max(dx, dy);
+}
+
+// operator record of window cell c = grid cell (x, y): returns 1 / dg (0: no unknown, or outside the grid)
+template <bool L0>
+__device__ __forceinline__ float wide_stage_op(const VmMgbLevel &L, const Op<L0> &A, WideOp<L0> &op, int c, int x, int y, bool &in, size_t &ii)
+{
+    in = x >= 0 && x < L.w && y >= 0 && y < L.h;
+    ii = in ? (size_t)y * L.w + x : 0;
+    if constexpr (L0) {
+        const uint32_t m = in ? (uint32_t)A.info[ii] : 0u;
+        op.m[c] = (uint8_t)m;
+        return k_of_dg0(m >> 4);
+    } else {
+        const float k = A.pk[ii], we = A.pwe[ii], ws = A.pws[ii];
+        op.w[c] = make_float2(in && x + 1 < L.w ? we : 0.0f, in && y + 1 < L.h ? ws : 0.0f);
+        return in ? k : 0.0f;
+    }
+}
+
+// one half-sweep: f(window cell, index, own) for the thread's two own cells of the colour (index = 0, 1: the pair of
+// rows) and for its apron cells of that colour within maxd of the tile (index = the slot)
+template <class Fn>
+__device__ __forceinline__ void wide_sweep(int tx, int ty, int tid, bool black, int maxd, Fn f)
+{
+    const int j0 = black ? ((tx & 1) ^ 1) : (tx & 1);    // own rows 4 ty + j: black <=> (tx + j) odd
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+        f((HL2 + 4 * ty + j0 + 2 * m) * LW2 + HL2 + tx, m, true);
+#pragma unroll
+    for (int sl = 0; sl < NSLOT2; ++sl) {
+        const int k = tid + 256 * sl;
+        if (k < NHALO2) {
+            const int c = halo2_cell(k), cx = c % LW2, cy = c / LW2;
+            if ((((cx + cy) & 1) != 0) == black && tile_dist(cx, cy) <= maxd)
+                f(c, sl, false);
+        }
+    }
+}
+
+template <bool L0>
+__global__ __launch_bounds__(256) void k_mgb_restrict2(const VmMgbSys *__restrict__ sys, int l, uint64_t active)
+{
+    if (!sys_active(active))
+        return;
+    const VmMgbSys &S = sys[blockIdx.z];
+    const VmMgbLevel &FL = S.lv[l], &C = S.lv[l + 1];
+    if ((int)blockIdx.x >= G(FL.ntiles)[0])
+        return;
+    const uint32_t tb = G(FL.tiles)[blockIdx.x];
+    const int x0 = (int)(tb & 0xffffu) * TW, y0 = (int)(tb >> 16) * TH;
+    const Op<L0> F(FL);
+    __shared__ float4 vals[LN2];
+    __shared__ WideOp<L0> op;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+    const float4 zero = make_float4(0, 0, 0, 0);
+    // stage: red cells b / dg, black cells b, 1 / dg in .w (no unknown: zeros, selected)
+    auto stage = [&](int c, int x, int y) {
+        bool in;
+        size_t ii;
+        const float inv = wide_stage_op<L0>(FL, F, op, c, x, y, in, ii);
+        const float4 b = f4_sel(inv > 0.0f, ld3(FL.b, ii), zero);
+        float4 v = ((x + y) & 1) == 0 ? f4_scale(inv, b) : b;
+        v.w = inv;
+        vals[c] = v;
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        stage((HL2 + 4 * ty + j) * LW2 + HL2 + tx, x0 + tx, y0 + 4 * ty + j);
+#pragma unroll
+    for (int sl = 0; sl < NSLOT2; ++sl) {
+        const int k = tid + 256 * sl;
+        if (k < NHALO2) {
+            const int c = halo2_cell(k);
+            stage(c, x0 - HL2 + c % LW2, y0 - HL2 + c / LW2);
+        }
+    }
+    __syncthreads();
+    wide_sweep(tx, ty, tid, true, 3, [&](int c, int, bool) {           // x_b1
+        const float4 me = vals[c], s = op.nbsum(vals, c);
+        vals[c] = f4_sel(me.w > 0.0f, make_float4(me.w * (me.x + s.x), me.w * (me.y + s.y), me.w * (me.z + s.z), me.w), zero);
+    });
+    __syncthreads();
+    float4 xr2[2] = {zero, zero};
+    wide_sweep(tx, ty, tid, false, 2, [&](int c, int m, bool own) {    // d_r in place of x_r1; the tile's x_r2
+        const float4 me = vals[c], s = op.nbsum(vals, c);
+        const float4 d = f4_sel(me.w > 0.0f, make_float4(me.w * s.x, me.w * s.y, me.w * s.z, me.w), zero);
+        vals[c] = d;
+        if (own)
+            xr2[m & 1] = make_float4(me.x + d.x, me.y + d.y, me.z + d.z, 0);
+    });
+    {
+        const int jr = tx & 1, fw = FL.w, fh = FL.h;
+        VmV3 *const xr = FL.xr;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int x = x0 + tx, y = y0 + 4 * ty + jr + 2 * m;
+            if (x < fw && y < fh)
+                st3(xr, ((size_t)y * fw + x) >> 1, xr2[m]);
+        }
+    }
+    __syncthreads();
+    wide_sweep(tx, ty, tid, true, 1, [&](int c, int, bool) {           // d_b in place of x_b1
+        const float4 me = vals[c], s = op.nbsum(vals, c);
+        vals[c] = f4_sel(me.w > 0.0f, make_float4(me.w * s.x, me.w * s.y, me.w * s.z, me.w), zero);
+    });
+    __syncthreads();
+    // residual on the thread's two red cells, summed over the aggregate (its other red cell is the neighbouring lane's)
+    const int jr = tx & 1;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int row = 4 * ty + jr + 2 * m, c = (HL2 + row) * LW2 + HL2 + tx;
+        float4 r = vals[c].w > 0.0f ? op.nbsum(vals, c) : zero;
+        r.x += __shfl_xor(r.x, 1); r.y += __shfl_xor(r.y, 1); r.z += __shfl_xor(r.z, 1);
+        const int X = (x0 + tx) >> 1, Y = (y0 + row) >> 1;
+        if ((tx & 1) == 0 && X < C.w && Y < C.h)
+            st3(C.b, (size_t)Y * C.w + X, r);
+    }
+}
+
+template <bool L0>
+__global__ __launch_bounds__(256) void k_mgb_prolong2(const VmMgbSys *__restrict__ sys, int l, int k, uint64_t active)
+{
+    if (!sys_active(active))
+        return;
+    const VmMgbSys &S = sys[blockIdx.z];
+    const VmMgbLevel &FL = S.lv[l], &C = S.lv[l + 1];
+    const bool live = (int)blockIdx.x < G(FL.ntiles)[0];
+    double rz[3] = {0, 0, 0};
+    if (live) {
+        const uint32_t tb = G(FL.tiles)[blockIdx.x];
+        const int x0 = (int)(tb & 0xffffu) * TW, y0 = (int)(tb >> 16) * TH;
+        const Op<L0> F(FL);
+        __shared__ float4 vals[LN2];
+        __shared__ WideOp<L0> op;
+        const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+        const float4 zero = make_float4(0, 0, 0, 0);
+        const int cw = C.w;
+        // stage: red cells x_r2 + xc(aggregate), black cells b; returns b where a later half-sweep of this thread needs it
+        auto stage = [&](int c, int x, int y, int dist) {
+            bool in;
+            size_t ii;
+            const float inv = wide_stage_op<L0>(FL, F, op, c, x, y, in, ii);
+            const bool unk = inv > 0.0f, red = ((x + y) & 1) == 0;
+            float4 b = zero, v;
+            if (red ? dist <= 2 : dist <= 3)
+                b = f4_sel(unk, ld3(FL.b, ii), zero);
+            if (red) {
+                const float4 xr = ld3(FL.xr, ii >> 1), cor = ld3(C.x, in ? (size_t)(y >> 1) * cw + (x >> 1) : 0);
+                v = f4_sel(unk, make_float4(xr.x + cor.x, xr.y + cor.y, xr.z + cor.z, 0), zero);
+            } else {
+                v = b;
+            }
+            v.w = inv;
+            vals[c] = v;
+            return b;
+        };
+        float4 bown[4], bapr[NSLOT2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            bown[j] = stage((HL2 + 4 * ty + j) * LW2 + HL2 + tx, x0 + tx, y0 + 4 * ty + j, 0);
+#pragma unroll
+        for (int sl = 0; sl < NSLOT2; ++sl) {
+            const int kk = tid + 256 * sl;
+            bapr[sl] = zero;
+            if (kk < NHALO2) {
+                const int c = halo2_cell(kk), cx = c % LW2, cy = c / LW2;
+                bapr[sl] = stage(c, x0 - HL2 + cx, y0 - HL2 + cy, tile_dist(cx, cy));
+            }
+        }
+        __syncthreads();
+        const bool odd = (tx & 1) != 0;                  // own cells 1, 3 are red, 0, 2 black
+        wide_sweep(tx, ty, tid, true, 3, [&](int c, int, bool) {       // x_b3
+            const float4 me = vals[c], s = op.nbsum(vals, c);
+            vals[c] = f4_sel(me.w > 0.0f, make_float4(me.w * (me.x + s.x), me.w * (me.y + s.y), me.w * (me.z + s.z), me.w), zero);
+        });
+        __syncthreads();
+        wide_sweep(tx, ty, tid, false, 2, [&](int c, int m, bool own) { // e_r in place of x_r2 + xc
+            const float4 me = vals[c], s = op.nbsum(vals, c);
+            const float4 b = own ? f4_sel(odd, bown[(2 * m + 1) & 3], bown[(2 * m) & 3]) : bapr[m < NSLOT2 ? m : 0];
+            vals[c] = f4_sel(me.w > 0.0f, make_float4(me.w * (b.x + s.x) - me.x, me.w * (b.y + s.y) - me.y, me.w * (b.z + s.z) - me.z, me.w), zero);
+        });
+        __syncthreads();
+        float4 out[4];
+        wide_sweep(tx, ty, tid, true, 1, [&](int c, int m, bool own) {  // x_b4
+            const float4 me = vals[c], s = op.nbsum(vals, c);
+            const float4 xn = f4_sel(me.w > 0.0f, make_float4(me.x + me.w * s.x, me.y + me.w * s.y, me.z + me.w * s.z, me.w), zero);
+            vals[c] = xn;
+            if (own) {
+                out[(2 * m) & 3] = xn;                   // the black one of the pair (2 m, 2 m + 1); the red one follows
+                out[(2 * m + 1) & 3] = xn;
+            }
+        });
+        __syncthreads();
+        const int jr = tx & 1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {                    // x_r4
+            const int c = (HL2 + 4 * ty + jr + 2 * m) * LW2 + HL2 + tx;
+            const float inv = vals[c].w;
+            const float4 s = op.nbsum(vals, c), b = f4_sel(odd, bown[2 * m + 1], bown[2 * m]);
+            const float4 xr = f4_sel(inv > 0.0f, make_float4(inv * (b.x + s.x), inv * (b.y + s.y), inv * (b.z + s.z), 0), zero);
+            out[2 * m] = f4_sel(odd, out[2 * m], xr);            // even tx: cell 2 m is red
+            out[2 * m + 1] = f4_sel(odd, xr, out[2 * m + 1]);    // odd tx: cell 2 m + 1 is red
+        }
+        const int fw = FL.w, fh = FL.h;
+        VmV3 *const fx = FL.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + tx, y = y0 + 4 * ty + j;
+            if (x < fw && y < fh) {
+                st3(fx, (size_t)y * fw + x, out[j]);
+                if (L0) {       // b is zero where there is no unknown (stage)
+                    rz[0] += (double)bown[j].x * out[j].x; rz[1] += (double)bown[j].y * out[j].y; rz[2] += (double)bown[j].z * out[j].z;
+                }
+            }
+        }
+    }
+    if (L0)
+        block_sum3(rz[0], rz[1], rz[2], S.sc->rz[k & 1]);
+}
+
+// ---------------------------------------------------------------------------
 // The tail of the cycle: every level from l0 on (their cells fit VM_MGB_TAIL_X / _B, vm_mgb.h) in ONE workgroup.  All of
 // their state lives in LDS for the whole cycle -- iterates with 1 / dg in .w, the right-hand sides of the levels below
 // l0, the edge weights -- and level l0's right-hand side in registers: the ~26 dependent half-sweeps and transfers of
@@ -749,6 +1008,7 @@ constexpr int TAILK = (VM_MGB_TAIL_X + TAILT - 1) / TAILT; // cells of level l0 
 struct TailLevel {
     int w, h, n;
     int xo, bo;          // offsets of the level's iterate (and weights) / right-hand side in the LDS pools (bo < 0: level l0)
+    int nu;              // red-black sweeps each way
 };
 
 __device__ __forceinline__ float4 tail_nbsum(const float4 *x, const float2 *wt, int i, int cx, int cy, int w)
@@ -806,6 +1066,36 @@ __device__ __forceinline__ void tail_restrict(const TailLevel &T, const TailLeve
     __syncthreads();
 }
 
+// ... after more than one sweep: the residual of a red cell is dg x (what one more red half-sweep would change), still
+// zero on the black ones; the two red cells of an aggregate add themselves to its entry (two adds commute: deterministic)
+__device__ __forceinline__ void tail_restrict_any(const TailLevel &T, const TailLevel &TC, const float4 *x, const float2 *wt, const float4 *bl,
+                                                  const float4 *b0, float4 *bc)
+{
+    for (int i = threadIdx.x; i < TC.n; i += TAILT)
+        bc[i] = make_float4(0, 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TAILK; ++k) {
+        const int i = threadIdx.x + TAILT * k;
+        if (i >= T.n)
+            break;
+        const int cx = i % T.w, cy = i / T.w;
+        if (((cx + cy) & 1) != 0)
+            continue;
+        const float4 me = x[i];
+        if (!(me.w > 0.0f))
+            continue;
+        const float4 b = bl ? bl[i] : b0[k];
+        const float4 s = tail_nbsum(x, wt, i, cx, cy, T.w);
+        const float dg = 1.0f / me.w;
+        float4 *dst = bc + (cy >> 1) * TC.w + (cx >> 1);
+        atomicAdd(&dst->x, dg * (me.w * (b.x + s.x) - me.x));
+        atomicAdd(&dst->y, dg * (me.w * (b.y + s.y) - me.y));
+        atomicAdd(&dst->z, dg * (me.w * (b.z + s.z) - me.z));
+    }
+    __syncthreads();
+}
+
 template <bool L0>
 __global__ __launch_bounds__(TAILT) void k_mgb_tail(const VmMgbSys *__restrict__ sys, int l0, uint64_t active)
 {
@@ -820,7 +1110,7 @@ __global__ __launch_bounds__(TAILT) void k_mgb_tail(const VmMgbSys *__restrict__
         int xo = 0, bo = 0;
         for (int j = 0; j < nl; ++j) {
             const VmMgbLevel &L = S.lv[l0 + j];
-            T[j] = TailLevel{L.w, L.h, L.w * L.h, xo, j ? bo : -1};
+            T[j] = TailLevel{L.w, L.h, L.w * L.h, xo, j ? bo : -1, L.nu};
             xo += L.w * L.h;
             if (j) bo += L.w * L.h;
         }
@@ -859,9 +1149,14 @@ __global__ __launch_bounds__(TAILT) void k_mgb_tail(const VmMgbSys *__restrict__
         float4 *x = xp + T[j].xo;
         const float2 *wt = wp + T[j].xo;
         const float4 *b = j ? bp + T[j].bo : nullptr;
-        tail_half(T[j], x, wt, b, b0, true, true);
-        tail_half(T[j], x, wt, b, b0, false, false);
-        tail_restrict(T[j], T[j + 1], x, wt, bp + T[j + 1].bo);
+        for (int sw = 0; sw < T[j].nu; ++sw) {
+            tail_half(T[j], x, wt, b, b0, true, sw == 0);
+            tail_half(T[j], x, wt, b, b0, false, false);
+        }
+        if (T[j].nu == 1)
+            tail_restrict(T[j], T[j + 1], x, wt, bp + T[j + 1].bo);
+        else
+            tail_restrict_any(T[j], T[j + 1], x, wt, b, b0, bp + T[j + 1].bo);
     }
     // the coarsest grid: symmetric sweeps from zero (red, black ... then black, red ...)
     {
@@ -893,8 +1188,10 @@ __global__ __launch_bounds__(TAILT) void k_mgb_tail(const VmMgbSys *__restrict__
             }
         }
         __syncthreads();
-        tail_half(T[j], x, wt, b, b0, false, false);
-        tail_half(T[j], x, wt, b, b0, true, false);
+        for (int sw = 0; sw < T[j].nu; ++sw) {
+            tail_half(T[j], x, wt, b, b0, false, false);
+            tail_half(T[j], x, wt, b, b0, true, false);
+        }
     }
     const VmMgbLevel &L = S.lv[l0];
     for (int i = threadIdx.x; i < T[0].n; i += TAILT)
@@ -929,20 +1226,34 @@ void vm_mgb_launch_init(const VmMgbSys *sys, int nsys, int nb0, uint64_t active,
     hipLaunchKernelGGL(k_mgb_init, dim3(groups(nb0), 1, nsys), blk2, 0, s, sys, active);
 }
 
-void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nt_fine, uint64_t active, hipStream_t s)
+void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nu, int nt_fine, uint64_t active, hipStream_t s)
 {
-    if (l == 0)
-        hipLaunchKernelGGL(k_mgb_restrict<true>, dim3(nt_fine, 1, nsys), blk2, 0, s, sys, l, active);
-    else
-        hipLaunchKernelGGL(k_mgb_restrict<false>, dim3(nt_fine, 1, nsys), blk2, 0, s, sys, l, active);
+    const dim3 grid(nt_fine, 1, nsys);
+    if (nu == 2) {
+        if (l == 0)
+            hipLaunchKernelGGL(k_mgb_restrict2<true>, grid, blk2, 0, s, sys, l, active);
+        else
+            hipLaunchKernelGGL(k_mgb_restrict2<false>, grid, blk2, 0, s, sys, l, active);
+    } else if (l == 0) {
+        hipLaunchKernelGGL(k_mgb_restrict<true>, grid, blk2, 0, s, sys, l, active);
+    } else {
+        hipLaunchKernelGGL(k_mgb_restrict<false>, grid, blk2, 0, s, sys, l, active);
+    }
 }
 
-void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nt_fine, int k, uint64_t active, hipStream_t s)
+void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nu, int nt_fine, int k, uint64_t active, hipStream_t s)
 {
-    if (l == 0)
-        hipLaunchKernelGGL(k_mgb_prolong<true>, dim3(nt_fine, 1, nsys), blk2, 0, s, sys, l, k, active);
-    else
-        hipLaunchKernelGGL(k_mgb_prolong<false>, dim3(nt_fine, 1, nsys), blk2, 0, s, sys, l, k, active);
+    const dim3 grid(nt_fine, 1, nsys);
+    if (nu == 2) {
+        if (l == 0)
+            hipLaunchKernelGGL(k_mgb_prolong2<true>, grid, blk2, 0, s, sys, l, k, active);
+        else
+            hipLaunchKernelGGL(k_mgb_prolong2<false>, grid, blk2, 0, s, sys, l, k, active);
+    } else if (l == 0) {
+        hipLaunchKernelGGL(k_mgb_prolong<true>, grid, blk2, 0, s, sys, l, k, active);
+    } else {
+        hipLaunchKernelGGL(k_mgb_prolong<false>, grid, blk2, 0, s, sys, l, k, active);
+    }
 }
 
 void vm_mgb_launch_tail(const VmMgbSys *sys, int nsys, int l, uint64_t active, hipStream_t s)

@@ -42,6 +42,25 @@ int mg_tail_level(const std::vector<std::pair<int, int>> &sz)
     return l;
 }
 
+// red-black sweeps each way on level l of the cycle (VmMgbLevel::nu), by kind of system: VM_MGB_NU_POISSON / _QPATH
+// (vm_mgb.h: measured choices).  VM_MGB_NU = "a,b,c" overrides both for experiments: sweeps per level from level 0 on, the
+// last entry repeats; 1 or 2 on the levels the tile kernels sweep (larger values are cut to 2 there), 1 .. 9 inside the
+// one-workgroup tail
+int mg_nu(int l, bool in_tail, bool qpath)
+{
+    static const std::vector<int> env = [] {
+        std::vector<int> t;
+        if (const char *e = getenv("VM_MGB_NU"))
+            for (const char *q = e; *q; ++q)
+                if (*q >= '1' && *q <= '9') t.push_back(*q - '0');
+        return t;
+    }();
+    static const std::vector<int> poisson{VM_MGB_NU_POISSON}, path{VM_MGB_NU_QPATH};
+    const std::vector<int> &table = !env.empty() ? env : qpath ? path : poisson;
+    const int nu = table[std::min((size_t)l, table.size() - 1)];
+    return in_tail ? nu : std::min(nu, 2);
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -55,7 +74,7 @@ struct MgbWork {          // one system's device workspace, carved from f->pws2[
     uint8_t *type;
     char *xcoarse;        // the x arrays of levels >= 1, contiguous (cleared per extension)
     size_t xcoarse_bytes;
-    VmV3 *Xbest;          // optional (mgb_carve with_best): the iterate with the smallest residual seen near the tolerance
+    VmV3 *Xbest;          // optional (mgb_carve qpath): the iterate with the smallest residual seen near the tolerance
     int *counts;          // nblocks per level, then ntiles per level (device)
     int tail;             // first level of the cycle's one-workgroup tail
 };
@@ -68,12 +87,12 @@ size_t mgb_bytes(int w, int h, bool with_best = false)
     for (size_t l = 0; l < sz.size(); ++l) {
         const size_t N = (size_t)sz[l].first * sz[l].second;
         const size_t nb = (size_t)((sz[l].first + 63) / 64) * ((sz[l].second + 3) / 4);
-        need += (l ? 4 * al256(N * 4) : 0) + 2 * al256(N * 12) + 3 * al256(nb * 4);
+        need += (l ? 4 * al256(N * 4) : 0) + 2 * al256(N * 12) + al256((N + 1) / 2 * 12) + 3 * al256(nb * 4);
     }
     return need + (with_best ? al256(N0 * 12) : 0);
 }
 
-void mgb_carve(MgbWork &W, int w, int h, char *b, bool with_best = false)
+void mgb_carve(MgbWork &W, int w, int h, char *b, bool qpath = false)
 {
     const auto sz = mg_sizes(w, h);
     const size_t N0 = (size_t)w * h;
@@ -103,6 +122,8 @@ void mgb_carve(MgbWork &W, int w, int h, char *b, bool with_best = false)
             L.k = (float *)b; b += al256(N * 4);
         }
         L.b = (VmV3 *)b; b += al256(N * 12);
+        L.nu = mg_nu((int)l, (int)l >= W.tail, qpath);
+        L.xr = (VmV3 *)b; b += al256((N + 1) / 2 * 12);
         L.flags = (uint32_t *)b; b += al256(nb * 4);
         L.blocks = (uint32_t *)b; b += al256(nb * 4);
         L.nblocks = W.counts + l;
@@ -118,7 +139,7 @@ void mgb_carve(MgbWork &W, int w, int h, char *b, bool with_best = false)
         b += al256((size_t)sz[l].first * sz[l].second * 12);
     }
     W.xcoarse_bytes = (size_t)(b - W.xcoarse);
-    W.Xbest = with_best ? (VmV3 *)b : nullptr;
+    W.Xbest = qpath ? (VmV3 *)b : nullptr;     // (the quadratic path keeps the best iterate seen: mgb_solve)
 }
 
 // z = M^-1 r of every active system: one V(1,1) cycle; iteration k's r.z lands in rz[k & 1].  nb / nt: blocks / tiles
@@ -128,12 +149,12 @@ void mgb_vcycle(const VmMgbSys *dev, int nsys, const MgbWork &W0, const std::vec
 {
     const int tail = W0.tail;       // levels tail .. nlev - 1 run in one workgroup
     for (int l = 0; l < tail; ++l)
-        vm_mgb_launch_restrict(dev, nsys, l, nt[l], active, s);
+        vm_mgb_launch_restrict(dev, nsys, l, W0.S.lv[l].nu, nt[l], active, s);
     vm_mgb_launch_tail(dev, nsys, tail, active, s);
     if (tail == 0)
         vm_mgb_launch_dot_rz(dev, nsys, nb[0], k, active, s);
     for (int l = tail - 1; l >= 0; --l)
-        vm_mgb_launch_prolong(dev, nsys, l, nt[l], k, active, s);
+        vm_mgb_launch_prolong(dev, nsys, l, W0.S.lv[l].nu, nt[l], k, active, s);
 }
 
 double mgb_rel(const VmMgbScalars &h, int par)
