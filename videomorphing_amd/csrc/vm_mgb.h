@@ -95,6 +95,9 @@ struct VmMgbSys {
 #define VM_MGB_TAIL_X 5120
 #define VM_MGB_TAIL_B 2048
 #endif
+// ... and no level of the tail may hold more than this many PAIRS of cells, ceil(w / 2) h (the tail's threads are dealt
+// pairs, three each)
+#define VM_MGB_TAIL_PAIRS 3072
 
 // set-up: level 0 from the type map, Galerkin coarsening (2x2 aggregates, edge weights x 1/2), block flags on the way
 void vm_mgb_launch_level0(const VmMgbSys *sys, int nsys, int gx, int gy, hipStream_t s);

@@ -756,7 +756,9 @@ __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict_
 
 constexpr int HL2 = 4, LW2 = TW + 2 * HL2, LH2 = TH + 2 * HL2, LN2 = LW2 * LH2, NHALO2 = LN2 - TW * TH;   // 72 x 24, 704 apron cells
 constexpr int NSLOT2 = (NHALO2 + 255) / 256;             // apron cells per thread: 3
-template <bool L0> using WideOp = TileOpT<L0, LW2, LN2>;
+// (the weight records of the window's last row are never read -- a cell within 3 of the tile looks west and north, never at
+//  the row below the apron's last -- and leaving them out brings the coarse levels' window to 40 KB: four workgroups per CU)
+template <bool L0> using WideOp = TileOpT<L0, LW2, LN2 - LW2>;
 
 // window index of apron cell number k (0 .. NHALO2 - 1): four rows above, four below, four columns left and right
 __device__ __forceinline__ int halo2_cell(int k)
@@ -783,11 +785,13 @@ __device__ __forceinline__ float wide_stage_op(const VmMgbLevel &L, const Op<L0>
     ii = in ? (size_t)y * L.w + x : 0;
     if constexpr (L0) {
         const uint32_t m = in ? (uint32_t)A.info[ii] : 0u;
-        op.m[c] = (uint8_t)m;
+        if (c < LN2 - LW2)
+            op.m[c] = (uint8_t)m;
         return k_of_dg0(m >> 4);
     } else {
         const float k = A.pk[ii], we = A.pwe[ii], ws = A.pws[ii];
-        op.w[c] = make_float2(in && x + 1 < L.w ? we : 0.0f, in && y + 1 < L.h ? ws : 0.0f);
+        if (c < LN2 - LW2)
+            op.w[c] = make_float2(in && x + 1 < L.w ? we : 0.0f, in && y + 1 < L.h ? ws : 0.0f);
         return in ? k : 0.0f;
     }
 }
@@ -1003,43 +1007,75 @@ __global__ __launch_bounds__(256) void k_mgb_prolong2(const VmMgbSys *__restrict
 // x ~500 instructions x 4 cycles per phase of level l0), not the round trips.
 
 constexpr int TAILT = 1024;                              // threads of the tail's workgroup
-constexpr int TAILK = (VM_MGB_TAIL_X + TAILT - 1) / TAILT; // cells of level l0 a thread owns at most
+constexpr int TAILKP = VM_MGB_TAIL_PAIRS / TAILT;        // pairs of cells of a tail level a thread owns at most
 
+// A half-sweep touches the cells of ONE colour.  Threads are dealt PAIRS of cells -- (2 px, cy) and (2 px + 1, cy), of which
+// exactly one is red -- so every lane of a wave has a cell in every half-sweep (dealt single cells, half the lanes idle while
+// the wave still pays every LDS instruction: the tail is one workgroup on one CU, its ~40 half-sweeps are its whole time).
 struct TailLevel {
     int w, h, n;
     int xo, bo;          // offsets of the level's iterate (and weights) / right-hand side in the LDS pools (bo < 0: level l0)
     int nu;              // red-black sweeps each way
+    int pw, np;          // pairs per row = ceil(w / 2), pairs of the level
+    float rw, rpw;       // 1 / w, 1 / pw
 };
-
-__device__ __forceinline__ float4 tail_nbsum(const float4 *x, const float2 *wt, int i, int cx, int cy, int w)
+// index -> (column, row) on a grid of `per_row` columns without an integer division (~40 instructions on this hardware, per
+// cell and half-sweep): (q + 1/2) / per_row lies at least 1 / (2 per_row) from an integer, the float product is off by < 1e-5
+__device__ __forceinline__ void tail_split(int q, int per_row, float r, int &col, int &row)
 {
-    const float2 me = wt[i];
-    float4 s = make_float4(0, 0, 0, 0);
-    if (me.x != 0.0f) s = f4_axpy(me.x, x[i + 1], s);
-    if (cx > 0) { const float wW = wt[i - 1].x; if (wW != 0.0f) s = f4_axpy(wW, x[i - 1], s); }
-    if (me.y != 0.0f) s = f4_axpy(me.y, x[i + w], s);
-    if (cy > 0) { const float wN = wt[i - w].y; if (wN != 0.0f) s = f4_axpy(wN, x[i - w], s); }
+    row = (int)(((float)q + 0.5f) * r);
+    col = q - row * per_row;
+}
+__device__ __forceinline__ void tail_xy(const TailLevel &T, int i, int &cx, int &cy) { tail_split(i, T.w, T.rw, cx, cy); }
+// the cell of colour `red` of pair q: its index, coordinates, whether it is the pair's second cell; false: outside the grid
+__device__ __forceinline__ bool tail_cell(const TailLevel &T, int q, bool red, int &i, int &cx, int &cy, bool &second)
+{
+    int px;
+    tail_split(q, T.pw, T.rpw, px, cy);
+    second = ((cy & 1) != 0) == red;                     // red <=> (cx + cy) even
+    cx = 2 * px + (second ? 1 : 0);
+    i = cy * T.w + cx;
+    return cx < T.w;
+}
+
+// sum over the neighbours of cell i = (cx, cy) of weight x value.  All eight LDS reads are issued at once, whatever the
+// weights say (indices clamped to the level, a missing edge's weight made 0 by a select): one round trip per cell instead of
+// a chain of up to seven dependent ones.  A zero weight times the finite value that stands at the clamped index adds an
+// exact zero: the sums are what skipping gave.
+__device__ __forceinline__ float4 tail_nbsum(const float4 *x, const float2 *wt, int i, int cx, int cy, int w, int h)
+{
+    const bool hw = cx > 0, hn = cy > 0, he = cx + 1 < w, hs = cy + 1 < h;
+    const int iw = hw ? i - 1 : i, in = hn ? i - w : i, ie = he ? i + 1 : i, is = hs ? i + w : i;
+    const float2 me = wt[i], ww = wt[iw], wn = wt[in];
+    const float4 xe = x[ie], xw = x[iw], xs = x[is], xn = x[in];
+    const float wE = he ? me.x : 0.0f, wW = hw ? ww.x : 0.0f, wS = hs ? me.y : 0.0f, wN = hn ? wn.y : 0.0f;
+    float4 s = make_float4(wE * xe.x, wE * xe.y, wE * xe.z, 0);
+    s = f4_axpy(wW, xw, s);
+    s = f4_axpy(wS, xs, s);
+    s = f4_axpy(wN, xn, s);
     return s;
 }
 
 // one Gauss-Seidel half-sweep of colour `red` on a tail level: x = (b + sum_nb w x) / dg.  b: the level's right-hand
-// side in LDS, or (level l0) nullptr: the thread's registers b0.  first: the opening red half-sweep from zero, x = b / dg.
-__device__ __forceinline__ void tail_half(const TailLevel &T, float4 *x, const float2 *wt, const float4 *bl, const float4 *b0, bool red, bool first)
+// side in LDS, or (level l0) nullptr: the thread's registers, b0[k][0 / 1] = the first / second cell of its pair k.
+// first: the opening red half-sweep from zero, x = b / dg.
+__device__ __forceinline__ void tail_half(const TailLevel &T, float4 *x, const float2 *wt, const float4 *bl, const float4 (*b0)[2], bool red, bool first)
 {
 #pragma unroll
-    for (int k = 0; k < TAILK; ++k) {
-        const int i = threadIdx.x + TAILT * k;
-        if (i >= T.n)
+    for (int k = 0; k < TAILKP; ++k) {
+        const int q = threadIdx.x + TAILT * k;
+        if (q >= T.np)
             break;
-        const int cx = i % T.w, cy = i / T.w;
-        if ((((cx + cy) & 1) == 0) != red)
+        int i, cx, cy;
+        bool second;
+        if (!tail_cell(T, q, red, i, cx, cy, second))
             continue;
-        const float inv = x[i].w;
-        if (!(inv > 0.0f))
-            continue;                                    // no unknown: stays (0, 0, 0, 0)
-        const float4 b = bl ? bl[i] : b0[k];
-        const float4 s = first ? make_float4(0, 0, 0, 0) : tail_nbsum(x, wt, i, cx, cy, T.w);
-        x[i] = make_float4(inv * (b.x + s.x), inv * (b.y + s.y), inv * (b.z + s.z), inv);
+        // (every read before the test of 1 / dg: one LDS round trip per cell)
+        const float4 me = x[i];
+        const float4 b = bl ? bl[i] : f4_sel(second, b0[k][1], b0[k][0]);
+        const float4 s = first ? make_float4(0, 0, 0, 0) : tail_nbsum(x, wt, i, cx, cy, T.w, T.h);
+        if (me.w > 0.0f)                                 // no unknown: stays (0, 0, 0, 0)
+            x[i] = make_float4(me.w * (b.x + s.x), me.w * (b.y + s.y), me.w * (b.z + s.z), me.w);
     }
     __syncthreads();
 }
@@ -1048,7 +1084,8 @@ __device__ __forceinline__ void tail_half(const TailLevel &T, float4 *x, const f
 __device__ __forceinline__ void tail_restrict(const TailLevel &T, const TailLevel &TC, const float4 *x, const float2 *wt, float4 *bc)
 {
     for (int i = threadIdx.x; i < TC.n; i += TAILT) {
-        const int X = i % TC.w, Y = i / TC.w;
+        int X, Y;
+        tail_xy(TC, i, X, Y);
         float4 r = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int d = 0; d < 2; ++d) {                    // the aggregate's red cells: (2X, 2Y) and (2X + 1, 2Y + 1)
@@ -1058,7 +1095,7 @@ __device__ __forceinline__ void tail_restrict(const TailLevel &T, const TailLeve
             const int q = cy * T.w + cx;
             if (!(x[q].w > 0.0f))
                 continue;
-            const float4 s = tail_nbsum(x, wt, q, cx, cy, T.w);
+            const float4 s = tail_nbsum(x, wt, q, cx, cy, T.w, T.h);
             r.x += s.x; r.y += s.y; r.z += s.z;
         }
         bc[i] = r;
@@ -1067,26 +1104,25 @@ __device__ __forceinline__ void tail_restrict(const TailLevel &T, const TailLeve
 }
 
 // ... after more than one sweep: the residual of a red cell is dg x (what one more red half-sweep would change), still
-// zero on the black ones; the two red cells of an aggregate add themselves to its entry (two adds commute: deterministic)
+// zero on the black ones; the two red cells of an aggregate add themselves to its entry (two adds commute: deterministic),
+// which the caller has zeroed before the level's half-sweeps (their barriers order the zeros before the adds)
 __device__ __forceinline__ void tail_restrict_any(const TailLevel &T, const TailLevel &TC, const float4 *x, const float2 *wt, const float4 *bl,
-                                                  const float4 *b0, float4 *bc)
+                                                  const float4 (*b0)[2], float4 *bc)
 {
-    for (int i = threadIdx.x; i < TC.n; i += TAILT)
-        bc[i] = make_float4(0, 0, 0, 0);
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < TAILK; ++k) {
-        const int i = threadIdx.x + TAILT * k;
-        if (i >= T.n)
+    for (int k = 0; k < TAILKP; ++k) {
+        const int q = threadIdx.x + TAILT * k;
+        if (q >= T.np)
             break;
-        const int cx = i % T.w, cy = i / T.w;
-        if (((cx + cy) & 1) != 0)
+        int i, cx, cy;
+        bool second;
+        if (!tail_cell(T, q, true, i, cx, cy, second))
             continue;
         const float4 me = x[i];
+        const float4 b = bl ? bl[i] : f4_sel(second, b0[k][1], b0[k][0]);
+        const float4 s = tail_nbsum(x, wt, i, cx, cy, T.w, T.h);
         if (!(me.w > 0.0f))
             continue;
-        const float4 b = bl ? bl[i] : b0[k];
-        const float4 s = tail_nbsum(x, wt, i, cx, cy, T.w);
         const float dg = 1.0f / me.w;
         float4 *dst = bc + (cy >> 1) * TC.w + (cx >> 1);
         atomicAdd(&dst->x, dg * (me.w * (b.x + s.x) - me.x));
@@ -1110,27 +1146,37 @@ __global__ __launch_bounds__(TAILT) void k_mgb_tail(const VmMgbSys *__restrict__
         int xo = 0, bo = 0;
         for (int j = 0; j < nl; ++j) {
             const VmMgbLevel &L = S.lv[l0 + j];
-            T[j] = TailLevel{L.w, L.h, L.w * L.h, xo, j ? bo : -1, L.nu};
+            const int pw = (L.w + 1) / 2;
+            T[j] = TailLevel{L.w, L.h, L.w * L.h, xo, j ? bo : -1, L.nu, pw, pw * L.h, 1.0f / (float)L.w, 1.0f / (float)pw};
             xo += L.w * L.h;
             if (j) bo += L.w * L.h;
         }
     }
     __syncthreads();
-    // stage: 1 / dg and the weights of the edges to the east / south of every tail cell; level l0's right-hand side
-    float4 b0[TAILK];
+    // stage: 1 / dg and the weights of the edges to the east / south of every tail cell; level l0's right-hand side, by
+    // the pairs the thread will sweep
+    float4 b0[TAILKP][2];
     {
         const VmMgbLevel &L = S.lv[l0];
         const Op<L0> A(L);
 #pragma unroll
-        for (int k = 0; k < TAILK; ++k) {
-            const int i = threadIdx.x + TAILT * k;
-            b0[k] = make_float4(0, 0, 0, 0);
-            if (i < T[0].n) {
-                const Stencil st = stencil_of(A, i % T[0].w, i / T[0].w, (size_t)i);
-                const float inv = A.k((size_t)i);
-                xp[i] = make_float4(0, 0, 0, inv);
-                wp[i] = make_float2(st.wE, st.wS);
-                if (inv > 0.0f) b0[k] = ld3(L.b, (size_t)i);
+        for (int k = 0; k < TAILKP; ++k) {
+            const int q = threadIdx.x + TAILT * k;
+            b0[k][0] = b0[k][1] = make_float4(0, 0, 0, 0);
+            if (q < T[0].np) {
+                int px, cy;
+                tail_split(q, T[0].pw, T[0].rpw, px, cy);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int cx = 2 * px + e, i = cy * T[0].w + cx;
+                    if (cx < T[0].w) {
+                        const Stencil st = stencil_of(A, cx, cy, (size_t)i);
+                        const float inv = A.k((size_t)i);
+                        xp[i] = make_float4(0, 0, 0, inv);
+                        wp[i] = make_float2(st.wE, st.wS);
+                        if (inv > 0.0f) b0[k][e] = ld3(L.b, (size_t)i);
+                    }
+                }
             }
         }
     }
@@ -1138,7 +1184,9 @@ __global__ __launch_bounds__(TAILT) void k_mgb_tail(const VmMgbSys *__restrict__
         const VmMgbLevel &L = S.lv[l0 + j];
         const Op<false> A(L);
         for (int i = threadIdx.x; i < T[j].n; i += TAILT) {
-            const Stencil st = stencil_of(A, i % T[j].w, i / T[j].w, (size_t)i);
+            int cx, cy;
+            tail_xy(T[j], i, cx, cy);
+            const Stencil st = stencil_of(A, cx, cy, (size_t)i);
             xp[T[j].xo + i] = make_float4(0, 0, 0, A.k((size_t)i));
             wp[T[j].xo + i] = make_float2(st.wE, st.wS);
         }
@@ -1149,6 +1197,9 @@ __global__ __launch_bounds__(TAILT) void k_mgb_tail(const VmMgbSys *__restrict__
         float4 *x = xp + T[j].xo;
         const float2 *wt = wp + T[j].xo;
         const float4 *b = j ? bp + T[j].bo : nullptr;
+        if (T[j].nu != 1)
+            for (int i = threadIdx.x; i < T[j + 1].n; i += TAILT)
+                bp[T[j + 1].bo + i] = make_float4(0, 0, 0, 0);
         for (int sw = 0; sw < T[j].nu; ++sw) {
             tail_half(T[j], x, wt, b, b0, true, sw == 0);
             tail_half(T[j], x, wt, b, b0, false, false);
@@ -1177,15 +1228,16 @@ __global__ __launch_bounds__(TAILT) void k_mgb_tail(const VmMgbSys *__restrict__
         const float2 *wt = wp + T[j].xo;
         const float4 *xc = xp + T[j + 1].xo;
         const float4 *b = j ? bp + T[j].bo : nullptr;
-        const int w = T[j].w, cw = T[j + 1].w;
-        for (int i = threadIdx.x; i < T[j].n; i += TAILT) {
-            const int cx = i % w, cy = i / w;
-            const float4 f = x[i];
+        const int cw = T[j + 1].w;
+        for (int q = threadIdx.x; q < T[j].np; q += TAILT) {
+            int i, cx, cy;
+            bool second;
+            if (!tail_cell(T[j], q, true, i, cx, cy, second))
+                continue;
+            const float4 f = x[i], c = xc[(cy >> 1) * cw + (cx >> 1)];
             // (a red cell without an unknown holds 0 and stays 0: its aggregate may hold unknowns and a correction)
-            if (((cx + cy) & 1) == 0 && f.w > 0.0f) {
-                const float4 c = xc[(cy >> 1) * cw + (cx >> 1)];
+            if (f.w > 0.0f)
                 x[i] = make_float4(f.x + c.x, f.y + c.y, f.z + c.z, f.w);
-            }
         }
         __syncthreads();
         for (int sw = 0; sw < T[j].nu; ++sw) {

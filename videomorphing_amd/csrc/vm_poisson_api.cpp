@@ -34,7 +34,8 @@ int mg_tail_level(const std::vector<std::pair<int, int>> &sz)
     int l = (int)sz.size() - 1;
     while (l > 0) {
         const size_t here = (size_t)sz[l].first * sz[l].second, up = (size_t)sz[l - 1].first * sz[l - 1].second;
-        if (below + here + up > VM_MGB_TAIL_X || below + here > VM_MGB_TAIL_B)
+        if (below + here + up > VM_MGB_TAIL_X || below + here > VM_MGB_TAIL_B ||
+            (size_t)((sz[l - 1].first + 1) / 2) * sz[l - 1].second > VM_MGB_TAIL_PAIRS)
             break;
         below += here;
         --l;
