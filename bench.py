@@ -1014,8 +1014,10 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
             for f4 in frs4[1:]:
                 f4.close()
         # roofline of the solve: algorithmic bytes = unknowns x PCG iterations x 190 B (level 0: restriction 16 +
-        # prolongation 28 + direction / operator 49 + update 73; coarse levels ~25) over the HIP-event time of the batch
-        # (classification, fill, hierarchy set-up and paste included in the time, not in the bytes)
+        # prolongation 28 + direction / operator 49 + update 73; coarse levels ~25, their second sweep from level 2 down < 2)
+        # over the HIP-event time of the batch (classification, fill, hierarchy set-up and paste included in the time, not in
+        # the bytes: with fewer, stronger iterations this fraction FALLS while the solve gets faster -- the dominant kernel's
+        # fraction below is the bandwidth statement)
         unknowns = (w + 2 * ex) * (h + 2 * ex) - (w - 2) * (h - 2)         # outside pixels + the one-pixel ring inside
         key = "tol_%g" % POISSON_TOL
         its = pe[key]["cg_iterations"]

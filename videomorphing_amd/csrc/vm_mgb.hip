@@ -998,13 +998,14 @@ __global__ __launch_bounds__(256) void k_mgb_prolong2(const VmMgbSys *__restrict
 }
 
 // ---------------------------------------------------------------------------
-// The tail of the cycle: every level from l0 on (their cells fit VM_MGB_TAIL_X / _B, vm_mgb.h) in ONE workgroup.  All of
-// their state lives in LDS for the whole cycle -- iterates with 1 / dg in .w, the right-hand sides of the levels below
-// l0, the edge weights -- and level l0's right-hand side in registers: the ~26 dependent half-sweeps and transfers of
-// the tail touch memory only at the two ends.  Measured (four tail levels of a 1080p canvas, 4410 cells): 37.8 us per
-// cycle against 39.5 with the operators read from L2 in every half-sweep -- the tail is one workgroup on one CU and what
-// bounds it is its own instruction stream (index arithmetic per cell, waves half empty on a one-colour half-sweep: 16 waves
-// x ~500 instructions x 4 cycles per phase of level l0), not the round trips.
+// The tail of the cycle: every level from l0 on (their cells fit VM_MGB_TAIL_X / _B / _PAIRS, vm_mgb.h) in ONE workgroup.
+// All of their state lives in LDS for the whole cycle -- iterates with 1 / dg in .w, the right-hand sides of the levels
+// below l0, the edge weights -- and level l0's right-hand side in registers: the ~40 dependent half-sweeps and transfers
+// of the tail touch memory only at the two ends.  One workgroup on one CU: what bounds it is its own instruction stream
+// and LDS round trips per half-sweep.  Measured on the four tail levels of a 1080p canvas (4410 cells), two sweeps per
+// level each way: 59.6 us per cycle with threads dealt single cells, dependent weight -> value reads and an integer
+// division per cell; 51.0 with all reads of a cell issued at once and float index arithmetic; 39.4 with threads dealt
+// pairs of cells (below).
 
 constexpr int TAILT = 1024;                              // threads of the tail's workgroup
 constexpr int TAILKP = VM_MGB_TAIL_PAIRS / TAILT;        // pairs of cells of a tail level a thread owns at most
