@@ -1,6 +1,6 @@
 // vm_mgb.h -- the compositor's linear solver: multigrid-preconditioned CG, batched over systems, ring-only, fused
 // (launchers of vm_mgb.hip).  The system is PoissonExt.cpp:214-312's screened 5-point operator (MKL DSS is the
-// reference's solver, :321-329) or the quadratic path's Neumann Laplacian (QuadraticPath.cpp:111-215); one V(1,1)
+// reference's solver, :321-329) or the quadratic path's Neumann Laplacian (QuadraticPath.cpp:111-215); one V
 // cycle of a 2x2-aggregation multigrid per PCG iteration:
 //   * a SYSTEM is one side of one frame; blockIdx.z = system, so both sides of a frame (CPoissonExt::run's two
 //     prepare / poissonExtend pairs, PoissonExt.cpp:29-35, which do not depend on each other) -- and several frames --

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void k_mgb_dot_rz(const VmMgbSys *__restrict__
 }
 
 // ---------------------------------------------------------------------------
-// V(1,1) cycle with symmetric red-black Gauss-Seidel smoothing.  Colour of a cell: red <=> (x + y) even.
+// The cycle with ONE symmetric red-black Gauss-Seidel sweep each way (VmMgbLevel::nu == 1).  Colour of a cell: red <=> (x + y) even.
 //
 // Pre-smoothing from a zero guess, red then black:      x_r = b_r / dg_r,   x_b = (b_b + sum_nb w x_r) / dg_b.
 // Its residual is zero on black cells (their equations were just solved) and sum_nb w x_b on red cells (dg_r x_r = b_r),
@@ -751,8 +751,8 @@ __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict_
 //                      x_b4 = x_b3 + (sum w e_r) / dg_b           (black, <= 1)
 //                      x_r4 = (b_r + sum w x_b4) / dg_r           (red, the tile's)
 // every half-sweep reads the other colour only and writes its own cells: in place, one float4 per window cell.
-// Costs 27 % more staged cells and 6 + 10 bytes per cell for xr; on the 2304 x 1464 canvas V(2,2) on every level takes
-// 7 PCG iterations to 1e-5 where V(1,1) takes 11 (tools/exp/mg_prototype.py).
+// Costs 27 % more staged cells and 6 + 10 bytes per cell for xr; on the 2304 x 1464 canvas two sweeps on every level take
+// 7 PCG iterations to 1e-5 where one takes 11, two from level 2 down 9 (tools/exp/mg_prototype.py; vm_mgb.h: the choice).
 
 constexpr int HL2 = 4, LW2 = TW + 2 * HL2, LH2 = TH + 2 * HL2, LN2 = LW2 * LH2, NHALO2 = LN2 - TW * TH;   // 72 x 24, 704 apron cells
 constexpr int NSLOT2 = (NHALO2 + 255) / 256;             // apron cells per thread: 3

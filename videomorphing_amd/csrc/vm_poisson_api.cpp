@@ -143,7 +143,7 @@ void mgb_carve(MgbWork &W, int w, int h, char *b, bool qpath = false)
     W.Xbest = qpath ? (VmV3 *)b : nullptr;     // (the quadratic path keeps the best iterate seen: mgb_solve)
 }
 
-// z = M^-1 r of every active system: one V(1,1) cycle; iteration k's r.z lands in rz[k & 1].  nb / nt: blocks / tiles
+// z = M^-1 r of every active system: one V cycle (sweeps per level: VmMgbLevel::nu); iteration k's r.z lands in rz[k & 1].  nb / nt: blocks / tiles
 // per level (the largest count among the systems)
 void mgb_vcycle(const VmMgbSys *dev, int nsys, const MgbWork &W0, const std::vector<int> &nb, const std::vector<int> &nt, int k,
                 uint64_t active, hipStream_t s)
