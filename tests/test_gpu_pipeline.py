@@ -314,6 +314,33 @@ def test_poisson_on_random_outside_regions(gpu_ctx, oracle, seed):
     fr.close()
 
 
+@pytest.mark.parametrize("w,h,ex", [(1, 1698, 1), (2, 3396, 2), (1698, 1, 1), (3, 1700, 1), (5, 1020, 0)])
+def test_poisson_on_thin_canvases(gpu_ctx, oracle, w, h, ex):
+    """canvases a few cells wide and thousands long: grids of the hierarchy with w = 3 hold more PAIRS of cells
+    (ceil(w / 2) h) than the tail's threads are dealt -- 3 x 1700 at level 0, 3 x 1700 as level 1 of a 6 x 3400 canvas -- so
+    the one-workgroup tail has to start a level later (VM_MGB_TAIL_PAIRS); rows of one cell; ex = 0 with holes only"""
+    rng = np.random.RandomState(w + h)
+    rgb0, rgb1 = synth.make_rgb_pair(w, h, frame=2)
+    v = (0.3 * rng.randn(h, w, 2)).astype(np.float32)
+    e0, e1 = morph.make_extended(rgb0, ex), morph.make_extended(rgb1, ex)
+    if ex == 0:
+        e0[100:140, 1:3, 3] = 255
+        e1[500:520, :, 3] = 255
+    fr = morph.Frame(gpu_ctx, w, h, ex)
+    try:
+        fr.upload(e0, e1, v, None)
+        (i1, r1), (i2, r2), _ = fr.poisson_extend_both(tol=1e-6)
+        assert 0 < i1 < 40 and 0 < i2 < 40 and r1 <= 1e-6 and r2 <= 1e-6
+        for side, ext, other in ((1, e0, e1), (2, e1, e0)):
+            ref, _, _ = oracle.poisson_extend(ext, w, h, ex, other[ex:ex + h, ex:ex + w].copy(), v, side, tol=1e-9)
+            out = fr.download_ext(side)
+            assert out[..., 3].max() == 0
+            d = np.abs(out[..., :3].astype(int) - ref[..., :3].astype(int))
+            assert d.max() <= 1, (side, d.max())
+    finally:
+        fr.close()
+
+
 _CYCLE_CHILD = r"""
 import sys
 import numpy as np
