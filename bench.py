@@ -57,7 +57,8 @@ ALG_BYTES_PER_VISIT = 100.0      # 76 B read + 24 B written per 
 FLOP_PER_EVAL = 25 * 45 + 2 * 30  # 25 ssim() of ~45 flop-eq + 2 bilinear taps of ~30
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_FLOPS = 157e12         # MI355X_MICROARCH.md: f32 vector peak
-POISSON_ALG_BYTES = 190.0        # algorithmic bytes per unknown and PCG iteration of the Poisson solver
+POISSON_ALG_BYTES = 190.0        # algorithmic bytes per unknown and PCG iteration of the Poisson solver ...
+POISSON_ALG_BYTES_FUSED = 178.0  # ... and in batches of more than four systems: the update rides in the level-0 restriction, r is not read twice
 from fullsize_fixture import POISSON_TIMED_TOLS      # noqa: E402  the tolerances the full-size oracle fixtures verify (<= 1 colour level)
 POISSON_TOL = POISSON_TIMED_TOLS[0]
 SCHED = ("k_optimize<true> (TILE schedule, dense kernel)", "k_optimize<false> (TILE schedule, lean kernel for pruned sweeps)",
@@ -580,9 +581,12 @@ def load_poisson_pmc(path=None):
     batch (profiles/poisson_traffic_latest.json, written by tools/prof_pmc.sh + tools/pmc_summary.py); None if absent"""
     try:
         d = json.load(open(path or os.path.join(ROOT, "profiles", "poisson_traffic_latest.json")))
-        upd = d.get("per_kernel_bytes_per_launch", {}).get("k_mgb_update")
+        per = d.get("per_kernel_bytes_per_launch", {})
+        nsys = float(d.get("systems_per_launch", 8))
+        dominant = {name: per[key] / nsys for name, key in (("k_mgb_update", "k_mgb_update"), ("k_mgb_restrict<true, true>", "void k_mgb_restrict<true, true>"))
+                    if per.get(key)}
         return {"bytes_per_system_iteration": float(d["bytes_per_system_iteration"]), "source": d["source"],
-                "update_bytes_per_system_launch": float(upd) / float(d.get("systems_per_launch", 8)) if upd else None}
+                "dominant_bytes_per_system_launch": dominant}
     except Exception:
         return None
 
@@ -1024,21 +1028,28 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         alg = unknowns * sum(its) * POISSON_ALG_BYTES
         gbs = alg / (pe[key]["ms_per_frame"] * 1e-3) / 1e9
         its4 = pe[key + "_four_frames_per_batch"]["cg_iterations"]
-        gbs4 = unknowns * sum(its4) * POISSON_ALG_BYTES / (4 * pe[key + "_four_frames_per_batch"]["ms_per_frame"] * 1e-3) / 1e9
+        gbs4 = unknowns * sum(its4) * POISSON_ALG_BYTES_FUSED / (4 * pe[key + "_four_frames_per_batch"]["ms_per_frame"] * 1e-3) / 1e9
         pmc = load_poisson_pmc()
+        # the launch that carries the PCG update, average of a 4-frame batch, HIP events in this run: in a batch of eight systems the
+        # level-0 restriction with the update fused in (reads p, q, x, r and the operator byte, writes x, r and the coarse right-hand
+        # side = 76 B per unknown of every active system); k_mgb_update by itself (73 B) if the library did not fuse.
+        # profiles/r06_poisson4_kernel_stats.csv holds rocprofv3's average of the same kernel
+        fused = bool(dom) and dom[1] > 0 and dom[3] == dom[1]
+        dk_name, dk_bytes = ("k_mgb_restrict<true, true>", 76.0) if fused else ("k_mgb_update", 73.0)
         pe["roofline"] = {"bound": "hbm", "kernel": "multigrid-PCG solve of both sides of one frame as one batch (13 launches per iteration; the level-0 "
                                                      "kernels k_mgb_update / k_mgb_dirspmv / k_mgb_prolong / k_mgb_restrict: profiles/r06_compositor_*)",
                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                          "four_frames_per_batch": {"achieved": round(gbs4, 1), "frac": round(gbs4 / HBM_PEAK_GBS, 4)},
-                          # k_mgb_update (x += alpha p, r -= alpha q, r.r: reads p, q, x, r and the operator byte, writes x, r = 73 B per
-                          # unknown of every active system), average launch of a 4-frame batch, HIP events in this run;
-                          # profiles/r06_poisson4_kernel_stats.csv holds rocprofv3's average of the same kernel
+                          "four_frames_per_batch": {"achieved": round(gbs4, 1), "frac": round(gbs4 / HBM_PEAK_GBS, 4),
+                                                    "alg_bytes_per_unknown_iteration": POISSON_ALG_BYTES_FUSED,
+                                                    "kernel": "12 launches per iteration: the update rides in the level-0 restriction"},
                           "dominant_kernel": dom and dom[1] > 0 and {
-                              "kernel": "k_mgb_update", "launches": dom[1], "launch_us": round(dom[0] / dom[1], 2),
-                              "alg_bytes_per_launch": round(dom[2] / dom[1] * unknowns * 73.0),
-                              "achieved": round(dom[2] * unknowns * 73.0 / (dom[0] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(dom[2] * unknowns * 73.0 / (dom[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                              "traffic": pmc and pmc.get("update_bytes_per_system_launch") and round(pmc["update_bytes_per_system_launch"] * dom[2] / dom[1])},
+                              "kernel": dk_name, "launches": dom[1], "launch_us": round(dom[0] / dom[1], 2),
+                              "alg_bytes_per_unknown": dk_bytes,
+                              "alg_bytes_per_launch": round(dom[2] / dom[1] * unknowns * dk_bytes),
+                              "achieved": round(dom[2] * unknowns * dk_bytes / (dom[0] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(dom[2] * unknowns * dk_bytes / (dom[0] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              "traffic": pmc and pmc.get("dominant_bytes_per_system_launch", {}).get(dk_name) and
+                              round(pmc["dominant_bytes_per_system_launch"][dk_name] * dom[2] / dom[1])},
                           "traffic": round(pmc["bytes_per_system_iteration"] * sum(its)) if (pmc and (w, h, ex) == (1920, 1080, 192)) else None,
                           "traffic_source": pmc and pmc["source"],
                           "alg_bytes_per_unknown_iteration": POISSON_ALG_BYTES, "unknowns_per_side": unknowns, "tol": POISSON_TOL}

@@ -133,7 +133,8 @@ def test_bench_extras_of_round_5():
                                                            "tol_1e-06_four_frames_per_batch"}          # nothing timed at an unverified tolerance
     assert pe["tol_1e-05_four_frames_per_batch"]["ms_per_frame"] < pe["tol_1e-05"]["ms_per_frame"] and prf["four_frames_per_batch"]["frac"] > prf["frac"]
     dk = prf["dominant_kernel"]       # measured live with HIP events (vm_dbg_poisson_profile)
-    assert dk["kernel"] == "k_mgb_update" and dk["launches"] >= 8 and 20 < dk["launch_us"] < 400 and 0.3 < dk["frac"] < 1.0
+    # (a 4-frame batch: the PCG update rides in the level-0 restriction; VM_MGB_FUSE_MIN_SYS=0 would make it k_mgb_update)
+    assert dk["kernel"] in ("k_mgb_restrict<true, true>", "k_mgb_update") and dk["launches"] >= 6 and 20 < dk["launch_us"] < 400 and 0.3 < dk["frac"] < 1.0
     assert abs(dk["frac"] - dk["achieved"] / dk["peak"]) < 1e-3 and (dk["traffic"] is None or dk["traffic"] > 0.9 * dk["alg_bytes_per_launch"])
     assert p30["second_lane_gain"] >= 1.0 and 0 <= p30["second_lane_streams_rejected"] <= 4      # the lanes are chosen by measurement
     assert p30["runs"] == 3 and len(p30["ms_per_pair_each_run"]) == 3 and p30["ms_per_pair"] <= p30["ms_per_pair_median"]

@@ -158,7 +158,7 @@ def load():
         "vm_rccl_comm_init_all": [i, C.POINTER(i), C.POINTER(vp)],
         "vm_bcast_params": [C.POINTER(vp), C.POINTER(vp), i, i, C.POINTER(ParamBlock), C.POINTER(ParamBlock)],
         "vm_bcast_bytes": [C.POINTER(vp), C.POINTER(vp), i, i, vp, C.c_uint64, C.POINTER(vp)],
-        "vm_dbg_poisson_profile": [vp, i, C.POINTER(C.c_double), C.POINTER(i), C.POINTER(C.c_double)],
+        "vm_dbg_poisson_profile": [vp, i, C.POINTER(C.c_double), C.POINTER(i), C.POINTER(C.c_double), C.POINTER(i)],
         "vm_video_create": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i), i, C.POINTER(vp)],
         "vm_video_levels": [vp],
         "vm_video_level_dims": [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(f)],

@@ -113,11 +113,12 @@ struct vm_ctx {
     int use_graphs = -1;             // -1: not decided yet, 0: off (VM_NO_GRAPH or a failed capture), 1: on
     void *mgb_sys = nullptr;         // device descriptors of the systems of the current Poisson batch (vm_poisson_api.cpp)
     void *mgb_shared = nullptr;      // ... and their PCG scalars + block / tile counts, contiguous: ONE clear and ONE read-back per check for the whole batch
-    // vm_dbg_poisson_profile: HIP-event time of the solver's dominant kernel (k_mgb_update), summed over the launches of
-    // the solves since the probe was switched on, and what those launches processed
+    // vm_dbg_poisson_profile: HIP-event time of the launch that carries the PCG update (k_mgb_update, or the level-0
+    // restriction with the update fused in), summed over the launches of the solves since the probe was switched on,
+    // and what those launches processed
     bool mgb_prof = false;
     double mgb_prof_us = 0, mgb_prof_unknown_launches = 0;
-    int mgb_prof_launches = 0;
+    int mgb_prof_launches = 0, mgb_prof_fused = 0;
 };
 
 struct vm_level {

@@ -70,6 +70,9 @@ struct VmMgbSys {
     int nlev;
     VmMgbLevel lv[VM_MGB_MAXLEV];
     VmV3 *X, *P[2], *Q;
+    // the PCG residual of iteration k: R[k & 1].  R[0] == lv[0].b always; R[1] is a buffer of its own when the update rides in
+    // the level-0 restriction (vm_mgb.hip: k_mgb_restrict<true, true>), else R[0] again (k_mgb_update works in place)
+    VmV3 *R[2];
     const uint8_t *type;     // level 0's type map (PoissonExt.cpp:59-101)
     VmMgbScalars *sc;
 };
@@ -107,7 +110,9 @@ void vm_mgb_launch_compact(const VmMgbSys *sys, int nsys, int nlev_max, hipStrea
 void vm_mgb_launch_init(const VmMgbSys *sys, int nsys, int nb0, uint64_t active, hipStream_t s);
 // V-cycle pieces
 // (nu: the level's sweeps each way, VmMgbLevel::nu of every system of the batch)
-void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nu, int nt_fine, uint64_t active, hipStream_t s);   // lv[l+1].b from lv[l], over lv[l]'s tiles
+// lv[l+1].b from lv[l], over lv[l]'s tiles; k: the PCG iteration (level 0 reads R[k & 1]); upd (l == 0, nu == 1, k >= 1): the
+// update of iteration k - 1 first (x += alpha p, R[k & 1] = R[(k - 1) & 1] - alpha q, rr[(k - 1) & 1]) -- instead of vm_mgb_launch_update
+void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nu, int nt_fine, int k, bool upd, uint64_t active, hipStream_t s);
 void vm_mgb_launch_prolong(const VmMgbSys *sys, int nsys, int l, int nu, int nt_fine, int k, uint64_t active, hipStream_t s);   // lv[l].x; l == 0: rz[k & 1] += r.z
 void vm_mgb_launch_tail(const VmMgbSys *sys, int nsys, int l, uint64_t active, hipStream_t s);             // levels l .. nlev - 1 in one workgroup
 void vm_mgb_launch_dot_rz(const VmMgbSys *sys, int nsys, int nb0, int k, uint64_t active, hipStream_t s);                           // hierarchies that are all tail only

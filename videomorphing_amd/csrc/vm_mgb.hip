@@ -543,8 +543,8 @@ template <bool L0> using TileOp = TileOpT<L0, LW, LN>;
 // the grid or without an unknown gets zeros (selected, never multiplied: memory nobody wrote may hold anything).
 // Returns b (zeros likewise).
 template <bool L0>
-__device__ __forceinline__ float4 stage_cell(const VmMgbLevel &L, const Op<L0> &A, TileOp<L0> &op, float4 *vals, int c, int x, int y,
-                                             const VmV3 *__restrict__ xc, int cw)
+__device__ __forceinline__ float4 stage_cell(const VmMgbLevel &L, const VmV3 *__restrict__ bsrc, const Op<L0> &A, TileOp<L0> &op, float4 *vals, int c,
+                                             int x, int y, const VmV3 *__restrict__ xc, int cw)
 {
     const bool in = x >= 0 && x < L.w && y >= 0 && y < L.h;
     const size_t ii = in ? (size_t)y * L.w + x : 0;
@@ -558,7 +558,7 @@ __device__ __forceinline__ float4 stage_cell(const VmMgbLevel &L, const Op<L0> &
         inv = in ? k : 0.0f;
         op.w[c] = make_float2(in && x + 1 < L.w ? we : 0.0f, in && y + 1 < L.h ? ws : 0.0f);
     }
-    const float4 braw = ld3(L.b, ii);
+    const float4 braw = ld3(bsrc, ii);
     float4 cor = make_float4(0, 0, 0, 0);
     if (xc)
         cor = ld3(xc, in ? (size_t)(y >> 1) * cw + (x >> 1) : 0);
@@ -603,60 +603,126 @@ __device__ __forceinline__ float4 black_update(const TileOp<L0> &op, float4 *val
     return me;
 }
 
-// C.b = P^T (F.b - A x),  x = red-black pre-smoothing of F.b from zero, over F's tile list
-template <bool L0>
-__global__ __launch_bounds__(256) void k_mgb_restrict(const VmMgbSys *__restrict__ sys, int l, uint64_t active)
+// C.b = P^T (F.b - A x),  x = red-black pre-smoothing of F.b from zero, over F's tile list.  Level 0's right-hand side is
+// the PCG residual of iteration k, S.R[k & 1].
+// UPD (level 0, k >= 1): the PCG update of iteration k - 1 rides in front -- alpha = rz / pq of that iteration;
+// x += alpha p and r_k = r_{k-1} - alpha q on the tile's own cells (stored; r.r accumulated where k_mgb_update would have),
+// r_k recomputed on the apron.  r ping-pongs (S.R[(k - 1) & 1] -> S.R[k & 1]): a tile's apron is another tile's interior,
+// which may or may not have been rewritten yet.  The separate update kernel streamed 73 B per unknown at the HBM ceiling;
+// here its loads travel with a kernel that waits for latency, not for bytes, and r is not read twice.
+template <bool L0, bool UPD>
+__global__ __launch_bounds__(256) void k_mgb_restrict(const VmMgbSys *__restrict__ sys, int l, int k, uint64_t active)
 {
+    static_assert(L0 || !UPD, "the PCG update rides on level 0 only");
     if (!sys_active(active))
         return;
     const VmMgbSys &S = sys[blockIdx.z];
     const VmMgbLevel &FL = S.lv[l], &C = S.lv[l + 1];
-    if ((int)blockIdx.x >= G(FL.ntiles)[0])
+    const bool live = (int)blockIdx.x < G(FL.ntiles)[0];
+    if (!UPD && !live)
         return;
-    const uint32_t tb = G(FL.tiles)[blockIdx.x];
-    const int x0 = (int)(tb & 0xffffu) * TW, y0 = (int)(tb >> 16) * TH;
-    const Op<L0> F(FL);
-    __shared__ float4 vals[LN];
-    __shared__ TileOp<L0> op;
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+    float al[3] = {0, 0, 0};
+    if constexpr (UPD) {        // (what k_mgb_update(k - 1) does first: its scalars, its clears)
+        const int par = (k - 1) & 1;
+        if (blockIdx.x == 0) {
+            slot_clear(S.sc->rz[par ^ 1]);
+            slot_clear(S.sc->pq[par ^ 1]);
+        }
+        double rz[3], pq[3];
+        slot_sums2(S.sc->rz[par], S.sc->pq[par], rz, pq);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        stage_cell<L0>(FL, F, op, vals, (HL + 4 * ty + j) * LW + HL + tx, x0 + tx, y0 + 4 * ty + j, nullptr, 0);
-    for (int k = tid; k < NHALO; k += 256) {
-        const int c = halo_cell(k);
-        stage_cell<L0>(FL, F, op, vals, c, x0 - HL + c % LW, y0 - HL + c / LW, nullptr, 0);
+        for (int c = 0; c < 3; ++c)
+            al[c] = pq[c] > 0 ? (float)(rz[c] / pq[c]) : 0.0f;
     }
-    __syncthreads();
-    // black half-sweep: the thread's own two black cells, and the black cells of the ring at distance 1.  A black
-    // cell reads red neighbours only and writes itself: in place.
-    const int jb = (tx & 1) ^ 1;                         // own cells j = jb, jb + 2 are black ((tx + j) odd)
+    double rr[3] = {0, 0, 0};
+    if (live) {
+        const uint32_t tb = G(FL.tiles)[blockIdx.x];
+        const int x0 = (int)(tb & 0xffffu) * TW, y0 = (int)(tb >> 16) * TH;
+        const Op<L0> F(FL);
+        __shared__ float4 vals[LN];
+        __shared__ TileOp<L0> op;
+        const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+        if constexpr (UPD) {
+            const VmV3 *__restrict__ Ro = S.R[(k - 1) & 1], *__restrict__ Q = S.Q, *__restrict__ P = S.P[(k - 1) & 1];
+            VmV3 *Rn = S.R[k & 1], *X = S.X;
+            // window cell c = grid cell (x, y): r_k there (zeros without an unknown), staged like stage_cell stages b
+            auto stage_upd = [&](int c, int x, int y, bool own) {
+                const bool in = x >= 0 && x < FL.w && y >= 0 && y < FL.h;
+                const size_t ii = in ? (size_t)y * FL.w + x : 0;
+                const uint32_t m = in ? (uint32_t)F.info[ii] : 0u;
+                op.m[c] = (uint8_t)m;
+                const float inv = k_of_dg0(m >> 4);
+                const bool unk = inv > 0.0f;
+                const float4 ro = ld3(Ro, ii), q = ld3(Q, ii);
+                float4 pv = make_float4(0, 0, 0, 0), xv = pv;
+                if (own) {
+                    pv = ld3(P, ii);
+                    xv = ld3(X, ii);
+                }
+                // (p, q are only written inside blocks that hold an unknown: selected, never trusted, elsewhere)
+                const float4 r = f4_sel(unk, make_float4(ro.x - al[0] * q.x, ro.y - al[1] * q.y, ro.z - al[2] * q.z, 0), make_float4(0, 0, 0, 0));
+                if (own && unk) {
+                    st3(X, ii, make_float4(xv.x + al[0] * pv.x, xv.y + al[1] * pv.y, xv.z + al[2] * pv.z, 0));
+                    st3(Rn, ii, r);
+                    rr[0] += (double)r.x * r.x; rr[1] += (double)r.y * r.y; rr[2] += (double)r.z * r.z;
+                }
+                float4 v = r;
+                if (((x + y) & 1) == 0)
+                    v = make_float4(inv * r.x, inv * r.y, inv * r.z, 0);
+                v.w = inv;
+                vals[c] = v;
+            };
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int c = (HL + 4 * ty + jb + 2 * m) * LW + HL + tx;
-        float4 xn;
-        black_update<L0>(op, vals, c, xn);
-        vals[c] = xn;
-    }
-    if (tid < NRING1) {
-        const int c = ring1_cell(tid);
-        if (((c % LW + c / LW) & 1) != 0) {              // window parity == grid parity (HL, x0, y0 are even)
+            for (int j = 0; j < 4; ++j)
+                stage_upd((HL + 4 * ty + j) * LW + HL + tx, x0 + tx, y0 + 4 * ty + j, true);
+            for (int kk = tid; kk < NHALO; kk += 256) {
+                const int c = halo_cell(kk);
+                stage_upd(c, x0 - HL + c % LW, y0 - HL + c / LW, false);
+            }
+        } else {
+            const VmV3 *__restrict__ bsrc = L0 ? S.R[k & 1] : FL.b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                stage_cell<L0>(FL, bsrc, F, op, vals, (HL + 4 * ty + j) * LW + HL + tx, x0 + tx, y0 + 4 * ty + j, nullptr, 0);
+            for (int kk = tid; kk < NHALO; kk += 256) {
+                const int c = halo_cell(kk);
+                stage_cell<L0>(FL, bsrc, F, op, vals, c, x0 - HL + c % LW, y0 - HL + c / LW, nullptr, 0);
+            }
+        }
+        __syncthreads();
+        // black half-sweep: the thread's own two black cells, and the black cells of the ring at distance 1.  A black
+        // cell reads red neighbours only and writes itself: in place.
+        const int jb = (tx & 1) ^ 1;                         // own cells j = jb, jb + 2 are black ((tx + j) odd)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c = (HL + 4 * ty + jb + 2 * m) * LW + HL + tx;
             float4 xn;
             black_update<L0>(op, vals, c, xn);
             vals[c] = xn;
         }
-    }
-    __syncthreads();
-    // residual on the thread's two red cells, summed over the aggregate (its other red cell is the neighbouring lane's)
-    const int jr = tx & 1;
+        if (tid < NRING1) {
+            const int c = ring1_cell(tid);
+            if (((c % LW + c / LW) & 1) != 0) {              // window parity == grid parity (HL, x0, y0 are even)
+                float4 xn;
+                black_update<L0>(op, vals, c, xn);
+                vals[c] = xn;
+            }
+        }
+        __syncthreads();
+        // residual on the thread's two red cells, summed over the aggregate (its other red cell is the neighbouring lane's)
+        const int jr = tx & 1;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int row = 4 * ty + jr + 2 * m, c = (HL + row) * LW + HL + tx;
-        float4 r = vals[c].w > 0.0f ? op.nbsum(vals, c) : make_float4(0, 0, 0, 0);
-        r.x += __shfl_xor(r.x, 1); r.y += __shfl_xor(r.y, 1); r.z += __shfl_xor(r.z, 1);
-        const int X = (x0 + tx) >> 1, Y = (y0 + row) >> 1;
-        if ((tx & 1) == 0 && X < C.w && Y < C.h)
-            st3(C.b, (size_t)Y * C.w + X, r);
+        for (int m = 0; m < 2; ++m) {
+            const int row = 4 * ty + jr + 2 * m, c = (HL + row) * LW + HL + tx;
+            float4 r = vals[c].w > 0.0f ? op.nbsum(vals, c) : make_float4(0, 0, 0, 0);
+            r.x += __shfl_xor(r.x, 1); r.y += __shfl_xor(r.y, 1); r.z += __shfl_xor(r.z, 1);
+            const int X = (x0 + tx) >> 1, Y = (y0 + row) >> 1;
+            if ((tx & 1) == 0 && X < C.w && Y < C.h)
+                st3(C.b, (size_t)Y * C.w + X, r);
+        }
     }
+    if constexpr (UPD)
+        block_sum3(rr[0], rr[1], rr[2], S.sc->rr[(k - 1) & 1]);
 }
 
 // F.x = black, red post-smoothing of x + P C.x (x = the red-black pre-smoothing of F.b from zero), over F's tile list;
@@ -677,13 +743,14 @@ __global__ __launch_bounds__(256) void k_mgb_prolong(const VmMgbSys *__restrict_
         __shared__ float4 vals[LN];
         __shared__ TileOp<L0> op;
         const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+        const VmV3 *__restrict__ bsrc = L0 ? S.R[k & 1] : FL.b;     // level 0: the PCG residual of iteration k
         float4 bown[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            bown[j] = stage_cell<L0>(FL, F, op, vals, (HL + 4 * ty + j) * LW + HL + tx, x0 + tx, y0 + 4 * ty + j, C.x, C.w);
+            bown[j] = stage_cell<L0>(FL, bsrc, F, op, vals, (HL + 4 * ty + j) * LW + HL + tx, x0 + tx, y0 + 4 * ty + j, C.x, C.w);
         for (int kk = tid; kk < NHALO; kk += 256) {
             const int c = halo_cell(kk);
-            stage_cell<L0>(FL, F, op, vals, c, x0 - HL + c % LW, y0 - HL + c / LW, C.x, C.w);
+            stage_cell<L0>(FL, bsrc, F, op, vals, c, x0 - HL + c % LW, y0 - HL + c / LW, C.x, C.w);
         }
         __syncthreads();
         // (the cells' results and right-hand sides sit in registers indexed by j: the colour-dependent cell is picked by
@@ -1279,7 +1346,7 @@ void vm_mgb_launch_init(const VmMgbSys *sys, int nsys, int nb0, uint64_t active,
     hipLaunchKernelGGL(k_mgb_init, dim3(groups(nb0), 1, nsys), blk2, 0, s, sys, active);
 }
 
-void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nu, int nt_fine, uint64_t active, hipStream_t s)
+void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nu, int nt_fine, int k, bool upd, uint64_t active, hipStream_t s)
 {
     const dim3 grid(nt_fine, 1, nsys);
     if (nu == 2) {
@@ -1287,10 +1354,12 @@ void vm_mgb_launch_restrict(const VmMgbSys *sys, int nsys, int l, int nu, int nt
             hipLaunchKernelGGL(k_mgb_restrict2<true>, grid, blk2, 0, s, sys, l, active);
         else
             hipLaunchKernelGGL(k_mgb_restrict2<false>, grid, blk2, 0, s, sys, l, active);
+    } else if (l == 0 && upd) {
+        hipLaunchKernelGGL((k_mgb_restrict<true, true>), grid, blk2, 0, s, sys, l, k, active);
     } else if (l == 0) {
-        hipLaunchKernelGGL(k_mgb_restrict<true>, grid, blk2, 0, s, sys, l, active);
+        hipLaunchKernelGGL((k_mgb_restrict<true, false>), grid, blk2, 0, s, sys, l, k, active);
     } else {
-        hipLaunchKernelGGL(k_mgb_restrict<false>, grid, blk2, 0, s, sys, l, active);
+        hipLaunchKernelGGL((k_mgb_restrict<false, false>), grid, blk2, 0, s, sys, l, k, active);
     }
 }
 

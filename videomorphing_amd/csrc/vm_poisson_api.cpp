@@ -78,13 +78,16 @@ struct MgbWork {          // one system's device workspace, carved from f->pws2[
     VmV3 *Xbest;          // optional (mgb_carve qpath): the iterate with the smallest residual seen near the tolerance
     int *counts;          // nblocks per level, then ntiles per level (device)
     int tail;             // first level of the cycle's one-workgroup tail
+    VmV3 *r1;             // second buffer of the PCG residual, for ...
+    bool fused;           // ... the PCG update riding in the level-0 restriction (the residual ping-pongs between S.R[0] and S.R[1]):
+                          // can this system's hierarchy do it (mgb_carve); whether a solve does: mgb_solve
 };
 
 size_t mgb_bytes(int w, int h, bool with_best = false)
 {
     const auto sz = mg_sizes(w, h);
     const size_t N0 = (size_t)w * h;
-    size_t need = 2 * al256(N0) + al256(sizeof(VmMgbScalars)) + al256(2 * VM_MGB_MAXLEV * sizeof(int)) + 4 * al256(N0 * 12);
+    size_t need = 2 * al256(N0) + al256(sizeof(VmMgbScalars)) + al256(2 * VM_MGB_MAXLEV * sizeof(int)) + 5 * al256(N0 * 12);
     for (size_t l = 0; l < sz.size(); ++l) {
         const size_t N = (size_t)sz[l].first * sz[l].second;
         const size_t nb = (size_t)((sz[l].first + 63) / 64) * ((sz[l].second + 3) / 4);
@@ -106,6 +109,7 @@ void mgb_carve(MgbWork &W, int w, int h, char *b, bool qpath = false)
     W.S.P[0] = (VmV3 *)b; b += al256(N0 * 12);
     W.S.P[1] = (VmV3 *)b; b += al256(N0 * 12);
     W.S.Q = (VmV3 *)b; b += al256(N0 * 12);
+    VmV3 *const r1 = (VmV3 *)b; b += al256(N0 * 12);
     W.S.nlev = (int)sz.size();
     for (size_t l = 0; l < sz.size(); ++l) {
         VmMgbLevel &L = W.S.lv[l];
@@ -141,21 +145,40 @@ void mgb_carve(MgbWork &W, int w, int h, char *b, bool qpath = false)
     }
     W.xcoarse_bytes = (size_t)(b - W.xcoarse);
     W.Xbest = qpath ? (VmV3 *)b : nullptr;     // (the quadratic path keeps the best iterate seen: mgb_solve)
+    // The PCG update can ride in the level-0 restriction wherever that kernel exists in its one-sweep form: level 0 swept by
+    // the tile kernels (not inside the tail) with one sweep each way
+    W.fused = W.tail > 0 && W.S.lv[0].nu == 1;
+    W.r1 = r1;
+    W.S.R[0] = W.S.R[1] = W.S.lv[0].b;
 }
 
-// z = M^-1 r of every active system: one V cycle (sweeps per level: VmMgbLevel::nu); iteration k's r.z lands in rz[k & 1].  nb / nt: blocks / tiles
-// per level (the largest count among the systems)
-void mgb_vcycle(const VmMgbSys *dev, int nsys, const MgbWork &W0, const std::vector<int> &nb, const std::vector<int> &nt, int k,
-                uint64_t active, hipStream_t s)
+// z = M^-1 r of every active system: one V cycle (sweeps per level: VmMgbLevel::nu); iteration k's r.z lands in rz[k & 1].
+// nb / nt: blocks / tiles per level (the largest count among the systems).  In two halves, because the residual norm
+// of iteration k - 1 comes out of the FIRST kernel of iteration k when the update rides in the level-0 restriction:
+//   mgb_iter_head(k): the PCG update of iteration k - 1 (k >= 1) -- inside the level-0 restriction of cycle k (fused), or
+//                     k_mgb_update by itself -- after which x, r and r.r of k completed iterations stand in memory;
+//   mgb_iter_rest(k): the rest of cycle k and p = z + beta p, q = A p.
+void mgb_iter_head(const VmMgbSys *dev, int nsys, bool fused, const std::vector<int> &nb, const std::vector<int> &nt, int k, uint64_t active,
+                   hipStream_t s)
+{
+    if (fused)
+        vm_mgb_launch_restrict(dev, nsys, 0, 1, nt[0], k, k > 0, active, s);
+    else if (k > 0)
+        vm_mgb_launch_update(dev, nsys, nb[0], k - 1, active, s);
+}
+
+void mgb_iter_rest(const VmMgbSys *dev, int nsys, const MgbWork &W0, bool fused, const std::vector<int> &nb, const std::vector<int> &nt, int k,
+                   uint64_t active, hipStream_t s)
 {
     const int tail = W0.tail;       // levels tail .. nlev - 1 run in one workgroup
-    for (int l = 0; l < tail; ++l)
-        vm_mgb_launch_restrict(dev, nsys, l, W0.S.lv[l].nu, nt[l], active, s);
+    for (int l = fused ? 1 : 0; l < tail; ++l)
+        vm_mgb_launch_restrict(dev, nsys, l, W0.S.lv[l].nu, nt[l], k, false, active, s);
     vm_mgb_launch_tail(dev, nsys, tail, active, s);
     if (tail == 0)
         vm_mgb_launch_dot_rz(dev, nsys, nb[0], k, active, s);
     for (int l = tail - 1; l >= 0; --l)
         vm_mgb_launch_prolong(dev, nsys, l, W0.S.lv[l].nu, nt[l], k, active, s);
+    vm_mgb_launch_dirspmv(dev, nsys, nb[0], k, active, s);
 }
 
 double mgb_rel(const VmMgbScalars &h, int par)
@@ -205,7 +228,15 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     VmMgbSys *dev = (VmMgbSys *)c->mgb_sys;
     std::vector<VmMgbSys> hs(nsys);
     const int nlev = W[0].S.nlev;
+    // The PCG update rides in the level-0 restriction for batches of more than 4 systems: measured on the 2304 x 1464 canvas
+    // (tools/exp/fuse_ab.sh, ms per frame, fused against the separate k_mgb_update): 8 systems 1.66 / 1.74 (2.00 / 2.09 at
+    // 1e-6), 4 systems 2.00 / 1.99, 2 systems 2.56 / 2.49, 1 system 1.82 / 1.78 per side -- the fused kernel is 194 us where
+    // update + restriction took 240, but a chip that one or two systems do not fill waits for its longer chain of loads.
+    // Same arithmetic either way.  VM_MGB_FUSE_MIN_SYS (dev switch): the smallest batch that fuses (0: never).
+    static const int fuse_min = [] { const char *e = getenv("VM_MGB_FUSE_MIN_SYS"); return e ? atoi(e) : 5; }();
+    const bool fused = W[0].fused && fuse_min > 0 && nsys >= fuse_min;
     for (int i = 0; i < nsys; ++i) {
+        W[i].S.R[1] = fused ? W[i].r1 : W[i].S.R[0];
         hs[i] = W[i].S;
         hs[i].sc = sc_dev + i;
         for (int l = 0; l < nlev; ++l) {
@@ -247,13 +278,13 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     // of the tolerance -- the cycle gains a decade in two to three iterations -- and every iteration from there: a solve
     // stops at the iteration that reaches the tolerance instead of up to three later.  The cadence is the SYSTEM's own
     // (next_check): where it stops, and so what it pastes, does not depend on its batch-mates.
-    while (true) {
-        {
-            int lo = nsys, hi = -1;          // the systems looked at now: one read-back of the span that holds them
-            for (int i = 0; i < nsys; ++i)
-                if (((active >> i) & 1) && next_check[i] == it) { lo = std::min(lo, i); hi = i; }
-            if (hi >= lo) VM_HIP(hipMemcpyAsync(&h[lo], sc_dev + lo, (size_t)(hi - lo + 1) * sizeof(VmMgbScalars), hipMemcpyDeviceToHost, s));
-        }
+    // check(it): the systems due after `it` completed iterations (mgb_iter_head(it) has been enqueued: x, r, r.r are theirs)
+    auto check = [&](int it) -> int {
+        int lo = nsys, hi = -1;          // the systems looked at now: one read-back of the span that holds them
+        for (int i = 0; i < nsys; ++i)
+            if (((active >> i) & 1) && next_check[i] == it) { lo = std::min(lo, i); hi = i; }
+        if (hi < lo) return VM_OK;
+        VM_HIP(hipMemcpyAsync(&h[lo], sc_dev + lo, (size_t)(hi - lo + 1) * sizeof(VmMgbScalars), hipMemcpyDeviceToHost, s));
         VM_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < nsys; ++i) {
             if (!((active >> i) & 1) || next_check[i] != it) continue;
@@ -286,26 +317,32 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
             }
             next_check[i] = std::min(max_it, it + (best[i] <= 30.0 * tol ? 1 : 4));
         }
-        if (!active) break;
-        int upto = max_it;
-        for (int i = 0; i < nsys; ++i)
-            if ((active >> i) & 1) upto = std::min(upto, next_check[i]);
-        for (; it < upto; ++it) {
-            mgb_vcycle(dev, nsys, W[0], nb, nt, it, active, s);
-            vm_mgb_launch_dirspmv(dev, nsys, nb[0], it, active, s);
-            if (c->mgb_prof) {           // the probe of vm_dbg_poisson_profile: events around the dominant kernel's launch
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                VM_HIP(hipEventCreate(&e0));
-                VM_HIP(hipEventCreate(&e1));
-                VM_HIP(hipEventRecord(e0, s));
-                vm_mgb_launch_update(dev, nsys, nb[0], it, active, s);
-                VM_HIP(hipEventRecord(e1, s));
-                prof_ev.push_back({e0, e1});
-                prof_sys.push_back(__builtin_popcountll(active));
-            } else {
-                vm_mgb_launch_update(dev, nsys, nb[0], it, active, s);
-            }
+        return VM_OK;
+    };
+    {
+        const int rc = check(0);
+        if (rc != VM_OK) return rc;
+    }
+    while (active) {
+        if (c->mgb_prof && it > 0) {     // the probe of vm_dbg_poisson_profile: events around the launch that carries the update
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            VM_HIP(hipEventCreate(&e0));
+            VM_HIP(hipEventCreate(&e1));
+            VM_HIP(hipEventRecord(e0, s));
+            mgb_iter_head(dev, nsys, fused, nb, nt, it, active, s);
+            VM_HIP(hipEventRecord(e1, s));
+            prof_ev.push_back({e0, e1});
+            prof_sys.push_back(__builtin_popcountll(active));
+        } else {
+            mgb_iter_head(dev, nsys, fused, nb, nt, it, active, s);
         }
+        if (it > 0) {
+            const int rc = check(it);
+            if (rc != VM_OK) return rc;
+            if (!active) break;
+        }
+        mgb_iter_rest(dev, nsys, W[0], fused, nb, nt, it, active, s);
+        ++it;
         VM_HIP(hipGetLastError());
     }
     for (int i = 0; i < nsys; ++i) {
@@ -319,6 +356,7 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
             if (hipEventElapsedTime(&ms, prof_ev[k].first, prof_ev[k].second) == hipSuccess) {
                 c->mgb_prof_us += 1e3 * ms;
                 c->mgb_prof_launches += 1;
+                c->mgb_prof_fused += fused ? 1 : 0;
                 c->mgb_prof_unknown_launches += prof_sys[k];        // active systems of that launch (x unknowns per system: the caller's)
             }
             hipEventDestroy(prof_ev[k].first);
@@ -330,22 +368,24 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
 
 // Diagnostic (bench.py's roofline of the compositor's HBM-bound kernel, measured live as the contract asks: HIP events on
 // the stream the kernel is launched on): on != 0 arms the probe and clears its sums; on == 0 disarms it and returns the
-// HIP-event time of the k_mgb_update launches since (microseconds, summed), their number, and the number of ACTIVE
-// systems summed over those launches (one launch streams 73 B per unknown of every active system).
-extern "C" int vm_dbg_poisson_profile(vm_ctx *c, int on, double *update_us, int *update_launches, double *active_systems)
+// HIP-event time of the launches that carried the PCG update since (microseconds, summed), their number, the number of
+// ACTIVE systems summed over those launches, and how many of them were the level-0 restriction with the update fused in
+// (k_mgb_restrict<true, true>: 76 B per unknown of every active system) rather than k_mgb_update by itself (73 B).
+extern "C" int vm_dbg_poisson_profile(vm_ctx *c, int on, double *update_us, int *update_launches, double *active_systems, int *fused_launches)
 {
     if (!c) return vm_fail(VM_E_INVALID, "vm_dbg_poisson_profile: ctx is NULL");
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (on) {
         c->mgb_prof = true;
         c->mgb_prof_us = c->mgb_prof_unknown_launches = 0;
-        c->mgb_prof_launches = 0;
+        c->mgb_prof_launches = c->mgb_prof_fused = 0;
         return VM_OK;
     }
     c->mgb_prof = false;
     if (update_us) *update_us = c->mgb_prof_us;
     if (update_launches) *update_launches = c->mgb_prof_launches;
     if (active_systems) *active_systems = c->mgb_prof_unknown_launches;
+    if (fused_launches) *fused_launches = c->mgb_prof_fused;
     return VM_OK;
 }
 

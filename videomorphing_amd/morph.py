@@ -119,11 +119,12 @@ class Context(object):
         return bool(ov.value)
 
     def poisson_profile(self, on):
-        """vm_dbg_poisson_profile: arm (on = True) the HIP-event probe around the linear solver's dominant kernel, or
-        disarm it and return (summed us, launches, active systems summed over the launches)"""
-        us, n, act = C.c_double(0), C.c_int(0), C.c_double(0)
-        capi.check(self._L.vm_dbg_poisson_profile(self._h, int(bool(on)), C.byref(us), C.byref(n), C.byref(act)))
-        return us.value, n.value, act.value
+        """vm_dbg_poisson_profile: arm (on = True) the HIP-event probe around the linear solver's dominant kernel (the launch
+        that carries the PCG update), or disarm it and return (summed us, launches, active systems summed over the launches,
+        launches of the form with the update fused into the level-0 restriction)"""
+        us, n, act, fused = C.c_double(0), C.c_int(0), C.c_double(0), C.c_int(0)
+        capi.check(self._L.vm_dbg_poisson_profile(self._h, int(bool(on)), C.byref(us), C.byref(n), C.byref(act), C.byref(fused)))
+        return us.value, n.value, act.value, fused.value
 
     def set_commit_order(self, order=0):
         """diagnostic (EXACT): the order a phase's commits are folded in -- 0 row-major (the oracle's),
