@@ -1,6 +1,6 @@
 """profiles/poisson_traffic_latest.json from the PMC summary of tools/prof_poisson4.py (tools/prof_pmc.sh r06p4 ...): HBM bytes
 per system and PCG iteration = sum over the kernels of the iteration (update, dirspmv, the cycle's restrictions / prolongations
-of every level, the tail) of launches x bytes per launch / launches of k_mgb_update / systems per launch.
+of every level, the tail) of launches x bytes per launch / PCG iterations (= launches of k_mgb_dirspmv) / systems per launch.
 usage: python tools/poisson_traffic.py gpurun_out/prof_r06p4/r06p4_pmc_summary.csv profiles/r06_poisson4_pmc_summary.csv [systems per launch]"""
 import csv
 import json
@@ -12,7 +12,8 @@ src, committed = sys.argv[1], sys.argv[2]
 nsys = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 rows = {r["kernel"]: r for r in csv.DictReader(open(src))}
 it_kernels = [k for k in rows if any(t in k for t in ("k_mgb_update", "k_mgb_dirspmv", "k_mgb_prolong", "k_mgb_restrict", "k_mgb_tail", "k_mgb_dot_rz"))]
-iters = int(rows["k_mgb_update"]["launches"])
+# PCG iterations profiled = launches of the kernel that applies the operator (every iteration has exactly one)
+iters = sum(int(rows[k]["launches"]) for k in rows if "k_mgb_dirspmv" in k)
 total = sum(float(rows[k]["HBM_bytes_per_launch_corrected"]) * int(rows[k]["launches"]) for k in it_kernels)
 doc = {
     "bytes_per_system_iteration": total / iters / nsys,
