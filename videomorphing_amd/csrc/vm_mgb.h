@@ -19,7 +19,10 @@
 //     bookkeeping lives in accumulators indexed by the iteration's parity, cleared by the kernel that provably runs
 //     between their last reader and next writer;
 //   * all grids of <= ~6 k cells together (the last four of nine for a 1080p canvas, down to <= 64 cells) are one
-//     workgroup's work in LDS: 13 launches per PCG iteration.
+//     workgroup's work in LDS: 13 launches per PCG iteration;
+//   * in batches of more than four systems the PCG update (x += alpha p, r -= alpha q, r.r) rides in front of the level-0
+//     restriction of the next cycle, whose loads wait for latency while k_mgb_update streamed at the HBM ceiling: 12 launches,
+//     the residual read once (it ping-pongs between two buffers: a tile's apron is another tile's interior).
 #ifndef VM_MGB_H
 #define VM_MGB_H
 
