@@ -57,8 +57,8 @@ ALG_BYTES_PER_VISIT = 100.0      # 76 B read + 24 B written per 
 FLOP_PER_EVAL = 25 * 45 + 2 * 30  # 25 ssim() of ~45 flop-eq + 2 bilinear taps of ~30
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_FLOPS = 157e12         # MI355X_MICROARCH.md: f32 vector peak
-POISSON_ALG_BYTES = 190.0        # algorithmic bytes per unknown and PCG iteration of the Poisson solver ...
-POISSON_ALG_BYTES_FUSED = 178.0  # ... and in batches of more than four systems: the update rides in the level-0 restriction, r is not read twice
+POISSON_ALG_BYTES = 178.0        # algorithmic bytes per unknown and PCG iteration of the Poisson solver (190 until the PCG
+POISSON_ALG_BYTES_FUSED = 178.0  # update moved into the level-0 restriction: the residual is no longer read twice)
 from fullsize_fixture import POISSON_TIMED_TOLS      # noqa: E402  the tolerances the full-size oracle fixtures verify (<= 1 colour level)
 POISSON_TOL = POISSON_TIMED_TOLS[0]
 SCHED = ("k_optimize<true> (TILE schedule, dense kernel)", "k_optimize<false> (TILE schedule, lean kernel for pruned sweeps)",
@@ -1017,8 +1017,8 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         finally:
             for f4 in frs4[1:]:
                 f4.close()
-        # roofline of the solve: algorithmic bytes = unknowns x PCG iterations x 190 B (level 0: restriction 16 +
-        # prolongation 28 + direction / operator 49 + update 73; coarse levels ~25, their second sweep from level 2 down < 2)
+        # roofline of the solve: algorithmic bytes = unknowns x PCG iterations x 178 B (level 0: update + restriction
+        # in one kernel 76, prolongation 28, direction / operator 49; coarse levels ~25, their second sweep from level 2 down < 2)
         # over the HIP-event time of the batch (classification, fill, hierarchy set-up and paste included in the time, not in
         # the bytes: with fewer, stronger iterations this fraction FALLS while the solve gets faster -- the dominant kernel's
         # fraction below is the bandwidth statement)
@@ -1036,12 +1036,12 @@ def run_extras(args, np, capi, morph, synth, L, blk, ctx, p, w, h, nlev, FIXED, 
         # profiles/r06_poisson4_kernel_stats.csv holds rocprofv3's average of the same kernel
         fused = bool(dom) and dom[1] > 0 and dom[3] == dom[1]
         dk_name, dk_bytes = ("k_mgb_restrict<true, true>", 76.0) if fused else ("k_mgb_update", 73.0)
-        pe["roofline"] = {"bound": "hbm", "kernel": "multigrid-PCG solve of both sides of one frame as one batch (13 launches per iteration; the level-0 "
-                                                     "kernels k_mgb_update / k_mgb_dirspmv / k_mgb_prolong / k_mgb_restrict: profiles/r06_compositor_*)",
+        pe["roofline"] = {"bound": "hbm", "kernel": "multigrid-PCG solve of both sides of one frame as one batch (12 launches per iteration; the level-0 "
+                                                     "kernels k_mgb_restrict<true, true> (with the PCG update) / k_mgb_dirspmv / k_mgb_prolong: profiles/r06_compositor_*)",
                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                           "four_frames_per_batch": {"achieved": round(gbs4, 1), "frac": round(gbs4 / HBM_PEAK_GBS, 4),
                                                     "alg_bytes_per_unknown_iteration": POISSON_ALG_BYTES_FUSED,
-                                                    "kernel": "12 launches per iteration: the update rides in the level-0 restriction"},
+                                                    "kernel": "the same solve, four frames = eight systems per batch"},
                           "dominant_kernel": dom and dom[1] > 0 and {
                               "kernel": dk_name, "launches": dom[1], "launch_us": round(dom[0] / dom[1], 2),
                               "alg_bytes_per_unknown": dk_bytes,

@@ -397,9 +397,9 @@ int  vm_poisson_extend_frames(vm_frame *const *frames, int n, float tol, int max
                               int *iters, float *rel_res, float *elapsed_ms);
 /* Diagnostic of the solver behind vm_poisson_extend* / vm_frame_quadratic_path (the reference: MKL DSS, Algorithm/PoissonExt.cpp:321-329,
  * timed by clock() around CPoissonExt::run, :21, 38-39): on != 0 arms a probe that brackets every launch of the solver's
- * dominant kernel -- the one that carries the PCG update x += alpha p, r -= alpha q, r.r: k_mgb_update by itself (a pure stream of
- * 73 bytes per unknown) in batches of up to four systems, the level-0 restriction of the multigrid cycle with the update fused in
- * (76 bytes per unknown) in larger ones -- with HIP events on the context's stream; on == 0 disarms it and returns the summed
+ * dominant kernel -- the one that carries the PCG update x += alpha p, r -= alpha q, r.r: the level-0 restriction of the multigrid
+ * cycle with the update fused in (76 bytes per unknown), or k_mgb_update by itself (a pure stream of 73 bytes per unknown) where a
+ * system is too small to have a level-0 restriction -- with HIP events on the context's stream; on == 0 disarms it and returns the summed
  * event time (microseconds), the number of launches, the number of active systems summed over them and how many of the launches
  * were of the fused form.  Any of the four may be NULL.  bench.py's `poisson_extend_1080p_ex192.roofline.dominant_kernel`. */
 int  vm_dbg_poisson_profile(vm_ctx *ctx, int on, double *update_us, int *update_launches, double *active_systems, int *fused_launches);

@@ -20,9 +20,10 @@
 //     between their last reader and next writer;
 //   * all grids of <= ~6 k cells together (the last four of nine for a 1080p canvas, down to <= 64 cells) are one
 //     workgroup's work in LDS: 13 launches per PCG iteration;
-//   * in batches of more than four systems the PCG update (x += alpha p, r -= alpha q, r.r) rides in front of the level-0
-//     restriction of the next cycle, whose loads wait for latency while k_mgb_update streamed at the HBM ceiling: 12 launches,
-//     the residual read once (it ping-pongs between two buffers: a tile's apron is another tile's interior).
+//   * the PCG update (x += alpha p, r -= alpha q, r.r) rides in front of the level-0 restriction of the next cycle, whose
+//     loads wait for latency while k_mgb_update streamed at the HBM ceiling: 12 launches, the residual read once (it
+//     ping-pongs between two buffers: a tile's apron is another tile's interior).  k_mgb_update by itself remains for
+//     hierarchies whose level 0 sits inside the tail or makes two sweeps.
 #ifndef VM_MGB_H
 #define VM_MGB_H
 

@@ -621,6 +621,46 @@ __global__ __launch_bounds__(256) void k_mgb_restrict(const VmMgbSys *__restrict
     const bool live = (int)blockIdx.x < G(FL.ntiles)[0];
     if (!UPD && !live)
         return;
+    double rr[3] = {0, 0, 0};
+    // UPD: every load of the tile is ISSUED before anything is computed or stored (the stores to x and r could alias the
+    // loads as far as the compiler knows: cell by cell, each cell's loads would wait for the previous cell's stores -- six
+    // dependent round trips), and before alpha is looked up: the scalars' round trip and barrier pass under the loads
+    constexpr int NH = (NHALO + 255) / 256;                  // apron cells per thread: 2
+    float4 o_r[4], o_q[4], o_p[4], o_x[4], h_r[NH], h_q[NH];
+    uint32_t o_m[4], h_m[NH];
+    size_t o_i[4];
+    int x0 = 0, y0 = 0;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+    if constexpr (UPD) {
+        if (live) {
+            const uint32_t tb = G(FL.tiles)[blockIdx.x];
+            x0 = (int)(tb & 0xffffu) * TW;
+            y0 = (int)(tb >> 16) * TH;
+            const VM_G uint8_t *__restrict__ info = G(FL.info);
+            const VmV3 *__restrict__ Ro = S.R[(k - 1) & 1], *__restrict__ Q = S.Q, *__restrict__ P = S.P[(k - 1) & 1], *__restrict__ X = S.X;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = x0 + tx, y = y0 + 4 * ty + j;
+                const bool in = x < FL.w && y < FL.h;
+                o_i[j] = in ? (size_t)y * FL.w + x : 0;
+                o_m[j] = in ? (uint32_t)info[o_i[j]] : 0u;
+                o_r[j] = ld3(Ro, o_i[j]); o_q[j] = ld3(Q, o_i[j]); o_p[j] = ld3(P, o_i[j]); o_x[j] = ld3(X, o_i[j]);
+            }
+#pragma unroll
+            for (int e = 0; e < NH; ++e) {
+                const int kk = tid + 256 * e;
+                h_m[e] = 0u;
+                h_r[e] = h_q[e] = make_float4(0, 0, 0, 0);
+                if (kk < NHALO) {
+                    const int c = halo_cell(kk), x = x0 - HL + c % LW, y = y0 - HL + c / LW;
+                    const bool in = x >= 0 && x < FL.w && y >= 0 && y < FL.h;
+                    const size_t ii = in ? (size_t)y * FL.w + x : 0;
+                    h_m[e] = in ? (uint32_t)info[ii] : 0u;
+                    h_r[e] = ld3(Ro, ii); h_q[e] = ld3(Q, ii);
+                }
+            }
+        }
+    }
     float al[3] = {0, 0, 0};
     if constexpr (UPD) {        // (what k_mgb_update(k - 1) does first: its scalars, its clears)
         const int par = (k - 1) & 1;
@@ -634,50 +674,44 @@ __global__ __launch_bounds__(256) void k_mgb_restrict(const VmMgbSys *__restrict
         for (int c = 0; c < 3; ++c)
             al[c] = pq[c] > 0 ? (float)(rz[c] / pq[c]) : 0.0f;
     }
-    double rr[3] = {0, 0, 0};
     if (live) {
-        const uint32_t tb = G(FL.tiles)[blockIdx.x];
-        const int x0 = (int)(tb & 0xffffu) * TW, y0 = (int)(tb >> 16) * TH;
+        if constexpr (!UPD) {
+            const uint32_t tb = G(FL.tiles)[blockIdx.x];
+            x0 = (int)(tb & 0xffffu) * TW;
+            y0 = (int)(tb >> 16) * TH;
+        }
         const Op<L0> F(FL);
         __shared__ float4 vals[LN];
         __shared__ TileOp<L0> op;
-        const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
         if constexpr (UPD) {
-            const VmV3 *__restrict__ Ro = S.R[(k - 1) & 1], *__restrict__ Q = S.Q, *__restrict__ P = S.P[(k - 1) & 1];
             VmV3 *Rn = S.R[k & 1], *X = S.X;
-            // window cell c = grid cell (x, y): r_k there (zeros without an unknown), staged like stage_cell stages b
-            auto stage_upd = [&](int c, int x, int y, bool own) {
-                const bool in = x >= 0 && x < FL.w && y >= 0 && y < FL.h;
-                const size_t ii = in ? (size_t)y * FL.w + x : 0;
-                const uint32_t m = in ? (uint32_t)F.info[ii] : 0u;
+            // window cell c, its operator byte m, r_{k-1} and q there: stage r_k (zeros without an unknown) like stage_cell stages b
+            auto stage_upd = [&](int c, bool red, uint32_t m, float4 ro, float4 q) {
                 op.m[c] = (uint8_t)m;
                 const float inv = k_of_dg0(m >> 4);
-                const bool unk = inv > 0.0f;
-                const float4 ro = ld3(Ro, ii), q = ld3(Q, ii);
-                float4 pv = make_float4(0, 0, 0, 0), xv = pv;
-                if (own) {
-                    pv = ld3(P, ii);
-                    xv = ld3(X, ii);
-                }
                 // (p, q are only written inside blocks that hold an unknown: selected, never trusted, elsewhere)
-                const float4 r = f4_sel(unk, make_float4(ro.x - al[0] * q.x, ro.y - al[1] * q.y, ro.z - al[2] * q.z, 0), make_float4(0, 0, 0, 0));
-                if (own && unk) {
-                    st3(X, ii, make_float4(xv.x + al[0] * pv.x, xv.y + al[1] * pv.y, xv.z + al[2] * pv.z, 0));
-                    st3(Rn, ii, r);
-                    rr[0] += (double)r.x * r.x; rr[1] += (double)r.y * r.y; rr[2] += (double)r.z * r.z;
-                }
-                float4 v = r;
-                if (((x + y) & 1) == 0)
-                    v = make_float4(inv * r.x, inv * r.y, inv * r.z, 0);
+                const float4 r = f4_sel(inv > 0.0f, make_float4(ro.x - al[0] * q.x, ro.y - al[1] * q.y, ro.z - al[2] * q.z, 0), make_float4(0, 0, 0, 0));
+                float4 v = red ? make_float4(inv * r.x, inv * r.y, inv * r.z, 0) : r;
                 v.w = inv;
                 vals[c] = v;
+                return r;
             };
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                stage_upd((HL + 4 * ty + j) * LW + HL + tx, x0 + tx, y0 + 4 * ty + j, true);
-            for (int kk = tid; kk < NHALO; kk += 256) {
-                const int c = halo_cell(kk);
-                stage_upd(c, x0 - HL + c % LW, y0 - HL + c / LW, false);
+            for (int j = 0; j < 4; ++j) {
+                const float4 r = stage_upd((HL + 4 * ty + j) * LW + HL + tx, ((tx + j) & 1) == 0, o_m[j], o_r[j], o_q[j]);     // x0, y0 are even
+                if ((o_m[j] >> 4) != 0) {
+                    st3(X, o_i[j], make_float4(o_x[j].x + al[0] * o_p[j].x, o_x[j].y + al[1] * o_p[j].y, o_x[j].z + al[2] * o_p[j].z, 0));
+                    st3(Rn, o_i[j], r);
+                    rr[0] += (double)r.x * r.x; rr[1] += (double)r.y * r.y; rr[2] += (double)r.z * r.z;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NH; ++e) {
+                const int kk = tid + 256 * e;
+                if (kk < NHALO) {
+                    const int c = halo_cell(kk);
+                    stage_upd(c, ((c % LW + c / LW) & 1) == 0, h_m[e], h_r[e], h_q[e]);                                    // window parity == grid parity
+                }
             }
         } else {
             const VmV3 *__restrict__ bsrc = L0 ? S.R[k & 1] : FL.b;

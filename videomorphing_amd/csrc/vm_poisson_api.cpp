@@ -228,12 +228,12 @@ static int mgb_solve(vm_ctx *c, std::vector<MgbWork> &W, int nsys, float tol, in
     VmMgbSys *dev = (VmMgbSys *)c->mgb_sys;
     std::vector<VmMgbSys> hs(nsys);
     const int nlev = W[0].S.nlev;
-    // The PCG update rides in the level-0 restriction for batches of more than 4 systems: measured on the 2304 x 1464 canvas
-    // (tools/exp/fuse_ab.sh, ms per frame, fused against the separate k_mgb_update): 8 systems 1.66 / 1.74 (2.00 / 2.09 at
-    // 1e-6), 4 systems 2.00 / 1.99, 2 systems 2.56 / 2.49, 1 system 1.82 / 1.78 per side -- the fused kernel is 194 us where
-    // update + restriction took 240, but a chip that one or two systems do not fill waits for its longer chain of loads.
-    // Same arithmetic either way.  VM_MGB_FUSE_MIN_SYS (dev switch): the smallest batch that fuses (0: never).
-    static const int fuse_min = [] { const char *e = getenv("VM_MGB_FUSE_MIN_SYS"); return e ? atoi(e) : 5; }();
+    // The PCG update rides in the level-0 restriction wherever the hierarchy allows it.  Measured on the 2304 x 1464 canvas
+    // (tools/exp/fuse_ab.sh, ms per frame at 1e-5, fused against the separate k_mgb_update): 8 systems per batch 1.61 / 1.70,
+    // 4 systems 1.95 / 1.99, 2 systems 2.49 / 2.51, one system 1.78 / 1.81 per side (with the fused kernel's loads issued cell
+    // by cell it lost on one and two systems, 2.56 / 2.49: vm_mgb.hip).  Same arithmetic either way.
+    // VM_MGB_FUSE_MIN_SYS (dev switch): the smallest batch that fuses (0: never).
+    static const int fuse_min = [] { const char *e = getenv("VM_MGB_FUSE_MIN_SYS"); return e ? atoi(e) : 1; }();
     const bool fused = W[0].fused && fuse_min > 0 && nsys >= fuse_min;
     for (int i = 0; i < nsys; ++i) {
         W[i].S.R[1] = fused ? W[i].r1 : W[i].S.R[0];
